@@ -1,0 +1,187 @@
+/* libm2mixer -- C ABI of the MI355X-native M2-Mixer training hot path.
+ *
+ * The reference (bezirganyan/m2-mixer) is pure Python: it has NO FFI for this path.  Its
+ * "operator interface" is the nn.Module protocol of modules/mixer.py.  Each entry point below
+ * names the reference code it replaces (paths relative to the reference checkout); the Python
+ * binding a maintainer would add lives in m2_mixer_amd/_lib.py and is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'ed / torch CUDA storage) unless noted;
+ *   - tensors are dense row-major fp32 unless noted; "packed" operands are built by m2m_pack_*;
+ *   - `stream` is a hipStream_t passed as void*; all calls are asynchronous on that stream,
+ *     allocate nothing and never synchronise (they can be captured into a hipGraph);
+ *   - return value: 0 ok; -1 unsupported shape / bad argument (nothing launched, see
+ *     m2m_last_error()); -2 HIP runtime error.  There is no CPU fallback anywhere.
+ */
+#ifndef M2MIXER_H
+#define M2MIXER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M2M_ABI_VERSION 1
+#define M2M_MAX_BLOCKS 8      /* MixerBlocks per m2m_tower; longer towers are chained by the caller */
+#define M2M_ROWS_PER_WG 64    /* token rows one workgroup keeps on chip */
+
+#define M2M_PREC_BF16 0       /* bf16 operands, fp32 accumulate, fp32 residual stream / LayerNorm */
+#define M2M_PREC_F32 1        /* exact fp32 MFMA (parity mode: matches the reference CPU path to ~1e-5) */
+
+/* One MixerBlock (reference: modules/mixer.py:25-47).  Parameter names = reference state-dict keys. */
+typedef struct m2m_block {
+    /* fp32 master parameters */
+    const float* ln1_w;   /* token_mix.0.weight            (D)    */
+    const float* ln1_b;   /* token_mix.0.bias              (D)    */
+    const float* tok_w1;  /* token_mix.2.net.0.weight      (T, N) */
+    const float* tok_b1;  /* token_mix.2.net.0.bias        (T)    */
+    const float* tok_w2;  /* token_mix.2.net.3.weight      (N, T) */
+    const float* tok_b2;  /* token_mix.2.net.3.bias        (N)    */
+    const float* ln2_w;   /* channel_mix.0.weight          (D)    */
+    const float* ln2_b;   /* channel_mix.0.bias            (D)    */
+    const float* ch_w1;   /* channel_mix.1.net.0.weight    (C, D) */
+    const float* ch_b1;   /* channel_mix.1.net.0.bias      (C)    */
+    const float* ch_w2;   /* channel_mix.1.net.3.weight    (D, C) */
+    const float* ch_b2;   /* channel_mix.1.net.3.bias      (D)    */
+    /* packed MFMA-operand copies of ch_w1 / ch_w2 in the tower's precision (m2m_pack_tower) */
+    void* w1n;            /* NAT  [i=c][k=d] = W1[c][d]   forward GEMM1, recompute in backward        */
+    void* w2c;            /* CHN  [i=d][k=c] = W2[d][c]   forward GEMM2                               */
+    void* w2tn;           /* NAT  [i=c][k=d] = W2[d][c]   backward dH = dY W2                         */
+    void* w1tc;           /* CHN  [i=d][k=c] = W1[c][d]   backward dA = dH W1                         */
+    float* ch_b1p;        /* ch_b1 zero-padded to Cp                                                  */
+    /* fp32 gradients (accumulated with +=; the caller zeroes them), same shapes as the parameters */
+    float* g_ln1_w; float* g_ln1_b; float* g_tok_w1; float* g_tok_b1; float* g_tok_w2; float* g_tok_b2;
+    float* g_ln2_w; float* g_ln2_b; float* g_ch_w1; float* g_ch_b1; float* g_ch_w2; float* g_ch_b2;
+    /* activations saved by forward(training) for backward: (B*N, D) fp32 each */
+    float* x_in;          /* block input                                */
+    float* x_mid;         /* after the token-mixing residual            */
+    /* packed operands written by m2m_tower_backward for m2m_tower_wgrad (per 64-row tile) */
+    void* a_nat;          /* LN2(x_mid)          NAT [i=m][k=d] */
+    void* at_chn;         /* LN2(x_mid)^T        CHN [i=d][k=m] */
+    void* dy_nat;         /* d(channel MLP out)  NAT [i=m][k=d] */
+    void* dyt_chn;        /* its transpose       CHN [i=d][k=m] */
+} m2m_block;
+
+/* A stack of MixerBlocks + optional final LayerNorm: the body of MLPMixer / FusionMixer /
+ * MLPMixerNoPatching (reference: modules/mixer.py:125-132, :158-162, :182-186). */
+typedef struct m2m_tower {
+    int32_t prec;          /* M2M_PREC_*                                       */
+    int32_t D, N, T, C;    /* hidden_dim, num_patch, token_dim, channel_dim    */
+    int32_t Cp;            /* C rounded up to a multiple of 32 (packed operands are zero-padded) */
+    int32_t nblocks;       /* <= M2M_MAX_BLOCKS                                */
+    int32_t has_final_ln;  /* 1: apply layer_norm after the blocks             */
+    float p_drop;          /* nn.Dropout p of the four dropout sites of every block */
+    uint32_t site_base;    /* distinguishes this tower's dropout streams       */
+    const float* lnf_w;    /* layer_norm.weight (D) */
+    const float* lnf_b;    /* layer_norm.bias   (D) */
+    float* g_lnf_w;
+    float* g_lnf_b;
+    float* x_final;        /* saved input of the final LayerNorm (B*N, D) */
+    m2m_block blk[M2M_MAX_BLOCKS];
+} m2m_tower;
+
+/* Patch embedding = Conv2d(Cin, D, (ph,pw), stride=(ph,pw)) + 'b c h w -> b (h w) c'
+ * (reference: modules/mixer.py:143-146) or, with H = N, ph = 1, pw = W = K, the plain
+ * Linear(K, D) of MLPMixerNoPatching.proj (modules/mixer.py:171,180). */
+typedef struct m2m_embed {
+    int32_t prec;
+    int32_t Cin, H, W, ph, pw;  /* input (B, Cin, H, W); patch (ph, pw) */
+    int32_t D;                   /* output channels */
+    int32_t K;                   /* Cin*ph*pw */
+    int32_t Kp;                  /* K rounded up to the packed k-block (32 bf16 / 16 fp32) */
+    const float* w;              /* to_patch_embedding.0.weight (D, Cin, ph, pw) == (D, K) */
+    const float* b;              /* to_patch_embedding.0.bias   (D) */
+    void* wn;                    /* packed NAT [i=d][k] */
+    float* g_w;
+    float* g_b;
+} m2m_embed;
+
+/* ---- library ------------------------------------------------------------------------------------ */
+int m2m_abi_version(void);
+const char* m2m_last_error(void);         /* thread-local, host string */
+/* bytes of one packed copy of an (I x K) operand in precision `prec` */
+int64_t m2m_packed_bytes(int prec, int64_t I, int64_t K);
+
+/* ---- operand packing (after every optimizer step) ------------------------------------------------- */
+/* Generic: dst = packed image (mode 0 NAT / 1 CHN) of X[i][k] = src[i*stride_i + k*stride_k], i<I, k<K,
+ * zero padded to (ceil16(I), ceil KB(K)).  order_k_major: 0 -> block(ib,kb) at ib*nKB+kb, 1 -> kb*nIB+ib. */
+int m2m_pack(int prec, int mode, int order_k_major, const float* src, int64_t stride_i, int64_t stride_k,
+             int64_t I, int64_t K, void* dst, void* stream);
+int m2m_pack_tower(const m2m_tower* t, void* stream);     /* w1n, w2c, w2tn, w1tc, ch_b1p of every block */
+int m2m_pack_embed(const m2m_embed* e, void* stream);
+
+/* ---- forward ------------------------------------------------------------------------------------ */
+/* x0 (B*N, D) = patches(input) W^T + b.   Replaces MLPMixer.to_patch_embedding / MLPMixerNoPatching.proj. */
+int m2m_embed_forward(const m2m_embed* e, const float* input, int B, float* x0, void* stream);
+
+/* Blocks + final LayerNorm over a (B, N, D) input.  Replaces the `for mixer_block in self.mixer_blocks`
+ * loop + self.layer_norm of MLPMixer/FusionMixer/MLPMixerNoPatching.forward (modules/mixer.py:125-132).
+ *   x0, x0_sample_stride : input tokens; sample b starts at x0 + b*x0_sample_stride (elements)
+ *   out, out_sample_stride: output tokens (lets two towers write the halves of one fused buffer,
+ *                           which is ConcatFusion(dim=1), modules/fusion.py:116-117)
+ *   pooled (B, D) or NULL : mean over tokens of the output (x.mean(dim=1), models/avmnist.py:271-272,
+ *                           modules/classification.py:89-90)
+ *   training              : 1 -> dropout active (seed/step select the masks) and activations saved */
+int m2m_tower_forward(const m2m_tower* t, const float* x0, int64_t x0_sample_stride, int B,
+                      float* out, int64_t out_sample_stride, float* pooled,
+                      int training, uint32_t seed, uint32_t step, void* stream);
+
+/* ---- backward ----------------------------------------------------------------------------------- */
+/* Reverse pass through final LayerNorm + blocks.
+ *   d_out / d_out_sample_stride : gradient wrt the tower output tokens, or NULL
+ *   d_pooled (B, D)             : gradient wrt `pooled`, or NULL (adds d_pooled/N to every token)
+ *   d_x0 / d_x0_sample_stride   : gradient wrt the tower input tokens (written)
+ * Accumulates the LayerNorm, token-mixing and ch_b2 gradients; writes the packed operands that
+ * m2m_tower_wgrad needs for the channel-mixing weight gradients. */
+int m2m_tower_backward(const m2m_tower* t, int B, const float* d_out, int64_t d_out_sample_stride,
+                       const float* d_pooled, float* d_x0, int64_t d_x0_sample_stride,
+                       uint32_t seed, uint32_t step, void* stream);
+/* g_ch_w1, g_ch_b1, g_ch_w2 of every block (hidden activations recomputed, never stored). */
+int m2m_tower_wgrad(const m2m_tower* t, int B, uint32_t seed, uint32_t step, void* stream);
+/* g_w += d_x0^T patches(input), g_b += column sums of d_x0. */
+int m2m_embed_wgrad(const m2m_embed* e, const float* input, const float* d_x0, int B, void* stream);
+
+/* ---- heads + multi-head loss (models/avmnist.py:271-298, models/mimic.py:106-121) ------------------ */
+/* For each of nheads heads h: logits_h = pooled_h W_h^T + b_h (K classes), CrossEntropyLoss (mean),
+ * total loss = sum_h head_weight[h] * loss_h.  Writes logits (nheads, B, K), losses (nheads+1: per head,
+ * then total), preds (nheads, B) int32 argmax; and, if d_pooled != NULL, the gradients
+ * d_pooled_h (B, D_h) and += g_w_h, g_b_h.  All heads share D here (true for every BASELINE config). */
+typedef struct m2m_head {
+    const float* pooled;  /* (B, D)  */
+    const float* w;       /* (K, D)  */
+    const float* b;       /* (K)     */
+    float* g_w;
+    float* g_b;
+    float* d_pooled;      /* (B, D) or NULL */
+    float weight;         /* coefficient of this head's mean loss in the total */
+} m2m_head;
+int m2m_heads_ce(const m2m_head* heads, int nheads, const int64_t* labels, int B, int D, int K,
+                 float* logits, float* losses, int32_t* preds, void* stream);
+
+/* ---- optimizer (torch.optim.Adam as configured at models/avmnist.py:413-415) ---------------------- */
+/* state: device float[4] = {step (as float count), lr, unused, unused}; the kernel reads lr and the
+ * step count from it, so a captured graph can be replayed while the host edits lr.  m2m_adam_step
+ * increments state[0] on the stream before updating. */
+int m2m_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  float* state, float beta1, float beta2, float eps, float weight_decay,
+                  float grad_scale, void* stream);
+
+/* ---- test hooks ----------------------------------------------------------------------------------- */
+/* keep-mask (uint8, 1 keep) the kernels use for dropout site `site` (0 tok hidden, 1 tok out,
+ * 2 channel hidden, 3 channel out) of block `blk` of tower t at (seed, step): rows x cols elements with
+ * the index convention of the kernels (see DESIGN.md "Dropout"). */
+int m2m_dropout_mask(const m2m_tower* t, int blk, int site, int B, uint32_t seed, uint32_t step,
+                     uint8_t* mask, void* stream);
+/* y = gelu(x), dy = gelu'(x) elementwise with the device implementation (n floats). */
+int m2m_gelu_probe(const float* x, float* y, float* dy, int64_t n, void* stream);
+/* C (I x J, fp32) = A (I x K) * B(J x K)^T through pack + MFMA, mode_b 0: B packed NAT, plain product;
+ * 1: chained: C = (A B^T) is fed as operand of a second product with Bc (J2 x J): C2 = C * Bc^T.
+ * Exercises the fragment layouts end to end. */
+int m2m_gemm_probe(int prec, const float* A, const float* Bm, int I, int J, int K,
+                   const float* Bc, int J2, float* C, float* C2, void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M2MIXER_H */

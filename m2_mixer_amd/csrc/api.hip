@@ -1,0 +1,267 @@
+// Library plumbing, operand packing, Adam, and the small probe kernels used by the tests.
+#include "tile.h"
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void m2m_set_error(const char* msg, const char* file, int line) {
+    snprintf(g_err, sizeof(g_err), "%s (%s:%d)", msg, file, line);
+}
+
+extern "C" const char* m2m_last_error(void) { return g_err; }
+extern "C" int m2m_abi_version(void) { return M2M_ABI_VERSION; }
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+extern "C" int64_t m2m_packed_bytes(int prec, int64_t I, int64_t K) {
+    const int64_t kb = prec == PREC_BF16 ? 32 : 16;
+    return ceil_div(I, 16) * ceil_div(K, kb) * 1024;
+}
+
+int m2m_check_tower(const m2m_tower* t, int B) {
+    if (!t) { m2m_set_error("null tower", __FILE__, __LINE__); return -1; }
+    if (t->prec != PREC_BF16 && t->prec != PREC_F32) { m2m_set_error("bad prec", __FILE__, __LINE__); return -1; }
+    if (t->nblocks < 0 || t->nblocks > M2M_MAX_BLOCKS) { m2m_set_error("nblocks out of range", __FILE__, __LINE__); return -1; }
+    if (t->N < 1 || t->N > 8) { m2m_set_error("num_patch N must be in [1, 8] in this build", __FILE__, __LINE__); return -1; }
+    if (t->T < 8 || t->T > 32 || (t->T % 8) != 0) { m2m_set_error("token_dim T must be a multiple of 8, <= 32 in this build", __FILE__, __LINE__); return -1; }
+    if (t->Cp % 32 != 0 || t->Cp < t->C || t->C < 1) { m2m_set_error("Cp must be C rounded up to a multiple of 32", __FILE__, __LINE__); return -1; }
+    if (B < 1) { m2m_set_error("B < 1", __FILE__, __LINE__); return -1; }
+    if ((int64_t)B * t->N * (int64_t)t->Cp >= (1LL << 32)) { m2m_set_error("B*N*Cp exceeds the 32-bit dropout counter", __FILE__, __LINE__); return -1; }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// packing: one thread per 16-byte lane slot
+// ---------------------------------------------------------------------------------------------------
+template <int P>
+__global__ void pack_kernel(int mode, int order_k_major, const float* __restrict__ src, long stride_i, long stride_k,
+                            long I, long K, char* __restrict__ dst, long nIB, long nKB) {
+    typedef Prec<P> Pr;
+    const long slot = (long)blockIdx.x * blockDim.x + threadIdx.x;   // global lane slot
+    const long nslots = nIB * nKB * 64;
+    if (slot >= nslots) return;
+    const long blk = slot >> 6;
+    const int lane = (int)(slot & 63), g = lane >> 4, il = lane & 15;
+    long ib, kb;
+    if (order_k_major) { kb = blk / nIB; ib = blk % nIB; } else { ib = blk / nKB; kb = blk % nKB; }
+    const long i = ib * 16 + il;
+    Frag f;
+    f.u = u32x4_t{0u, 0u, 0u, 0u};
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < Pr::EPL; ++e) {
+        const long k = kb * Pr::KB + Pr::kmap(mode, g, e);
+        v[e] = (i < I && k < K) ? src[i * stride_i + k * stride_k] : 0.f;
+    }
+    if (P == PREC_BF16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f.u[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f.f[e] = v[e];
+    }
+    *reinterpret_cast<u32x4_t*>(dst + slot * 16) = f.u;
+}
+
+// I, K: valid extents (reads are guarded); Ip, Kp: extents of the zero-padded image
+static int pack_impl(int prec, int mode, int order_k_major, const float* src, int64_t stride_i, int64_t stride_k,
+                     int64_t I, int64_t K, int64_t Ip, int64_t Kp, void* dst, void* stream) {
+    if (prec != PREC_BF16 && prec != PREC_F32) { m2m_set_error("bad prec", __FILE__, __LINE__); return -1; }
+    const long KB = prec == PREC_BF16 ? 32 : 16;
+    const long nIB = ceil_div(Ip, 16), nKB = ceil_div(Kp, KB);
+    const long nslots = nIB * nKB * 64;
+    const int threads = 256;
+    const long grid = ceil_div(nslots, threads);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (prec == PREC_BF16)
+        hipLaunchKernelGGL(pack_kernel<PREC_BF16>, dim3((unsigned)grid), dim3(threads), 0, st, mode, order_k_major, src,
+                           (long)stride_i, (long)stride_k, (long)I, (long)K, (char*)dst, nIB, nKB);
+    else
+        hipLaunchKernelGGL(pack_kernel<PREC_F32>, dim3((unsigned)grid), dim3(threads), 0, st, mode, order_k_major, src,
+                           (long)stride_i, (long)stride_k, (long)I, (long)K, (char*)dst, nIB, nKB);
+    M2M_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int m2m_pack(int prec, int mode, int order_k_major, const float* src, int64_t stride_i, int64_t stride_k,
+                        int64_t I, int64_t K, void* dst, void* stream) {
+    return pack_impl(prec, mode, order_k_major, src, stride_i, stride_k, I, K, I, K, dst, stream);
+}
+
+__global__ void pad_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int np) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < np) dst[i] = i < n ? src[i] : 0.f;
+}
+
+extern "C" int m2m_pack_tower(const m2m_tower* t, void* stream) {
+    if (int rc = m2m_check_tower(t, 1)) return rc;
+    const int D = t->D, C = t->C, Cp = t->Cp;
+    for (int b = 0; b < t->nblocks; ++b) {
+        const m2m_block* k = &t->blk[b];
+        int rc;
+        // W1 (C, D): NAT [i=c][k=d] k-minor ; CHN [i=d][k=c] k-major (transposed read)
+        if ((rc = pack_impl(t->prec, PACK_NAT, 0, k->ch_w1, D, 1, C, D, Cp, D, k->w1n, stream))) return rc;
+        if ((rc = pack_impl(t->prec, PACK_CHN, 1, k->ch_w1, 1, D, D, C, D, Cp, k->w1tc, stream))) return rc;
+        // W2 (D, C): CHN [i=d][k=c] k-major ; NAT [i=c][k=d] k-minor (transposed read)
+        if ((rc = pack_impl(t->prec, PACK_CHN, 1, k->ch_w2, C, 1, D, C, D, Cp, k->w2c, stream))) return rc;
+        if ((rc = pack_impl(t->prec, PACK_NAT, 0, k->ch_w2, 1, C, C, D, Cp, D, k->w2tn, stream))) return rc;
+        hipLaunchKernelGGL(pad_copy_kernel, dim3((Cp + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           k->ch_b1, k->ch_b1p, C, Cp);
+        M2M_CHECK_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+extern "C" int m2m_pack_embed(const m2m_embed* e, void* stream) {
+    if (!e) { m2m_set_error("null embed", __FILE__, __LINE__); return -1; }
+    return pack_impl(e->prec, PACK_NAT, 0, e->w, e->K, 1, e->D, e->K, e->D, e->Kp, e->wn, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam defaults, no amsgrad): models/avmnist.py:413-415
+// ---------------------------------------------------------------------------------------------------
+__global__ void adam_bump_kernel(float* state) { state[0] += 1.0f; }
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ gr, float* __restrict__ m,
+                            float* __restrict__ v, long n, const float* __restrict__ state, float b1, float b2,
+                            float eps, float wd, float gscale) {
+    const float stepf = state[0], lr = state[1];
+    const float bc1 = 1.0f - powf(b1, stepf);
+    const float bc2 = 1.0f - powf(b2, stepf);
+    const float step_size = lr / bc1;
+    const float inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float g = gr[i] * gscale;
+        const float pv = p[i];
+        if (wd != 0.f) g = __builtin_fmaf(wd, pv, g);
+        const float mi = b1 * m[i] + (1.0f - b1) * g;
+        const float vi = b2 * v[i] + (1.0f - b2) * g * g;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        p[i] = pv - step_size * (mi / denom);
+    }
+}
+
+extern "C" int m2m_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
+                             float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, st, state);
+    const int threads = 256;
+    long grid = ceil_div(n, threads);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)grid), dim3(threads), 0, st, param, grad, exp_avg, exp_avg_sq, (long)n,
+                       state, beta1, beta2, eps, weight_decay, grad_scale);
+    M2M_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// probes (tests only)
+// ---------------------------------------------------------------------------------------------------
+__global__ void gelu_probe_kernel(const float* x, float* y, float* dy, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        float a, b;
+        gelu_grad_f(x[i], a, b);
+        y[i] = gelu_f(x[i]);
+        dy[i] = b;
+        (void)a;
+    }
+}
+extern "C" int m2m_gelu_probe(const float* x, float* y, float* dy, int64_t n, void* stream) {
+    hipLaunchKernelGGL(gelu_probe_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y, dy, (long)n);
+    M2M_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void dropout_mask_kernel(unsigned int key, unsigned int thr, long n, uint8_t* mask) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        Drop d; d.key = key; d.thr = thr; d.scale = 1.f;
+        mask[i] = drop_keep(d, (unsigned int)i) ? 1 : 0;
+    }
+}
+extern "C" int m2m_dropout_mask(const m2m_tower* t, int blk, int site, int B, uint32_t seed, uint32_t step, uint8_t* mask, void* stream) {
+    if (int rc = m2m_check_tower(t, B)) return rc;
+    if (site < 0 || site > 3 || blk < 0 || blk >= t->nblocks) { m2m_set_error("bad site/blk", __FILE__, __LINE__); return -1; }
+    // element counts in kernel index order: 0 (B,D,T)  1 (B,D,N)  2 (B*N, Cp)  3 (B*N, D)
+    long n = 0;
+    if (site == 0) n = (long)B * t->D * t->T;
+    if (site == 1) n = (long)B * t->D * t->N;
+    if (site == 2) n = (long)B * t->N * t->Cp;
+    if (site == 3) n = (long)B * t->N * t->D;
+    const unsigned int key = m2m_site_key(seed, step, t->site_base + 4u * blk + site);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       key, m2m_drop_thr(t->p_drop), n, mask);
+    M2M_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// C = A B^T with every operand going through the packed layouts; then C2 = C Bc^T with C's
+// accumulators chained as the second product's A operand.  One wave per 16 rows of A.
+template <int P>
+__global__ void gemm_probe_kernel(const char* Ap /*NAT [i][k] k-minor*/, const char* Bp /*NAT [j][k] k-minor*/,
+                                  const char* Bcp /*CHN [j2][k=j] k-major*/, int I, int J, int K, int J2, float* C, float* C2) {
+    typedef Prec<P> Pr;
+    const int lane = threadIdx.x & 63, g = lane >> 4, il = lane & 15;
+    const int it = blockIdx.x;                 // 16-row tile of A
+    const int nKB = (K + Pr::KB - 1) / Pr::KB;
+    const int nJT = (J + 15) / 16;
+    const int nJ2T = (J2 + 15) / 16;
+    // swapped product: Ct[j][i] = B A^T so that the accumulator (rows j) chains into k = j
+    for (int jp = 0; jp < (nJT + 1) / 2; ++jp) {
+        f32x4_t acc[2];
+        for (int t = 0; t < 2; ++t) {
+            acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            const int jt = 2 * jp + t;
+            if (jt < nJT)
+                for (int kb = 0; kb < nKB; ++kb) {
+                    const Frag b = ld_frag_global(Bp, (long)jt * nKB + kb, lane);
+                    const Frag a = ld_frag_global(Ap, (long)it * nKB + kb, lane);
+                    Pr::mma(acc[t], b, a);
+                }
+            // acc[t][r] = C[i = 16 it + il][j = 16 jt + 4g + r]
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * it + il, j = 16 * jt + 4 * g + r;
+                if (jt < nJT && i < I && j < J) C[(long)i * J + j] = acc[t][r];
+            }
+        }
+        if (C2) {
+            Frag hf[Chain<P>::NF];
+            Chain<P>::make(acc[0], acc[1], hf);
+            for (int f = 0; f < Chain<P>::NF; ++f)
+                for (int j2t = 0; j2t < nJ2T; ++j2t) {
+                    const Frag w = ld_frag_global(Bcp, (long)(jp * Chain<P>::NF + f) * nJ2T + j2t, lane);
+                    f32x4_t o = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    Pr::mma(o, hf[f], w);
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * it + 4 * g + r, j2 = 16 * j2t + il;
+                        if (i < I && j2 < J2) atomicAdd(&C2[(long)i * J2 + j2], o[r]);
+                    }
+                }
+        }
+    }
+}
+
+extern "C" int m2m_gemm_probe(int prec, const float* A, const float* Bm, int I, int J, int K, const float* Bc, int J2,
+                              float* C, float* C2, void* workspace, void* stream) {
+    char* ws = reinterpret_cast<char*>(workspace);
+    const int64_t ab = m2m_packed_bytes(prec, I, K), bb = m2m_packed_bytes(prec, J, K);
+    char* Ap = ws; char* Bp = ws + ab; char* Bcp = Bp + bb;
+    int rc;
+    if ((rc = m2m_pack(prec, PACK_NAT, 0, A, K, 1, I, K, Ap, stream))) return rc;
+    if ((rc = m2m_pack(prec, PACK_NAT, 0, Bm, K, 1, J, K, Bp, stream))) return rc;
+    if (Bc && (rc = m2m_pack(prec, PACK_CHN, 1, Bc, J, 1, J2, J, Bcp, stream))) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (C2) M2M_CHECK_HIP(hipMemsetAsync(C2, 0, sizeof(float) * (size_t)I * J2, st));
+    const int grid = (I + 15) / 16;
+    if (prec == PREC_BF16)
+        hipLaunchKernelGGL(gemm_probe_kernel<PREC_BF16>, dim3(grid), dim3(64), 0, st, Ap, Bp, Bc ? Bcp : nullptr, I, J, K, J2, C, Bc ? C2 : nullptr);
+    else
+        hipLaunchKernelGGL(gemm_probe_kernel<PREC_F32>, dim3(grid), dim3(64), 0, st, Ap, Bp, Bc ? Bcp : nullptr, I, J, K, J2, C, Bc ? C2 : nullptr);
+    M2M_CHECK_HIP(hipGetLastError());
+    return 0;
+}

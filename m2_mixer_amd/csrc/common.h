@@ -1,0 +1,188 @@
+// Device-side building blocks shared by every kernel of libm2mixer (gfx950 / CDNA4 only).
+//
+//  * Prec<P>: the arithmetic a kernel is instantiated for.
+//      P = 0  bf16 operands, fp32 accumulate  (v_mfma_f32_16x16x32_bf16)
+//      P = 1  fp32 operands, fp32 accumulate  (v_mfma_f32_16x16x4_f32, exact fp32; the parity mode)
+//  * "packed block": 16 (row-or-column index i) x KB (contraction index k) operand elements stored as
+//    64 lanes x 16 bytes, lane-major, so that ONE 16-byte access per lane (global_load_dwordx4 or
+//    ds_read_b128, both fully contiguous over the wave) yields ready-to-issue MFMA operand registers.
+//    Two k orders exist:
+//      NAT  natural: the order the MFMA defines           (bf16: k = 8g + e   ; fp32 step e: k = 4e + g)
+//      CHN  chained: the order in which a previous MFMA's accumulator rows sit in a lane's registers,
+//           so an accumulator tile becomes the next MFMA's operand with no lane movement
+//                                                         (bf16: k = 16(e>>2) + 4g + (e&3) ; fp32: k = 4g + e)
+//    with g = lane >> 4, i = lane & 15, e = element index inside the lane's 16 bytes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define M2M_WAVE 64
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+enum { PREC_BF16 = 0, PREC_F32 = 1 };
+enum { PACK_NAT = 0, PACK_CHN = 1 };
+
+// 16-byte operand fragment, viewed either way.
+union Frag {
+    u32x4_t u;
+    f32x4_t f;
+    bf16x8_t h;
+};
+
+template <int P> struct Prec;
+
+template <> struct Prec<PREC_BF16> {
+    typedef __bf16 elem_t;
+    static constexpr int KB = 32;        // k extent of one packed block
+    static constexpr int ESZ = 2;
+    static constexpr int EPL = 8;        // elements per lane in a block
+    // acc(16x16) += A(16 x 32) * B(32 x 16); a supplies rows, b supplies columns
+    static __device__ __forceinline__ void mma(f32x4_t& acc, const Frag& a, const Frag& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int kmap(int mode, int g, int e) {
+        return mode == PACK_NAT ? 8 * g + e : 16 * (e >> 2) + 4 * g + (e & 3);
+    }
+};
+
+template <> struct Prec<PREC_F32> {
+    typedef float elem_t;
+    static constexpr int KB = 16;
+    static constexpr int ESZ = 4;
+    static constexpr int EPL = 4;
+    static __device__ __forceinline__ void mma(f32x4_t& acc, const Frag& a, const Frag& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.f[0], b.f[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.f[1], b.f[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.f[2], b.f[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.f[3], b.f[3], acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int kmap(int mode, int g, int e) {
+        return mode == PACK_NAT ? 4 * e + g : 4 * g + e;
+    }
+};
+
+// ---- fragment <-> memory -------------------------------------------------------------------------
+static __device__ __forceinline__ Frag ld_frag_global(const void* base, long block, int lane) {
+    Frag f;
+    f.u = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(base) + block * 1024 + lane * 16);
+    return f;
+}
+static __device__ __forceinline__ Frag ld_frag_lds(const char* base, int block, int lane) {
+    Frag f;
+    f.u = *reinterpret_cast<const u32x4_t*>(base + block * 1024 + lane * 16);
+    return f;
+}
+
+static __device__ __forceinline__ unsigned short f2bf(float x) {
+    __bf16 b = (__bf16)x;
+    return __builtin_bit_cast(unsigned short, b);
+}
+static __device__ __forceinline__ unsigned int pack_bf2(float lo, float hi) {
+    return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+}
+static __device__ __forceinline__ float bf2f(unsigned short b) {
+    return __builtin_bit_cast(float, (unsigned int)b << 16);
+}
+
+// Store ONE element into a packed image in LDS/global: logical (i, k) of the matrix the image holds.
+// nkb_stride / nib_stride: block index = ib * s_i + kb * s_k.
+template <int P>
+static __device__ __forceinline__ void st_packed_elem(char* base, int mode, int i, int k, int s_i, int s_k, float v) {
+    typedef Prec<P> Pr;
+    const int ib = i >> 4, il = i & 15;
+    const int kb = k / Pr::KB, kl = k % Pr::KB;
+    int g, e;
+    if (P == PREC_BF16) {
+        if (mode == PACK_NAT) { g = kl >> 3; e = kl & 7; }
+        else { g = (kl >> 2) & 3; e = ((kl >> 4) << 2) | (kl & 3); }
+    } else {
+        if (mode == PACK_NAT) { g = kl & 3; e = kl >> 2; }
+        else { g = kl >> 2; e = kl & 3; }
+    }
+    char* p = base + (long)(ib * s_i + kb * s_k) * 1024 + (g * 16 + il) * 16 + e * Pr::ESZ;
+    if (P == PREC_BF16) *reinterpret_cast<unsigned short*>(p) = f2bf(v);
+    else *reinterpret_cast<float*>(p) = v;
+}
+
+// ---- math -----------------------------------------------------------------------------------------
+// erf(x) as an odd rational polynomial on [-4, 4] (|err| < 5e-7, checked against scipy in
+// tests/test_host_math.py); no exp, one reciprocal.  Coefficients: the float erf rational used by Eigen.
+static __device__ __forceinline__ float erf_fast(float x) {
+    x = __builtin_fminf(__builtin_fmaxf(x, -4.0f), 4.0f);
+    const float x2 = x * x;
+    float p = -2.72614225801306e-10f;
+    p = __builtin_fmaf(x2, p, 2.77068142495902e-08f);
+    p = __builtin_fmaf(x2, p, -2.10102402082508e-06f);
+    p = __builtin_fmaf(x2, p, -5.69250639462346e-05f);
+    p = __builtin_fmaf(x2, p, -7.34990630326855e-04f);
+    p = __builtin_fmaf(x2, p, -2.95459980854025e-03f);
+    p = __builtin_fmaf(x2, p, -1.60960333262415e-02f);
+    p = x * p;
+    float q = -1.45660718464996e-05f;
+    q = __builtin_fmaf(x2, q, -2.13374055278905e-04f);
+    q = __builtin_fmaf(x2, q, -1.68282697438203e-03f);
+    q = __builtin_fmaf(x2, q, -7.37332916720468e-03f);
+    q = __builtin_fmaf(x2, q, -1.42647390514189e-02f);
+    return p * __builtin_amdgcn_rcpf(q);
+}
+
+static __device__ __forceinline__ float gelu_f(float x) {
+    return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f));
+}
+// gelu(x) and d gelu / dx = Phi(x) + x phi(x)
+static __device__ __forceinline__ void gelu_grad_f(float x, float& g, float& dg) {
+    const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    g = x * cdf;
+    dg = __builtin_fmaf(x, pdf, cdf);
+}
+
+// ---- dropout: counter-based, stateless ---------------------------------------------------------------
+// keep(element) = 16 bits of mix32(key ^ word) < thr16, two elements per 32-bit word.  The same
+// function is evaluated by forward, backward and the weight-gradient pass, so no mask is ever stored.
+// key = site key derived on the host (m2m_dropout_key); thr16 = round((1-p) * 65536).
+static __device__ __forceinline__ unsigned int mix32(unsigned int x) {
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+struct Drop {
+    unsigned int key;
+    unsigned int thr;   // keep iff 16-bit draw < thr ; thr == 65536 keeps everything
+    float scale;        // 65536 / thr
+};
+static __device__ __forceinline__ bool drop_keep(const Drop& d, unsigned int idx) {
+    const unsigned int w = mix32(d.key ^ (idx >> 1));
+    const unsigned int r = (idx & 1) ? (w >> 16) : (w & 0xFFFFu);
+    return r < d.thr;
+}
+// four consecutive elements idx0..idx0+3, idx0 % 4 == 0  -> two hashes
+static __device__ __forceinline__ void drop_keep4(const Drop& d, unsigned int idx0, bool keep[4]) {
+    const unsigned int w0 = mix32(d.key ^ (idx0 >> 1));
+    const unsigned int w1 = mix32(d.key ^ ((idx0 >> 1) + 1));
+    keep[0] = (w0 & 0xFFFFu) < d.thr;
+    keep[1] = (w0 >> 16) < d.thr;
+    keep[2] = (w1 & 0xFFFFu) < d.thr;
+    keep[3] = (w1 >> 16) < d.thr;
+}
+
+// ---- wave helpers -----------------------------------------------------------------------------------
+static __device__ __forceinline__ float wave_sum_xor(float v, int width) {
+    // butterfly over `width` adjacent lanes (width power of two <= 64)
+    for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+#define M2M_CHECK_HIP(expr)                                                      \
+    do {                                                                         \
+        hipError_t _e = (expr);                                                  \
+        if (_e != hipSuccess) { m2m_set_error(hipGetErrorString(_e), __FILE__, __LINE__); return -2; } \
+    } while (0)
+
+void m2m_set_error(const char* msg, const char* file, int line);

@@ -1,0 +1,247 @@
+// Patch embedding (modules/mixer.py:143-146) and the plain input projection of MLPMixerNoPatching
+// (modules/mixer.py:171,180), forward and weight gradient.
+//
+//   x0[m][d] = sum_k patch[m][k] W[d][k] + b[d],   m = b*N + (gy*GW + gx),  k = c*ph*pw + py*pw + px
+//
+// The conv with stride == kernel is an unfold + GEMM; the unfold is done on the fly while staging the
+// input (read once, coalesced along image rows) into LDS, the weight fragments come straight from the
+// packed NAT copy in global memory.
+#include "tile.h"
+
+#define EMB_KS 128          // k extent staged per step (floats)
+#define EMB_LD (EMB_KS + 4)
+
+struct PatchGeom {
+    int Cin, H, W, ph, pw, GW, N, K;
+};
+static __device__ __forceinline__ long patch_addr(const PatchGeom& pg, long m, int k) {
+    const long b = m / pg.N;
+    const int n = (int)(m % pg.N);
+    const int gy = n / pg.GW, gx = n % pg.GW;
+    const int c = k / (pg.ph * pg.pw), rem = k % (pg.ph * pg.pw);
+    const int py = rem / pg.pw, px = rem % pg.pw;
+    return ((b * pg.Cin + c) * pg.H + gy * pg.ph + py) * (long)pg.W + gx * pg.pw + px;
+}
+
+// stage patches[m0 .. m0+63][k0 .. k0+EMB_KS) into an fp32 LDS tile (zero outside M / K)
+static __device__ __forceinline__ void stage_patches(const float* __restrict__ in, const PatchGeom& pg, long m0, long M, int k0,
+                                                     float* tile, int tid) {
+    for (int idx = tid; idx < BM * EMB_KS; idx += NTHREADS) {
+        const int r = idx / EMB_KS, kk = idx % EMB_KS;
+        const long m = m0 + r;
+        const int k = k0 + kk;
+        float v = 0.f;
+        if (m < M && k < pg.K) v = in[patch_addr(pg, m, k)];
+        tile[r * EMB_LD + kk] = v;
+    }
+}
+
+template <int P, int D>
+__global__ __launch_bounds__(NTHREADS) void embed_fwd_kernel(const m2m_embed em, const float* __restrict__ in, long M, int N,
+                                                             float* __restrict__ x0) {
+    typedef Prec<P> Pr;
+    constexpr int DT = D / 16, KSB = EMB_KS / Pr::KB;     // k-blocks per stage
+    constexpr int DPW = (DT + 3) / 4;                      // d-tiles per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* tile = reinterpret_cast<float*>(smem);          // [BM][EMB_LD] fp32
+    char* img = smem + BM * EMB_LD * 4;                    // packed NAT [mt][kb] of the stage
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
+    PatchGeom pg{em.Cin, em.H, em.W, em.ph, em.pw, em.W / em.pw, N, em.K};
+    const long m0 = (long)blockIdx.x * BM;
+    const int nKB = em.Kp / Pr::KB;
+
+    f32x4_t acc[MT][DPW];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) acc[mt][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < em.Kp; k0 += EMB_KS) {
+        __syncthreads();
+        stage_patches(in, pg, m0, M, k0, tile, tid);
+        __syncthreads();
+        for (int slot = tid; slot < MT * KSB * 64; slot += NTHREADS) {
+            const int blk = slot >> 6;
+            *reinterpret_cast<u32x4_t*>(img + slot * 16) =
+                gather_slot<P>(tile, EMB_LD, PACK_NAT, false, blk / KSB, blk % KSB, slot & 63);
+        }
+        __syncthreads();
+        const int kb0 = k0 / Pr::KB;
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) {
+            const int dt = wave + 4 * j;
+            if (dt < DT) {
+                for (int kb = 0; kb < KSB && kb0 + kb < nKB; ++kb) {
+                    const Frag w = ld_frag_global(em.wn, (long)dt * nKB + kb0 + kb, lane);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const Frag a = ld_frag_lds(img, mt * KSB + kb, lane);
+                        Pr::mma(acc[mt][j], a, w);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) {
+        const int dt = wave + 4 * j;
+        if (dt < DT) {
+            const int d = 16 * dt + il;
+            const float bv = em.b[d];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long m = m0 + 16 * mt + 4 * g + r;
+                    if (m < M) x0[m * D + d] = acc[mt][j][r] + bv;
+                }
+        }
+    }
+}
+
+// g_w[d][k] += sum_m dx0[m][d] patch[m][k];  workgroup = 64 k columns, loops over all rows.
+template <int P, int D>
+__global__ __launch_bounds__(NTHREADS) void embed_wgrad_kernel(const m2m_embed em, const float* __restrict__ in,
+                                                               const float* __restrict__ dx0, long M, int N) {
+    typedef Prec<P> Pr;
+    constexpr int DT = D / 16, NKM = BM / Pr::KB, XLD = TileGeom<D>::XLD;
+    constexpr int KC = 64, KCT = KC / 16, PLD = KC + 4;
+    constexpr int DPW = (DT + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* dxt = reinterpret_cast<float*>(smem);                  // [BM][XLD]   dx0 tile
+    float* pt = dxt + BM * XLD;                                    // [BM][PLD]   patch tile
+    char* aimg = reinterpret_cast<char*>(pt + BM * PLD);           // NAT X[i=d][k=m]  blocks [dt][kbm]
+    char* bimg = aimg + BM * D * Pr::ESZ;                          // NAT X[i=kk][k=m] blocks [kt][kbm]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
+    PatchGeom pg{em.Cin, em.H, em.W, em.ph, em.pw, em.W / em.pw, N, em.K};
+    const int k0 = blockIdx.x * KC;
+
+    f32x4_t acc[DPW][KCT];
+#pragma unroll
+    for (int j = 0; j < DPW; ++j)
+#pragma unroll
+        for (int kt = 0; kt < KCT; ++kt) acc[j][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;                                               // bias gradient (block 0 only), thread d
+
+    for (long m0 = 0; m0 < M; m0 += BM) {
+        __syncthreads();
+        for (int idx = tid; idx < BM * (D / 4); idx += NTHREADS) {
+            const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m0 + r < M) v = *reinterpret_cast<const float4*>(dx0 + (m0 + r) * D + c);
+            *reinterpret_cast<float4*>(dxt + r * XLD + c) = v;
+        }
+        for (int idx = tid; idx < BM * KC; idx += NTHREADS) {
+            const int r = idx / KC, kk = idx % KC;
+            const long m = m0 + r;
+            const int k = k0 + kk;
+            float v = 0.f;
+            if (m < M && k < pg.K) v = in[patch_addr(pg, m, k)];
+            pt[r * PLD + kk] = v;
+        }
+        __syncthreads();
+        if (blockIdx.x == 0 && tid < D) {
+            float s = 0.f;
+            for (int r = 0; r < BM; ++r) s += dxt[r * XLD + tid];
+            bsum += s;
+        }
+        for (int slot = tid; slot < DT * NKM * 64; slot += NTHREADS) {
+            const int blk = slot >> 6;
+            *reinterpret_cast<u32x4_t*>(aimg + slot * 16) =
+                gather_slot<P>(dxt, XLD, PACK_NAT, true, blk / NKM, blk % NKM, slot & 63);
+        }
+        for (int slot = tid; slot < KCT * NKM * 64; slot += NTHREADS) {
+            const int blk = slot >> 6;
+            *reinterpret_cast<u32x4_t*>(bimg + slot * 16) =
+                gather_slot<P>(pt, PLD, PACK_NAT, true, blk / NKM, blk % NKM, slot & 63);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) {
+            const int dt = wave + 4 * j;
+            if (dt < DT) {
+#pragma unroll
+                for (int kbm = 0; kbm < NKM; ++kbm) {
+                    const Frag a = ld_frag_lds(aimg, dt * NKM + kbm, lane);
+#pragma unroll
+                    for (int kt = 0; kt < KCT; ++kt) {
+                        const Frag b = ld_frag_lds(bimg, kt * NKM + kbm, lane);
+                        Pr::mma(acc[j][kt], a, b);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) {
+        const int dt = wave + 4 * j;
+        if (dt < DT) {
+#pragma unroll
+            for (int kt = 0; kt < KCT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int d = 16 * dt + 4 * g + r, k = k0 + 16 * kt + il;
+                    if (k < em.K) em.g_w[(long)d * em.K + k] += acc[j][kt][r];
+                }
+        }
+    }
+    if (blockIdx.x == 0 && tid < D) em.g_b[tid] += bsum;
+}
+
+static int check_embed(const m2m_embed* e, int B) {
+    if (!e || B < 1) { m2m_set_error("embed: bad argument", __FILE__, __LINE__); return -1; }
+    if (e->H % e->ph || e->W % e->pw) { m2m_set_error("embed: image not divisible by patch", __FILE__, __LINE__); return -1; }
+    if (e->K != e->Cin * e->ph * e->pw) { m2m_set_error("embed: K != Cin*ph*pw", __FILE__, __LINE__); return -1; }
+    const int KB = e->prec == PREC_BF16 ? 32 : 16;
+    if (e->Kp % KB || e->Kp < e->K) { m2m_set_error("embed: Kp must be K rounded up to the k-block", __FILE__, __LINE__); return -1; }
+    return 0;
+}
+
+template <int P, int D>
+static int launch_embed_fwd(const m2m_embed* e, const float* in, int B, float* x0, hipStream_t st) {
+    const int N = (e->H / e->ph) * (e->W / e->pw);
+    const long M = (long)B * N;
+    const size_t lds = (size_t)BM * EMB_LD * 4 + (size_t)BM * EMB_KS * Prec<P>::ESZ;
+    auto kern = embed_fwd_kernel<P, D>;
+    static bool done = false;
+    if (!done) { M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((M + BM - 1) / BM)), dim3(NTHREADS), lds, st, *e, in, M, N, x0);
+    M2M_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+template <int P, int D>
+static int launch_embed_wgrad(const m2m_embed* e, const float* in, const float* dx0, int B, hipStream_t st) {
+    const int N = (e->H / e->ph) * (e->W / e->pw);
+    const long M = (long)B * N;
+    const size_t lds = (size_t)BM * TileGeom<D>::XLD * 4 + (size_t)BM * 68 * 4 + (size_t)BM * D * Prec<P>::ESZ + (size_t)BM * 64 * Prec<P>::ESZ;
+    auto kern = embed_wgrad_kernel<P, D>;
+    static bool done = false;
+    if (!done) { M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((e->K + 63) / 64)), dim3(NTHREADS), lds, st, *e, in, dx0, M, N);
+    M2M_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int m2m_embed_forward(const m2m_embed* e, const float* input, int B, float* x0, void* stream) {
+    if (int rc = check_embed(e, B)) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define M2M_EF_CASE(PP, DD) if (e->prec == PP && e->D == DD) return launch_embed_fwd<PP, DD>(e, input, B, x0, st);
+    M2M_EF_CASE(PREC_BF16, 32) M2M_EF_CASE(PREC_BF16, 64) M2M_EF_CASE(PREC_BF16, 128)
+    M2M_EF_CASE(PREC_F32, 32) M2M_EF_CASE(PREC_F32, 64) M2M_EF_CASE(PREC_F32, 128)
+#undef M2M_EF_CASE
+    m2m_set_error("embed_forward: unsupported (prec, D)", __FILE__, __LINE__);
+    return -1;
+}
+
+extern "C" int m2m_embed_wgrad(const m2m_embed* e, const float* input, const float* d_x0, int B, void* stream) {
+    if (int rc = check_embed(e, B)) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define M2M_EW_CASE(PP, DD) if (e->prec == PP && e->D == DD) return launch_embed_wgrad<PP, DD>(e, input, d_x0, B, st);
+    M2M_EW_CASE(PREC_BF16, 32) M2M_EW_CASE(PREC_BF16, 64) M2M_EW_CASE(PREC_BF16, 128)
+    M2M_EW_CASE(PREC_F32, 32) M2M_EW_CASE(PREC_F32, 64) M2M_EW_CASE(PREC_F32, 128)
+#undef M2M_EW_CASE
+    m2m_set_error("embed_wgrad: unsupported (prec, D)", __FILE__, __LINE__);
+    return -1;
+}

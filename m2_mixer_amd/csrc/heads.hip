@@ -1,0 +1,119 @@
+// Classification heads + multi-head cross-entropy, forward and backward in one launch.
+//
+// Reference: models/avmnist.py:271-298 -- classifier_image/audio = nn.Linear on tokens.mean(dim=1),
+// classifier_fusion = StandardClassifier (mean over tokens -> Linear, modules/classification.py:89-90),
+// three nn.CrossEntropyLoss() (mean), loss = (w Lf + ow Li + ow La) * 3, preds = softmax(.).argmax(1).
+// The token means ("pooled") are produced by the tower forward kernel; this kernel consumes them.
+#include "tile.h"
+
+#define HEAD_S 64       // samples per workgroup
+#define HEAD_MAXK 32
+#define HEAD_MAXH 4
+
+struct HeadArgs {
+    m2m_head h[HEAD_MAXH];
+};
+
+__global__ __launch_bounds__(NTHREADS) void heads_ce_kernel(const HeadArgs ha, const int64_t* __restrict__ labels, int B, int D,
+                                                            int K, float* __restrict__ logits_out, float* __restrict__ losses,
+                                                            int32_t* __restrict__ preds, int nheads) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int DL = D + 1;
+    float* pl = reinterpret_cast<float*>(smem);          // pooled tile [HEAD_S][DL]
+    float* wl = pl + HEAD_S * DL;                         // weights     [K][DL]
+    float* lg = wl + HEAD_MAXK * DL;                      // logits / dlogits [HEAD_S][HEAD_MAXK]
+    float* red = lg + HEAD_S * HEAD_MAXK;                 // [HEAD_S] loss terms
+
+    const int tid = threadIdx.x;
+    const int hI = blockIdx.y;
+    const m2m_head& hd = ha.h[hI];
+    const int s0 = blockIdx.x * HEAD_S;
+    const int ns = min(HEAD_S, B - s0);
+
+    for (int idx = tid; idx < HEAD_S * D; idx += NTHREADS) {
+        const int s = idx / D, d = idx % D;
+        pl[s * DL + d] = s < ns ? hd.pooled[(long)(s0 + s) * D + d] : 0.f;
+    }
+    for (int idx = tid; idx < K * D; idx += NTHREADS) wl[(idx / D) * DL + idx % D] = hd.w[idx];
+    __syncthreads();
+    // logits
+    for (int idx = tid; idx < HEAD_S * K; idx += NTHREADS) {
+        const int s = idx / K, k = idx % K;
+        float a = hd.b[k];
+        for (int d = 0; d < D; ++d) a = __builtin_fmaf(pl[s * DL + d], wl[k * DL + d], a);
+        lg[s * HEAD_MAXK + k] = a;
+        if (s < ns) logits_out[((long)hI * B + s0 + s) * K + k] = a;
+    }
+    __syncthreads();
+    // softmax / loss / prediction / dlogits, one thread per sample
+    if (tid < HEAD_S) {
+        float term = 0.f;
+        if (tid < ns) {
+            const int s = tid;
+            const int y = (int)labels[s0 + s];
+            float mx = lg[s * HEAD_MAXK];
+            int am = 0;
+            for (int k = 1; k < K; ++k) { const float v = lg[s * HEAD_MAXK + k]; if (v > mx) { mx = v; am = k; } }
+            float se = 0.f;
+            for (int k = 0; k < K; ++k) se += __expf(lg[s * HEAD_MAXK + k] - mx);
+            const float lse = __logf(se) + mx;
+            term = lse - lg[s * HEAD_MAXK + y];
+            const float scale = hd.weight / (float)B;
+            const float inv = 1.0f / se;
+            for (int k = 0; k < K; ++k) {
+                const float p = __expf(lg[s * HEAD_MAXK + k] - mx) * inv;
+                lg[s * HEAD_MAXK + k] = scale * (p - (k == y ? 1.f : 0.f));
+            }
+            preds[(long)hI * B + s0 + s] = am;
+        } else {
+            for (int k = 0; k < K; ++k) lg[tid * HEAD_MAXK + k] = 0.f;
+        }
+        red[tid] = term;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+        for (int s = 0; s < HEAD_S; ++s) t += red[s];
+        t /= (float)B;
+        atomicAdd(losses + hI, t);
+        atomicAdd(losses + nheads, t * hd.weight);
+    }
+    if (hd.d_pooled) {
+        for (int idx = tid; idx < ns * D; idx += NTHREADS) {
+            const int s = idx / D, d = idx % D;
+            float a = 0.f;
+            for (int k = 0; k < K; ++k) a = __builtin_fmaf(lg[s * HEAD_MAXK + k], wl[k * DL + d], a);
+            hd.d_pooled[(long)(s0 + s) * D + d] = a;
+        }
+        for (int idx = tid; idx < K * D; idx += NTHREADS) {
+            const int k = idx / D, d = idx % D;
+            float a = 0.f;
+            for (int s = 0; s < HEAD_S; ++s) a = __builtin_fmaf(lg[s * HEAD_MAXK + k], pl[s * DL + d], a);
+            atomicAdd(hd.g_w + idx, a);
+        }
+        if (tid < K) {
+            float a = 0.f;
+            for (int s = 0; s < HEAD_S; ++s) a += lg[s * HEAD_MAXK + tid];
+            atomicAdd(hd.g_b + tid, a);
+        }
+    }
+}
+
+extern "C" int m2m_heads_ce(const m2m_head* heads, int nheads, const int64_t* labels, int B, int D, int K, float* logits,
+                            float* losses, int32_t* preds, void* stream) {
+    if (!heads || nheads < 1 || nheads > HEAD_MAXH || K < 2 || K > HEAD_MAXK || D < 1 || D > 512 || B < 1) {
+        m2m_set_error("heads_ce: unsupported (nheads<=4, K<=32, D<=512)", __FILE__, __LINE__);
+        return -1;
+    }
+    HeadArgs ha;
+    for (int i = 0; i < nheads; ++i) ha.h[i] = heads[i];
+    for (int i = nheads; i < HEAD_MAXH; ++i) ha.h[i] = heads[0];
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    M2M_CHECK_HIP(hipMemsetAsync(losses, 0, sizeof(float) * (nheads + 1), st));
+    const size_t lds = sizeof(float) * ((size_t)HEAD_S * (D + 1) + (size_t)HEAD_MAXK * (D + 1) + HEAD_S * HEAD_MAXK + HEAD_S);
+    static bool done = false;
+    if (!done) { M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(heads_ce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); done = true; }
+    hipLaunchKernelGGL(heads_ce_kernel, dim3((B + HEAD_S - 1) / HEAD_S, nheads), dim3(NTHREADS), lds, st, ha, labels, B, D, K, logits, losses, preds, nheads);
+    M2M_CHECK_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,470 @@
+// Backward of a stack of MixerBlocks (+ final LayerNorm): the data-gradient chain -- one launch per tower.
+//
+// Same tiling as the forward: a workgroup owns 64 token rows (whole samples) and walks the blocks in
+// reverse with the fp32 gradient stream of those rows resident in LDS.  Per block:
+//   channel mixing:  dYd = dY * mask_out;  A = LN2(x_mid) recomputed from the saved x_mid;
+//                    per 32 hidden columns and wave:  Hpre^T = W1 A^T + b1,  dHact^T = W2^T dYd^T   (MFMA)
+//                    dHpre = dHact * mask * gelu'(Hpre) on the accumulators, chained straight into
+//                    dA += dHpre W1 (MFMA).  LayerNorm backward, residual add.
+//   token mixing:    recompute LN1(x_in) and the token MLP per (sample, channel) on the VALU; eight lanes
+//                    share a column and split the T hidden units, so the token-weight gradients are
+//                    accumulated in registers and reduced once per block.
+// Small parameter gradients (LayerNorm, token MLP, ch_b2) are added to the fp32 gradient buffers with
+// float atomics.  The channel-mixing WEIGHT gradients need a reduction over all rows and are left to
+// tower_wgrad.hip; this kernel writes the packed operand tiles (A, A^T, dYd, dYd^T) it needs.
+#include "tile.h"
+
+// row statistics from an arbitrary fp32 source (LDS or global) with row stride ld; invalid rows read as 0
+template <int D>
+static __device__ __forceinline__ void row_stats_src(const float* src, long ld, bool valid, int j, float v[D / 4],
+                                                     float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < D / 16; ++i) {
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) q = *reinterpret_cast<const float4*>(src + 16 * i + 4 * j);
+        v[4 * i + 0] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+        s += (q.x + q.y) + (q.z + q.w);
+    }
+    (void)ld;
+    s = wave_sum_xor(s, 4);
+    mean = s * (1.0f / D);
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < D / 4; ++i) { const float c = v[i] - mean; s2 = __builtin_fmaf(c, c, s2); }
+    s2 = wave_sum_xor(s2, 4);
+    const float vv = s2 * (1.0f / D) + 1e-5f;
+    rstd = __builtin_amdgcn_rsqf(vv);
+    rstd = rstd * (1.5f - 0.5f * vv * rstd * rstd);
+}
+
+// LayerNorm backward for the whole tile.
+//   xg      : global saved LN input, row r at xg + r*D (rows >= R treated as zero)
+//   up      : LDS tile, upstream gradient wrt the LN output                       [BM][XLD]
+//   dxs     : LDS tile, receives (accumulate ? += : =) the gradient wrt the LN input
+//   prod    : LDS tile, receives up * xhat (for the gamma gradient)
+// then column sums -> atomicAdd into g_w (gamma) / g_b (beta).  Contains two __syncthreads().
+template <int D>
+static __device__ __forceinline__ void ln_backward_tile(const float* xg, int R, const float* up, const float* gamma,
+                                                        float* dxs, bool accumulate, float* prod, float* g_w, float* g_b,
+                                                        int tid) {
+    constexpr int XLD = TileGeom<D>::XLD;
+    const int r = tid >> 2, j = tid & 3;
+    const bool valid = r < R;
+    float v[D / 4], mean, rstd;
+    row_stats_src<D>(xg + (long)r * D, D, valid, j, v, mean, rstd);
+    float gsum = 0.f, gxsum = 0.f;
+    float gv[D / 4];
+#pragma unroll
+    for (int e = 0; e < D / 4; ++e) {
+        const int c = ln_col(e, j);
+        const float xh = (v[e] - mean) * rstd;
+        const float u = up[r * XLD + c];
+        const float gg = u * gamma[c];
+        gv[e] = gg;
+        v[e] = xh;
+        gsum += gg;
+        gxsum = __builtin_fmaf(gg, xh, gxsum);
+        prod[r * XLD + c] = valid ? u * xh : 0.f;
+    }
+    gsum = wave_sum_xor(gsum, 4) * (1.0f / D);
+    gxsum = wave_sum_xor(gxsum, 4) * (1.0f / D);
+#pragma unroll
+    for (int e = 0; e < D / 4; ++e) {
+        const int c = ln_col(e, j);
+        const float dx = rstd * (gv[e] - gsum - v[e] * gxsum);
+        if (accumulate) { if (valid) dxs[r * XLD + c] += dx; }
+        else dxs[r * XLD + c] = valid ? dx : 0.f;
+    }
+    __syncthreads();
+    for (int d = tid; d < 2 * D; d += NTHREADS) {
+        const float* src = d < D ? prod : up;
+        const int c = d < D ? d : d - D;
+        float s = 0.f;
+        for (int rr = 0; rr < R; ++rr) s += src[rr * XLD + c];
+        atomicAdd((d < D ? g_w : g_b) + c, s);
+    }
+    __syncthreads();
+}
+
+template <int P, int D, int NMAX, int TTMAX>
+__global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw, int B, const float* __restrict__ d_out,
+                                                             long d_out_ss, const float* __restrict__ d_pooled,
+                                                             float* __restrict__ d_x0, long d_x0_ss, unsigned int seed,
+                                                             unsigned int step) {
+    typedef Prec<P> Pr;
+    typedef TileGeom<D> G;
+    constexpr int XLD = G::XLD, DT = G::DT, KD = D / Pr::KB, NF = Chain<P>::NF;
+    constexpr int TILE_F = BM * XLD;                    // floats in one fp32 tile
+    constexpr int IMG_B = BM * D * Pr::ESZ;             // bytes of one packed 64-row image
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int XREG_B = (2 * IMG_B > TILE_F * 4) ? 2 * IMG_B : TILE_F * 4;
+    float* dxs = reinterpret_cast<float*>(smem);        // gradient stream
+    float* ub = dxs + TILE_F;                            // scratch tile
+    char* xreg = reinterpret_cast<char*>(ub + TILE_F);   // packed A image | packed dYd image, aliased by the
+    char* at = xreg;                                     // scratch tile xh once the hidden-column loop is done
+    char* dyp = xreg + IMG_B;
+    float* xh = reinterpret_cast<float*>(xreg);
+    float* rstd_s = reinterpret_cast<float*>(xreg + XREG_B);   // [BM]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
+    const int N = tw.N, T = tw.T, Cp = tw.Cp;
+    const int SPW = BM / N;
+    const int s0 = blockIdx.x * SPW;
+    const int ns = min(SPW, B - s0);
+    const int R = ns * N;
+    const long row0 = (long)s0 * N;
+    const long tile_off = (long)blockIdx.x * IMG_B;
+
+    // ---- upstream gradient of the tower output ----
+    {
+        const float invN = 1.0f / (float)N;
+        for (int idx = tid; idx < BM * (D / 4); idx += NTHREADS) {
+            const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < R) {
+                if (d_out) v = *reinterpret_cast<const float4*>(d_out + (long)(s0 + r / N) * d_out_ss + (long)(r % N) * D + c);
+                if (d_pooled) {
+                    const float4 p = *reinterpret_cast<const float4*>(d_pooled + (long)(s0 + r / N) * D + c);
+                    v.x += p.x * invN; v.y += p.y * invN; v.z += p.z * invN; v.w += p.w * invN;
+                }
+            }
+            *reinterpret_cast<float4*>((tw.has_final_ln ? ub : dxs) + r * XLD + c) = v;
+        }
+        __syncthreads();
+        if (tw.has_final_ln)
+            ln_backward_tile<D>(tw.x_final + row0 * D, R, ub, tw.lnf_w, dxs, false, xh, tw.g_lnf_w, tw.g_lnf_b, tid);
+    }
+
+    for (int b = tw.nblocks - 1; b >= 0; --b) {
+        const m2m_block& bk = tw.blk[b];
+        const unsigned int site = tw.site_base + 4u * b;
+        const Drop dr_th = make_drop(true, tw.p_drop, seed, step, site + 0);
+        const Drop dr_to = make_drop(true, tw.p_drop, seed, step, site + 1);
+        const Drop dr_ch = make_drop(true, tw.p_drop, seed, step, site + 2);
+        const Drop dr_co = make_drop(true, tw.p_drop, seed, step, site + 3);
+        const bool dropping = dr_th.thr < 65536u;
+
+        // ================= channel mixing backward =================
+        // (C1) dYd = dY * mask_out -> fp32 temp (ub)
+        for (int idx = tid; idx < BM * D; idx += NTHREADS) {
+            const int r = idx / D, d = idx % D;
+            float v = dxs[r * XLD + d];
+            if (dropping) v = drop_keep(dr_co, (unsigned int)(row0 + r) * D + d) ? v * dr_co.scale : 0.f;
+            ub[r * XLD + d] = (r < R) ? v : 0.f;
+        }
+        __syncthreads();
+        // ch_b2 gradient: column sums of dYd
+        for (int d = tid; d < D; d += NTHREADS) {
+            float s = 0.f;
+            for (int r = 0; r < R; ++r) s += ub[r * XLD + d];
+            atomicAdd(bk.g_ch_b2 + d, s);
+        }
+        // pack dYd: NAT [m][d] (LDS image + global copy) and CHN [d][m] (global, for the weight gradients)
+        pack_tile_nat<P, D>(ub, dyp, tid);
+        pack_tile_chn_t<P, D>(ub, reinterpret_cast<char*>(bk.dyt_chn) + tile_off, tid);
+        __syncthreads();
+        copy16(reinterpret_cast<char*>(bk.dy_nat) + tile_off, dyp, IMG_B, tid);
+        // (C2) A = LN2(x_mid) -> fp32 tile (ub) -> packed images
+        {
+            const int r = tid >> 2, j = tid & 3;
+            float v[D / 4], mean, rstd;
+            row_stats_src<D>(bk.x_mid + (row0 + r) * D, D, r < R, j, v, mean, rstd);
+#pragma unroll
+            for (int e = 0; e < D / 4; ++e) {
+                const int c = ln_col(e, j);
+                ub[r * XLD + c] = (v[e] - mean) * rstd * bk.ln2_w[c] + bk.ln2_b[c];
+            }
+        }
+        __syncthreads();
+        pack_tile_nat<P, D>(ub, at, tid);
+        pack_tile_chn_t<P, D>(ub, reinterpret_cast<char*>(bk.at_chn) + tile_off, tid);
+        __syncthreads();
+        copy16(reinterpret_cast<char*>(bk.a_nat) + tile_off, at, IMG_B, tid);
+
+        // (C3) hidden-column loop
+        f32x4_t dacc[MT][DT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) dacc[mt][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const int npairs = Cp >> 5;
+        for (int q = wave; q < npairs; q += 4) {
+            Frag w1f[2][KD], w2f[2][KD];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int kb = 0; kb < KD; ++kb) {
+                    w1f[t][kb] = ld_frag_global(bk.w1n, (long)(2 * q + t) * KD + kb, lane);
+                    w2f[t][kb] = ld_frag_global(bk.w2tn, (long)(2 * q + t) * KD + kb, lane);
+                }
+            f32x4_t bias[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) bias[t] = *reinterpret_cast<const f32x4_t*>(bk.ch_b1p + 32 * q + 16 * t + 4 * g);
+            Frag hf[MT][NF];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x4_t hacc[2] = {bias[0], bias[1]};
+                f32x4_t gacc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int kb = 0; kb < KD; ++kb) {
+                    const Frag a = ld_frag_lds(at, mt * KD + kb, lane);
+                    const Frag dy = ld_frag_lds(dyp, mt * KD + kb, lane);
+                    Pr::mma(hacc[0], w1f[0][kb], a);
+                    Pr::mma(hacc[1], w1f[1][kb], a);
+                    Pr::mma(gacc[0], w2f[0][kb], dy);
+                    Pr::mma(gacc[1], w2f[1][kb], dy);
+                }
+                const unsigned int m = (unsigned int)(row0 + mt * 16 + il);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    bool keep[4] = {true, true, true, true};
+                    if (dropping) drop_keep4(dr_ch, m * (unsigned int)Cp + 32 * q + 16 * t + 4 * g, keep);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float gl, dgl;
+                        gelu_grad_f(hacc[t][r], gl, dgl);
+                        float v = gacc[t][r] * dgl;
+                        if (dropping) v = keep[r] ? v * dr_ch.scale : 0.f;
+                        gacc[t][r] = v;
+                    }
+                }
+                Chain<P>::make(gacc[0], gacc[1], hf[mt]);
+            }
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const Frag w = ld_frag_global(bk.w1tc, (long)(q * NF + f) * DT + dt, lane);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) Pr::mma(dacc[mt][dt], hf[mt][f], w);
+                }
+            }
+        }
+        __syncthreads();   // every wave is done reading the packed images that xh aliases
+        // (C4) dA = sum of the four waves' partials -> ub
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float* p = ub + (mt * 16 + 4 * g + r) * XLD + dt * 16 + il;
+                            *p = (w == 0) ? dacc[mt][dt][r] : (*p + dacc[mt][dt][r]);
+                        }
+            }
+            __syncthreads();
+        }
+        // (C5) LayerNorm-2 backward; dx_mid = dY + LN2'(dA)
+        ln_backward_tile<D>(bk.x_mid + row0 * D, R, ub, bk.ln2_w, dxs, true, xh, bk.g_ln2_w, bk.g_ln2_b, tid);
+
+        // ================= token mixing backward =================
+        // (T1) xhat1 -> xh, U = LN1(x_in) -> ub, rstd -> rstd_s
+        {
+            const int r = tid >> 2, j = tid & 3;
+            float v[D / 4], mean, rstd;
+            row_stats_src<D>(bk.x_in + (row0 + r) * D, D, r < R, j, v, mean, rstd);
+            if (j == 0) rstd_s[r] = rstd;
+#pragma unroll
+            for (int e = 0; e < D / 4; ++e) {
+                const int c = ln_col(e, j);
+                const float xhv = (v[e] - mean) * rstd;
+                xh[r * XLD + c] = xhv;
+                ub[r * XLD + c] = xhv * bk.ln1_w[c] + bk.ln1_b[c];
+            }
+        }
+        __syncthreads();
+        {
+            const int tg = tid & 7, pl = tid >> 3;
+            const int TT = T >> 3;
+            float w1r[TTMAX][NMAX], w2r[NMAX][TTMAX], b1r[TTMAX];
+            float aw1[TTMAX][NMAX], aw2[NMAX][TTMAX], ab1[TTMAX], ab2[NMAX];
+#pragma unroll
+            for (int tt = 0; tt < TTMAX; ++tt) {
+                const int t = tg * TT + tt;
+                b1r[tt] = (tt < TT) ? bk.tok_b1[t] : 0.f;
+                ab1[tt] = 0.f;
+#pragma unroll
+                for (int n = 0; n < NMAX; ++n) {
+                    const bool ok = (tt < TT) && (n < N);
+                    w1r[tt][n] = ok ? bk.tok_w1[t * N + n] : 0.f;
+                    w2r[n][tt] = ok ? bk.tok_w2[n * T + t] : 0.f;
+                    aw1[tt][n] = 0.f;
+                    aw2[n][tt] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n) ab2[n] = 0.f;
+
+            const int npairs_tok = ns * D;
+            const int iters = (npairs_tok + 31) / 32;
+            for (int it = 0; it < iters; ++it) {
+                const int p = it * 32 + pl;
+                const bool pv = p < npairs_tok;          // keep all lanes in the shuffles below
+                const int sl = pv ? p / D : 0, d = pv ? p % D : 0;
+                const unsigned int bd = (unsigned int)(s0 + sl) * D + d;
+                float un[NMAX], dv[NMAX], du[NMAX];
+#pragma unroll
+                for (int n = 0; n < NMAX; ++n) {
+                    un[n] = 0.f; dv[n] = 0.f; du[n] = 0.f;
+                    if (pv && n < N) {
+                        un[n] = ub[(sl * N + n) * XLD + d];
+                        float v = dxs[(sl * N + n) * XLD + d];
+                        if (dropping) v = drop_keep(dr_to, bd * N + n) ? v * dr_to.scale : 0.f;
+                        dv[n] = v;
+                    }
+                }
+#pragma unroll
+                for (int tt = 0; tt < TTMAX; ++tt) {
+                    if (tt < TT) {
+                        const int t = tg * TT + tt;
+                        float h = b1r[tt], dh = 0.f;
+#pragma unroll
+                        for (int n = 0; n < NMAX; ++n) {
+                            h = __builtin_fmaf(w1r[tt][n], un[n], h);
+                            dh = __builtin_fmaf(w2r[n][tt], dv[n], dh);
+                        }
+                        float gl, dgl;
+                        gelu_grad_f(h, gl, dgl);
+                        bool keep = true;
+                        if (dropping) keep = drop_keep(dr_th, bd * T + t);
+                        const float sc = dropping ? dr_th.scale : 1.0f;
+                        const float hact = keep ? gl * sc : 0.f;
+                        const float dhp = (keep && pv) ? dh * sc * dgl : 0.f;
+                        ab1[tt] += dhp;
+#pragma unroll
+                        for (int n = 0; n < NMAX; ++n) {
+                            aw2[n][tt] = __builtin_fmaf(dv[n], hact, aw2[n][tt]);
+                            aw1[tt][n] = __builtin_fmaf(dhp, un[n], aw1[tt][n]);
+                            du[n] = __builtin_fmaf(dhp, w1r[tt][n], du[n]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int n = 0; n < NMAX; ++n) {
+                    if (n < N) {
+                        float s = du[n];
+                        s += __shfl_xor(s, 1, 64);
+                        s += __shfl_xor(s, 2, 64);
+                        s += __shfl_xor(s, 4, 64);
+                        if (pv && tg == 0) {
+                            ub[(sl * N + n) * XLD + d] = s;
+                            ab2[n] += dv[n];
+                        }
+                    }
+                }
+            }
+            // reduce the token-weight gradients over the 8 columns a wave handles at a time, then atomics
+#pragma unroll
+            for (int tt = 0; tt < TTMAX; ++tt) {
+                if (tt < TT) {
+                    const int t = tg * TT + tt;
+                    float s = ab1[tt];
+                    s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+                    if (lane < 8) atomicAdd(bk.g_tok_b1 + t, s);
+#pragma unroll
+                    for (int n = 0; n < NMAX; ++n) {
+                        if (n < N) {
+                            float a = aw1[tt][n], c = aw2[n][tt];
+                            a += __shfl_xor(a, 8, 64); a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+                            c += __shfl_xor(c, 8, 64); c += __shfl_xor(c, 16, 64); c += __shfl_xor(c, 32, 64);
+                            if (lane < 8) {
+                                atomicAdd(bk.g_tok_w1 + t * N + n, a);
+                                atomicAdd(bk.g_tok_w2 + n * T + t, c);
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n) {
+                if (n < N) {
+                    float s = ab2[n];   // non-zero on tg == 0 lanes only
+                    s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+                    if (lane == 0) atomicAdd(bk.g_tok_b2 + n, s);
+                }
+            }
+        }
+        __syncthreads();
+        // (T2) LayerNorm-1 backward: dx_in = dx_mid + LN1'(dU); gamma/beta gradients
+        {
+            const int r = tid >> 2, j = tid & 3;
+            const bool valid = r < R;
+            const float rstd = rstd_s[r];
+            float gv[D / 4], xv[D / 4];
+            float gsum = 0.f, gxsum = 0.f;
+#pragma unroll
+            for (int e = 0; e < D / 4; ++e) {
+                const int c = ln_col(e, j);
+                const float u = ub[r * XLD + c];
+                const float xhv = xh[r * XLD + c];
+                const float gg = u * bk.ln1_w[c];
+                gv[e] = gg; xv[e] = xhv;
+                gsum += gg;
+                gxsum = __builtin_fmaf(gg, xhv, gxsum);
+                xh[r * XLD + c] = valid ? u * xhv : 0.f;       // product tile for the gamma gradient
+            }
+            gsum = wave_sum_xor(gsum, 4) * (1.0f / D);
+            gxsum = wave_sum_xor(gxsum, 4) * (1.0f / D);
+            if (valid) {
+#pragma unroll
+                for (int e = 0; e < D / 4; ++e) {
+                    const int c = ln_col(e, j);
+                    dxs[r * XLD + c] += rstd * (gv[e] - gsum - xv[e] * gxsum);
+                }
+            }
+        }
+        __syncthreads();
+        for (int d = tid; d < 2 * D; d += NTHREADS) {
+            const float* src = d < D ? xh : ub;
+            const int c = d < D ? d : d - D;
+            float s = 0.f;
+            for (int rr = 0; rr < R; ++rr) s += src[rr * XLD + c];
+            atomicAdd((d < D ? bk.g_ln1_w : bk.g_ln1_b) + c, s);
+        }
+        __syncthreads();
+    }
+
+    // ---- gradient wrt the tower input ----
+    for (int idx = tid; idx < R * (D / 4); idx += NTHREADS) {
+        const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
+        *reinterpret_cast<float4*>(d_x0 + (long)(s0 + r / N) * d_x0_ss + (long)(r % N) * D + c) =
+            *reinterpret_cast<const float4*>(dxs + r * XLD + c);
+    }
+}
+
+template <int P, int D>
+static int launch_bwd(const m2m_tower* t, int B, const float* d_out, long d_out_ss, const float* d_pooled, float* d_x0,
+                      long d_x0_ss, unsigned int seed, unsigned int step, hipStream_t st) {
+    const int SPW = BM / t->N;
+    const int grid = (B + SPW - 1) / SPW;
+    const size_t tile_b = (size_t)BM * TileGeom<D>::XLD * sizeof(float), img_b = (size_t)BM * D * Prec<P>::ESZ;
+    const size_t lds = 2 * tile_b + (2 * img_b > tile_b ? 2 * img_b : tile_b) + BM * sizeof(float);
+    auto kern = tower_bwd_kernel<P, D, 8, 4>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, st, *t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step);
+    M2M_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int m2m_check_tower(const m2m_tower* t, int B);
+
+extern "C" int m2m_tower_backward(const m2m_tower* t, int B, const float* d_out, int64_t d_out_ss, const float* d_pooled,
+                                  float* d_x0, int64_t d_x0_ss, uint32_t seed, uint32_t step, void* stream) {
+    if (int rc = m2m_check_tower(t, B)) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define M2M_BWD_CASE(PP, DD) \
+    if (t->prec == PP && t->D == DD) return launch_bwd<PP, DD>(t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step, st);
+    M2M_BWD_CASE(PREC_BF16, 32) M2M_BWD_CASE(PREC_BF16, 64) M2M_BWD_CASE(PREC_BF16, 128)
+    M2M_BWD_CASE(PREC_F32, 32) M2M_BWD_CASE(PREC_F32, 64) M2M_BWD_CASE(PREC_F32, 128)
+#undef M2M_BWD_CASE
+    m2m_set_error("tower_backward: unsupported (prec, D)", __FILE__, __LINE__);
+    return -1;
+}

@@ -1,0 +1,257 @@
+// Forward of a stack of MixerBlocks (+ final LayerNorm) -- one launch per tower.
+//
+// Reference semantics: MixerBlock.forward (modules/mixer.py:42-47) applied num_mixers times, then
+// layer_norm (modules/mixer.py:128-131, :158-161, :182-185).
+//
+// Workgroup = 64 token rows (whole samples), resident in LDS as fp32 for the entire tower:
+//   token mixing   LN1 -> per (sample, channel) MLP over the N tokens on the VALU (N, T are tiny)
+//   channel mixing LN2 -> packed operand image in LDS; each wave takes 32 hidden columns at a time:
+//                  H^T[c][m] = W1 A^T (MFMA, W1 fragments straight from global in packed order),
+//                  bias + erf-GELU + dropout on the accumulators, which then ARE the A operand of
+//                  Y[m][d] += H W2^T (chained k order) -- the hidden activation never leaves registers.
+//   the four waves' partial Y are summed through LDS, then bias + dropout + residual.
+#include "tile.h"
+
+template <int P, int D, int NMAX>
+__global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw, const float* __restrict__ x0,
+                                                             long x0_ss, int B, float* __restrict__ out, long out_ss,
+                                                             float* __restrict__ pooled, int training,
+                                                             unsigned int seed, unsigned int step) {
+    typedef Prec<P> Pr;
+    typedef TileGeom<D> G;
+    constexpr int XLD = G::XLD, DT = G::DT, KD = D / Pr::KB, NF = Chain<P>::NF;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = reinterpret_cast<float*>(smem);                 // residual stream  [BM][XLD]
+    float* ub = xs + BM * XLD;                                   // scratch tile     [BM][XLD]
+    char* at = reinterpret_cast<char*>(ub + BM * XLD);           // packed A image   BM*D*ESZ bytes
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
+    const int N = tw.N, T = tw.T, Cp = tw.Cp;
+    const int SPW = BM / N;
+    const int s0 = blockIdx.x * SPW;
+    const int ns = min(SPW, B - s0);
+    const int R = ns * N;
+    const long row0 = (long)s0 * N;                              // first global token row of this tile
+
+    // ---- load the input tile (rows >= R are zero) ----
+    for (int idx = tid; idx < BM * (D / 4); idx += NTHREADS) {
+        const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < R) v = *reinterpret_cast<const float4*>(x0 + (long)(s0 + r / N) * x0_ss + (long)(r % N) * D + c);
+        *reinterpret_cast<float4*>(xs + r * XLD + c) = v;
+    }
+    __syncthreads();
+
+    for (int b = 0; b < tw.nblocks; ++b) {
+        const m2m_block& bk = tw.blk[b];
+        const unsigned int site = tw.site_base + 4u * b;
+        const Drop dr_th = make_drop(training, tw.p_drop, seed, step, site + 0);
+        const Drop dr_to = make_drop(training, tw.p_drop, seed, step, site + 1);
+        const Drop dr_ch = make_drop(training, tw.p_drop, seed, step, site + 2);
+        const Drop dr_co = make_drop(training, tw.p_drop, seed, step, site + 3);
+        const bool dropping = dr_th.thr < 65536u;
+
+        // ---- save block input, LN1 -> ub ----
+        if (training) {
+            for (int idx = tid; idx < R * (D / 4); idx += NTHREADS) {
+                const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
+                *reinterpret_cast<float4*>(bk.x_in + (row0 + r) * D + c) = *reinterpret_cast<const float4*>(xs + r * XLD + c);
+            }
+        }
+        ln_to_tile<D>(xs, ub, bk.ln1_w, bk.ln1_b, tid);
+        __syncthreads();
+
+        // ---- token mixing: one thread per (sample, channel) column (modules/mixer.py:30-35) ----
+        for (int p = tid; p < ns * D; p += NTHREADS) {
+            const int sl = p / D, d = p % D;
+            const unsigned int bd = (unsigned int)(s0 + sl) * D + d;
+            float un[NMAX], o[NMAX];
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n) {
+                un[n] = (n < N) ? ub[(sl * N + n) * XLD + d] : 0.f;
+                o[n] = (n < N) ? bk.tok_b2[n] : 0.f;
+            }
+            for (int t = 0; t < T; ++t) {
+                float h = bk.tok_b1[t];
+#pragma unroll
+                for (int n = 0; n < NMAX; ++n)
+                    if (n < N) h = __builtin_fmaf(bk.tok_w1[t * N + n], un[n], h);
+                h = gelu_f(h);
+                if (dropping) h = drop_keep(dr_th, bd * T + t) ? h * dr_th.scale : 0.f;
+#pragma unroll
+                for (int n = 0; n < NMAX; ++n)
+                    if (n < N) o[n] = __builtin_fmaf(bk.tok_w2[n * T + t], h, o[n]);
+            }
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n) {
+                if (n < N) {
+                    float v = o[n];
+                    if (dropping) v = drop_keep(dr_to, bd * N + n) ? v * dr_to.scale : 0.f;
+                    xs[(sl * N + n) * XLD + d] += v;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- save x_mid, LN2 -> packed operand image ----
+        if (training) {
+            for (int idx = tid; idx < R * (D / 4); idx += NTHREADS) {
+                const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
+                *reinterpret_cast<float4*>(bk.x_mid + (row0 + r) * D + c) = *reinterpret_cast<const float4*>(xs + r * XLD + c);
+            }
+        }
+        ln_to_tile<D>(xs, ub, bk.ln2_w, bk.ln2_b, tid);
+        __syncthreads();
+        pack_tile_nat<P, D>(ub, at, tid);
+        __syncthreads();
+
+        // ---- channel mixing (modules/mixer.py:37-40), each wave owns 32 hidden columns per step ----
+        f32x4_t yacc[MT][DT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) yacc[mt][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+        const int npairs = Cp >> 5;
+        for (int q = wave; q < npairs; q += 4) {
+            Frag w1f[2][KD];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int kb = 0; kb < KD; ++kb) w1f[t][kb] = ld_frag_global(bk.w1n, (long)(2 * q + t) * KD + kb, lane);
+            f32x4_t bias[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) bias[t] = *reinterpret_cast<const f32x4_t*>(bk.ch_b1p + 32 * q + 16 * t + 4 * g);
+
+            f32x4_t hacc[MT][2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                hacc[mt][0] = bias[0];
+                hacc[mt][1] = bias[1];
+#pragma unroll
+                for (int kb = 0; kb < KD; ++kb) {
+                    const Frag a = ld_frag_lds(at, mt * KD + kb, lane);
+                    Pr::mma(hacc[mt][0], w1f[0][kb], a);
+                    Pr::mma(hacc[mt][1], w1f[1][kb], a);
+                }
+            }
+            // bias is already in; GELU + dropout on the accumulators (row c = 4g + r, column m = il)
+            Frag hf[MT][NF];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const unsigned int m = (unsigned int)(row0 + mt * 16 + il);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    bool keep[4] = {true, true, true, true};
+                    if (dropping) drop_keep4(dr_ch, m * (unsigned int)Cp + 32 * q + 16 * t + 4 * g, keep);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = gelu_f(hacc[mt][t][r]);
+                        if (dropping) v = keep[r] ? v * dr_ch.scale : 0.f;
+                        hacc[mt][t][r] = v;
+                    }
+                }
+                Chain<P>::make(hacc[mt][0], hacc[mt][1], hf[mt]);
+            }
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const Frag w2 = ld_frag_global(bk.w2c, (long)(q * NF + f) * DT + dt, lane);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) Pr::mma(yacc[mt][dt], hf[mt][f], w2);
+                }
+            }
+        }
+
+        // ---- sum the four waves' partial Y in LDS (fixed order: deterministic) ----
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float* p = ub + (mt * 16 + 4 * g + r) * XLD + dt * 16 + il;
+                            *p = (w == 0) ? yacc[mt][dt][r] : (*p + yacc[mt][dt][r]);
+                        }
+            }
+            __syncthreads();
+        }
+        // ---- + bias, dropout, residual ----
+        for (int idx = tid; idx < R * D; idx += NTHREADS) {
+            const int r = idx / D, d = idx % D;
+            float v = ub[r * XLD + d] + bk.ch_b2[d];
+            if (dropping) v = drop_keep(dr_co, (unsigned int)(row0 + r) * D + d) ? v * dr_co.scale : 0.f;
+            xs[r * XLD + d] += v;
+        }
+        __syncthreads();
+    }
+
+    // ---- final LayerNorm (modules/mixer.py:131,161,185), output + token mean ----
+    if (training && tw.x_final) {
+        for (int idx = tid; idx < R * (D / 4); idx += NTHREADS) {
+            const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
+            *reinterpret_cast<float4*>(tw.x_final + (row0 + r) * D + c) = *reinterpret_cast<const float4*>(xs + r * XLD + c);
+        }
+    }
+    const float* res = xs;
+    if (tw.has_final_ln) {
+        ln_to_tile<D>(xs, ub, tw.lnf_w, tw.lnf_b, tid);
+        res = ub;
+        __syncthreads();
+    }
+    for (int idx = tid; idx < R * (D / 4); idx += NTHREADS) {
+        const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
+        *reinterpret_cast<float4*>(out + (long)(s0 + r / N) * out_ss + (long)(r % N) * D + c) =
+            *reinterpret_cast<const float4*>(res + r * XLD + c);
+    }
+    if (pooled) {
+        const float inv = 1.0f / (float)N;
+        for (int p = tid; p < ns * D; p += NTHREADS) {
+            const int sl = p / D, d = p % D;
+            float s = 0.f;
+            for (int n = 0; n < N; ++n) s += res[(sl * N + n) * XLD + d];
+            pooled[(long)(s0 + sl) * D + d] = s * inv;
+        }
+    }
+}
+
+template <int P, int D>
+static size_t fwd_lds_bytes() {
+    return (size_t)2 * BM * TileGeom<D>::XLD * sizeof(float) + (size_t)BM * D * Prec<P>::ESZ;
+}
+
+template <int P, int D>
+static int launch_fwd(const m2m_tower* t, const float* x0, long x0_ss, int B, float* out, long out_ss, float* pooled,
+                      int training, unsigned int seed, unsigned int step, hipStream_t st) {
+    const int SPW = BM / t->N;
+    const int grid = (B + SPW - 1) / SPW;
+    const size_t lds = fwd_lds_bytes<P, D>();
+    auto kern = tower_fwd_kernel<P, D, 8>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, st, *t, x0, x0_ss, B, out, out_ss, pooled, training, seed, step);
+    M2M_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int m2m_check_tower(const m2m_tower* t, int B);
+
+extern "C" int m2m_tower_forward(const m2m_tower* t, const float* x0, int64_t x0_ss, int B, float* out, int64_t out_ss,
+                                 float* pooled, int training, uint32_t seed, uint32_t step, void* stream) {
+    if (int rc = m2m_check_tower(t, B)) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define M2M_FWD_CASE(PP, DD) \
+    if (t->prec == PP && t->D == DD) return launch_fwd<PP, DD>(t, x0, x0_ss, B, out, out_ss, pooled, training, seed, step, st);
+    M2M_FWD_CASE(PREC_BF16, 32) M2M_FWD_CASE(PREC_BF16, 64) M2M_FWD_CASE(PREC_BF16, 128)
+    M2M_FWD_CASE(PREC_F32, 32) M2M_FWD_CASE(PREC_F32, 64) M2M_FWD_CASE(PREC_F32, 128)
+#undef M2M_FWD_CASE
+    m2m_set_error("tower_forward: unsupported (prec, D)", __FILE__, __LINE__);
+    return -1;
+}

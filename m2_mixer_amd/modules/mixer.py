@@ -1,0 +1,267 @@
+"""Mixer building blocks with the reference's module protocol, backed by libm2mixer.so.
+
+Mirrors the public surface of the reference's modules/mixer.py -- class names, constructor
+signatures (extra kwargs swallowed, as `get_block_by_name(**cfg)` splats the whole cfg dict),
+`.num_patch`, `forward(x) -> (B, N, D)` and, exactly, the state-dict keys so
+the published checkpoints load.  The sub-modules below exist to own parameters under those keys;
+their torch forward() is never used: `forward` hands the tensors to the HIP tower kernels
+(csrc/tower_fwd.hip, tower_bwd.hip, tower_wgrad.hip) through a torch.autograd.Function.
+
+There is no CPU path: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import itertools
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from .. import _lib as L
+from .. import config
+from ..runtime import BLOCK_FIELDS, BLOCK_KEYS, EmbedRuntime, TowerRuntime
+
+_site_counter = itertools.count(0)
+
+
+def _param_holder_ff(dim: int, hidden: int, dropout: float, out_dim: Optional[int] = None) -> nn.Module:
+    return FeedForward(dim, hidden, dropout, out_dim)
+
+
+class FeedForward(nn.Module):
+    """Linear -> GELU(erf) -> Dropout -> Linear -> Dropout (reference: modules/mixer.py:9-22).
+    Parameter container (keys net.0.*, net.3.*); computed inside the fused kernels."""
+
+    def __init__(self, dim, hidden_dim, dropout=0., out_dim=None):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(dim, hidden_dim), nn.GELU(), nn.Dropout(dropout),
+                                 nn.Linear(hidden_dim, out_dim or dim), nn.Dropout(dropout))
+
+    def forward(self, x):  # pragma: no cover - never on the product path
+        raise RuntimeError("FeedForward is fused into the MixerBlock HIP kernels; call the enclosing block/tower")
+
+
+def _block_tensors(block: "MixerBlock") -> dict:
+    sd = dict(block.named_parameters())
+    return {f: sd[BLOCK_KEYS[f]] for f in BLOCK_FIELDS}
+
+
+class _TowerFunction(torch.autograd.Function):
+    """x (B, N, D) -> blocks (+ final LayerNorm) -> (B, N, D)."""
+
+    @staticmethod
+    def forward(ctx, x, owner, need_grad, *params):
+        # NB: grad mode is switched off inside Function.forward, so the caller decides `need_grad`
+        rt: TowerRuntime = owner._rt
+        B = x.shape[0]
+        N, D = rt.N, rt.D
+        dropping = owner.training and owner.dropout_p > 0
+        rt.desc.p_drop = float(owner.dropout_p) if dropping else 0.0
+        seed, step = config.dropout_seed(), owner._bump_step() if dropping else 0
+        out = torch.empty(B, N, D, device=x.device, dtype=torch.float32)
+        rt.forward(x, N * D, B, out, N * D, None, need_grad or dropping, seed, step)
+        ctx.owner, ctx.B, ctx.seed, ctx.step = owner, B, seed, step
+        ctx.gen = owner._fwd_generation = owner._fwd_generation + 1
+        ctx.nparams = len(params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        owner = ctx.owner
+        rt: TowerRuntime = owner._rt
+        if ctx.gen != owner._fwd_generation:
+            raise RuntimeError("this tower ran another forward before backward; saved activations were overwritten")
+        B, N, D = ctx.B, rt.N, rt.D
+        flat = torch.zeros(rt.grad_numel(), device=dout.device, dtype=torch.float32)
+        views = rt.bind_grads(flat)
+        dx = torch.empty(B, N, D, device=dout.device, dtype=torch.float32)
+        rt.backward(B, dout.contiguous(), N * D, None, dx, N * D, ctx.seed, ctx.step)
+        rt.wgrad(B, ctx.seed, ctx.step)
+        return (dx, None, None) + tuple(views)
+
+
+class _EmbedFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inp, owner, w, b):
+        rt: EmbedRuntime = owner._ert
+        B = inp.shape[0]
+        x0 = torch.empty(B, rt.N, rt.D, device=inp.device, dtype=torch.float32)
+        rt.forward(inp, B, x0)
+        ctx.owner, ctx.B = owner, B
+        ctx.save_for_backward(inp)
+        return x0
+
+    @staticmethod
+    def backward(ctx, dx0):
+        rt: EmbedRuntime = ctx.owner._ert
+        (inp,) = ctx.saved_tensors
+        g_w = torch.zeros_like(rt._keep["w"])
+        g_b = torch.zeros_like(rt._keep["b"])
+        rt.bind_grads(g_w, g_b)
+        rt.wgrad(inp, dx0.contiguous(), ctx.B)
+        return None, None, g_w, g_b
+
+
+class _HipTower(nn.Module):
+    """Shared machinery: a list of MixerBlocks (+ optional final LayerNorm) run as one HIP tower."""
+
+    def _init_tower(self, hidden_dim, num_patch, token_dim, channel_dim, dropout, precision=None):
+        self.hidden_dim, self.token_dim, self.channel_dim = hidden_dim, token_dim, channel_dim
+        self.dropout_p = float(dropout)
+        self.precision = precision
+        self._rt: Optional[TowerRuntime] = None
+        self._fwd_generation = 0
+        self._drop_step = 0
+        self._site_base = 1024 * next(_site_counter)
+
+    def _bump_step(self) -> int:
+        self._drop_step += 1
+        return self._drop_step
+
+    def _tower_blocks(self) -> List["MixerBlock"]:
+        raise NotImplementedError
+
+    def _final_ln(self) -> Optional[nn.LayerNorm]:
+        return getattr(self, "layer_norm", None)
+
+    def _runtime(self) -> TowerRuntime:
+        blocks = [_block_tensors(b) for b in self._tower_blocks()]
+        ln = self._final_ln()
+        lnf = (ln.weight, ln.bias) if ln is not None else None
+        prec = config.prec_id(self.precision)
+        if self._rt is None or self._rt.prec != prec:
+            self._rt = TowerRuntime(self.hidden_dim, self.num_patch, self.token_dim, self.channel_dim, len(blocks),
+                                    ln is not None, self.dropout_p, prec, self._site_base)
+            self._rt.bind_params(blocks, lnf)
+        elif self._rt.params_changed(blocks, lnf):
+            self._rt.bind_params(blocks, lnf)
+        self._rt.pack()
+        return self._rt
+
+    def _run_tower(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError("m2_mixer_amd modules run on the GPU only (MI355X); there is no CPU path")
+        if x.dim() != 3 or x.shape[1] != self.num_patch or x.shape[2] != self.hidden_dim:
+            raise RuntimeError(f"expected (B, {self.num_patch}, {self.hidden_dim}) tokens, got {tuple(x.shape)}")
+        self._runtime()
+        blocks = [_block_tensors(b) for b in self._tower_blocks()]
+        params = [bp[f] for bp in blocks for f in BLOCK_FIELDS]
+        ln = self._final_ln()
+        if ln is not None:
+            params += [ln.weight, ln.bias]
+        need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        return _TowerFunction.apply(x.contiguous().float(), self, need_grad, *params)
+
+
+class MixerBlock(_HipTower):
+    """token-mixing MLP + channel-mixing MLP with residuals (reference: modules/mixer.py:25-47)."""
+
+    def __init__(self, hidden_dim, num_patch, token_dim, channel_dim, dropout=0.):
+        super().__init__()
+        self.num_patch = num_patch
+        # index 1 / 3 of token_mix are the reference's parameter-free Rearrange layers
+        self.token_mix = nn.Sequential(nn.LayerNorm(hidden_dim), nn.Identity(),
+                                       _param_holder_ff(num_patch, token_dim, dropout), nn.Identity())
+        self.channel_mix = nn.Sequential(nn.LayerNorm(hidden_dim), _param_holder_ff(hidden_dim, channel_dim, dropout))
+        self._init_tower(hidden_dim, num_patch, token_dim, channel_dim, dropout)
+
+    def _tower_blocks(self):
+        return [self]
+
+    def forward(self, x):
+        return self._run_tower(x)
+
+
+def _make_blocks(n, hidden_dim, num_patch, token_dim, channel_dim, dropout) -> nn.ModuleList:
+    return nn.ModuleList([MixerBlock(hidden_dim, num_patch, token_dim, channel_dim, dropout=dropout) for _ in range(n)])
+
+
+class FusionMixer(_HipTower):
+    """MixerBlocks + LayerNorm over already-embedded tokens (reference: modules/mixer.py:112-132)."""
+
+    def __init__(self, hidden_dim, num_patches, num_mixers, token_dim, channel_dim, dropout=0., **kwargs):
+        super().__init__()
+        self.num_patch = num_patches
+        self.mixer_blocks = _make_blocks(num_mixers, hidden_dim, num_patches, token_dim, channel_dim, dropout)
+        self.layer_norm = nn.LayerNorm(hidden_dim)
+        self._init_tower(hidden_dim, num_patches, token_dim, channel_dim, dropout, kwargs.get("precision"))
+
+    def _tower_blocks(self):
+        return list(self.mixer_blocks)
+
+    def forward(self, x):
+        return self._run_tower(x)
+
+
+class MLPMixer(_HipTower):
+    """Conv patch embedding -> MixerBlocks -> LayerNorm (reference: modules/mixer.py:135-162)."""
+
+    def __init__(self, in_channels, hidden_dim, patch_size, image_size, num_mixers, token_dim, channel_dim,
+                 dropout=0., **kwargs):
+        super().__init__()
+        if image_size[0] % patch_size or image_size[1] % patch_size:
+            raise AssertionError('Image dimensions must be divisible by the patch size.')
+        self.in_channels, self.patch_size, self.image_size = in_channels, patch_size, list(image_size)
+        self.num_patch = (image_size[0] // patch_size) * (image_size[1] // patch_size)
+        # index 1 is the reference's Rearrange('b c h w -> b (h w) c')
+        self.to_patch_embedding = nn.Sequential(nn.Conv2d(in_channels, hidden_dim, patch_size, patch_size), nn.Identity())
+        self.mixer_blocks = _make_blocks(num_mixers, hidden_dim, self.num_patch, token_dim, channel_dim, dropout)
+        self.layer_norm = nn.LayerNorm(hidden_dim)
+        self._init_tower(hidden_dim, self.num_patch, token_dim, channel_dim, dropout, kwargs.get("precision"))
+        self._ert: Optional[EmbedRuntime] = None
+
+    def _tower_blocks(self):
+        return list(self.mixer_blocks)
+
+    def _embed(self, x):
+        conv = self.to_patch_embedding[0]
+        prec = config.prec_id(self.precision)
+        if self._ert is None or self._ert.prec != prec:
+            self._ert = EmbedRuntime(self.in_channels, self.image_size[0], self.image_size[1], self.patch_size,
+                                     self.patch_size, self.hidden_dim, prec)
+            self._ert.bind_params(conv.weight, conv.bias)
+        elif self._ert.params_changed(conv.weight, conv.bias):
+            self._ert.bind_params(conv.weight, conv.bias)
+        self._ert.pack()
+        return _EmbedFunction.apply(x.contiguous().float(), self, conv.weight, conv.bias)
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("m2_mixer_amd modules run on the GPU only (MI355X); there is no CPU path")
+        if tuple(x.shape[1:]) != (self.in_channels, self.image_size[0], self.image_size[1]):
+            raise RuntimeError(f"expected (B, {self.in_channels}, {self.image_size[0]}, {self.image_size[1]}), got {tuple(x.shape)}")
+        return self._run_tower(self._embed(x))
+
+
+class MLPMixerNoPatching(_HipTower):
+    """Linear projection of given tokens -> MixerBlocks -> LayerNorm (reference: modules/mixer.py:165-186)."""
+
+    def __init__(self, hidden_dim, num_patch, num_mixers, token_dim, channel_dim, embedding_dim, proj_dim,
+                 dropout=0., **kwargs):
+        super().__init__()
+        if proj_dim != hidden_dim:
+            raise ValueError("MLPMixerNoPatching needs proj_dim == hidden_dim (as in the reference's forward)")
+        self.num_patch = num_patch
+        self.embedding_dim = embedding_dim
+        self.proj = nn.Linear(embedding_dim, proj_dim)
+        self.mixer_blocks = _make_blocks(num_mixers, hidden_dim, num_patch, token_dim, channel_dim, dropout)
+        self.layer_norm = nn.LayerNorm(hidden_dim)
+        self._init_tower(hidden_dim, num_patch, token_dim, channel_dim, dropout, kwargs.get("precision"))
+        self._ert: Optional[EmbedRuntime] = None
+
+    def _tower_blocks(self):
+        return list(self.mixer_blocks)
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("m2_mixer_amd modules run on the GPU only (MI355X); there is no CPU path")
+        prec = config.prec_id(self.precision)
+        if self._ert is None or self._ert.prec != prec:
+            # (B, N, K) rows == a (B, 1, N, K) image cut into (1, K) patches
+            self._ert = EmbedRuntime(1, self.num_patch, self.embedding_dim, 1, self.embedding_dim, self.hidden_dim, prec)
+            self._ert.bind_params(self.proj.weight, self.proj.bias)
+        elif self._ert.params_changed(self.proj.weight, self.proj.bias):
+            self._ert.bind_params(self.proj.weight, self.proj.bias)
+        self._ert.pack()
+        x0 = _EmbedFunction.apply(x.contiguous().float(), self, self.proj.weight, self.proj.bias)
+        return self._run_tower(x0)

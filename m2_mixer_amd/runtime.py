@@ -1,0 +1,263 @@
+"""Host-side state of the HIP towers: descriptor structs, packed weight copies, saved-activation
+buffers and the launches.  Pure plumbing -- every FLOP of the hot path is in libm2mixer.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+# block parameter order used everywhere on the host side; values are the reference's state-dict keys
+# relative to a MixerBlock
+BLOCK_KEYS = {
+    "ln1_w": "token_mix.0.weight", "ln1_b": "token_mix.0.bias",
+    "tok_w1": "token_mix.2.net.0.weight", "tok_b1": "token_mix.2.net.0.bias",
+    "tok_w2": "token_mix.2.net.3.weight", "tok_b2": "token_mix.2.net.3.bias",
+    "ln2_w": "channel_mix.0.weight", "ln2_b": "channel_mix.0.bias",
+    "ch_w1": "channel_mix.1.net.0.weight", "ch_b1": "channel_mix.1.net.0.bias",
+    "ch_w2": "channel_mix.1.net.3.weight", "ch_b2": "channel_mix.1.net.3.bias",
+}
+BLOCK_FIELDS = list(BLOCK_KEYS.keys())
+
+
+def block_param_shapes(D: int, N: int, T: int, Cc: int) -> Dict[str, tuple]:
+    return {"ln1_w": (D,), "ln1_b": (D,), "tok_w1": (T, N), "tok_b1": (T,), "tok_w2": (N, T), "tok_b2": (N,),
+            "ln2_w": (D,), "ln2_b": (D,), "ch_w1": (Cc, D), "ch_b1": (Cc,), "ch_w2": (D, Cc), "ch_b2": (D,)}
+
+
+def _check_tensor(t: torch.Tensor, shape, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: m2_mixer_amd runs on the GPU only (got a {t.device} tensor); "
+                           "there is no CPU path -- the CPU restatement under oracle/ is test infrastructure")
+    if t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != tuple(shape):
+        raise RuntimeError(f"{name}: expected contiguous float32 {tuple(shape)}, got {t.dtype} {tuple(t.shape)}")
+
+
+class TowerRuntime:
+    """One m2m_tower: `nblocks` MixerBlocks (+ final LayerNorm) over (B, N, D) tokens."""
+
+    def __init__(self, D: int, N: int, T: int, Cc: int, nblocks: int, has_final_ln: bool, p_drop: float,
+                 prec: int, site_base: int = 0):
+        if nblocks > L.MAX_BLOCKS:
+            raise RuntimeError(f"a tower holds at most {L.MAX_BLOCKS} blocks; chain towers for more")
+        self.D, self.N, self.T, self.C, self.nblocks = D, N, T, Cc, nblocks
+        self.Cp = (Cc + 31) // 32 * 32
+        self.prec = prec
+        self.has_final_ln = bool(has_final_ln)
+        self.desc = L.Tower()
+        d = self.desc
+        d.prec, d.D, d.N, d.T, d.C, d.Cp = prec, D, N, T, Cc, self.Cp
+        d.nblocks, d.has_final_ln = nblocks, int(self.has_final_ln)
+        d.p_drop = float(p_drop)
+        d.site_base = site_base
+        self._keep: Dict[str, object] = {}      # keeps every tensor whose pointer sits in the descriptor alive
+        self._param_ptrs: List[int] = []
+        self._param_versions: List[int] = []
+        self._packed_for: Optional[List[int]] = None
+        self._bufB = 0
+        self.device = None
+
+    # ---- parameters --------------------------------------------------------------------------------
+    def bind_params(self, blocks: Sequence[Dict[str, torch.Tensor]], lnf: Optional[Sequence[torch.Tensor]]):
+        """blocks[i][field] for field in BLOCK_FIELDS; lnf = (weight, bias) of the final LayerNorm."""
+        shapes = block_param_shapes(self.D, self.N, self.T, self.C)
+        ptrs, vers = [], []
+        for i, bp in enumerate(blocks):
+            for f in BLOCK_FIELDS:
+                t = bp[f]
+                _check_tensor(t, shapes[f], f"block {i} {BLOCK_KEYS[f]}")
+                setattr(self.desc.blk[i], f, t.data_ptr())
+                ptrs.append(t.data_ptr())
+                vers.append(t._version)
+            self._keep[f"params{i}"] = dict(bp)
+        if self.has_final_ln:
+            for t, f in zip(lnf, ("lnf_w", "lnf_b")):
+                _check_tensor(t, (self.D,), f"layer_norm {f}")
+                setattr(self.desc, f, t.data_ptr())
+                ptrs.append(t.data_ptr())
+                vers.append(t._version)
+            self._keep["lnf"] = tuple(lnf)
+        self.device = blocks[0]["ln1_w"].device if blocks else lnf[0].device
+        self._param_ptrs, self._param_versions = ptrs, vers
+        self._ensure_packed_buffers()
+
+    def params_changed(self, blocks, lnf) -> bool:
+        """True when any parameter storage moved (rebind needed)."""
+        ptrs = [bp[f].data_ptr() for bp in blocks for f in BLOCK_FIELDS]
+        if self.has_final_ln:
+            ptrs += [lnf[0].data_ptr(), lnf[1].data_ptr()]
+        return ptrs != self._param_ptrs
+
+    def _ensure_packed_buffers(self):
+        if "packed0" in self._keep or self.nblocks == 0:
+            return
+        nb = L.packed_bytes(self.prec, self.Cp, self.D)
+        for i in range(self.nblocks):
+            bufs = {k: torch.zeros(nb, dtype=torch.uint8, device=self.device) for k in ("w1n", "w2c", "w2tn", "w1tc")}
+            bufs["ch_b1p"] = torch.zeros(self.Cp, dtype=torch.float32, device=self.device)
+            for k, v in bufs.items():
+                setattr(self.desc.blk[i], k, v.data_ptr())
+            self._keep[f"packed{i}"] = bufs
+
+    def pack(self, force: bool = False):
+        """Refresh the packed MFMA-operand copies when the master weights changed."""
+        cur = []
+        for i in range(self.nblocks):
+            bp = self._keep[f"params{i}"]
+            cur += [bp["ch_w1"]._version, bp["ch_w2"]._version, bp["ch_b1"]._version]
+        if force or cur != self._packed_for:
+            L.check(L.lib().m2m_pack_tower(C.byref(self.desc), L.stream_ptr()), "pack_tower")
+            self._packed_for = cur
+
+    # ---- activations saved for backward ---------------------------------------------------------------
+    def ensure_buffers(self, B: int):
+        if B <= self._bufB:
+            return
+        spw = L.ROWS_PER_WG // self.N
+        ntiles = (B + spw - 1) // spw
+        esz = 2 if self.prec == L.PREC_BF16 else 4
+        img = ntiles * L.ROWS_PER_WG * self.D * esz
+        M = B * self.N
+        for i in range(self.nblocks):
+            bufs = {"x_in": torch.empty(M, self.D, device=self.device), "x_mid": torch.empty(M, self.D, device=self.device)}
+            for k in ("a_nat", "at_chn", "dy_nat", "dyt_chn"):
+                bufs[k] = torch.zeros(img, dtype=torch.uint8, device=self.device)
+            for k, v in bufs.items():
+                setattr(self.desc.blk[i], k, v.data_ptr())
+            self._keep[f"saved{i}"] = bufs
+        xf = torch.empty(M, self.D, device=self.device)
+        self.desc.x_final = xf.data_ptr()
+        self._keep["x_final"] = xf
+        self._bufB = B
+
+    # ---- gradients -----------------------------------------------------------------------------------
+    def grad_numel(self) -> int:
+        shapes = block_param_shapes(self.D, self.N, self.T, self.C)
+        n = sum(int(torch.Size(s).numel()) for s in shapes.values()) * self.nblocks
+        return n + (2 * self.D if self.has_final_ln else 0)
+
+    def bind_grads(self, flat: torch.Tensor) -> List[torch.Tensor]:
+        """Point every g_* at a slice of `flat` (fp32, >= grad_numel()); returns the views in
+        bind_params order (blocks' BLOCK_FIELDS, then lnf weight, bias)."""
+        shapes = block_param_shapes(self.D, self.N, self.T, self.C)
+        views, off = [], 0
+        for i in range(self.nblocks):
+            for f in BLOCK_FIELDS:
+                n = int(torch.Size(shapes[f]).numel())
+                v = flat[off:off + n].view(shapes[f])
+                setattr(self.desc.blk[i], "g_" + f, v.data_ptr())
+                views.append(v)
+                off += n
+        if self.has_final_ln:
+            for f in ("g_lnf_w", "g_lnf_b"):
+                v = flat[off:off + self.D]
+                setattr(self.desc, f, v.data_ptr())
+                views.append(v)
+                off += self.D
+        self._keep["grads"] = flat
+        return views
+
+    def bind_grad_tensors(self, blocks_g: Sequence[Dict[str, torch.Tensor]], lnf_g):
+        for i, bg in enumerate(blocks_g):
+            for f in BLOCK_FIELDS:
+                setattr(self.desc.blk[i], "g_" + f, bg[f].data_ptr())
+        if self.has_final_ln:
+            self.desc.g_lnf_w, self.desc.g_lnf_b = lnf_g[0].data_ptr(), lnf_g[1].data_ptr()
+        self._keep["grads"] = (blocks_g, lnf_g)
+
+    # ---- launches --------------------------------------------------------------------------------------
+    def forward(self, x0: torch.Tensor, x0_ss: int, B: int, out: torch.Tensor, out_ss: int,
+                pooled: Optional[torch.Tensor], training: bool, seed: int, step: int):
+        if training:
+            self.ensure_buffers(B)
+        L.check(L.lib().m2m_tower_forward(C.byref(self.desc), x0.data_ptr(), x0_ss, B, out.data_ptr(), out_ss,
+                                          L.ptr(pooled), int(training), seed & 0xFFFFFFFF, step & 0xFFFFFFFF,
+                                          L.stream_ptr()), "tower_forward")
+
+    def backward(self, B: int, d_out: Optional[torch.Tensor], d_out_ss: int, d_pooled: Optional[torch.Tensor],
+                 d_x0: torch.Tensor, d_x0_ss: int, seed: int, step: int):
+        L.check(L.lib().m2m_tower_backward(C.byref(self.desc), B, L.ptr(d_out), d_out_ss, L.ptr(d_pooled),
+                                           d_x0.data_ptr(), d_x0_ss, seed & 0xFFFFFFFF, step & 0xFFFFFFFF,
+                                           L.stream_ptr()), "tower_backward")
+
+    def wgrad(self, B: int, seed: int, step: int):
+        L.check(L.lib().m2m_tower_wgrad(C.byref(self.desc), B, seed & 0xFFFFFFFF, step & 0xFFFFFFFF, L.stream_ptr()),
+                "tower_wgrad")
+
+    def dropout_mask(self, blk: int, site: int, B: int, seed: int, step: int) -> torch.Tensor:
+        """Keep-mask (uint8) of one dropout site in the kernels' index order (test hook)."""
+        n = {0: B * self.D * self.T, 1: B * self.D * self.N, 2: B * self.N * self.Cp, 3: B * self.N * self.D}[site]
+        m = torch.empty(n, dtype=torch.uint8, device=self.device)
+        L.check(L.lib().m2m_dropout_mask(C.byref(self.desc), blk, site, B, seed & 0xFFFFFFFF, step & 0xFFFFFFFF,
+                                         m.data_ptr(), L.stream_ptr()), "dropout_mask")
+        return m
+
+
+class EmbedRuntime:
+    """m2m_embed: Conv2d(Cin, D, (ph, pw), stride=(ph, pw)) + rearrange, or Linear(K, D) on (B, N, K) rows."""
+
+    def __init__(self, Cin: int, H: int, W: int, ph: int, pw: int, D: int, prec: int):
+        self.desc = L.Embed()
+        d = self.desc
+        kb = 32 if prec == L.PREC_BF16 else 16
+        K = Cin * ph * pw
+        d.prec, d.Cin, d.H, d.W, d.ph, d.pw, d.D, d.K = prec, Cin, H, W, ph, pw, D, K
+        d.Kp = (K + kb - 1) // kb * kb
+        self.N = (H // ph) * (W // pw)
+        self.D, self.K, self.prec = D, K, prec
+        self._keep = {}
+        self._packed_for = None
+
+    def bind_params(self, w: torch.Tensor, b: torch.Tensor):
+        if not w.is_cuda:
+            raise RuntimeError("patch embedding: m2_mixer_amd runs on the GPU only; there is no CPU path")
+        if w.dtype != torch.float32 or not w.is_contiguous() or w.numel() != self.D * self.K:
+            raise RuntimeError(f"embedding weight: expected contiguous float32 with {self.D * self.K} elements")
+        self.desc.w, self.desc.b = w.data_ptr(), b.data_ptr()
+        self._keep["w"], self._keep["b"] = w, b
+        if "wn" not in self._keep:
+            wn = torch.zeros(L.packed_bytes(self.prec, self.D, self.desc.Kp), dtype=torch.uint8, device=w.device)
+            self.desc.wn = wn.data_ptr()
+            self._keep["wn"] = wn
+
+    def params_changed(self, w, b) -> bool:
+        return w.data_ptr() != self.desc.w or b.data_ptr() != self.desc.b
+
+    def pack(self, force: bool = False):
+        v = self._keep["w"]._version
+        if force or v != self._packed_for:
+            L.check(L.lib().m2m_pack_embed(C.byref(self.desc), L.stream_ptr()), "pack_embed")
+            self._packed_for = v
+
+    def bind_grads(self, g_w: torch.Tensor, g_b: torch.Tensor):
+        self.desc.g_w, self.desc.g_b = g_w.data_ptr(), g_b.data_ptr()
+        self._keep["g"] = (g_w, g_b)
+
+    def forward(self, inp: torch.Tensor, B: int, x0: torch.Tensor):
+        L.check(L.lib().m2m_embed_forward(C.byref(self.desc), inp.data_ptr(), B, x0.data_ptr(), L.stream_ptr()),
+                "embed_forward")
+
+    def wgrad(self, inp: torch.Tensor, d_x0: torch.Tensor, B: int):
+        L.check(L.lib().m2m_embed_wgrad(C.byref(self.desc), inp.data_ptr(), d_x0.data_ptr(), B, L.stream_ptr()),
+                "embed_wgrad")
+
+
+def heads_ce(heads: Sequence[dict], labels: torch.Tensor, B: int, D: int, K: int):
+    """heads: dicts with pooled, w, b, g_w, g_b, d_pooled (tensors or None) and weight.
+    Returns logits (nh, B, K), losses (nh + 1), preds (nh, B) int32."""
+    nh = len(heads)
+    arr = (L.Head * nh)()
+    for i, h in enumerate(heads):
+        arr[i].pooled, arr[i].w, arr[i].b = h["pooled"].data_ptr(), h["w"].data_ptr(), h["b"].data_ptr()
+        arr[i].g_w, arr[i].g_b, arr[i].d_pooled = L.ptr(h.get("g_w")), L.ptr(h.get("g_b")), L.ptr(h.get("d_pooled"))
+        arr[i].weight = float(h["weight"])
+    dev = labels.device
+    logits = torch.empty(nh, B, K, device=dev)
+    losses = torch.empty(nh + 1, device=dev)
+    preds = torch.empty(nh, B, dtype=torch.int32, device=dev)
+    L.check(L.lib().m2m_heads_ce(arr, nh, labels.data_ptr(), B, D, K, logits.data_ptr(), losses.data_ptr(),
+                                 preds.data_ptr(), L.stream_ptr()), "heads_ce")
+    return logits, losses, preds
