@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""Headline benchmark: AV-MNIST M2-Mixer-B training samples/s (fwd + bwd + Adam), bf16, per-GPU batch 512.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement): metric/value/unit/..., plus
+  "roofline"     dominant kernel: algorithmic FLOPs per launch / its mean duration (HIP events on the launch
+                 stream) against the dense bf16 MFMA peak,
+  "cpu_baseline" the CPU oracle's training step timed on this box's host cores (rank 0, N = 1 only).
+Synthetic data of the dataset's shape (image U[0,1) (B,1,28,28), audio U[0,1) (B,1,112,112), labels randint(10),
+numpy default_rng(1234 + rank)), torch-default random init under seed 42.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense peaks, MI355X_MICROARCH.md "Chip-level parameters"
+
+# AV-MNIST M2-Mixer-B  (reference cfg/avmnist/avmnist_m2-mixer_B.yml:24-56)
+CFG_B = dict(dropout=0.5, num_classes=10,
+             image=dict(in_channels=1, hidden_dim=128, patch_size=14, image_size=[28, 28], token_dim=32, channel_dim=3072, num_mixers=4),
+             audio=dict(in_channels=1, hidden_dim=128, patch_size=56, image_size=[112, 112], token_dim=32, channel_dim=3072, num_mixers=4),
+             multimodal=dict(hidden_dim=128, token_dim=32, channel_dim=3078, num_mixers=2))
+CFG_S = dict(dropout=0.1, num_classes=10,
+             image=dict(in_channels=1, hidden_dim=32, patch_size=14, image_size=[28, 28], token_dim=16, channel_dim=256, num_mixers=2),
+             audio=dict(in_channels=1, hidden_dim=32, patch_size=56, image_size=[112, 112], token_dim=16, channel_dim=256, num_mixers=2),
+             multimodal=dict(hidden_dim=32, token_dim=16, channel_dim=256, num_mixers=1))
+
+
+def n_patch(c):
+    return (c["image_size"][0] // c["patch_size"]) * (c["image_size"][1] // c["patch_size"])
+
+
+def algorithmic_flops(cfg, B):
+    """2*MACs of every Linear/Conv: forward, dgrad, wgrad (no recompute, no elementwise) -- SURVEY.md section 8d.
+    Returns per-launch-kind forward FLOPs; dgrad == wgrad == forward for every GEMM."""
+    out = {}
+    for name, c, N in (("image", cfg["image"], n_patch(cfg["image"])), ("audio", cfg["audio"], n_patch(cfg["audio"])),
+                       ("fusion", cfg["multimodal"], n_patch(cfg["image"]) + n_patch(cfg["audio"]))):
+        D, T, C, nb = c["hidden_dim"], c["token_dim"], c["channel_dim"], c["num_mixers"]
+        M = B * N
+        chan = 2 * 2 * M * D * C * nb
+        tok = 2 * 2 * B * D * N * T * nb
+        out[name] = {"channel": chan, "token": tok}
+        if "patch_size" in c:
+            out[name]["embed"] = 2 * M * D * c["in_channels"] * c["patch_size"] ** 2
+    K = cfg["num_classes"]
+    out["heads"] = 3 * 2 * B * K * cfg["image"]["hidden_dim"]
+    return out
+
+
+def total_train_flops(cfg, B):
+    a = algorithmic_flops(cfg, B)
+    fwd = sum(sum(v.values()) for k, v in a.items() if k != "heads") + a["heads"]
+    # input gradients of the two patch embeddings are not needed (dgrad of embed skipped): fwd + dgrad + wgrad
+    emb = sum(v.get("embed", 0) for k, v in a.items() if k != "heads")
+    return 3 * fwd - emb
+
+
+def make_batch(cfg, B, seed, device):
+    rng = np.random.default_rng(seed)
+    ih, iw = cfg["image"]["image_size"]
+    ah, aw = cfg["audio"]["image_size"]
+    image = torch.from_numpy(rng.random((B, 1, ih, iw), dtype=np.float32)).to(device)
+    audio = torch.from_numpy(rng.random((B, 1, ah, aw), dtype=np.float32)).to(device)
+    labels = torch.from_numpy(rng.integers(0, cfg["num_classes"], size=(B,), dtype=np.int64)).to(device)
+    return image, audio, labels
+
+
+def cpu_baseline(cfg, B, budget_s=20.0):
+    """The CPU oracle's training step (fwd + autograd bwd + Adam, dropout masks drawn like nn.Dropout) on all
+    host cores; bounded to ~budget_s of wall-clock."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import gen_util as G
+    from oracle import m2mixer_oracle as O
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    shapes = G.avmnist_shapes(cfg)
+    params = dict(G.make_params(shapes, 42))
+    image, audio, labels = (t.cpu() for t in make_batch(cfg, B, 1234, "cpu"))
+    state, gen = {}, torch.Generator().manual_seed(0)
+    p = cfg["dropout"]
+
+    def step():
+        masks = O.avmnist_random_masks(cfg, B, p, gen) if p > 0 else None
+        O.avmnist_train_step(image, audio, labels, params, cfg, state, lr=1e-2, drop_p=p, masks=masks)
+
+    t0 = time.perf_counter()
+    step()                                    # warm-up (allocator, thread pool)
+    warm = time.perf_counter() - t0
+    n = max(2, min(50, int(budget_s / max(warm, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    dt = time.perf_counter() - t0
+    return {"value": round(B * n / dt, 2), "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"{n} training steps of the fp32 CPU oracle (oracle/m2mixer_oracle.py), batch {B}, "
+                      f"{dt / n * 1e3:.0f} ms/step, torch {torch.__version__} CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=512, help="per-GPU batch (cfg batch_size is per process)")
+    ap.add_argument("--model", default="B", choices=["B", "S"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--grad-compress", default=None, choices=[None, "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--profile-steps", type=int, default=10, help="eager steps with HIP events around every launch")
+    args = ap.parse_args()
+
+    from m2_mixer_amd import parallel
+    from m2_mixer_amd.engine import AVMnistEngine
+
+    rank, local_rank, world = parallel.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    cfg = CFG_B if args.model == "B" else CFG_S
+    B = args.batch
+
+    eng = AVMnistEngine(cfg, B, device=dev, precision=args.precision, lr=1e-2, seed=42)
+    parallel.broadcast_parameters(eng.flat_p)
+    eng.pack()
+    image, audio, labels = make_batch(cfg, B, parallel.shard_batch_seed(1234, rank), dev)
+    sync = parallel.GradSync(compress=args.grad_compress) if world > 1 else None
+
+    if args.no_graph:
+        def step():
+            eng.train_step(image, audio, labels, sync)
+    else:
+        replay = eng.capture(image, audio, labels, sync)
+
+        def step():
+            replay()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    loss_end = float(eng.losses[3])
+
+    # ---- per-launch timing (HIP events on the launch stream), eager pass of the very same step ----
+    kern = profile_launches(eng, image, audio, labels, args.profile_steps) if rank == 0 else None
+
+    if rank != 0:
+        return
+    ms = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+    flops_step = total_train_flops(cfg, B)
+    peak = MFMA_PEAK_TFLOPS[args.precision]
+    dom = max(kern.items(), key=lambda kv: kv[1]["us_per_step"])
+    roof = {"bound": "mfma", "kernel": dom[0], "achieved": round(dom[1]["flops_per_launch"] / (dom[1]["us_per_launch"] * 1e-6) / 1e12, 2),
+            "peak": peak, "unit": "TFLOP/s", "traffic": None}
+    roof["frac"] = round(roof["achieved"] / peak, 4)
+    out = {
+        "metric": "training samples/sec AV-MNIST M2-Mixer-%s %s" % (args.model, args.precision),
+        "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": f"AV-MNIST M2-Mixer-{args.model}: fwd + bwd + Adam, dropout {cfg['dropout']}, per-GPU batch {B}, "
+                               f"global batch {B * world}, {eng.n_params} params",
+                   "parallelism": f"dp{world}", "launch": "eager" if args.no_graph else "hipGraph"},
+        "roofline": roof,
+        "step_mfma_frac": round(world * B * args.steps / elapsed / world * flops_step / B / (peak * 1e12), 4),
+        "algorithmic_gflop_per_step": round(flops_step / 1e9, 2),
+        "kernels_us": {k: round(v["us_per_step"], 1) for k, v in kern.items()},
+        "final_loss": round(loss_end, 4),
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, B, args.cpu_budget)
+    print(json.dumps(out), flush=True)
+
+
+def profile_launches(eng, image, audio, labels, nsteps):
+    """Mean duration of every launch of the training step, measured with events recorded on the stream the
+    launches go to (torch's current stream == the stream handed to libm2mixer)."""
+    import types
+    cfg, B = eng.cfg, eng.B
+    alg = algorithmic_flops(cfg, B)
+    spans = {}
+
+    def timed(name, fn, flops):
+        def wrapper(*a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **kw)
+            e1.record()
+            spans.setdefault(name, {"events": [], "flops": flops})["events"].append((e0, e1))
+            return r
+        return wrapper
+
+    saved = []
+
+    def patch(obj, attr, name, flops):
+        orig = getattr(obj, attr)
+        saved.append((obj, attr, orig))
+        setattr(obj, attr, timed(name, orig, flops))
+
+    for tname, rt in (("image", eng.t_img), ("audio", eng.t_aud), ("fusion", eng.t_fus)):
+        f = alg[tname]
+        patch(rt, "forward", f"tower_fwd[{tname}]", f["channel"] + f["token"])
+        patch(rt, "backward", f"tower_bwd[{tname}]", f["channel"] + f["token"] * 2)   # dgrad of both MLPs + token wgrad
+        patch(rt, "wgrad", f"tower_wgrad[{tname}]", f["channel"])
+        patch(rt, "pack", f"pack[{tname}]", 0)
+    for tname, e in (("image", eng.e_img), ("audio", eng.e_aud)):
+        patch(e, "forward", f"embed_fwd[{tname}]", alg[tname]["embed"])
+        patch(e, "wgrad", f"embed_wgrad[{tname}]", alg[tname]["embed"])
+    import m2_mixer_amd.engine as E
+    orig_heads = E.heads_ce
+    E.heads_ce = timed("heads_ce", orig_heads, alg["heads"] * 3)
+    try:
+        for _ in range(nsteps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            eng.flat_g.zero_()
+            e1.record()
+            spans.setdefault("zero_grad", {"events": [], "flops": 0})["events"].append((e0, e1))
+            eng._forward(image, audio, labels, True, True)
+            eng._backward(image, audio)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            from m2_mixer_amd import _lib as L
+            L.check(L.lib().m2m_adam_step(eng.flat_p.data_ptr(), eng.flat_g.data_ptr(), eng.flat_m.data_ptr(),
+                                          eng.flat_v.data_ptr(), eng.n_params, eng.adam_state.data_ptr(), eng.betas[0],
+                                          eng.betas[1], eng.eps, eng.weight_decay, 1.0, L.stream_ptr()))
+            e1.record()
+            spans.setdefault("adam", {"events": [], "flops": 0})["events"].append((e0, e1))
+            L.check(L.lib().m2m_counter_add(eng.drop_step.data_ptr(), 1, L.stream_ptr()))
+            eng.pack()
+        torch.cuda.synchronize()
+    finally:
+        for obj, attr, orig in saved:
+            setattr(obj, attr, orig)
+        E.heads_ce = orig_heads
+    out = {}
+    for name, sp in spans.items():
+        times = [a.elapsed_time(b) * 1e3 for a, b in sp["events"]]      # us
+        times = times[len(times) // 5:]                                   # drop the first fifth
+        per_launch = float(np.mean(times))
+        launches_per_step = len(sp["events"]) / nsteps
+        out[name] = {"us_per_launch": per_launch, "us_per_step": per_launch * launches_per_step, "flops_per_launch": sp["flops"]}
+    return out
+
+
+if __name__ == "__main__":
+    main()

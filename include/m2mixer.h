@@ -122,10 +122,13 @@ int m2m_embed_forward(const m2m_embed* e, const float* input, int B, float* x0, 
  *                           which is ConcatFusion(dim=1), modules/fusion.py:116-117)
  *   pooled (B, D) or NULL : mean over tokens of the output (x.mean(dim=1), models/avmnist.py:271-272,
  *                           modules/classification.py:89-90)
- *   training              : 1 -> dropout active (seed/step select the masks) and activations saved */
+ *   training              : 1 -> dropout active and activations saved
+ *   seed, step, step_dev  : dropout stream = f(seed, step + (step_dev ? *step_dev : 0), site, element); step_dev is a
+ *                           device counter so that a captured hipGraph draws fresh masks on every replay
+ *                           (m2m_counter_add bumps it); backward / wgrad must be given the same values */
 int m2m_tower_forward(const m2m_tower* t, const float* x0, int64_t x0_sample_stride, int B,
                       float* out, int64_t out_sample_stride, float* pooled,
-                      int training, uint32_t seed, uint32_t step, void* stream);
+                      int training, uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream);
 
 /* ---- backward ----------------------------------------------------------------------------------- */
 /* Reverse pass through final LayerNorm + blocks.
@@ -136,9 +139,9 @@ int m2m_tower_forward(const m2m_tower* t, const float* x0, int64_t x0_sample_str
  * m2m_tower_wgrad needs for the channel-mixing weight gradients. */
 int m2m_tower_backward(const m2m_tower* t, int B, const float* d_out, int64_t d_out_sample_stride,
                        const float* d_pooled, float* d_x0, int64_t d_x0_sample_stride,
-                       uint32_t seed, uint32_t step, void* stream);
+                       uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream);
 /* g_ch_w1, g_ch_b1, g_ch_w2 of every block (hidden activations recomputed, never stored). */
-int m2m_tower_wgrad(const m2m_tower* t, int B, uint32_t seed, uint32_t step, void* stream);
+int m2m_tower_wgrad(const m2m_tower* t, int B, uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream);
 /* g_w += d_x0^T patches(input), g_b += column sums of d_x0. */
 int m2m_embed_wgrad(const m2m_embed* e, const float* input, const float* d_x0, int B, void* stream);
 
@@ -166,6 +169,9 @@ int m2m_heads_ce(const m2m_head* heads, int nheads, const int64_t* labels, int B
 int m2m_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   float* state, float beta1, float beta2, float eps, float weight_decay,
                   float grad_scale, void* stream);
+
+/* *counter += delta on the stream (device uint32). */
+int m2m_counter_add(uint32_t* counter, uint32_t delta, void* stream);
 
 /* ---- test hooks ----------------------------------------------------------------------------------- */
 /* keep-mask (uint8, 1 keep) the kernels use for dropout site `site` (0 tok hidden, 1 tok out,

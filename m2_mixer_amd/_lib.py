@@ -68,10 +68,11 @@ SIGNATURES = {
     "m2m_pack_embed": (C.c_int, [C.POINTER(Embed), _fp]),
     "m2m_embed_forward": (C.c_int, [C.POINTER(Embed), _fp, C.c_int, _fp, _fp]),
     "m2m_tower_forward": (C.c_int, [C.POINTER(Tower), _fp, C.c_int64, C.c_int, _fp, C.c_int64, _fp, C.c_int,
-                                    C.c_uint32, C.c_uint32, _fp]),
+                                    C.c_uint32, C.c_uint32, _fp, _fp]),
     "m2m_tower_backward": (C.c_int, [C.POINTER(Tower), C.c_int, _fp, C.c_int64, _fp, _fp, C.c_int64,
-                                     C.c_uint32, C.c_uint32, _fp]),
-    "m2m_tower_wgrad": (C.c_int, [C.POINTER(Tower), C.c_int, C.c_uint32, C.c_uint32, _fp]),
+                                     C.c_uint32, C.c_uint32, _fp, _fp]),
+    "m2m_tower_wgrad": (C.c_int, [C.POINTER(Tower), C.c_int, C.c_uint32, C.c_uint32, _fp, _fp]),
+    "m2m_counter_add": (C.c_int, [_fp, C.c_uint32, _fp]),
     "m2m_embed_wgrad": (C.c_int, [C.POINTER(Embed), _fp, _fp, C.c_int, _fp]),
     "m2m_heads_ce": (C.c_int, [C.POINTER(Head), C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp]),
     "m2m_adam_step": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, _fp, C.c_float, C.c_float, C.c_float, C.c_float,

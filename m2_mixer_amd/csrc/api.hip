@@ -158,6 +158,13 @@ extern "C" int m2m_adam_step(float* param, const float* grad, float* exp_avg, fl
     return 0;
 }
 
+__global__ void counter_add_kernel(unsigned int* c, unsigned int d) { *c += d; }
+extern "C" int m2m_counter_add(uint32_t* counter, uint32_t delta, void* stream) {
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream), counter, delta);
+    M2M_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // probes (tests only)
 // ---------------------------------------------------------------------------------------------------

@@ -91,7 +91,7 @@ template <int P, int D, int NMAX, int TTMAX>
 __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw, int B, const float* __restrict__ d_out,
                                                              long d_out_ss, const float* __restrict__ d_pooled,
                                                              float* __restrict__ d_x0, long d_x0_ss, unsigned int seed,
-                                                             unsigned int step) {
+                                                             unsigned int step_host, const unsigned int* __restrict__ step_dev) {
     typedef Prec<P> Pr;
     typedef TileGeom<D> G;
     constexpr int XLD = G::XLD, DT = G::DT, KD = D / Pr::KB, NF = Chain<P>::NF;
@@ -116,6 +116,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
     const int R = ns * N;
     const long row0 = (long)s0 * N;
     const long tile_off = (long)blockIdx.x * IMG_B;
+    const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
 
     // ---- upstream gradient of the tower output ----
     {
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
 
 template <int P, int D>
 static int launch_bwd(const m2m_tower* t, int B, const float* d_out, long d_out_ss, const float* d_pooled, float* d_x0,
-                      long d_x0_ss, unsigned int seed, unsigned int step, hipStream_t st) {
+                      long d_x0_ss, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
     const int SPW = BM / t->N;
     const int grid = (B + SPW - 1) / SPW;
     const size_t tile_b = (size_t)BM * TileGeom<D>::XLD * sizeof(float), img_b = (size_t)BM * D * Prec<P>::ESZ;
@@ -449,7 +450,7 @@ static int launch_bwd(const m2m_tower* t, int B, const float* d_out, long d_out_
         M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, st, *t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, st, *t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step, step_dev);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -457,11 +458,11 @@ static int launch_bwd(const m2m_tower* t, int B, const float* d_out, long d_out_
 int m2m_check_tower(const m2m_tower* t, int B);
 
 extern "C" int m2m_tower_backward(const m2m_tower* t, int B, const float* d_out, int64_t d_out_ss, const float* d_pooled,
-                                  float* d_x0, int64_t d_x0_ss, uint32_t seed, uint32_t step, void* stream) {
+                                  float* d_x0, int64_t d_x0_ss, uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream) {
     if (int rc = m2m_check_tower(t, B)) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define M2M_BWD_CASE(PP, DD) \
-    if (t->prec == PP && t->D == DD) return launch_bwd<PP, DD>(t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step, st);
+    if (t->prec == PP && t->D == DD) return launch_bwd<PP, DD>(t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step, step_dev, st);
     M2M_BWD_CASE(PREC_BF16, 32) M2M_BWD_CASE(PREC_BF16, 64) M2M_BWD_CASE(PREC_BF16, 128)
     M2M_BWD_CASE(PREC_F32, 32) M2M_BWD_CASE(PREC_F32, 64) M2M_BWD_CASE(PREC_F32, 128)
 #undef M2M_BWD_CASE

@@ -16,7 +16,8 @@ template <int P, int D, int NMAX>
 __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw, const float* __restrict__ x0,
                                                              long x0_ss, int B, float* __restrict__ out, long out_ss,
                                                              float* __restrict__ pooled, int training,
-                                                             unsigned int seed, unsigned int step) {
+                                                             unsigned int seed, unsigned int step_host,
+                                                             const unsigned int* __restrict__ step_dev) {
     typedef Prec<P> Pr;
     typedef TileGeom<D> G;
     constexpr int XLD = G::XLD, DT = G::DT, KD = D / Pr::KB, NF = Chain<P>::NF;
@@ -33,6 +34,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw,
     const int ns = min(SPW, B - s0);
     const int R = ns * N;
     const long row0 = (long)s0 * N;                              // first global token row of this tile
+    const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
 
     // ---- load the input tile (rows >= R are zero) ----
     for (int idx = tid; idx < BM * (D / 4); idx += NTHREADS) {
@@ -226,7 +228,7 @@ static size_t fwd_lds_bytes() {
 
 template <int P, int D>
 static int launch_fwd(const m2m_tower* t, const float* x0, long x0_ss, int B, float* out, long out_ss, float* pooled,
-                      int training, unsigned int seed, unsigned int step, hipStream_t st) {
+                      int training, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
     const int SPW = BM / t->N;
     const int grid = (B + SPW - 1) / SPW;
     const size_t lds = fwd_lds_bytes<P, D>();
@@ -236,7 +238,7 @@ static int launch_fwd(const m2m_tower* t, const float* x0, long x0_ss, int B, fl
         M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, st, *t, x0, x0_ss, B, out, out_ss, pooled, training, seed, step);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, st, *t, x0, x0_ss, B, out, out_ss, pooled, training, seed, step, step_dev);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -244,11 +246,11 @@ static int launch_fwd(const m2m_tower* t, const float* x0, long x0_ss, int B, fl
 int m2m_check_tower(const m2m_tower* t, int B);
 
 extern "C" int m2m_tower_forward(const m2m_tower* t, const float* x0, int64_t x0_ss, int B, float* out, int64_t out_ss,
-                                 float* pooled, int training, uint32_t seed, uint32_t step, void* stream) {
+                                 float* pooled, int training, uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream) {
     if (int rc = m2m_check_tower(t, B)) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define M2M_FWD_CASE(PP, DD) \
-    if (t->prec == PP && t->D == DD) return launch_fwd<PP, DD>(t, x0, x0_ss, B, out, out_ss, pooled, training, seed, step, st);
+    if (t->prec == PP && t->D == DD) return launch_fwd<PP, DD>(t, x0, x0_ss, B, out, out_ss, pooled, training, seed, step, step_dev, st);
     M2M_FWD_CASE(PREC_BF16, 32) M2M_FWD_CASE(PREC_BF16, 64) M2M_FWD_CASE(PREC_BF16, 128)
     M2M_FWD_CASE(PREC_F32, 32) M2M_FWD_CASE(PREC_F32, 64) M2M_FWD_CASE(PREC_F32, 128)
 #undef M2M_FWD_CASE

@@ -13,7 +13,8 @@
 
 template <int P, int D>
 __global__ __launch_bounds__(NTHREADS) void tower_wgrad_kernel(const m2m_tower tw, int ntiles, int tiles_per_group,
-                                                               int rows_per_tile, unsigned int seed, unsigned int step) {
+                                                               int rows_per_tile, unsigned int seed, unsigned int step_host,
+                                                               const unsigned int* __restrict__ step_dev) {
     typedef Prec<P> Pr;
     constexpr int DT = D / 16, KD = D / Pr::KB, NF = Chain<P>::NF;
     constexpr int IMG_B = BM * D * Pr::ESZ;
@@ -30,6 +31,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_wgrad_kernel(const m2m_tower t
     const int Cp = tw.Cp, C = tw.C;
     const int q = blockIdx.x * 4 + wave;             // this wave's pair of 16-column tiles
     const bool active = q < (Cp >> 5);
+    const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
     const unsigned int site = tw.site_base + 4u * blockIdx.y;
     const Drop dr_ch = make_drop(true, tw.p_drop, seed, step, site + 2);
     const bool dropping = dr_ch.thr < 65536u;
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_wgrad_kernel(const m2m_tower t
 }
 
 template <int P, int D>
-static int launch_wgrad(const m2m_tower* t, int B, unsigned int seed, unsigned int step, hipStream_t st) {
+static int launch_wgrad(const m2m_tower* t, int B, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
     const int SPW = BM / t->N;
     const int ntiles = (B + SPW - 1) / SPW;
     const int nsl = ((t->Cp >> 5) + 3) / 4;
@@ -176,18 +178,18 @@ static int launch_wgrad(const m2m_tower* t, int B, unsigned int seed, unsigned i
         M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(nsl, t->nblocks, groups), dim3(NTHREADS), lds, st, *t, ntiles, tpg, SPW * t->N, seed, step);
+    hipLaunchKernelGGL(kern, dim3(nsl, t->nblocks, groups), dim3(NTHREADS), lds, st, *t, ntiles, tpg, SPW * t->N, seed, step, step_dev);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 int m2m_check_tower(const m2m_tower* t, int B);
 
-extern "C" int m2m_tower_wgrad(const m2m_tower* t, int B, uint32_t seed, uint32_t step, void* stream) {
+extern "C" int m2m_tower_wgrad(const m2m_tower* t, int B, uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream) {
     if (int rc = m2m_check_tower(t, B)) return rc;
     if (t->nblocks == 0) return 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define M2M_WG_CASE(PP, DD) if (t->prec == PP && t->D == DD) return launch_wgrad<PP, DD>(t, B, seed, step, st);
+#define M2M_WG_CASE(PP, DD) if (t->prec == PP && t->D == DD) return launch_wgrad<PP, DD>(t, B, seed, step, step_dev, st);
     M2M_WG_CASE(PREC_BF16, 32) M2M_WG_CASE(PREC_BF16, 64) M2M_WG_CASE(PREC_BF16, 128)
     M2M_WG_CASE(PREC_F32, 32) M2M_WG_CASE(PREC_F32, 64) M2M_WG_CASE(PREC_F32, 128)
 #undef M2M_WG_CASE

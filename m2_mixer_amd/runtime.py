@@ -170,22 +170,23 @@ class TowerRuntime:
 
     # ---- launches --------------------------------------------------------------------------------------
     def forward(self, x0: torch.Tensor, x0_ss: int, B: int, out: torch.Tensor, out_ss: int,
-                pooled: Optional[torch.Tensor], training: bool, seed: int, step: int):
+                pooled: Optional[torch.Tensor], training: bool, seed: int, step: int,
+                step_dev: Optional[torch.Tensor] = None):
         if training:
             self.ensure_buffers(B)
         L.check(L.lib().m2m_tower_forward(C.byref(self.desc), x0.data_ptr(), x0_ss, B, out.data_ptr(), out_ss,
                                           L.ptr(pooled), int(training), seed & 0xFFFFFFFF, step & 0xFFFFFFFF,
-                                          L.stream_ptr()), "tower_forward")
+                                          L.ptr(step_dev), L.stream_ptr()), "tower_forward")
 
     def backward(self, B: int, d_out: Optional[torch.Tensor], d_out_ss: int, d_pooled: Optional[torch.Tensor],
-                 d_x0: torch.Tensor, d_x0_ss: int, seed: int, step: int):
+                 d_x0: torch.Tensor, d_x0_ss: int, seed: int, step: int, step_dev: Optional[torch.Tensor] = None):
         L.check(L.lib().m2m_tower_backward(C.byref(self.desc), B, L.ptr(d_out), d_out_ss, L.ptr(d_pooled),
                                            d_x0.data_ptr(), d_x0_ss, seed & 0xFFFFFFFF, step & 0xFFFFFFFF,
-                                           L.stream_ptr()), "tower_backward")
+                                           L.ptr(step_dev), L.stream_ptr()), "tower_backward")
 
-    def wgrad(self, B: int, seed: int, step: int):
-        L.check(L.lib().m2m_tower_wgrad(C.byref(self.desc), B, seed & 0xFFFFFFFF, step & 0xFFFFFFFF, L.stream_ptr()),
-                "tower_wgrad")
+    def wgrad(self, B: int, seed: int, step: int, step_dev: Optional[torch.Tensor] = None):
+        L.check(L.lib().m2m_tower_wgrad(C.byref(self.desc), B, seed & 0xFFFFFFFF, step & 0xFFFFFFFF, L.ptr(step_dev),
+                                        L.stream_ptr()), "tower_wgrad")
 
     def dropout_mask(self, blk: int, site: int, B: int, seed: int, step: int) -> torch.Tensor:
         """Keep-mask (uint8) of one dropout site in the kernels' index order (test hook)."""
@@ -245,9 +246,9 @@ class EmbedRuntime:
                 "embed_wgrad")
 
 
-def heads_ce(heads: Sequence[dict], labels: torch.Tensor, B: int, D: int, K: int):
+def heads_ce(heads: Sequence[dict], labels: torch.Tensor, B: int, D: int, K: int, out=None):
     """heads: dicts with pooled, w, b, g_w, g_b, d_pooled (tensors or None) and weight.
-    Returns logits (nh, B, K), losses (nh + 1), preds (nh, B) int32."""
+    Returns logits (nh, B, K), losses (nh + 1), preds (nh, B) int32 (written into `out` if given)."""
     nh = len(heads)
     arr = (L.Head * nh)()
     for i, h in enumerate(heads):
@@ -255,9 +256,12 @@ def heads_ce(heads: Sequence[dict], labels: torch.Tensor, B: int, D: int, K: int
         arr[i].g_w, arr[i].g_b, arr[i].d_pooled = L.ptr(h.get("g_w")), L.ptr(h.get("g_b")), L.ptr(h.get("d_pooled"))
         arr[i].weight = float(h["weight"])
     dev = labels.device
-    logits = torch.empty(nh, B, K, device=dev)
-    losses = torch.empty(nh + 1, device=dev)
-    preds = torch.empty(nh, B, dtype=torch.int32, device=dev)
+    if out is not None:
+        logits, losses, preds = out
+    else:
+        logits = torch.empty(nh, B, K, device=dev)
+        losses = torch.empty(nh + 1, device=dev)
+        preds = torch.empty(nh, B, dtype=torch.int32, device=dev)
     L.check(L.lib().m2m_heads_ce(arr, nh, labels.data_ptr(), B, D, K, logits.data_ptr(), losses.data_ptr(),
                                  preds.data_ptr(), L.stream_ptr()), "heads_ce")
     return logits, losses, preds

@@ -311,3 +311,20 @@ def avmnist_train_step(image, audio, labels, params: Params, cfg: dict, opt_stat
     out = {k: (v.detach() if isinstance(v, Tensor) else v) for k, v in out.items()}
     out["grads"] = grads
     return out
+
+
+def avmnist_random_masks(cfg: dict, B: int, p: float, generator: Optional[torch.Generator] = None) -> dict:
+    """Bernoulli keep-masks for every dropout site of the three towers (what nn.Dropout draws in the
+    reference's train mode); used by the cpu_baseline leg so that the CPU step does the same work."""
+    def n_patch(c):
+        return (c["image_size"][0] // c["patch_size"]) * (c["image_size"][1] // c["patch_size"])
+
+    def tower(c, N):
+        D, T, C = c["hidden_dim"], c["token_dim"], c["channel_dim"]
+        f = lambda *s: (torch.rand(*s, generator=generator) >= p).float()
+        return [{"tok_h": f(B, D, T), "tok_o": f(B, D, N), "ch_h": f(B, N, C), "ch_o": f(B, N, D)}
+                for _ in range(c["num_mixers"])]
+
+    ni, na = n_patch(cfg["image"]), n_patch(cfg["audio"])
+    return {"image": tower(cfg["image"], ni), "audio": tower(cfg["audio"], na),
+            "fusion": tower(cfg["multimodal"], ni + na)}

@@ -233,11 +233,55 @@ def t_heads_adam():
     print("  adam 3 steps err", rel(pd, pt.detach()))
 
 
+def t_engine():
+    section("AVMnistEngine (fused step) vs oracle train steps")
+    from m2_mixer_amd.engine import AVMnistEngine
+    for size, B, precs in (("S", 8, ("fp32", "bf16")), ("B", 8, ("fp32", "bf16"))):
+        cfg = dict(G.AVMNIST[size])
+        cfg0 = dict(cfg, dropout=0.0)
+        shapes = G.avmnist_shapes(cfg)
+        image, audio, labels = G.avmnist_batch(B, 12, cfg)
+        for prec in precs:
+            params = dict(G.make_params(shapes, 11))
+            eng = AVMnistEngine(cfg0, B, precision=prec, lr=1e-2, init=False)
+            assert list(eng.shapes.keys()) == list(shapes.keys())
+            eng.load_state_dict(params)
+            state = {}
+            di, da, dl = image.to(dev), audio.to(dev), labels.to(dev)
+            for step in range(2):
+                ro = O.avmnist_train_step(image, audio, labels, params, cfg, state, lr=1e-2)
+                eng.train_step(di, da, dl)
+                torch.cuda.synchronize()
+                print(f"  {size} {prec} step{step}: loss {float(eng.losses[3]):.6f} vs {float(ro['loss']):.6f}  "
+                      f"logits {rel(eng.logits[2], ro['logits'])} img {rel(eng.logits[0], ro['image_logits'])} "
+                      f"preds eq {bool((eng.preds[2].cpu() == ro['preds']).all())}")
+                if step == 0:
+                    worst = sorted(((rel(eng.grads[k], g)[0] / (float(g.abs().max()) + 1e-9), k, rel(eng.grads[k], g)) for k, g in ro["grads"].items()
+                                    if not k.endswith("token_mix.2.net.3.bias")), reverse=True)[:5]
+                    for w in worst:
+                        print(f"      grad {w[1]:55s} err {w[2][0]:.3e} ref max {w[2][1]:.3e}")
+            worst = sorted(((rel(eng.params[k], v)[0], k) for k, v in params.items() if not k.endswith("token_mix.2.net.3.bias")), reverse=True)[:3]
+            print("      params after 2 steps, worst abs err:", [(round(a, 6), k) for a, k in worst])
+    # graph capture + dropout: losses must change between replays (fresh masks) and stay finite
+    cfg = dict(G.AVMNIST["B"])
+    B = 64
+    eng = AVMnistEngine(cfg, B, precision="bf16", lr=1e-3)
+    image, audio, labels = (t.to(dev) for t in G.avmnist_batch(B, 5, cfg))
+    replay = eng.capture(image, audio, labels)
+    ls = []
+    for i in range(6):
+        replay()
+        torch.cuda.synchronize()
+        ls.append([round(float(v), 4) for v in eng.losses])
+    print("  graph replays (B, bf16, dropout 0.5) losses:", ls)
+    print("  adam step counter", float(eng.adam_state[0]), "dropout counter", int(eng.drop_step[0]))
+
+
 if __name__ == "__main__":
     print(torch.cuda.get_device_name(0), torch.__version__)
     t0 = time.time()
     which = sys.argv[1:] or ["gemm", "gelu", "blocks", "dropout", "avmnist", "heads"]
-    table = dict(gemm=t_gemm, gelu=t_gelu, blocks=t_blocks, dropout=t_dropout, avmnist=t_avmnist, heads=t_heads_adam)
+    table = dict(engine=t_engine, gemm=t_gemm, gelu=t_gelu, blocks=t_blocks, dropout=t_dropout, avmnist=t_avmnist, heads=t_heads_adam)
     for w in which:
         run(table[w])
     print("elapsed %.1fs" % (time.time() - t0))
