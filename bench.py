@@ -85,7 +85,12 @@ def cpu_baseline(cfg, B, budget_s=20.0):
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import gen_util as G
     from oracle import m2mixer_oracle as O
-    threads = os.cpu_count() or 1
+    # the GPU box gives one job a 16-core share whatever os.cpu_count() says: oversubscribing it is pathological
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, int(os.environ.get("M2M_CPU_THREADS", "16"))))
     torch.set_num_threads(threads)
     shapes = G.avmnist_shapes(cfg)
     params = dict(G.make_params(shapes, 42))
@@ -100,6 +105,7 @@ def cpu_baseline(cfg, B, budget_s=20.0):
     t0 = time.perf_counter()
     step()                                    # warm-up (allocator, thread pool)
     warm = time.perf_counter() - t0
+    log(f"cpu baseline: {threads} threads, first step {warm:.2f} s")
     n = max(2, min(50, int(budget_s / max(warm, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(n):
@@ -108,6 +114,10 @@ def cpu_baseline(cfg, B, budget_s=20.0):
     return {"value": round(B * n / dt, 2), "unit": "samples/s", "cores": threads, "kind": "port",
             "sample": f"{n} training steps of the fp32 CPU oracle (oracle/m2mixer_oracle.py), batch {B}, "
                       f"{dt / n * 1e3:.0f} ms/step, torch {torch.__version__} CPU"}
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -136,6 +146,7 @@ def main():
     cfg = CFG_B if args.model == "B" else CFG_S
     B = args.batch
 
+    log(f"rank {rank}/{world}: building engine (model {args.model}, batch {B}, {args.precision})")
     eng = AVMnistEngine(cfg, B, device=dev, precision=args.precision, lr=1e-2, seed=42)
     parallel.broadcast_parameters(eng.flat_p)
     eng.pack()
@@ -156,15 +167,18 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    log("warm-up")
     for _ in range(args.warmup):
         step()
     barrier()
+    log(f"timing {args.steps} steps")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
     loss_end = float(eng.losses[3])
+    log(f"timed region {elapsed * 1e3:.1f} ms; profiling launches")
 
     # ---- per-launch timing (HIP events on the launch stream), eager pass of the very same step ----
     kern = profile_launches(eng, image, audio, labels, args.profile_steps) if rank == 0 else None
@@ -194,6 +208,7 @@ def main():
         "final_loss": round(loss_end, 4),
     }
     if world == 1 and not args.no_cpu_baseline:
+        log("cpu baseline (oracle) ...")
         out["cpu_baseline"] = cpu_baseline(cfg, B, args.cpu_budget)
     print(json.dumps(out), flush=True)
 
