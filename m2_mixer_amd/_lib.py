@@ -14,12 +14,12 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libm2mixer.so")
+LIB_PATH = os.environ.get("M2M_LIB_PATH", os.path.join(_HERE, "libm2mixer.so"))   # override: diagnostic builds
 CSRC = os.path.join(_HERE, "csrc")
 
 ABI_VERSION = 1
 MAX_BLOCKS = 8
-ROWS_PER_WG = 64
+ROWS_PER_WG = 32
 PREC_BF16, PREC_F32 = 0, 1
 PREC_BY_NAME = {"bf16": PREC_BF16, "fp32": PREC_F32, "f32": PREC_F32}
 

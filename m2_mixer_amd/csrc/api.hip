@@ -184,11 +184,18 @@ extern "C" int m2m_gelu_probe(const float* x, float* y, float* dy, int64_t n, vo
     return 0;
 }
 
-__global__ void dropout_mask_kernel(unsigned int key, unsigned int thr, long n, uint8_t* mask) {
+// Mirrors the kernels' mask functions.  mode 0: generic 16-bit draw per element index;
+// mode 1 (token sites at p == 0.5): one word per row (row = sample*D + channel), bit = column;
+// mode 2 (channel-hidden site): drop_keep_mc on (row, column).
+__global__ void dropout_mask_kernel(unsigned int key, unsigned int thr, long n, unsigned int cols, int mode, uint8_t* mask) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         Drop d; d.key = key; d.thr = thr; d.scale = 1.f;
-        mask[i] = drop_keep(d, (unsigned int)i) ? 1 : 0;
+        bool k;
+        if (mode == 1) k = (mix32(key ^ (unsigned int)(i / cols)) >> (unsigned int)(i % cols)) & 1u;
+        else if (mode == 2) k = drop_keep_mc(d, (unsigned int)(i / cols), (unsigned int)(i % cols), cols);
+        else k = drop_keep(d, (unsigned int)i);
+        mask[i] = k ? 1 : 0;
     }
 }
 extern "C" int m2m_dropout_mask(const m2m_tower* t, int blk, int site, int B, uint32_t seed, uint32_t step, uint8_t* mask, void* stream) {
@@ -201,8 +208,14 @@ extern "C" int m2m_dropout_mask(const m2m_tower* t, int blk, int site, int B, ui
     if (site == 2) n = (long)B * t->N * t->Cp;
     if (site == 3) n = (long)B * t->N * t->D;
     const unsigned int key = m2m_site_key(seed, step, t->site_base + 4u * blk + site);
+    const unsigned int thr = m2m_drop_thr(t->p_drop);
+    unsigned int cols = 1;
+    int mode = 0;
+    if (site == 2) { cols = t->Cp; mode = 2; }
+    else if (site == 0 && thr == 32768u) { cols = t->T; mode = 1; }
+    else if (site == 1 && thr == 32768u) { cols = t->N; mode = 1; }
     hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       key, m2m_drop_thr(t->p_drop), n, mask);
+                       key, thr, n, cols, mode, mask);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -173,9 +173,19 @@ static __device__ __forceinline__ void drop_keep4(const Drop& d, unsigned int id
 }
 
 // ---- wave helpers -----------------------------------------------------------------------------------
+// Sum over groups of `width` adjacent lanes (width in {4, 8, 16}: DPP, stays in the VALU; 32, 64: the last
+// steps go through ds_bpermute).  Every lane of a group ends up with the group's sum.
+template <int CTRL>
+static __device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
 static __device__ __forceinline__ float wave_sum_xor(float v, int width) {
-    // butterfly over `width` adjacent lanes (width power of two <= 64)
-    for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += dpp_mov<0xB1>(v);                    // quad_perm [1,0,3,2]   : lane ^ 1
+    v += dpp_mov<0x4E>(v);                    // quad_perm [2,3,0,1]   : lane ^ 2
+    if (width >= 8) v += dpp_mov<0x141>(v);   // row_half_mirror       : pairs the two quads of 8 lanes
+    if (width >= 16) v += dpp_mov<0x140>(v);  // row_mirror            : pairs the two halves of 16 lanes
+    if (width >= 32) v += __shfl_xor(v, 16, 64);
+    if (width >= 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
 
@@ -186,3 +196,30 @@ static __device__ __forceinline__ float wave_sum_xor(float v, int width) {
     } while (0)
 
 void m2m_set_error(const char* msg, const char* file, int line);
+
+// ---- optional phase timers (diagnostic build only: make TIMERS=1 -> libm2mixer_timers.so) -------------
+// Workgroup 0 / thread 0 accumulates the 100 MHz wall clock spent between consecutive marks of a launch.
+#ifdef M2M_TIMERS
+#define TIMER_DECL(sym) static __device__ unsigned long long sym[32]
+#define TIMER_START() unsigned long long _tm_last = __builtin_amdgcn_s_memrealtime()
+#define TIMER_MARK(sym, i)                                                          \
+    do {                                                                            \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) { \
+            const unsigned long long _n = __builtin_amdgcn_s_memrealtime();         \
+            sym[i] += _n - _tm_last;                                                \
+            _tm_last = _n;                                                          \
+        }                                                                           \
+    } while (0)
+#define TIMER_READER(name, sym)                                                     \
+    extern "C" int name(unsigned long long* out, int reset) {                       \
+        unsigned long long z[32] = {0};                                             \
+        if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sym), sizeof(z)) != hipSuccess) return -2; \
+        if (reset && hipMemcpyToSymbol(HIP_SYMBOL(sym), z, sizeof(z)) != hipSuccess) return -2; \
+        return 0;                                                                   \
+    }
+#else
+#define TIMER_DECL(sym)
+#define TIMER_START()
+#define TIMER_MARK(sym, i)
+#define TIMER_READER(name, sym)
+#endif

@@ -4,36 +4,32 @@
 //   x0[m][d] = sum_k patch[m][k] W[d][k] + b[d],   m = b*N + (gy*GW + gx),  k = c*ph*pw + py*pw + px
 //
 // The conv with stride == kernel is an unfold + GEMM; the unfold is done on the fly while staging the
-// input (read once, coalesced along image rows) into LDS, the weight fragments come straight from the
-// packed NAT copy in global memory.
+// input (read once, coalesced along image rows) into LDS -- address = rowbase[m] + koff[k] from two
+// small LDS tables, so no integer division in the streaming loop -- and the weight fragments come
+// straight from the packed NAT copy in global memory.
 #include "tile.h"
 
 #define EMB_KS 128          // k extent staged per step (floats)
 #define EMB_LD (EMB_KS + 4)
+#define EMB_KMAX 4096       // largest padded K the offset table holds (AV-MNIST audio 3136, MM-IMDb 3072)
 
 struct PatchGeom {
     int Cin, H, W, ph, pw, GW, N, K;
 };
-static __device__ __forceinline__ long patch_addr(const PatchGeom& pg, long m, int k) {
+// offset of element k of a patch relative to the patch origin; -1 beyond K
+static __device__ __forceinline__ int patch_koff(const PatchGeom& pg, int k) {
+    if (k >= pg.K) return -1;
+    const int c = k / (pg.ph * pg.pw), rem = k % (pg.ph * pg.pw);
+    const int py = rem / pg.pw, px = rem % pg.pw;
+    return (c * pg.H + py) * pg.W + px;
+}
+// offset of the origin of token row m's patch; -1 beyond M
+static __device__ __forceinline__ long patch_rowbase(const PatchGeom& pg, long m, long M) {
+    if (m >= M) return -1;
     const long b = m / pg.N;
     const int n = (int)(m % pg.N);
     const int gy = n / pg.GW, gx = n % pg.GW;
-    const int c = k / (pg.ph * pg.pw), rem = k % (pg.ph * pg.pw);
-    const int py = rem / pg.pw, px = rem % pg.pw;
-    return ((b * pg.Cin + c) * pg.H + gy * pg.ph + py) * (long)pg.W + gx * pg.pw + px;
-}
-
-// stage patches[m0 .. m0+63][k0 .. k0+EMB_KS) into an fp32 LDS tile (zero outside M / K)
-static __device__ __forceinline__ void stage_patches(const float* __restrict__ in, const PatchGeom& pg, long m0, long M, int k0,
-                                                     float* tile, int tid) {
-    for (int idx = tid; idx < BM * EMB_KS; idx += NTHREADS) {
-        const int r = idx / EMB_KS, kk = idx % EMB_KS;
-        const long m = m0 + r;
-        const int k = k0 + kk;
-        float v = 0.f;
-        if (m < M && k < pg.K) v = in[patch_addr(pg, m, k)];
-        tile[r * EMB_LD + kk] = v;
-    }
+    return (b * pg.Cin * pg.H + gy * pg.ph) * (long)pg.W + gx * pg.pw;
 }
 
 template <int P, int D>
@@ -41,15 +37,20 @@ __global__ __launch_bounds__(NTHREADS) void embed_fwd_kernel(const m2m_embed em,
                                                              float* __restrict__ x0) {
     typedef Prec<P> Pr;
     constexpr int DT = D / 16, KSB = EMB_KS / Pr::KB;     // k-blocks per stage
-    constexpr int DPW = (DT + 3) / 4;                      // d-tiles per wave
+    constexpr int DPW = (DT + NWAVES - 1) / NWAVES;        // d-tiles per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* tile = reinterpret_cast<float*>(smem);          // [BM][EMB_LD] fp32
     char* img = smem + BM * EMB_LD * 4;                    // packed NAT [mt][kb] of the stage
+    int* koff = reinterpret_cast<int*>(img + BM * EMB_KS * Pr::ESZ);   // [Kp rounded up to EMB_KS]
+    long* rbase = reinterpret_cast<long*>(koff + EMB_KMAX);            // [BM]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
     PatchGeom pg{em.Cin, em.H, em.W, em.ph, em.pw, em.W / em.pw, N, em.K};
     const long m0 = (long)blockIdx.x * BM;
     const int nKB = em.Kp / Pr::KB;
+    const int kext = (em.Kp + EMB_KS - 1) / EMB_KS * EMB_KS;
+    for (int k = tid; k < kext; k += NTHREADS) koff[k] = patch_koff(pg, k);
+    if (tid < BM) rbase[tid] = patch_rowbase(pg, m0 + tid, M);
 
     f32x4_t acc[MT][DPW];
 #pragma unroll
@@ -59,7 +60,12 @@ __global__ __launch_bounds__(NTHREADS) void embed_fwd_kernel(const m2m_embed em,
 
     for (int k0 = 0; k0 < em.Kp; k0 += EMB_KS) {
         __syncthreads();
-        stage_patches(in, pg, m0, M, k0, tile, tid);
+        for (int idx = tid; idx < BM * EMB_KS; idx += NTHREADS) {
+            const int r = idx / EMB_KS, kk = idx % EMB_KS;
+            const long rb = rbase[r];
+            const int ko = koff[k0 + kk];
+            tile[r * EMB_LD + kk] = (rb >= 0 && ko >= 0) ? in[rb + ko] : 0.f;
+        }
         __syncthreads();
         for (int slot = tid; slot < MT * KSB * 64; slot += NTHREADS) {
             const int blk = slot >> 6;
@@ -70,7 +76,7 @@ __global__ __launch_bounds__(NTHREADS) void embed_fwd_kernel(const m2m_embed em,
         const int kb0 = k0 / Pr::KB;
 #pragma unroll
         for (int j = 0; j < DPW; ++j) {
-            const int dt = wave + 4 * j;
+            const int dt = wave + NWAVES * j;
             if (dt < DT) {
                 for (int kb = 0; kb < KSB && kb0 + kb < nKB; ++kb) {
                     const Frag w = ld_frag_global(em.wn, (long)dt * nKB + kb0 + kb, lane);
@@ -85,7 +91,7 @@ __global__ __launch_bounds__(NTHREADS) void embed_fwd_kernel(const m2m_embed em,
     }
 #pragma unroll
     for (int j = 0; j < DPW; ++j) {
-        const int dt = wave + 4 * j;
+        const int dt = wave + NWAVES * j;
         if (dt < DT) {
             const int d = 16 * dt + il;
             const float bv = em.b[d];
@@ -100,53 +106,60 @@ __global__ __launch_bounds__(NTHREADS) void embed_fwd_kernel(const m2m_embed em,
     }
 }
 
-// g_w[d][k] += sum_m dx0[m][d] patch[m][k];  workgroup = 64 k columns, loops over all rows.
+// g_w[d][k] += sum_m dx0[m][d] patch[m][k];  workgroup = 64 k columns x one group of row tiles.
 template <int P, int D>
 __global__ __launch_bounds__(NTHREADS) void embed_wgrad_kernel(const m2m_embed em, const float* __restrict__ in,
-                                                               const float* __restrict__ dx0, long M, int N) {
+                                                               const float* __restrict__ dx0, long M, int N, int tiles_per_group) {
     typedef Prec<P> Pr;
     constexpr int DT = D / 16, NKM = BM / Pr::KB, XLD = TileGeom<D>::XLD;
     constexpr int KC = 64, KCT = KC / 16, PLD = KC + 4;
-    constexpr int DPW = (DT + 3) / 4;
+    constexpr int DPW = (DT + NWAVES - 1) / NWAVES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* dxt = reinterpret_cast<float*>(smem);                  // [BM][XLD]   dx0 tile
     float* pt = dxt + BM * XLD;                                    // [BM][PLD]   patch tile
     char* aimg = reinterpret_cast<char*>(pt + BM * PLD);           // NAT X[i=d][k=m]  blocks [dt][kbm]
     char* bimg = aimg + BM * D * Pr::ESZ;                          // NAT X[i=kk][k=m] blocks [kt][kbm]
+    int* koff = reinterpret_cast<int*>(bimg + BM * KC * Pr::ESZ);  // [KC]
+    long* rbase = reinterpret_cast<long*>(koff + KC);              // [BM]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
     PatchGeom pg{em.Cin, em.H, em.W, em.ph, em.pw, em.W / em.pw, N, em.K};
     const int k0 = blockIdx.x * KC;
+    if (tid < KC) koff[tid] = patch_koff(pg, k0 + tid);
 
     f32x4_t acc[DPW][KCT];
 #pragma unroll
     for (int j = 0; j < DPW; ++j)
 #pragma unroll
         for (int kt = 0; kt < KCT; ++kt) acc[j][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;                                               // bias gradient (block 0 only), thread d
+    float bsum = 0.f;                                               // bias gradient (k-chunk 0 only), thread d
 
-    for (long m0 = 0; m0 < M; m0 += BM) {
+    const long ntiles = (M + BM - 1) / BM;
+    const long t_begin = (long)blockIdx.y * tiles_per_group;
+    const long t_end = min(ntiles, t_begin + tiles_per_group);
+    for (long tl = t_begin; tl < t_end; ++tl) {
+        const long m0 = tl * BM;
         __syncthreads();
+        if (tid < BM) rbase[tid] = patch_rowbase(pg, m0 + tid, M);
         for (int idx = tid; idx < BM * (D / 4); idx += NTHREADS) {
             const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m0 + r < M) v = *reinterpret_cast<const float4*>(dx0 + (m0 + r) * D + c);
             *reinterpret_cast<float4*>(dxt + r * XLD + c) = v;
         }
+        __syncthreads();
         for (int idx = tid; idx < BM * KC; idx += NTHREADS) {
             const int r = idx / KC, kk = idx % KC;
-            const long m = m0 + r;
-            const int k = k0 + kk;
-            float v = 0.f;
-            if (m < M && k < pg.K) v = in[patch_addr(pg, m, k)];
-            pt[r * PLD + kk] = v;
+            const long rb = rbase[r];
+            const int ko = koff[kk];
+            pt[r * PLD + kk] = (rb >= 0 && ko >= 0) ? in[rb + ko] : 0.f;
         }
-        __syncthreads();
         if (blockIdx.x == 0 && tid < D) {
             float s = 0.f;
             for (int r = 0; r < BM; ++r) s += dxt[r * XLD + tid];
             bsum += s;
         }
+        __syncthreads();
         for (int slot = tid; slot < DT * NKM * 64; slot += NTHREADS) {
             const int blk = slot >> 6;
             *reinterpret_cast<u32x4_t*>(aimg + slot * 16) =
@@ -160,7 +173,7 @@ __global__ __launch_bounds__(NTHREADS) void embed_wgrad_kernel(const m2m_embed e
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < DPW; ++j) {
-            const int dt = wave + 4 * j;
+            const int dt = wave + NWAVES * j;
             if (dt < DT) {
 #pragma unroll
                 for (int kbm = 0; kbm < NKM; ++kbm) {
@@ -174,20 +187,24 @@ __global__ __launch_bounds__(NTHREADS) void embed_wgrad_kernel(const m2m_embed e
             }
         }
     }
+    const bool single = gridDim.y == 1;
 #pragma unroll
     for (int j = 0; j < DPW; ++j) {
-        const int dt = wave + 4 * j;
+        const int dt = wave + NWAVES * j;
         if (dt < DT) {
 #pragma unroll
             for (int kt = 0; kt < KCT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int d = 16 * dt + 4 * g + r, k = k0 + 16 * kt + il;
-                    if (k < em.K) em.g_w[(long)d * em.K + k] += acc[j][kt][r];
+                    if (k < em.K) {
+                        float* p = em.g_w + (long)d * em.K + k;
+                        if (single) *p += acc[j][kt][r]; else atomicAdd(p, acc[j][kt][r]);
+                    }
                 }
         }
     }
-    if (blockIdx.x == 0 && tid < D) em.g_b[tid] += bsum;
+    if (blockIdx.x == 0 && tid < D) { if (single) em.g_b[tid] += bsum; else atomicAdd(em.g_b + tid, bsum); }
 }
 
 static int check_embed(const m2m_embed* e, int B) {
@@ -196,6 +213,7 @@ static int check_embed(const m2m_embed* e, int B) {
     if (e->K != e->Cin * e->ph * e->pw) { m2m_set_error("embed: K != Cin*ph*pw", __FILE__, __LINE__); return -1; }
     const int KB = e->prec == PREC_BF16 ? 32 : 16;
     if (e->Kp % KB || e->Kp < e->K) { m2m_set_error("embed: Kp must be K rounded up to the k-block", __FILE__, __LINE__); return -1; }
+    if (e->Kp > EMB_KMAX - EMB_KS) { m2m_set_error("embed: patch too large (Cin*ph*pw must be <= 3968)", __FILE__, __LINE__); return -1; }
     return 0;
 }
 
@@ -203,7 +221,7 @@ template <int P, int D>
 static int launch_embed_fwd(const m2m_embed* e, const float* in, int B, float* x0, hipStream_t st) {
     const int N = (e->H / e->ph) * (e->W / e->pw);
     const long M = (long)B * N;
-    const size_t lds = (size_t)BM * EMB_LD * 4 + (size_t)BM * EMB_KS * Prec<P>::ESZ;
+    const size_t lds = (size_t)BM * EMB_LD * 4 + (size_t)BM * EMB_KS * Prec<P>::ESZ + EMB_KMAX * 4 + BM * 8;
     auto kern = embed_fwd_kernel<P, D>;
     static bool done = false;
     if (!done) { M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
@@ -215,11 +233,19 @@ template <int P, int D>
 static int launch_embed_wgrad(const m2m_embed* e, const float* in, const float* dx0, int B, hipStream_t st) {
     const int N = (e->H / e->ph) * (e->W / e->pw);
     const long M = (long)B * N;
-    const size_t lds = (size_t)BM * TileGeom<D>::XLD * 4 + (size_t)BM * 68 * 4 + (size_t)BM * D * Prec<P>::ESZ + (size_t)BM * 64 * Prec<P>::ESZ;
+    const int nchunks = (e->K + 63) / 64;
+    const long ntiles = (M + BM - 1) / BM;
+    long groups = (128 + nchunks - 1) / nchunks;           // ~128 workgroups; row groups add with atomics
+    if (groups > ntiles / 4) groups = ntiles / 4;
+    if (groups < 1) groups = 1;
+    const int tpg = (int)((ntiles + groups - 1) / groups);
+    groups = (ntiles + tpg - 1) / tpg;
+    const size_t lds = (size_t)BM * TileGeom<D>::XLD * 4 + (size_t)BM * 68 * 4 + (size_t)BM * D * Prec<P>::ESZ +
+                       (size_t)BM * 64 * Prec<P>::ESZ + 64 * 4 + BM * 8;
     auto kern = embed_wgrad_kernel<P, D>;
     static bool done = false;
     if (!done) { M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)((e->K + 63) / 64)), dim3(NTHREADS), lds, st, *e, in, dx0, M, N);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nchunks, (unsigned)groups), dim3(NTHREADS), lds, st, *e, in, dx0, M, N, tpg);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -99,6 +99,12 @@ __global__ __launch_bounds__(NTHREADS) void heads_ce_kernel(const HeadArgs ha, c
     }
 }
 
+// losses are accumulated with atomics; they are cleared by a kernel (not a memset node: a 16-byte
+// hipMemsetAsync node was observed to write stale bytes on hipGraph replay).
+__global__ void zero_floats_kernel(float* p, int n) {
+    if ((int)threadIdx.x < n) p[threadIdx.x] = 0.f;
+}
+
 extern "C" int m2m_heads_ce(const m2m_head* heads, int nheads, const int64_t* labels, int B, int D, int K, float* logits,
                             float* losses, int32_t* preds, void* stream) {
     if (!heads || nheads < 1 || nheads > HEAD_MAXH || K < 2 || K > HEAD_MAXK || D < 1 || D > 512 || B < 1) {
@@ -109,7 +115,7 @@ extern "C" int m2m_heads_ce(const m2m_head* heads, int nheads, const int64_t* la
     for (int i = 0; i < nheads; ++i) ha.h[i] = heads[i];
     for (int i = nheads; i < HEAD_MAXH; ++i) ha.h[i] = heads[0];
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    M2M_CHECK_HIP(hipMemsetAsync(losses, 0, sizeof(float) * (nheads + 1), st));
+    hipLaunchKernelGGL(zero_floats_kernel, dim3(1), dim3(64), 0, st, losses, nheads + 1);
     const size_t lds = sizeof(float) * ((size_t)HEAD_S * (D + 1) + (size_t)HEAD_MAXK * (D + 1) + HEAD_S * HEAD_MAXK + HEAD_S);
     static bool done = false;
     if (!done) { M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(heads_ce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); done = true; }

@@ -1,15 +1,18 @@
-// Per-workgroup token-tile helpers shared by the forward and backward tower kernels.
+// Per-workgroup token-tile helpers shared by the forward / backward / weight-gradient tower kernels.
 //
-// A workgroup (256 threads = 4 waves, one per SIMD) owns BM = 64 token rows = SPW whole samples of
-// N tokens (token mixing couples the N tokens of a sample, channel mixing is row-wise), keeps the
-// fp32 residual stream of those rows in LDS for the whole tower and streams the weights past it.
+// A workgroup (512 threads = 8 waves, two per SIMD so that the VALU-heavy GELU / dropout epilogues of
+// one wave overlap the MFMA and load latency of its partner) owns BM = 32 token rows = SPW whole
+// samples of N tokens (token mixing couples the N tokens of a sample, channel mixing is row-wise),
+// keeps the fp32 residual stream of those rows in LDS for the whole tower and streams the weights past it.
 #pragma once
 #include "common.h"
 #include "../../include/m2mixer.h"
 
-#define BM 64
+#define BM 32
 #define MT (BM / 16)
-#define NTHREADS 256
+#define NTHREADS 512
+#define NWAVES 8
+#define TPR (NTHREADS / BM)        // threads per row in the row-wise (LayerNorm) phases: 16
 
 static __host__ __device__ __forceinline__ unsigned int m2m_mix32_hd(unsigned int x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
@@ -35,59 +38,77 @@ static __device__ __forceinline__ Drop make_drop(bool training, float p, unsigne
     return d;
 }
 
+// ---- dropout of the channel-mixing hidden activation (the hot site) -----------------------------------
+// Element (token row m, hidden column c).  One 32-bit word per (m, c >> 5) when p == 0.5 (bit c & 31
+// decides), otherwise one word per (m, c >> 1) with a 16-bit threshold compare.  Defined on (m, c) only,
+// so forward, backward and the weight-gradient pass -- which hold the elements in different lane
+// layouts -- regenerate identical masks.
+static __device__ __forceinline__ unsigned int drop_word_half(const Drop& d, unsigned int m, unsigned int cgroup, unsigned int ngroups) {
+    return mix32(d.key ^ (m * ngroups + cgroup));
+}
+static __device__ __forceinline__ bool drop_keep_mc(const Drop& d, unsigned int m, unsigned int c, unsigned int Cp) {
+    if (d.thr == 32768u) return (drop_word_half(d, m, c >> 5, Cp >> 5) >> (c & 31)) & 1u;
+    return drop_keep(d, m * Cp + c);
+}
+
 template <int D> struct TileGeom {
     static constexpr int XLD = D + 4;          // padded fp32 row stride (floats)
     static constexpr int DT = D / 16;
-    static constexpr int CPT = D / 4;          // columns per LayerNorm thread (4 threads per row)
+    static constexpr int EPT = D / TPR;        // elements per thread in row-wise phases
+    static_assert(D % 32 == 0 && D >= 32, "hidden_dim must be a multiple of 32");
 };
 
-// Row statistics of the fp32 tile `x` (BM rows, stride XLD): thread (r = tid>>2, j = tid&3) owns the
-// float4 chunks at columns 16*i + 4*j.  Two-pass (mean, then centred variance), biased variance, eps 1e-5.
-// v[] receives the thread's raw values.
+// column of element e (0..EPT-1) of row-thread j (0..TPR-1): float4 chunks interleaved over the 16
+// threads of a row (coalesced 256-byte segments); D == 32 degenerates to 2 contiguous columns.
 template <int D>
-static __device__ __forceinline__ void row_stats(const float* x, int tid, float v[D / 4], float& mean, float& rstd) {
-    constexpr int XLD = TileGeom<D>::XLD;
-    const int r = tid >> 2, j = tid & 3;
+static __device__ __forceinline__ int ln_col(int e, int j) {
+    if (D >= 64) return 64 * (e >> 2) + 4 * j + (e & 3);
+    return 2 * j + e;
+}
+
+// row statistics (mean, 1/std with biased variance, eps 1e-5) of one row held by TPR threads.
+// src points at the row (LDS or global); invalid rows read as zeros.
+template <int D>
+static __device__ __forceinline__ void row_stats(const float* src, bool valid, int j, float v[D / TPR], float& mean, float& rstd) {
+    constexpr int EPT = D / TPR;
     float s = 0.f;
+    if (D >= 64) {
 #pragma unroll
-    for (int i = 0; i < D / 16; ++i) {
-        const float4 q = *reinterpret_cast<const float4*>(x + r * XLD + 16 * i + 4 * j);
-        v[4 * i + 0] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
-        s += (q.x + q.y) + (q.z + q.w);
+        for (int i = 0; i < EPT / 4; ++i) {
+            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid) q = *reinterpret_cast<const float4*>(src + 64 * i + 4 * j);
+            v[4 * i + 0] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+            s += (q.x + q.y) + (q.z + q.w);
+        }
+    } else {
+        float2 q = make_float2(0.f, 0.f);
+        if (valid) q = *reinterpret_cast<const float2*>(src + 2 * j);
+        v[0] = q.x; v[1] = q.y;
+        s = q.x + q.y;
     }
-    s = wave_sum_xor(s, 4);
+    s = wave_sum_xor(s, TPR);
     mean = s * (1.0f / D);
     float s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < D / 4; ++i) { const float c = v[i] - mean; s2 = __builtin_fmaf(c, c, s2); }
-    s2 = wave_sum_xor(s2, 4);
-    rstd = __builtin_amdgcn_rsqf(s2 * (1.0f / D) + 1e-5f);
-    // one Newton step: v_rsq_f32 is ~1 ulp, the parity mode wants full fp32
+    for (int i = 0; i < EPT; ++i) { const float c = v[i] - mean; s2 = __builtin_fmaf(c, c, s2); }
+    s2 = wave_sum_xor(s2, TPR);
     const float vv = s2 * (1.0f / D) + 1e-5f;
-    rstd = rstd * (1.5f - 0.5f * vv * rstd * rstd);
+    rstd = __builtin_amdgcn_rsqf(vv);
+    rstd = rstd * (1.5f - 0.5f * vv * rstd * rstd);     // one Newton step: full fp32 accuracy for the parity mode
 }
 
-// column index of element e (0..D/4-1) of thread j
-static __device__ __forceinline__ int ln_col(int e, int j) { return 16 * (e >> 2) + 4 * j + (e & 3); }
-
-// LayerNorm of every row of x into the fp32 tile `dst` (same geometry).
+// LayerNorm of every row of the fp32 LDS tile x into the fp32 tile dst (same geometry).
 template <int D>
-static __device__ __forceinline__ void ln_to_tile(const float* x, float* dst, const float* gamma, const float* beta, int tid) {
-    constexpr int XLD = TileGeom<D>::XLD;
-    float v[D / 4], mean, rstd;
-    row_stats<D>(x, tid, v, mean, rstd);
-    const int r = tid >> 2, j = tid & 3;
+static __device__ __forceinline__ void ln_to_tile(const float* x, float* dst, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, int tid) {
+    constexpr int XLD = TileGeom<D>::XLD, EPT = D / TPR;
+    const int r = tid / TPR, j = tid % TPR;
+    float v[EPT], mean, rstd;
+    row_stats<D>(x + r * XLD, true, j, v, mean, rstd);
 #pragma unroll
-    for (int i = 0; i < D / 16; ++i) {
-        const int c = 16 * i + 4 * j;
-        const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
-        const float4 bt = *reinterpret_cast<const float4*>(beta + c);
-        float4 o;
-        o.x = (v[4 * i + 0] - mean) * rstd * gm.x + bt.x;
-        o.y = (v[4 * i + 1] - mean) * rstd * gm.y + bt.y;
-        o.z = (v[4 * i + 2] - mean) * rstd * gm.z + bt.z;
-        o.w = (v[4 * i + 3] - mean) * rstd * gm.w + bt.w;
-        *reinterpret_cast<float4*>(dst + r * XLD + c) = o;
+    for (int e = 0; e < EPT; ++e) {
+        const int c = ln_col<D>(e, j);
+        dst[r * XLD + c] = (v[e] - mean) * rstd * gamma[c] + beta[c];
     }
 }
 
@@ -118,8 +139,7 @@ static __device__ __forceinline__ u32x4_t gather_slot(const float* tile, int xld
 template <int P, int D>
 static __device__ __forceinline__ void pack_tile_nat(const float* tile, char* img, int tid) {
     constexpr int KD = D / Prec<P>::KB;
-#pragma unroll 2
-    for (int slot = tid; slot < MT * KD * 64; slot += NTHREADS) {
+    _Pragma("unroll 1") for (int slot = tid; slot < MT * KD * 64; slot += NTHREADS) {
         const int blk = slot >> 6;
         *reinterpret_cast<u32x4_t*>(img + slot * 16) =
             gather_slot<P>(tile, TileGeom<D>::XLD, PACK_NAT, false, blk / KD, blk % KD, slot & 63);
@@ -129,17 +149,16 @@ static __device__ __forceinline__ void pack_tile_nat(const float* tile, char* im
 template <int P, int D>
 static __device__ __forceinline__ void pack_tile_chn_t(const float* tile, char* img, int tid) {
     constexpr int DT = D / 16, NKM = BM / Prec<P>::KB;
-#pragma unroll 2
-    for (int slot = tid; slot < NKM * DT * 64; slot += NTHREADS) {
+    _Pragma("unroll 1") for (int slot = tid; slot < NKM * DT * 64; slot += NTHREADS) {
         const int blk = slot >> 6;
         *reinterpret_cast<u32x4_t*>(img + slot * 16) =
             gather_slot<P>(tile, TileGeom<D>::XLD, PACK_CHN, true, blk % DT, blk / DT, slot & 63);
     }
 }
 
-// copy a packed 64-row tile image (bytes) between LDS and global, 16 bytes per thread step
+// copy a packed tile image (bytes, multiple of 16) between LDS and global, 16 bytes per thread step
 static __device__ __forceinline__ void copy16(char* dst, const char* src, int bytes, int tid) {
-    for (int o = tid * 16; o < bytes; o += NTHREADS * 16)
+    _Pragma("unroll 1") for (int o = tid * 16; o < bytes; o += NTHREADS * 16)
         *reinterpret_cast<u32x4_t*>(dst + o) = *reinterpret_cast<const u32x4_t*>(src + o);
 }
 
@@ -161,3 +180,40 @@ template <> struct Chain<PREC_F32> {
         out[1].f = t1;
     }
 };
+
+// Sum the NWAVES per-wave partial [BM][D] accumulator sets through four LDS slabs, deterministically:
+// waves 0-3 store, waves 4-7 add, then the caller reads slab0 + slab1 + slab2 + slab3.
+// acc[mt][dt][r] = element (row 16 mt + 4 g + r, column 16 dt + il).  The slabs are TRANSPOSED,
+// [D][SLD] (column-major tiles), so the four rows a lane holds go out as one 16-byte access.
+#define SLD (BM + 4)
+template <int D> struct SlabGeom { static constexpr int FLOATS = D * SLD; };
+template <int D>
+static __device__ __forceinline__ void reduce_waves_to_slabs(f32x4_t (&acc)[MT][D / 16], float* slabs, int wave, int g, int il) {
+    constexpr int DT = D / 16;
+    float* my = slabs + (wave & 3) * SlabGeom<D>::FLOATS;
+    if (wave < 4) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                *reinterpret_cast<f32x4_t*>(my + (dt * 16 + il) * SLD + mt * 16 + 4 * g) = acc[mt][dt];
+    }
+    __syncthreads();
+    if (wave >= 4) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                f32x4_t* p = reinterpret_cast<f32x4_t*>(my + (dt * 16 + il) * SLD + mt * 16 + 4 * g);
+                *p = *p + acc[mt][dt];
+            }
+    }
+    __syncthreads();
+}
+// value of element (row r, column d) after reduce_waves_to_slabs
+template <int D>
+static __device__ __forceinline__ float slab_sum(const float* slabs, int r, int d) {
+    const float* s = slabs + d * SLD + r;
+    constexpr int F = SlabGeom<D>::FLOATS;
+    return (s[0] + s[F]) + (s[2 * F] + s[3 * F]);
+}

@@ -14,29 +14,8 @@
 // tower_wgrad.hip; this kernel writes the packed operand tiles (A, A^T, dYd, dYd^T) it needs.
 #include "tile.h"
 
-// row statistics from an arbitrary fp32 source (LDS or global) with row stride ld; invalid rows read as 0
-template <int D>
-static __device__ __forceinline__ void row_stats_src(const float* src, long ld, bool valid, int j, float v[D / 4],
-                                                     float& mean, float& rstd) {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < D / 16; ++i) {
-        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (valid) q = *reinterpret_cast<const float4*>(src + 16 * i + 4 * j);
-        v[4 * i + 0] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
-        s += (q.x + q.y) + (q.z + q.w);
-    }
-    (void)ld;
-    s = wave_sum_xor(s, 4);
-    mean = s * (1.0f / D);
-    float s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < D / 4; ++i) { const float c = v[i] - mean; s2 = __builtin_fmaf(c, c, s2); }
-    s2 = wave_sum_xor(s2, 4);
-    const float vv = s2 * (1.0f / D) + 1e-5f;
-    rstd = __builtin_amdgcn_rsqf(vv);
-    rstd = rstd * (1.5f - 0.5f * vv * rstd * rstd);
-}
+TIMER_DECL(g_tm_bwd);
+TIMER_READER(m2m_debug_timers_bwd, g_tm_bwd)
 
 // LayerNorm backward for the whole tile.
 //   xg      : global saved LN input, row r at xg + r*D (rows >= R treated as zero)
@@ -45,19 +24,19 @@ static __device__ __forceinline__ void row_stats_src(const float* src, long ld, 
 //   prod    : LDS tile, receives up * xhat (for the gamma gradient)
 // then column sums -> atomicAdd into g_w (gamma) / g_b (beta).  Contains two __syncthreads().
 template <int D>
-static __device__ __forceinline__ void ln_backward_tile(const float* xg, int R, const float* up, const float* gamma,
+static __device__ __forceinline__ void ln_backward_tile(const float* xg, int R, const float* up, const float* __restrict__ gamma,
                                                         float* dxs, bool accumulate, float* prod, float* g_w, float* g_b,
                                                         int tid) {
-    constexpr int XLD = TileGeom<D>::XLD;
-    const int r = tid >> 2, j = tid & 3;
+    constexpr int XLD = TileGeom<D>::XLD, EPT = D / TPR;
+    const int r = tid / TPR, j = tid % TPR;
     const bool valid = r < R;
-    float v[D / 4], mean, rstd;
-    row_stats_src<D>(xg + (long)r * D, D, valid, j, v, mean, rstd);
+    float v[EPT], mean, rstd;
+    row_stats<D>(xg + (long)r * D, valid, j, v, mean, rstd);
     float gsum = 0.f, gxsum = 0.f;
-    float gv[D / 4];
+    float gv[EPT];
 #pragma unroll
-    for (int e = 0; e < D / 4; ++e) {
-        const int c = ln_col(e, j);
+    for (int e = 0; e < EPT; ++e) {
+        const int c = ln_col<D>(e, j);
         const float xh = (v[e] - mean) * rstd;
         const float u = up[r * XLD + c];
         const float gg = u * gamma[c];
@@ -67,17 +46,17 @@ static __device__ __forceinline__ void ln_backward_tile(const float* xg, int R, 
         gxsum = __builtin_fmaf(gg, xh, gxsum);
         prod[r * XLD + c] = valid ? u * xh : 0.f;
     }
-    gsum = wave_sum_xor(gsum, 4) * (1.0f / D);
-    gxsum = wave_sum_xor(gxsum, 4) * (1.0f / D);
+    gsum = wave_sum_xor(gsum, TPR) * (1.0f / D);
+    gxsum = wave_sum_xor(gxsum, TPR) * (1.0f / D);
 #pragma unroll
-    for (int e = 0; e < D / 4; ++e) {
-        const int c = ln_col(e, j);
+    for (int e = 0; e < EPT; ++e) {
+        const int c = ln_col<D>(e, j);
         const float dx = rstd * (gv[e] - gsum - v[e] * gxsum);
         if (accumulate) { if (valid) dxs[r * XLD + c] += dx; }
         else dxs[r * XLD + c] = valid ? dx : 0.f;
     }
     __syncthreads();
-    for (int d = tid; d < 2 * D; d += NTHREADS) {
+    _Pragma("unroll 1") for (int d = tid; d < 2 * D; d += NTHREADS) {
         const float* src = d < D ? prod : up;
         const int c = d < D ? d : d - D;
         float s = 0.f;
@@ -99,14 +78,16 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
     constexpr int IMG_B = BM * D * Pr::ESZ;             // bytes of one packed 64-row image
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int XREG_B = (2 * IMG_B > TILE_F * 4) ? 2 * IMG_B : TILE_F * 4;
+    constexpr int SF = SlabGeom<D>::FLOATS;             // floats in one (transposed) reduction slab, >= TILE_F
+    static_assert(IMG_B <= SF * 4 && TILE_F <= SF, "packed image / fp32 tile must fit the slab it aliases");
     float* dxs = reinterpret_cast<float*>(smem);        // gradient stream
-    float* ub = dxs + TILE_F;                            // scratch tile
-    char* xreg = reinterpret_cast<char*>(ub + TILE_F);   // packed A image | packed dYd image, aliased by the
-    char* at = xreg;                                     // scratch tile xh once the hidden-column loop is done
-    char* dyp = xreg + IMG_B;
-    float* xh = reinterpret_cast<float*>(xreg);
-    float* rstd_s = reinterpret_cast<float*>(xreg + XREG_B);   // [BM]
+    float* slabs = dxs + TILE_F;                         // 4 slabs: S0 = ub (scratch), S1 = xh (scratch),
+    float* ub = slabs;                                   //   S2 / S3 hold the packed A / dYd images during the
+    float* xh = slabs + SF;                              //   hidden-column loop, then all four receive the waves'
+    char* at = reinterpret_cast<char*>(slabs + 2 * SF);  //   partial dA
+    char* dyp = reinterpret_cast<char*>(slabs + 3 * SF);
+    float* rstd_s = slabs + 4 * SF;                      // [BM]
+    float* dasum = rstd_s + BM;                          // [BM][XLD] summed dA (row-major)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
     const int N = tw.N, T = tw.T, Cp = tw.Cp;
@@ -118,10 +99,11 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
     const long tile_off = (long)blockIdx.x * IMG_B;
     const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
 
+    TIMER_START();
     // ---- upstream gradient of the tower output ----
     {
         const float invN = 1.0f / (float)N;
-        for (int idx = tid; idx < BM * (D / 4); idx += NTHREADS) {
+        _Pragma("unroll 1") for (int idx = tid; idx < BM * (D / 4); idx += NTHREADS) {
             const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < R) {
@@ -138,6 +120,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
             ln_backward_tile<D>(tw.x_final + row0 * D, R, ub, tw.lnf_w, dxs, false, xh, tw.g_lnf_w, tw.g_lnf_b, tid);
     }
 
+    TIMER_MARK(g_tm_bwd, 0);       // upstream + final LN backward
     for (int b = tw.nblocks - 1; b >= 0; --b) {
         const m2m_block& bk = tw.blk[b];
         const unsigned int site = tw.site_base + 4u * b;
@@ -146,10 +129,11 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
         const Drop dr_ch = make_drop(true, tw.p_drop, seed, step, site + 2);
         const Drop dr_co = make_drop(true, tw.p_drop, seed, step, site + 3);
         const bool dropping = dr_th.thr < 65536u;
+        const bool half = dr_th.thr == 32768u;
 
         // ================= channel mixing backward =================
         // (C1) dYd = dY * mask_out -> fp32 temp (ub)
-        for (int idx = tid; idx < BM * D; idx += NTHREADS) {
+        _Pragma("unroll 1") for (int idx = tid; idx < BM * D; idx += NTHREADS) {
             const int r = idx / D, d = idx % D;
             float v = dxs[r * XLD + d];
             if (dropping) v = drop_keep(dr_co, (unsigned int)(row0 + r) * D + d) ? v * dr_co.scale : 0.f;
@@ -157,7 +141,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
         }
         __syncthreads();
         // ch_b2 gradient: column sums of dYd
-        for (int d = tid; d < D; d += NTHREADS) {
+        _Pragma("unroll 1") for (int d = tid; d < D; d += NTHREADS) {
             float s = 0.f;
             for (int r = 0; r < R; ++r) s += ub[r * XLD + d];
             atomicAdd(bk.g_ch_b2 + d, s);
@@ -169,12 +153,12 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
         copy16(reinterpret_cast<char*>(bk.dy_nat) + tile_off, dyp, IMG_B, tid);
         // (C2) A = LN2(x_mid) -> fp32 tile (ub) -> packed images
         {
-            const int r = tid >> 2, j = tid & 3;
-            float v[D / 4], mean, rstd;
-            row_stats_src<D>(bk.x_mid + (row0 + r) * D, D, r < R, j, v, mean, rstd);
+            const int r = tid / TPR, j = tid % TPR;
+            float v[D / TPR], mean, rstd;
+            row_stats<D>(bk.x_mid + (row0 + r) * D, r < R, j, v, mean, rstd);
 #pragma unroll
-            for (int e = 0; e < D / 4; ++e) {
-                const int c = ln_col(e, j);
+            for (int e = 0; e < D / TPR; ++e) {
+                const int c = ln_col<D>(e, j);
                 ub[r * XLD + c] = (v[e] - mean) * rstd * bk.ln2_w[c] + bk.ln2_b[c];
             }
         }
@@ -184,6 +168,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
         __syncthreads();
         copy16(reinterpret_cast<char*>(bk.a_nat) + tile_off, at, IMG_B, tid);
 
+        TIMER_MARK(g_tm_bwd, 1);   // C1 + C2: dYd, A, packing, global copies
         // (C3) hidden-column loop
         f32x4_t dacc[MT][DT];
 #pragma unroll
@@ -191,7 +176,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) dacc[mt][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         const int npairs = Cp >> 5;
-        for (int q = wave; q < npairs; q += 4) {
+        for (int q = wave; q < npairs; q += NWAVES) {
             Frag w1f[2][KD], w2f[2][KD];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -218,17 +203,19 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
                     Pr::mma(gacc[1], w2f[1][kb], dy);
                 }
                 const unsigned int m = (unsigned int)(row0 + mt * 16 + il);
+                unsigned int word = 0xFFFFFFFFu;
+                if (half) word = drop_word_half(dr_ch, m, q, npairs);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     bool keep[4] = {true, true, true, true};
-                    if (dropping) drop_keep4(dr_ch, m * (unsigned int)Cp + 32 * q + 16 * t + 4 * g, keep);
+                    if (dropping && !half) drop_keep4(dr_ch, m * (unsigned int)Cp + 32 * q + 16 * t + 4 * g, keep);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float gl, dgl;
                         gelu_grad_f(hacc[t][r], gl, dgl);
-                        float v = gacc[t][r] * dgl;
-                        if (dropping) v = keep[r] ? v * dr_ch.scale : 0.f;
-                        gacc[t][r] = v;
+                        const float v = gacc[t][r] * dgl * dr_ch.scale;
+                        const bool k = half ? ((word >> (16 * t + 4 * g + r)) & 1u) : keep[r];
+                        gacc[t][r] = k ? v : 0.f;
                     }
                 }
                 Chain<P>::make(gacc[0], gacc[1], hf[mt]);
@@ -243,35 +230,29 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
                 }
             }
         }
+        TIMER_MARK(g_tm_bwd, 2);   // C3 hidden-column loop (wave 0)
         __syncthreads();   // every wave is done reading the packed images that xh aliases
-        // (C4) dA = sum of the four waves' partials -> ub
-        for (int w = 0; w < 4; ++w) {
-            if (wave == w) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float* p = ub + (mt * 16 + 4 * g + r) * XLD + dt * 16 + il;
-                            *p = (w == 0) ? dacc[mt][dt][r] : (*p + dacc[mt][dt][r]);
-                        }
-            }
-            __syncthreads();
+        // (C4) dA = sum of the eight waves' partials (through the four slabs) -> ub
+        reduce_waves_to_slabs<D>(dacc, slabs, wave, g, il);
+        _Pragma("unroll 1") for (int idx = tid; idx < BM * D; idx += NTHREADS) {
+            const int d = idx / BM, r = idx % BM;
+            dasum[r * XLD + d] = slab_sum<D>(slabs, r, d);
         }
+        __syncthreads();
         // (C5) LayerNorm-2 backward; dx_mid = dY + LN2'(dA)
-        ln_backward_tile<D>(bk.x_mid + row0 * D, R, ub, bk.ln2_w, dxs, true, xh, bk.g_ln2_w, bk.g_ln2_b, tid);
+        ln_backward_tile<D>(bk.x_mid + row0 * D, R, dasum, bk.ln2_w, dxs, true, xh, bk.g_ln2_w, bk.g_ln2_b, tid);
 
+        TIMER_MARK(g_tm_bwd, 3);   // C4 + C5: reduction, LN2 backward
         // ================= token mixing backward =================
         // (T1) xhat1 -> xh, U = LN1(x_in) -> ub, rstd -> rstd_s
         {
-            const int r = tid >> 2, j = tid & 3;
-            float v[D / 4], mean, rstd;
-            row_stats_src<D>(bk.x_in + (row0 + r) * D, D, r < R, j, v, mean, rstd);
+            const int r = tid / TPR, j = tid % TPR;
+            float v[D / TPR], mean, rstd;
+            row_stats<D>(bk.x_in + (row0 + r) * D, r < R, j, v, mean, rstd);
             if (j == 0) rstd_s[r] = rstd;
 #pragma unroll
-            for (int e = 0; e < D / 4; ++e) {
-                const int c = ln_col(e, j);
+            for (int e = 0; e < D / TPR; ++e) {
+                const int c = ln_col<D>(e, j);
                 const float xhv = (v[e] - mean) * rstd;
                 xh[r * XLD + c] = xhv;
                 ub[r * XLD + c] = xhv * bk.ln1_w[c] + bk.ln1_b[c];
@@ -301,20 +282,23 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
             for (int n = 0; n < NMAX; ++n) ab2[n] = 0.f;
 
             const int npairs_tok = ns * D;
-            const int iters = (npairs_tok + 31) / 32;
+            constexpr int PL = NTHREADS / 8;              // columns handled concurrently
+            const int iters = (npairs_tok + PL - 1) / PL;
             for (int it = 0; it < iters; ++it) {
-                const int p = it * 32 + pl;
+                const int p = it * PL + pl;
                 const bool pv = p < npairs_tok;          // keep all lanes in the shuffles below
                 const int sl = pv ? p / D : 0, d = pv ? p % D : 0;
                 const unsigned int bd = (unsigned int)(s0 + sl) * D + d;
                 float un[NMAX], dv[NMAX], du[NMAX];
+                const unsigned int wth = half ? mix32(dr_th.key ^ bd) : 0u;
+                const unsigned int wto = half ? mix32(dr_to.key ^ bd) : 0u;
 #pragma unroll
                 for (int n = 0; n < NMAX; ++n) {
                     un[n] = 0.f; dv[n] = 0.f; du[n] = 0.f;
                     if (pv && n < N) {
                         un[n] = ub[(sl * N + n) * XLD + d];
                         float v = dxs[(sl * N + n) * XLD + d];
-                        if (dropping) v = drop_keep(dr_to, bd * N + n) ? v * dr_to.scale : 0.f;
+                        if (dropping) v = (half ? ((wto >> n) & 1u) : drop_keep(dr_to, bd * N + n)) ? v * dr_to.scale : 0.f;
                         dv[n] = v;
                     }
                 }
@@ -331,7 +315,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
                         float gl, dgl;
                         gelu_grad_f(h, gl, dgl);
                         bool keep = true;
-                        if (dropping) keep = drop_keep(dr_th, bd * T + t);
+                        if (dropping) keep = half ? ((wth >> t) & 1u) : drop_keep(dr_th, bd * T + t);
                         const float sc = dropping ? dr_th.scale : 1.0f;
                         const float hact = keep ? gl * sc : 0.f;
                         const float dhp = (keep && pv) ? dh * sc * dgl : 0.f;
@@ -347,10 +331,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
 #pragma unroll
                 for (int n = 0; n < NMAX; ++n) {
                     if (n < N) {
-                        float s = du[n];
-                        s += __shfl_xor(s, 1, 64);
-                        s += __shfl_xor(s, 2, 64);
-                        s += __shfl_xor(s, 4, 64);
+                        const float s = wave_sum_xor(du[n], 8);      // over the 8 lanes that share the column
                         if (pv && tg == 0) {
                             ub[(sl * N + n) * XLD + d] = s;
                             ab2[n] += dv[n];
@@ -358,14 +339,21 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
                     }
                 }
             }
-            // reduce the token-weight gradients over the 8 columns a wave handles at a time, then atomics
+            // reduce the token-weight gradients: over the 8 columns a wave handles at a time (shuffles), over the
+            // 8 waves (LDS atomics into `red`, which reuses the dA tile), then ONE global atomic per value
+            // per workgroup (the same ~300 addresses are hit by every workgroup of the launch).
+            //   red layout: [0, T*N) dW1[t][n] | [T*N, 2TN) dW2[n][t] | [2TN, 2TN+T) db1[t] | [2TN+T, +N) db2[n]
+            float* red = dasum;
+            const int nred = 2 * T * N + T + N;
+            for (int i = tid; i < nred; i += NTHREADS) red[i] = 0.f;
+            __syncthreads();
 #pragma unroll
             for (int tt = 0; tt < TTMAX; ++tt) {
                 if (tt < TT) {
                     const int t = tg * TT + tt;
                     float s = ab1[tt];
                     s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-                    if (lane < 8) atomicAdd(bk.g_tok_b1 + t, s);
+                    if (lane < 8) atomicAdd(red + 2 * T * N + t, s);
 #pragma unroll
                     for (int n = 0; n < NMAX; ++n) {
                         if (n < N) {
@@ -373,8 +361,8 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
                             a += __shfl_xor(a, 8, 64); a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
                             c += __shfl_xor(c, 8, 64); c += __shfl_xor(c, 16, 64); c += __shfl_xor(c, 32, 64);
                             if (lane < 8) {
-                                atomicAdd(bk.g_tok_w1 + t * N + n, a);
-                                atomicAdd(bk.g_tok_w2 + n * T + t, c);
+                                atomicAdd(red + t * N + n, a);
+                                atomicAdd(red + T * N + n * T + t, c);
                             }
                         }
                     }
@@ -385,21 +373,28 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
                 if (n < N) {
                     float s = ab2[n];   // non-zero on tg == 0 lanes only
                     s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-                    if (lane == 0) atomicAdd(bk.g_tok_b2 + n, s);
+                    if (lane == 0) atomicAdd(red + 2 * T * N + T + n, s);
                 }
+            }
+            __syncthreads();
+            for (int i = tid; i < nred; i += NTHREADS) {
+                float* dst = i < T * N ? bk.g_tok_w1 + i
+                           : (i < 2 * T * N ? bk.g_tok_w2 + (i - T * N)
+                           : (i < 2 * T * N + T ? bk.g_tok_b1 + (i - 2 * T * N) : bk.g_tok_b2 + (i - 2 * T * N - T)));
+                atomicAdd(dst, red[i]);
             }
         }
         __syncthreads();
         // (T2) LayerNorm-1 backward: dx_in = dx_mid + LN1'(dU); gamma/beta gradients
         {
-            const int r = tid >> 2, j = tid & 3;
+            const int r = tid / TPR, j = tid % TPR;
             const bool valid = r < R;
             const float rstd = rstd_s[r];
-            float gv[D / 4], xv[D / 4];
+            float gv[D / TPR], xv[D / TPR];
             float gsum = 0.f, gxsum = 0.f;
 #pragma unroll
-            for (int e = 0; e < D / 4; ++e) {
-                const int c = ln_col(e, j);
+            for (int e = 0; e < D / TPR; ++e) {
+                const int c = ln_col<D>(e, j);
                 const float u = ub[r * XLD + c];
                 const float xhv = xh[r * XLD + c];
                 const float gg = u * bk.ln1_w[c];
@@ -408,18 +403,18 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
                 gxsum = __builtin_fmaf(gg, xhv, gxsum);
                 xh[r * XLD + c] = valid ? u * xhv : 0.f;       // product tile for the gamma gradient
             }
-            gsum = wave_sum_xor(gsum, 4) * (1.0f / D);
-            gxsum = wave_sum_xor(gxsum, 4) * (1.0f / D);
+            gsum = wave_sum_xor(gsum, TPR) * (1.0f / D);
+            gxsum = wave_sum_xor(gxsum, TPR) * (1.0f / D);
             if (valid) {
 #pragma unroll
-                for (int e = 0; e < D / 4; ++e) {
-                    const int c = ln_col(e, j);
+                for (int e = 0; e < D / TPR; ++e) {
+                    const int c = ln_col<D>(e, j);
                     dxs[r * XLD + c] += rstd * (gv[e] - gsum - xv[e] * gxsum);
                 }
             }
         }
         __syncthreads();
-        for (int d = tid; d < 2 * D; d += NTHREADS) {
+        _Pragma("unroll 1") for (int d = tid; d < 2 * D; d += NTHREADS) {
             const float* src = d < D ? xh : ub;
             const int c = d < D ? d : d - D;
             float s = 0.f;
@@ -427,24 +422,25 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
             atomicAdd((d < D ? bk.g_ln1_w : bk.g_ln1_b) + c, s);
         }
         __syncthreads();
+        TIMER_MARK(g_tm_bwd, 5);   // T2: LN1 backward
     }
 
     // ---- gradient wrt the tower input ----
-    for (int idx = tid; idx < R * (D / 4); idx += NTHREADS) {
+    _Pragma("unroll 1") for (int idx = tid; idx < R * (D / 4); idx += NTHREADS) {
         const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
         *reinterpret_cast<float4*>(d_x0 + (long)(s0 + r / N) * d_x0_ss + (long)(r % N) * D + c) =
             *reinterpret_cast<const float4*>(dxs + r * XLD + c);
     }
 }
 
-template <int P, int D>
+template <int P, int D, int NMAX>
 static int launch_bwd(const m2m_tower* t, int B, const float* d_out, long d_out_ss, const float* d_pooled, float* d_x0,
                       long d_x0_ss, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
     const int SPW = BM / t->N;
     const int grid = (B + SPW - 1) / SPW;
-    const size_t tile_b = (size_t)BM * TileGeom<D>::XLD * sizeof(float), img_b = (size_t)BM * D * Prec<P>::ESZ;
-    const size_t lds = 2 * tile_b + (2 * img_b > tile_b ? 2 * img_b : tile_b) + BM * sizeof(float);
-    auto kern = tower_bwd_kernel<P, D, 8, 4>;
+    const size_t tile_b = (size_t)BM * TileGeom<D>::XLD * sizeof(float);
+    const size_t lds = 2 * tile_b + 4 * SlabGeom<D>::FLOATS * sizeof(float) + BM * sizeof(float);
+    auto kern = tower_bwd_kernel<P, D, NMAX, 4>;
     static bool attr_done = false;
     if (!attr_done) {
         M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -462,7 +458,8 @@ extern "C" int m2m_tower_backward(const m2m_tower* t, int B, const float* d_out,
     if (int rc = m2m_check_tower(t, B)) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define M2M_BWD_CASE(PP, DD) \
-    if (t->prec == PP && t->D == DD) return launch_bwd<PP, DD>(t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step, step_dev, st);
+    if (t->prec == PP && t->D == DD) return t->N <= 4 ? launch_bwd<PP, DD, 4>(t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step, step_dev, st) \
+                                                      : launch_bwd<PP, DD, 8>(t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step, step_dev, st);
     M2M_BWD_CASE(PREC_BF16, 32) M2M_BWD_CASE(PREC_BF16, 64) M2M_BWD_CASE(PREC_BF16, 128)
     M2M_BWD_CASE(PREC_F32, 32) M2M_BWD_CASE(PREC_F32, 64) M2M_BWD_CASE(PREC_F32, 128)
 #undef M2M_BWD_CASE

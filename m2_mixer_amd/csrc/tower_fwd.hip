@@ -3,14 +3,19 @@
 // Reference semantics: MixerBlock.forward (modules/mixer.py:42-47) applied num_mixers times, then
 // layer_norm (modules/mixer.py:128-131, :158-161, :182-185).
 //
-// Workgroup = 64 token rows (whole samples), resident in LDS as fp32 for the entire tower:
-//   token mixing   LN1 -> per (sample, channel) MLP over the N tokens on the VALU (N, T are tiny)
+// Workgroup = 32 token rows (whole samples), resident in LDS as fp32 for the entire tower; 8 waves:
+//   token mixing   LN1 -> per (sample, channel) MLP over the N tokens on the VALU (N, T are tiny);
+//                  the token weights sit zero-padded in LDS (broadcast reads, no bounds branches)
 //   channel mixing LN2 -> packed operand image in LDS; each wave takes 32 hidden columns at a time:
-//                  H^T[c][m] = W1 A^T (MFMA, W1 fragments straight from global in packed order),
-//                  bias + erf-GELU + dropout on the accumulators, which then ARE the A operand of
-//                  Y[m][d] += H W2^T (chained k order) -- the hidden activation never leaves registers.
-//   the four waves' partial Y are summed through LDS, then bias + dropout + residual.
+//                  H^T[c][m] = W1 A^T (MFMA, W1 fragments straight from global in packed order, the next
+//                  step's fragments prefetched under the epilogue), bias + erf-GELU + dropout on the
+//                  accumulators, which then ARE the A operand of Y[m][d] += H W2^T (chained k order)
+//                  -- the hidden activation never leaves registers.
+//   the eight waves' partial Y are summed through LDS slabs, then bias + dropout + residual.
 #include "tile.h"
+
+TIMER_DECL(g_tm_fwd);
+TIMER_READER(m2m_debug_timers_fwd, g_tm_fwd)
 
 template <int P, int D, int NMAX>
 __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw, const float* __restrict__ x0,
@@ -21,11 +26,16 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw,
     typedef Prec<P> Pr;
     typedef TileGeom<D> G;
     constexpr int XLD = G::XLD, DT = G::DT, KD = D / Pr::KB, NF = Chain<P>::NF;
+    constexpr int TW_LD = 2 * NMAX + 4;                          // token-weight row: W1 | W2^T | b1 | pad
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* xs = reinterpret_cast<float*>(smem);                 // residual stream  [BM][XLD]
-    float* ub = xs + BM * XLD;                                   // scratch tile     [BM][XLD]
-    char* at = reinterpret_cast<char*>(ub + BM * XLD);           // packed A image   BM*D*ESZ bytes
+    float* xs = reinterpret_cast<float*>(smem);                  // residual stream  [BM][XLD]
+    float* slabs = xs + BM * XLD;                                 // 4 transposed slabs [D][SLD]; slab 0 doubles as scratch `ub`
+    float* ub = slabs;
+    static_assert(SlabGeom<D>::FLOATS >= BM * XLD, "scratch tile must fit in slab 0");
+    char* at = reinterpret_cast<char*>(slabs + 4 * SlabGeom<D>::FLOATS);   // packed A image   BM*D*ESZ bytes
+    float* tokw = reinterpret_cast<float*>(at + BM * D * Pr::ESZ);   // [T <= 32][TW_LD]
+    float* tokb2 = tokw + 32 * TW_LD;                             // [NMAX]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
     const int N = tw.N, T = tw.T, Cp = tw.Cp;
@@ -36,8 +46,9 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw,
     const long row0 = (long)s0 * N;                              // first global token row of this tile
     const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
 
+    TIMER_START();
     // ---- load the input tile (rows >= R are zero) ----
-    for (int idx = tid; idx < BM * (D / 4); idx += NTHREADS) {
+    _Pragma("unroll 1") for (int idx = tid; idx < BM * (D / 4); idx += NTHREADS) {
         const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < R) v = *reinterpret_cast<const float4*>(x0 + (long)(s0 + r / N) * x0_ss + (long)(r % N) * D + c);
@@ -53,52 +64,67 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw,
         const Drop dr_ch = make_drop(training, tw.p_drop, seed, step, site + 2);
         const Drop dr_co = make_drop(training, tw.p_drop, seed, step, site + 3);
         const bool dropping = dr_th.thr < 65536u;
+        const bool half = dr_th.thr == 32768u;
 
-        // ---- save block input, LN1 -> ub ----
+        // ---- save block input, LN1 -> ub; token-MLP weights -> LDS (zero-padded to NMAX tokens) ----
+        //   tokw[t][0..NMAX) = W1[t][n]   tokw[t][NMAX..2NMAX) = W2[n][t]   tokw[t][2NMAX] = b1[t]
         if (training) {
-            for (int idx = tid; idx < R * (D / 4); idx += NTHREADS) {
+            _Pragma("unroll 1") for (int idx = tid; idx < R * (D / 4); idx += NTHREADS) {
                 const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
                 *reinterpret_cast<float4*>(bk.x_in + (row0 + r) * D + c) = *reinterpret_cast<const float4*>(xs + r * XLD + c);
             }
         }
+        _Pragma("unroll 1") for (int idx = tid; idx < T * TW_LD; idx += NTHREADS) {
+            const int t = idx / TW_LD, j = idx % TW_LD;
+            float v = 0.f;
+            if (j < NMAX) { if (j < N) v = bk.tok_w1[t * N + j]; }
+            else if (j < 2 * NMAX) { if (j - NMAX < N) v = bk.tok_w2[(j - NMAX) * T + t]; }
+            else if (j == 2 * NMAX) v = bk.tok_b1[t];
+            tokw[idx] = v;
+        }
+        if (tid < NMAX) tokb2[tid] = tid < N ? bk.tok_b2[tid] : 0.f;
         ln_to_tile<D>(xs, ub, bk.ln1_w, bk.ln1_b, tid);
         __syncthreads();
+        TIMER_MARK(g_tm_fwd, 0);   // load / save / LN1
 
         // ---- token mixing: one thread per (sample, channel) column (modules/mixer.py:30-35) ----
-        for (int p = tid; p < ns * D; p += NTHREADS) {
+        _Pragma("unroll 1") for (int p = tid; p < ns * D; p += NTHREADS) {
             const int sl = p / D, d = p % D;
             const unsigned int bd = (unsigned int)(s0 + sl) * D + d;
             float un[NMAX], o[NMAX];
 #pragma unroll
             for (int n = 0; n < NMAX; ++n) {
                 un[n] = (n < N) ? ub[(sl * N + n) * XLD + d] : 0.f;
-                o[n] = (n < N) ? bk.tok_b2[n] : 0.f;
+                o[n] = tokb2[n];
             }
+            // p == 0.5: one 32-bit word per column decides all T (<= 32) hidden units / all N outputs
+            const unsigned int wth = half ? mix32(dr_th.key ^ bd) : 0u;
+            const unsigned int wto = half ? mix32(dr_to.key ^ bd) : 0u;
             for (int t = 0; t < T; ++t) {
-                float h = bk.tok_b1[t];
+                const float* wr = tokw + t * TW_LD;
+                float h = wr[2 * NMAX];
 #pragma unroll
-                for (int n = 0; n < NMAX; ++n)
-                    if (n < N) h = __builtin_fmaf(bk.tok_w1[t * N + n], un[n], h);
+                for (int n = 0; n < NMAX; ++n) h = __builtin_fmaf(wr[n], un[n], h);
                 h = gelu_f(h);
-                if (dropping) h = drop_keep(dr_th, bd * T + t) ? h * dr_th.scale : 0.f;
+                if (dropping) h = (half ? ((wth >> t) & 1u) : drop_keep(dr_th, bd * T + t)) ? h * dr_th.scale : 0.f;
 #pragma unroll
-                for (int n = 0; n < NMAX; ++n)
-                    if (n < N) o[n] = __builtin_fmaf(bk.tok_w2[n * T + t], h, o[n]);
+                for (int n = 0; n < NMAX; ++n) o[n] = __builtin_fmaf(wr[NMAX + n], h, o[n]);
             }
 #pragma unroll
             for (int n = 0; n < NMAX; ++n) {
                 if (n < N) {
                     float v = o[n];
-                    if (dropping) v = drop_keep(dr_to, bd * N + n) ? v * dr_to.scale : 0.f;
+                    if (dropping) v = (half ? ((wto >> n) & 1u) : drop_keep(dr_to, bd * N + n)) ? v * dr_to.scale : 0.f;
                     xs[(sl * N + n) * XLD + d] += v;
                 }
             }
         }
         __syncthreads();
+        TIMER_MARK(g_tm_fwd, 1);   // token mixing
 
         // ---- save x_mid, LN2 -> packed operand image ----
         if (training) {
-            for (int idx = tid; idx < R * (D / 4); idx += NTHREADS) {
+            _Pragma("unroll 1") for (int idx = tid; idx < R * (D / 4); idx += NTHREADS) {
                 const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
                 *reinterpret_cast<float4*>(bk.x_mid + (row0 + r) * D + c) = *reinterpret_cast<const float4*>(xs + r * XLD + c);
             }
@@ -107,6 +133,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw,
         __syncthreads();
         pack_tile_nat<P, D>(ub, at, tid);
         __syncthreads();
+        TIMER_MARK(g_tm_fwd, 2);   // save x_mid, LN2, pack
 
         // ---- channel mixing (modules/mixer.py:37-40), each wave owns 32 hidden columns per step ----
         f32x4_t yacc[MT][DT];
@@ -116,12 +143,20 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw,
             for (int dt = 0; dt < DT; ++dt) yacc[mt][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
         const int npairs = Cp >> 5;
-        for (int q = wave; q < npairs; q += 4) {
-            Frag w1f[2][KD];
+        Frag w1f[2][KD];
+        if (wave < npairs) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int kb = 0; kb < KD; ++kb) w1f[t][kb] = ld_frag_global(bk.w1n, (long)(2 * q + t) * KD + kb, lane);
+                for (int kb = 0; kb < KD; ++kb) w1f[t][kb] = ld_frag_global(bk.w1n, (long)(2 * wave + t) * KD + kb, lane);
+        }
+        for (int q = wave; q < npairs; q += NWAVES) {
+            // this step's W2 fragments: in flight during GEMM1 + epilogue
+            Frag w2f[NF][DT];
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) w2f[f][dt] = ld_frag_global(bk.w2c, (long)(q * NF + f) * DT + dt, lane);
             f32x4_t bias[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) bias[t] = *reinterpret_cast<const f32x4_t*>(bk.ch_b1p + 32 * q + 16 * t + 4 * g);
@@ -131,70 +166,71 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw,
             for (int mt = 0; mt < MT; ++mt) {
                 hacc[mt][0] = bias[0];
                 hacc[mt][1] = bias[1];
+            }
 #pragma unroll
-                for (int kb = 0; kb < KD; ++kb) {
+            for (int kb = 0; kb < KD; ++kb) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
                     const Frag a = ld_frag_lds(at, mt * KD + kb, lane);
                     Pr::mma(hacc[mt][0], w1f[0][kb], a);
                     Pr::mma(hacc[mt][1], w1f[1][kb], a);
                 }
             }
-            // bias is already in; GELU + dropout on the accumulators (row c = 4g + r, column m = il)
+            // prefetch the next step's W1 fragments under the epilogue
+            if (q + NWAVES < npairs) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int kb = 0; kb < KD; ++kb)
+                        w1f[t][kb] = ld_frag_global(bk.w1n, (long)(2 * (q + NWAVES) + t) * KD + kb, lane);
+            }
+            // bias is already in; GELU + dropout on the accumulators (row c = 32q + 16t + 4g + r, column m = il)
             Frag hf[MT][NF];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const unsigned int m = (unsigned int)(row0 + mt * 16 + il);
+                unsigned int word = 0xFFFFFFFFu;
+                if (half) word = drop_word_half(dr_ch, m, q, npairs);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     bool keep[4] = {true, true, true, true};
-                    if (dropping) drop_keep4(dr_ch, m * (unsigned int)Cp + 32 * q + 16 * t + 4 * g, keep);
+                    if (dropping && !half) drop_keep4(dr_ch, m * (unsigned int)Cp + 32 * q + 16 * t + 4 * g, keep);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float v = gelu_f(hacc[mt][t][r]);
-                        if (dropping) v = keep[r] ? v * dr_ch.scale : 0.f;
-                        hacc[mt][t][r] = v;
+                        float v = gelu_f(hacc[mt][t][r]) * dr_ch.scale;
+                        const bool k = half ? ((word >> (16 * t + 4 * g + r)) & 1u) : keep[r];
+                        hacc[mt][t][r] = k ? v : 0.f;
                     }
                 }
                 Chain<P>::make(hacc[mt][0], hacc[mt][1], hf[mt]);
             }
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {
+            for (int f = 0; f < NF; ++f)
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
-                    const Frag w2 = ld_frag_global(bk.w2c, (long)(q * NF + f) * DT + dt, lane);
+                for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) Pr::mma(yacc[mt][dt], hf[mt][f], w2);
-                }
-            }
+                    for (int mt = 0; mt < MT; ++mt) Pr::mma(yacc[mt][dt], hf[mt][f], w2f[f][dt]);
         }
+        TIMER_MARK(g_tm_fwd, 3);   // hidden-column loop (wave 0)
 
-        // ---- sum the four waves' partial Y in LDS (fixed order: deterministic) ----
-        for (int w = 0; w < 4; ++w) {
-            if (wave == w) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float* p = ub + (mt * 16 + 4 * g + r) * XLD + dt * 16 + il;
-                            *p = (w == 0) ? yacc[mt][dt][r] : (*p + yacc[mt][dt][r]);
-                        }
+        // ---- sum the eight waves' partial Y (deterministic order), then + bias, dropout, residual ----
+        __syncthreads();           // every wave is done with `at` / ub before the slabs are overwritten
+        reduce_waves_to_slabs<D>(yacc, slabs, wave, g, il);
+        _Pragma("unroll 1") for (int idx = tid; idx < BM * D; idx += NTHREADS) {
+            const int d = idx / BM, r = idx % BM;
+            if (r < R) {
+                float v = slab_sum<D>(slabs, r, d) + bk.ch_b2[d];
+                if (dropping) v = drop_keep(dr_co, (unsigned int)(row0 + r) * D + d) ? v * dr_co.scale : 0.f;
+                xs[r * XLD + d] += v;
             }
-            __syncthreads();
-        }
-        // ---- + bias, dropout, residual ----
-        for (int idx = tid; idx < R * D; idx += NTHREADS) {
-            const int r = idx / D, d = idx % D;
-            float v = ub[r * XLD + d] + bk.ch_b2[d];
-            if (dropping) v = drop_keep(dr_co, (unsigned int)(row0 + r) * D + d) ? v * dr_co.scale : 0.f;
-            xs[r * XLD + d] += v;
         }
         __syncthreads();
+        TIMER_MARK(g_tm_fwd, 4);   // wave reduction + bias/dropout/residual
     }
 
     // ---- final LayerNorm (modules/mixer.py:131,161,185), output + token mean ----
     if (training && tw.x_final) {
-        for (int idx = tid; idx < R * (D / 4); idx += NTHREADS) {
+        _Pragma("unroll 1") for (int idx = tid; idx < R * (D / 4); idx += NTHREADS) {
             const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
             *reinterpret_cast<float4*>(tw.x_final + (row0 + r) * D + c) = *reinterpret_cast<const float4*>(xs + r * XLD + c);
         }
@@ -205,34 +241,35 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw,
         res = ub;
         __syncthreads();
     }
-    for (int idx = tid; idx < R * (D / 4); idx += NTHREADS) {
+    _Pragma("unroll 1") for (int idx = tid; idx < R * (D / 4); idx += NTHREADS) {
         const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
         *reinterpret_cast<float4*>(out + (long)(s0 + r / N) * out_ss + (long)(r % N) * D + c) =
             *reinterpret_cast<const float4*>(res + r * XLD + c);
     }
     if (pooled) {
         const float inv = 1.0f / (float)N;
-        for (int p = tid; p < ns * D; p += NTHREADS) {
+        _Pragma("unroll 1") for (int p = tid; p < ns * D; p += NTHREADS) {
             const int sl = p / D, d = p % D;
             float s = 0.f;
             for (int n = 0; n < N; ++n) s += res[(sl * N + n) * XLD + d];
             pooled[(long)(s0 + sl) * D + d] = s * inv;
         }
     }
+    TIMER_MARK(g_tm_fwd, 5);       // final LN, output, pooled
 }
 
 template <int P, int D>
 static size_t fwd_lds_bytes() {
-    return (size_t)2 * BM * TileGeom<D>::XLD * sizeof(float) + (size_t)BM * D * Prec<P>::ESZ;
+    return (size_t)(BM * TileGeom<D>::XLD + 4 * SlabGeom<D>::FLOATS) * sizeof(float) + (size_t)BM * D * Prec<P>::ESZ + (32 * 20 + 8) * sizeof(float);
 }
 
-template <int P, int D>
+template <int P, int D, int NMAX>
 static int launch_fwd(const m2m_tower* t, const float* x0, long x0_ss, int B, float* out, long out_ss, float* pooled,
                       int training, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
     const int SPW = BM / t->N;
     const int grid = (B + SPW - 1) / SPW;
     const size_t lds = fwd_lds_bytes<P, D>();
-    auto kern = tower_fwd_kernel<P, D, 8>;
+    auto kern = tower_fwd_kernel<P, D, NMAX>;
     static bool attr_done = false;
     if (!attr_done) {
         M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -250,7 +287,8 @@ extern "C" int m2m_tower_forward(const m2m_tower* t, const float* x0, int64_t x0
     if (int rc = m2m_check_tower(t, B)) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define M2M_FWD_CASE(PP, DD) \
-    if (t->prec == PP && t->D == DD) return launch_fwd<PP, DD>(t, x0, x0_ss, B, out, out_ss, pooled, training, seed, step, step_dev, st);
+    if (t->prec == PP && t->D == DD) return t->N <= 4 ? launch_fwd<PP, DD, 4>(t, x0, x0_ss, B, out, out_ss, pooled, training, seed, step, step_dev, st) \
+                                                      : launch_fwd<PP, DD, 8>(t, x0, x0_ss, B, out, out_ss, pooled, training, seed, step, step_dev, st);
     M2M_FWD_CASE(PREC_BF16, 32) M2M_FWD_CASE(PREC_BF16, 64) M2M_FWD_CASE(PREC_BF16, 128)
     M2M_FWD_CASE(PREC_F32, 32) M2M_FWD_CASE(PREC_F32, 64) M2M_FWD_CASE(PREC_F32, 128)
 #undef M2M_FWD_CASE

@@ -3,13 +3,19 @@
 //   dW1[c][d] = sum_m dHpre[m][c] A[m][d]      dW2[d][c] = sum_m dYd[m][d] Hact[m][c]      db1[c] = sum_m dHpre[m][c]
 //
 // The contraction runs over ALL token rows, so the roles flip relative to the forward/backward chain:
-// a workgroup owns 128 hidden columns of one block (each wave 32, its W1 / W2^T fragments and its
-// 32x128 slices of dW1 and dW2^T stay in registers) and streams the 64-row operand tiles that
-// tower_bwd.hip wrote (A, A^T, dYd, dYd^T, already in packed MFMA order) through LDS.  Per tile it
-// recomputes Hpre = A W1^T + b1 and dHact = dYd W2 (hidden activations are never stored), applies
-// GELU / GELU' / dropout on the accumulators and chains them (k = row index) into the two products.
-// Row groups (grid.z) that share a column slice add their partial results with float atomics.
+// a workgroup owns 128 hidden columns of one block (each of its 8 waves 16; the wave's W1 / W2^T
+// fragments and its 16x128 slices of dW1 and dW2^T stay in registers: 2 waves per SIMD need <= 256 VGPRs) and streams the 32-row operand
+// tiles that tower_bwd.hip wrote (A, A^T, dYd, dYd^T, already in packed MFMA order) through a
+// double-buffered LDS stage (global loads of tile t+1 are issued before tile t is computed and written
+// to LDS after it).  Per tile it recomputes Hpre = A W1^T + b1 and dHact = dYd W2 (hidden activations
+// are never stored), applies GELU / GELU' / dropout on the accumulators and chains them (k = row
+// index) into the two products.  With one row group (the default when the launch already has enough
+// workgroups) every result element has a single owner and is written without atomics.
 #include "tile.h"
+#include <stdlib.h>
+
+TIMER_DECL(g_tm_wg);
+TIMER_READER(m2m_debug_timers_wgrad, g_tm_wg)
 
 template <int P, int D>
 __global__ __launch_bounds__(NTHREADS) void tower_wgrad_kernel(const m2m_tower tw, int ntiles, int tiles_per_group,
@@ -18,160 +24,186 @@ __global__ __launch_bounds__(NTHREADS) void tower_wgrad_kernel(const m2m_tower t
     typedef Prec<P> Pr;
     constexpr int DT = D / 16, KD = D / Pr::KB, NF = Chain<P>::NF;
     constexpr int IMG_B = BM * D * Pr::ESZ;
-    constexpr int NKM = BM / Pr::KB;                 // k-blocks over the 64 rows of a tile
+    constexpr int STAGE_B = 4 * IMG_B;                      // A | dYd | A^T | dYd^T of one tile
+    constexpr int NLD = STAGE_B / (NTHREADS * 16);          // 16-byte pieces per thread per tile
+    static_assert(STAGE_B % (NTHREADS * 16) == 0, "tile stage must split evenly over the threads");
+    static_assert(IMG_B % (NTHREADS * 16) == 0 || (NTHREADS * 16) % IMG_B == 0, "piece never straddles two images");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* a_nat = smem;
-    char* dy_nat = smem + IMG_B;
-    char* at_chn = smem + 2 * IMG_B;
-    char* dyt_chn = smem + 3 * IMG_B;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
     const m2m_block& bk = tw.blk[blockIdx.y];
     const int Cp = tw.Cp, C = tw.C;
-    const int q = blockIdx.x * 4 + wave;             // this wave's pair of 16-column tiles
-    const bool active = q < (Cp >> 5);
+    const int npairs = Cp >> 5;
+    const int ct = blockIdx.x * NWAVES + wave;              // this wave's 16-column tile
+    const bool active = ct < (Cp >> 4);
+    const int q = ct >> 1, tq = ct & 1;                     // pair / half of the pair (dropout word addressing)
     const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
     const unsigned int site = tw.site_base + 4u * blockIdx.y;
     const Drop dr_ch = make_drop(true, tw.p_drop, seed, step, site + 2);
     const bool dropping = dr_ch.thr < 65536u;
+    const bool half = dr_ch.thr == 32768u;
 
-    Frag w1f[2][KD], w2f[2][KD];
-    float bias[2];
-    f32x4_t dw1[2][DT], dw2[2][DT];
-    float db1[2] = {0.f, 0.f};
+    Frag w1f[KD], w2f[KD];
+    f32x4_t dw1[DT], dw2[DT];
+    float db1 = 0.f;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-#pragma unroll
-        for (int kb = 0; kb < KD; ++kb) {
-            w1f[t][kb].u = u32x4_t{0u, 0u, 0u, 0u};
-            w2f[t][kb].u = u32x4_t{0u, 0u, 0u, 0u};
-            if (active) {
-                w1f[t][kb] = ld_frag_global(bk.w1n, (long)(2 * q + t) * KD + kb, lane);
-                w2f[t][kb] = ld_frag_global(bk.w2tn, (long)(2 * q + t) * KD + kb, lane);
-            }
-        }
-        bias[t] = active ? bk.ch_b1p[32 * q + 16 * t + il] : 0.f;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            dw1[t][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            dw2[t][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < KD; ++kb) {
+        w1f[kb].u = u32x4_t{0u, 0u, 0u, 0u};
+        w2f[kb].u = u32x4_t{0u, 0u, 0u, 0u};
+        if (active) {
+            w1f[kb] = ld_frag_global(bk.w1n, (long)ct * KD + kb, lane);
+            w2f[kb] = ld_frag_global(bk.w2tn, (long)ct * KD + kb, lane);
         }
     }
+    const float bias = active ? bk.ch_b1p[16 * ct + il] : 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        dw1[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        dw2[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
 
+    // the four packed images of a tile, as NLD 16-byte pieces per thread
+    const char* src_a = reinterpret_cast<const char*>(bk.a_nat);
+    const char* src_dy = reinterpret_cast<const char*>(bk.dy_nat);
+    const char* src_at = reinterpret_cast<const char*>(bk.at_chn);
+    const char* src_dyt = reinterpret_cast<const char*>(bk.dyt_chn);
+    u32x4_t pre[NLD];
+#define STAGE_LOAD(tile_)                                                                          \
+    _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                              \
+        const int o = (i * NTHREADS + tid) * 16;                                                   \
+        const int img = o / IMG_B, oo = o % IMG_B;                                                 \
+        const char* sp = img == 0 ? src_a : (img == 1 ? src_dy : (img == 2 ? src_at : src_dyt));   \
+        pre[i] = *reinterpret_cast<const u32x4_t*>(sp + (long)(tile_) * IMG_B + oo);               \
+    }
+#define STAGE_STORE(buf_)                                                                          \
+    _Pragma("unroll") for (int i = 0; i < NLD; ++i)                                                \
+        *reinterpret_cast<u32x4_t*>((buf_) + (i * NTHREADS + tid) * 16) = pre[i];
+
+    TIMER_START();
     const int t_begin = blockIdx.z * tiles_per_group;
     const int t_end = min(ntiles, t_begin + tiles_per_group);
+    if (t_begin < t_end) {
+        STAGE_LOAD(t_begin)
+        STAGE_STORE(smem)
+    }
+    __syncthreads();
     for (int tile = t_begin; tile < t_end; ++tile) {
-        const long off = (long)tile * IMG_B;
-        __syncthreads();                               // previous tile fully consumed
-        copy16(a_nat, reinterpret_cast<const char*>(bk.a_nat) + off, IMG_B, tid);
-        copy16(dy_nat, reinterpret_cast<const char*>(bk.dy_nat) + off, IMG_B, tid);
-        copy16(at_chn, reinterpret_cast<const char*>(bk.at_chn) + off, IMG_B, tid);
-        copy16(dyt_chn, reinterpret_cast<const char*>(bk.dyt_chn) + off, IMG_B, tid);
-        __syncthreads();
-        if (!active) continue;
-        const unsigned int mrow0 = (unsigned int)tile * rows_per_tile;   // global token row of the tile's row 0
-
-        // two 16-row tiles at a time: their accumulators chain into one k-block (bf16) / two (fp32)
+        char* cur = smem + ((tile - t_begin) & 1) * STAGE_B;
+        char* nxt = smem + (((tile - t_begin) & 1) ^ 1) * STAGE_B;
+        const bool more = tile + 1 < t_end;
+        if (more) { STAGE_LOAD(tile + 1) }                   // in flight during this tile's math
+        const char* a_nat = cur;
+        const char* dy_nat = cur + IMG_B;
+        const char* at_chn = cur + 2 * IMG_B;
+        const char* dyt_chn = cur + 3 * IMG_B;
+        TIMER_MARK(g_tm_wg, 0);
+        if (active) {
+            const unsigned int mrow0 = (unsigned int)tile * rows_per_tile;   // global token row of the tile's row 0
+            // the tile's two 16-row sub-tiles chain into one k-block (bf16) / two (fp32)
+            f32x4_t hact[2], dhp[2];                        // [row sub-tile]
 #pragma unroll
-        for (int mb = 0; mb < MT / 2; ++mb) {
-            f32x4_t hact[2][2], dhp[2][2];             // [row tile in pair][column tile]
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int mt = 2 * mb + u;
-                f32x4_t hacc[2] = {f32x4_t{bias[0], bias[0], bias[0], bias[0]}, f32x4_t{bias[1], bias[1], bias[1], bias[1]}};
-                f32x4_t gacc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+            for (int u = 0; u < MT; ++u) {
+                f32x4_t hacc = f32x4_t{bias, bias, bias, bias};
+                f32x4_t gacc = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kb = 0; kb < KD; ++kb) {
-                    const Frag a = ld_frag_lds(a_nat, mt * KD + kb, lane);
-                    const Frag dy = ld_frag_lds(dy_nat, mt * KD + kb, lane);
-                    Pr::mma(hacc[0], a, w1f[0][kb]);
-                    Pr::mma(hacc[1], a, w1f[1][kb]);
-                    Pr::mma(gacc[0], dy, w2f[0][kb]);
-                    Pr::mma(gacc[1], dy, w2f[1][kb]);
+                    const Frag a = ld_frag_lds(a_nat, u * KD + kb, lane);
+                    const Frag dy = ld_frag_lds(dy_nat, u * KD + kb, lane);
+                    Pr::mma(hacc, a, w1f[kb]);
+                    Pr::mma(gacc, dy, w2f[kb]);
                 }
-                // accumulator element r: row m = 16 mt + 4 g + r, column c = 32 q + 16 t + il
+                // accumulator element r: row m = 16 u + 4 g + r, column c = 16 ct + il
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float gl, dgl;
-                        gelu_grad_f(hacc[t][r], gl, dgl);
-                        float hv = gl, dv = gacc[t][r] * dgl;
-                        if (dropping) {
-                            const unsigned int m = mrow0 + 16 * mt + 4 * g + r;
-                            const bool keep = drop_keep(dr_ch, m * (unsigned int)Cp + 32 * q + 16 * t + il);
-                            hv = keep ? hv * dr_ch.scale : 0.f;
-                            dv = keep ? dv * dr_ch.scale : 0.f;
-                        }
-                        hact[u][t][r] = hv;
-                        dhp[u][t][r] = dv;
-                        db1[t] += dv;
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned int m = mrow0 + 16 * u + 4 * g + r;
+                    float gl, dgl;
+                    gelu_grad_f(hacc[r], gl, dgl);
+                    bool keep = true;
+                    if (half) keep = (drop_word_half(dr_ch, m, q, npairs) >> (16 * tq + il)) & 1u;
+                    else if (dropping) keep = drop_keep(dr_ch, m * (unsigned int)Cp + 16 * ct + il);
+                    const float hv = keep ? gl * dr_ch.scale : 0.f;
+                    const float dv = keep ? gacc[r] * dgl * dr_ch.scale : 0.f;
+                    hact[u][r] = hv;
+                    dhp[u][r] = dv;
+                    db1 += dv;
                 }
             }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            TIMER_MARK(g_tm_wg, 1);
+            {
                 Frag hf[NF], df[NF];
-                Chain<P>::make(hact[0][t], hact[1][t], hf);
-                Chain<P>::make(dhp[0][t], dhp[1][t], df);
+                Chain<P>::make(hact[0], hact[1], hf);
+                Chain<P>::make(dhp[0], dhp[1], df);
 #pragma unroll
                 for (int f = 0; f < NF; ++f) {
-                    const int kbm = mb * NF + f;       // k-block over the tile's rows
 #pragma unroll
                     for (int dt = 0; dt < DT; ++dt) {
-                        const Frag at = ld_frag_lds(at_chn, kbm * DT + dt, lane);
-                        const Frag dyt = ld_frag_lds(dyt_chn, kbm * DT + dt, lane);
-                        Pr::mma(dw1[t][dt], df[f], at);
-                        Pr::mma(dw2[t][dt], hf[f], dyt);
+                        const Frag at = ld_frag_lds(at_chn, f * DT + dt, lane);
+                        const Frag dyt = ld_frag_lds(dyt_chn, f * DT + dt, lane);
+                        Pr::mma(dw1[dt], df[f], at);
+                        Pr::mma(dw2[dt], hf[f], dyt);
                     }
                 }
             }
+            TIMER_MARK(g_tm_wg, 2);
         }
+        if (more) { STAGE_STORE(nxt) }
+        __syncthreads();
+        TIMER_MARK(g_tm_wg, 3);
     }
+#undef STAGE_LOAD
+#undef STAGE_STORE
 
     if (!active) return;
     const bool single = gridDim.z == 1;
-    // ---- results: dw1[t][dt][r] = dW1[c = 32q + 16t + 4g + r][d = 16dt + il]; dw2 likewise = dW2[d][c] ----
+    // ---- results: dw1[dt][r] = dW1[c = 16ct + 4g + r][d = 16dt + il]; dw2 likewise = dW2[d][c] ----
+    {
+        const int c0 = 16 * ct + 4 * g;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d = 16 * dt + il;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int c = 32 * q + 16 * t + 4 * g + r, d = 16 * dt + il;
-                if (c < C) {
-                    if (single) {       // sole owner of these elements: plain read-modify-write
-                        bk.g_ch_w1[(long)c * D + d] += dw1[t][dt][r];
-                        bk.g_ch_w2[(long)d * C + c] += dw2[t][dt][r];
-                    } else {
-                        atomicAdd(bk.g_ch_w1 + (long)c * D + d, dw1[t][dt][r]);
-                        atomicAdd(bk.g_ch_w2 + (long)d * C + c, dw2[t][dt][r]);
-                    }
+                if (c0 + r < C) {
+                    float* p1 = bk.g_ch_w1 + (long)(c0 + r) * D + d;
+                    if (single) *p1 += dw1[dt][r]; else atomicAdd(p1, dw1[dt][r]);
                 }
             }
-        float s = db1[t];
+            float* p2 = bk.g_ch_w2 + (long)d * C + c0;      // four consecutive c of row d
+            if (single && c0 + 3 < C && (C & 3) == 0) {
+                float4 o = *reinterpret_cast<float4*>(p2);
+                o.x += dw2[dt][0]; o.y += dw2[dt][1]; o.z += dw2[dt][2]; o.w += dw2[dt][3];
+                *reinterpret_cast<float4*>(p2) = o;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c0 + r < C) { if (single) p2[r] += dw2[dt][r]; else atomicAdd(p2 + r, dw2[dt][r]); }
+            }
+        }
+        float s = db1;
         s += __shfl_xor(s, 16, 64);
         s += __shfl_xor(s, 32, 64);
-        const int c = 32 * q + 16 * t + il;
+        const int c = 16 * ct + il;
         if (g == 0 && c < C) { if (single) bk.g_ch_b1[c] += s; else atomicAdd(bk.g_ch_b1 + c, s); }
     }
+    TIMER_MARK(g_tm_wg, 4);        // result write-out
 }
 
 template <int P, int D>
 static int launch_wgrad(const m2m_tower* t, int B, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
     const int SPW = BM / t->N;
     const int ntiles = (B + SPW - 1) / SPW;
-    const int nsl = ((t->Cp >> 5) + 3) / 4;
-    // Row groups trade parallelism against float-atomic traffic (every group re-adds the whole slice):
-    // aim at ~192 workgroups per launch, at least 4 tiles per group.
-    int groups = (192 + (nsl * t->nblocks) / 2) / (nsl * t->nblocks);
+    const int nsl = ((t->Cp >> 4) + NWAVES - 1) / NWAVES;      // 128-column slices
+    // Row groups trade parallelism against float-atomic traffic (every extra group re-adds the whole slice);
+    // one group = single owner per element, no atomics.  Aim at >= ~96 workgroups per launch.
+    int groups = (96 + nsl * t->nblocks - 1) / (nsl * t->nblocks);
+    if (const char* e = getenv("M2M_WGRAD_GROUPS")) groups = atoi(e);
     if (groups < 1) groups = 1;
     int tpg = (ntiles + groups - 1) / groups;
     if (tpg < 4) tpg = 4;
     if (tpg > ntiles) tpg = ntiles;
     groups = (ntiles + tpg - 1) / tpg;
-    const size_t lds = (size_t)4 * BM * D * Prec<P>::ESZ;
+    const size_t lds = (size_t)2 * 4 * BM * D * Prec<P>::ESZ;
     auto kern = tower_wgrad_kernel<P, D>;
     static bool attr_done = false;
     if (!attr_done) {
