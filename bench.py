@@ -232,6 +232,7 @@ def profile_launches(eng, image, audio, labels, nsteps):
         return wrapper
 
     saved = []
+    was_concurrent, eng.concurrent = eng.concurrent, False     # serialise: one launch in flight at a time
 
     def patch(obj, attr, name, flops):
         orig = getattr(obj, attr)
@@ -274,6 +275,7 @@ def profile_launches(eng, image, audio, labels, nsteps):
         for obj, attr, orig in saved:
             setattr(obj, attr, orig)
         E.heads_ce = orig_heads
+        eng.concurrent = was_concurrent
     out = {}
     for name, sp in spans.items():
         times = [a.elapsed_time(b) * 1e3 for a, b in sp["events"]]      # us

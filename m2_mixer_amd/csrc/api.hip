@@ -94,22 +94,60 @@ __global__ void pad_copy_kernel(const float* __restrict__ src, float* __restrict
     if (i < np) dst[i] = i < n ? src[i] : 0.f;
 }
 
+// All packed copies of every block of a tower in ONE launch: blockIdx.y = 5 * block + which,
+// which: 0 w1n, 1 w1tc, 2 w2c, 3 w2tn (same layouts as pack_impl), 4 ch_b1p.
+template <int P>
+__global__ void pack_tower_kernel(const m2m_tower tw) {
+    typedef Prec<P> Pr;
+    const m2m_block& k = tw.blk[blockIdx.y / 5];
+    const int which = blockIdx.y % 5;
+    const long D = tw.D, C = tw.C, Cp = tw.Cp;
+    const long slot = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (which == 4) {
+        if (slot < Cp) k.ch_b1p[slot] = slot < C ? k.ch_b1[slot] : 0.f;
+        return;
+    }
+    // logical operand X[i][k] = src[i * si + kk * sk], i < I, kk < K, image padded to (Ip, Kp)
+    const float* src; long si, sk, I, K, Ip, Kp; int mode, kmajor; char* dst;
+    if (which == 0)      { src = k.ch_w1; si = D; sk = 1; I = C; K = D; Ip = Cp; Kp = D;  mode = PACK_NAT; kmajor = 0; dst = (char*)k.w1n; }
+    else if (which == 1) { src = k.ch_w1; si = 1; sk = D; I = D; K = C; Ip = D;  Kp = Cp; mode = PACK_CHN; kmajor = 1; dst = (char*)k.w1tc; }
+    else if (which == 2) { src = k.ch_w2; si = C; sk = 1; I = D; K = C; Ip = D;  Kp = Cp; mode = PACK_CHN; kmajor = 1; dst = (char*)k.w2c; }
+    else                 { src = k.ch_w2; si = 1; sk = C; I = C; K = D; Ip = Cp; Kp = D;  mode = PACK_NAT; kmajor = 0; dst = (char*)k.w2tn; }
+    const long nIB = Ip / 16, nKB = Kp / Pr::KB;
+    if (slot >= nIB * nKB * 64) return;
+    const long blk = slot >> 6;
+    const int lane = (int)(slot & 63), g = lane >> 4, il = lane & 15;
+    long ib, kb;
+    if (kmajor) { kb = blk / nIB; ib = blk % nIB; } else { ib = blk / nKB; kb = blk % nKB; }
+    const long i = ib * 16 + il;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < Pr::EPL; ++e) {
+        const long kk = kb * Pr::KB + Pr::kmap(mode, g, e);
+        v[e] = (i < I && kk < K) ? src[i * si + kk * sk] : 0.f;
+    }
+    Frag f;
+    if (P == PREC_BF16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f.u[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f.f[e] = v[e];
+    }
+    *reinterpret_cast<u32x4_t*>(dst + slot * 16) = f.u;
+}
+
 extern "C" int m2m_pack_tower(const m2m_tower* t, void* stream) {
     if (int rc = m2m_check_tower(t, 1)) return rc;
-    const int D = t->D, C = t->C, Cp = t->Cp;
-    for (int b = 0; b < t->nblocks; ++b) {
-        const m2m_block* k = &t->blk[b];
-        int rc;
-        // W1 (C, D): NAT [i=c][k=d] k-minor ; CHN [i=d][k=c] k-major (transposed read)
-        if ((rc = pack_impl(t->prec, PACK_NAT, 0, k->ch_w1, D, 1, C, D, Cp, D, k->w1n, stream))) return rc;
-        if ((rc = pack_impl(t->prec, PACK_CHN, 1, k->ch_w1, 1, D, D, C, D, Cp, k->w1tc, stream))) return rc;
-        // W2 (D, C): CHN [i=d][k=c] k-major ; NAT [i=c][k=d] k-minor (transposed read)
-        if ((rc = pack_impl(t->prec, PACK_CHN, 1, k->ch_w2, C, 1, D, C, D, Cp, k->w2c, stream))) return rc;
-        if ((rc = pack_impl(t->prec, PACK_NAT, 0, k->ch_w2, 1, C, C, D, Cp, D, k->w2tn, stream))) return rc;
-        hipLaunchKernelGGL(pad_copy_kernel, dim3((Cp + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                           k->ch_b1, k->ch_b1p, C, Cp);
-        M2M_CHECK_HIP(hipGetLastError());
-    }
+    if (t->nblocks == 0) return 0;
+    const long KB = t->prec == PREC_BF16 ? 32 : 16;
+    const long nslots = (long)(t->Cp / 16) * (t->D / KB) * 64;
+    const long need = nslots > t->Cp ? nslots : t->Cp;
+    const dim3 grid((unsigned)ceil_div(need, 256), (unsigned)(5 * t->nblocks));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (t->prec == PREC_BF16) hipLaunchKernelGGL(pack_tower_kernel<PREC_BF16>, grid, dim3(256), 0, st, *t);
+    else hipLaunchKernelGGL(pack_tower_kernel<PREC_F32>, grid, dim3(256), 0, st, *t);
+    M2M_CHECK_HIP(hipGetLastError());
     return 0;
 }
 

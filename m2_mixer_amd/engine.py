@@ -149,6 +149,10 @@ class AVMnistEngine:
         self.preds = torch.zeros(3, B, dtype=torch.int32, device=dev)
         self._graph = None
         self._static = None
+        # the audio tower / the fusion weight gradients run beside the image tower on side streams
+        self.s_aud = torch.cuda.Stream(device=dev)
+        self.s_fus = torch.cuda.Stream(device=dev)
+        self.concurrent = True
         self.pack()
 
     # ---- parameters --------------------------------------------------------------------------------------
@@ -193,12 +197,17 @@ class AVMnistEngine:
     def _forward(self, image, audio, labels, training: bool, with_grad: bool):
         B, D = self.B, self.D
         sd = self.drop_step if training else None
-        self.e_img.forward(image, B, self.x0_img)
-        self.e_aud.forward(audio, B, self.x0_aud)
         fs = self.Nf * D
         aud_half = self.fused.view(-1)[self.Ni * D:]
+        main = torch.cuda.current_stream()
+        side = self.s_aud if self.concurrent else main
+        side.wait_stream(main)
+        with torch.cuda.stream(side):                       # audio tower beside the image tower
+            self.e_aud.forward(audio, B, self.x0_aud)
+            self.t_aud.forward(self.x0_aud, self.Na * D, B, aud_half, fs, self.pool_aud, training, self.seed, 0, sd)
+        self.e_img.forward(image, B, self.x0_img)
         self.t_img.forward(self.x0_img, self.Ni * D, B, self.fused, fs, self.pool_img, training, self.seed, 0, sd)
-        self.t_aud.forward(self.x0_aud, self.Na * D, B, aud_half, fs, self.pool_aud, training, self.seed, 0, sd)
+        main.wait_stream(side)
         self.t_fus.forward(self.fused, fs, B, self.fus_out, fs, self.pool_fus, training, self.seed, 0, sd)
         P, Gr = self.params, self.grads
         heads = []
@@ -215,13 +224,22 @@ class AVMnistEngine:
         sd = self.drop_step
         self.t_fus.backward(B, None, 0, self.dpool_fus, self.d_fused, fs, self.seed, 0, sd)
         d_aud_half = self.d_fused.view(-1)[self.Ni * D:]
+        main = torch.cuda.current_stream()
+        s_a = self.s_aud if self.concurrent else main
+        s_f = self.s_fus if self.concurrent else main
+        s_a.wait_stream(main)
+        s_f.wait_stream(main)
+        with torch.cuda.stream(s_f):                        # fusion weight gradients need only the fusion backward
+            self.t_fus.wgrad(B, self.seed, 0, sd)
+        with torch.cuda.stream(s_a):
+            self.t_aud.backward(B, d_aud_half, fs, self.dpool_aud, self.dx0_aud, self.Na * D, self.seed, 0, sd)
+            self.t_aud.wgrad(B, self.seed, 0, sd)
+            self.e_aud.wgrad(audio, self.dx0_aud, B)
         self.t_img.backward(B, self.d_fused, fs, self.dpool_img, self.dx0_img, self.Ni * D, self.seed, 0, sd)
-        self.t_aud.backward(B, d_aud_half, fs, self.dpool_aud, self.dx0_aud, self.Na * D, self.seed, 0, sd)
-        self.t_fus.wgrad(B, self.seed, 0, sd)
         self.t_img.wgrad(B, self.seed, 0, sd)
-        self.t_aud.wgrad(B, self.seed, 0, sd)
         self.e_img.wgrad(image, self.dx0_img, B)
-        self.e_aud.wgrad(audio, self.dx0_aud, B)
+        main.wait_stream(s_a)
+        main.wait_stream(s_f)
 
     def forward_backward(self, image, audio, labels):
         """zero grads -> forward (dropout on) -> multi-head loss -> backward; gradients land in flat_g."""
