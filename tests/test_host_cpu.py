@@ -1,0 +1,224 @@
+"""CPU-side checks (run with -m "not gpu"): the C-ABI library loads and exports every declared symbol,
+the reference-shaped host surface (registry, ctor signatures, state-dict keys, fusion shape algebra),
+loud failure on CPU tensors, the data-parallel gradient sync over gloo, bench.py's FLOP accounting."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import gen_util as G
+from golden_util import load
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from m2_mixer_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "m2mixer.h")).read()
+    declared = set(re.findall(r"\b(m2m_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations found in include/m2mixer.h"
+    L = lib.lib()
+    missing = [n for n in sorted(declared) if not hasattr(L, n)]
+    assert not missing, f"declared but not exported: {missing}"
+    assert declared == set(lib.SIGNATURES), (declared ^ set(lib.SIGNATURES))
+    assert L.m2m_abi_version() == lib.ABI_VERSION
+    assert lib.packed_bytes(lib.PREC_BF16, 3104, 128) == L.m2m_packed_bytes(lib.PREC_BF16, 3104, 128)
+    assert lib.packed_bytes(lib.PREC_F32, 3078, 128) == L.m2m_packed_bytes(lib.PREC_F32, 3078, 128)
+
+
+def test_struct_layouts_match_header(lib):
+    import ctypes as C
+    # m2m_block: 12 params + 5 packed + 12 grads + 6 saved pointers; m2m_tower header is 40 bytes then 5 pointers
+    assert C.sizeof(lib.Block) == 35 * 8
+    assert C.sizeof(lib.Tower) == 40 + 5 * 8 + lib.MAX_BLOCKS * C.sizeof(lib.Block)
+    assert lib.Tower.blk.offset == 80
+    assert C.sizeof(lib.Embed) == 40 + 5 * 8
+    assert C.sizeof(lib.Head) == 6 * 8 + 8
+
+
+def test_registry_and_state_dict_keys():
+    from m2_mixer_amd import modules as M
+    cfg = G.AVMNIST["B"]
+    img = M.get_block_by_name(block_type="MLPMixer", **cfg["image"], dropout=0.5, extra_key_ignored=1)
+    aud = M.get_block_by_name(block_type="MLPMixer", **cfg["audio"], dropout=0.5)
+    fusion = M.get_fusion_by_name(fusion_function="ConcatFusion", block_type="FusionMixer", hidden_dim=128)
+    npatch = fusion.get_output_shape(img.num_patch, aud.num_patch, dim=1)
+    assert (img.num_patch, aud.num_patch, npatch) == (4, 4, 8)
+    fus = M.get_block_by_name(block_type="FusionMixer", fusion_function="ConcatFusion", **cfg["multimodal"],
+                              num_patches=npatch, dropout=0.5)
+    cls = M.get_classifier_by_name(classifier="StandardClassifier", num_classes=10, input_shape=[16, 49, 128],
+                                   hidden_dims=[1024, 512, 256, 32])
+    model = torch.nn.Module()
+    model.image_mixer, model.audio_mixer, model.fusion_mixer = img, aud, fus
+    model.classifier_image = torch.nn.Linear(128, 10)
+    model.classifier_audio = torch.nn.Linear(128, 10)
+    model.classifier_fusion = cls
+    sd = model.state_dict()
+    shapes = G.avmnist_shapes(cfg)          # verified against the reference's own state_dict in make_golden.py
+    assert list(sd.keys()) == list(shapes.keys())
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(shapes[k]), k
+    assert sum(v.numel() for v in sd.values()) == int(load("avmnist_B.npz")["n_params"]) == 8339354
+    with pytest.raises(AttributeError):
+        M.get_block_by_name(block_type="NoSuchBlock")
+    with pytest.raises(AssertionError):
+        M.MLPMixer(1, 32, 5, [28, 28], 1, 16, 64)
+
+
+def test_no_patching_and_mlp_keys():
+    from m2_mixer_amd import modules as M
+    cfg = G.MIMIC_H
+    t = M.get_block_by_name(block_type="MLPMixerNoPatching", in_channels=1, **cfg["time"], dropout=0.3)
+    st = M.get_block_by_name(block_type="MLP", in_channels=1, **cfg["static"], dropout=0.3)
+    m = torch.nn.Module()
+    m.time_mixer, m.static_extractor = t, st
+    want = [k for k in G.mimic_shapes(cfg) if k.startswith(("time_mixer.", "static_extractor."))]
+    assert list(m.state_dict().keys()) == want
+    # MLP is plain torch: runs on CPU and matches the oracle
+    from oracle import m2mixer_oracle as O
+    x = torch.randn(7, 5)
+    st.eval()
+    p = {"s." + k: v for k, v in st.state_dict().items()}
+    assert torch.allclose(st(x), O.mlp(x, p, "s.", 2, True), atol=1e-6)
+
+
+def test_cpu_tensors_fail_loudly():
+    from m2_mixer_amd import modules as M
+    blk = M.MixerBlock(32, 4, 16, 64)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        blk(torch.zeros(2, 4, 32))
+    mix = M.MLPMixer(1, 32, 14, [28, 28], 1, 16, 64)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        mix(torch.zeros(2, 1, 28, 28))
+    from m2_mixer_amd.engine import AVMnistEngine
+    with pytest.raises(RuntimeError, match="GPU only"):
+        AVMnistEngine(G.AVMNIST["S"], 4, device="cpu")
+
+
+def test_fusion_shape_algebra_matches_reference():
+    """The reference's tests/modules/test_fusion.py cases (the six that pass on the reference), checked
+    against values captured from the reference (tests/golden/fusion_shapes.npz)."""
+    from m2_mixer_amd.modules import ConcatFusion, SumFusion, MaxFusion, MeanFusion, ConcatDynaFusion, BiModalGatedUnit
+    gold = load("fusion_shapes.npz")
+    a, b = torch.rand(10, 20, 30), torch.rand(10, 20, 30)
+    f = ConcatFusion(useless_arg=1)
+    assert tuple(f(a, b).shape) == tuple(gold["concat//call"]) == (10, 40, 30)
+    assert f.get_output_shape(a.shape, b.shape) == tuple(gold["concat//shape"])
+    assert f.get_output_shape(20, 20, dim=1) == int(gold["concat//dim1"]) == 40
+    assert f.get_output_shape(20, 20, dim=0) == int(gold["concat//dim0"]) == 20
+    with pytest.raises(ValueError):
+        f.get_output_shape(a, b, dim=2)
+    for cls in (SumFusion, MaxFusion, MeanFusion):
+        g = cls(useless_arg=1)
+        assert tuple(g(a, b).shape) == tuple(gold[f"{cls.__name__}//call"])
+        assert g.get_output_shape(a.shape, b.shape) == tuple(gold[f"{cls.__name__}//shape"])
+        assert g.get_output_shape(20, 20, dim=1) == int(gold[f"{cls.__name__}//dim1"])
+        assert g.get_output_shape(20, 20, dim=0) == 20
+        with pytest.raises(ValueError):
+            g.get_output_shape(a, b, dim=2)
+    d = ConcatDynaFusion(useless_arg=1)
+    a4, b4 = torch.rand(10, 20, 20, 30), torch.rand(10, 20, 20, 30)
+    assert tuple(d(a4, b4).shape) == tuple(gold["dyna//call"])
+    assert d.get_output_shape(a4.shape, b4.shape) == tuple(gold["dyna//shape"])
+    assert d.get_output_shape(36, 36, dim=1) == int(gold["dyna//dim1"]) == 144
+    with pytest.raises(ValueError):
+        d.get_output_shape(a4, b4, dim=2)
+    bi = BiModalGatedUnit(30, 30, 30, useless_arg=1)
+    assert bi(a, b).shape == (10, 20, 30)
+    assert bi.get_output_shape(a.shape, b.shape) == (10, 20, 30)
+    assert bi.get_output_shape(20, 20, dim=1) == 20 and bi.get_output_shape(20, 20, dim=-1) == 30
+
+
+def test_engine_param_layout_matches_reference_order():
+    from m2_mixer_amd.engine import avmnist_param_shapes
+    for size in ("S", "M", "B"):
+        mine = avmnist_param_shapes(G.AVMNIST[size])
+        ref = G.avmnist_shapes(G.AVMNIST[size])
+        assert list(mine.items()) == [(k, tuple(v)) for k, v in ref.items()]
+
+
+def test_bench_flop_accounting():
+    sys.path.insert(0, ROOT)
+    import bench
+    # SURVEY.md section 8a / BASELINE.md: 235.846 MFLOP per training sample (79.753 forward) for M2-Mixer-B, 4.218 for S
+    assert abs(bench.total_train_flops(bench.CFG_B, 512) / 512 / 1e6 - 235.846) < 0.01
+    assert abs(bench.total_train_flops(bench.CFG_S, 32) / 32 / 1e6 - 4.218) < 0.01
+    a = bench.algorithmic_flops(bench.CFG_B, 1)
+    fwd = sum(sum(v.values()) for k, v in a.items() if k != "heads") + a["heads"]
+    assert abs(fwd / 1e6 - 79.753) < 0.01
+
+
+def test_erf_rational_coefficients():
+    """The device erf (csrc/common.h erf_fast) restated in numpy float32 against scipy."""
+    from scipy.special import erf
+    src = open(os.path.join(ROOT, "m2_mixer_amd", "csrc", "common.h")).read()
+    body = src[src.index("static __device__ __forceinline__ float erf_fast"):]
+    body = body[:body.index("return p * __builtin_amdgcn_rcpf(q);")]
+    coef = [np.float32(c) for c in re.findall(r"(-?\d\.\d+e-\d+)f", body)]
+    assert len(coef) == 12
+    x = np.linspace(-6, 6, 200001).astype(np.float32)
+    xc = np.clip(x, -4, 4)
+    x2 = xc * xc
+    p = coef[0]
+    for c in coef[1:7]:
+        p = x2 * p + c
+    p = xc * p
+    q = coef[7]
+    for c in coef[8:]:
+        q = x2 * q + c
+    assert np.abs(p / q - erf(x.astype(np.float64))).max() < 6e-7
+
+
+def _gloo_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from m2_mixer_amd import parallel
+    r, lr, w = parallel.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    p = torch.full((10,), float(rank))
+    parallel.broadcast_parameters(p)
+    scale = parallel.GradSync()(flat)
+    scale16 = parallel.GradSync(compress="bf16")(flat16 := (torch.ones(64) * (rank + 1)))
+    tmax = parallel.max_over_ranks(1.0 + rank, device="cpu")
+    q.put((rank, flat.clone(), scale, p.clone(), flat16.clone(), scale16, tmax, parallel.shard_batch_seed(1234, rank)))
+    torch.distributed.destroy_process_group()
+
+
+def test_grad_sync_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, flat, scale, prm, flat16, scale16, tmax, seed in out:
+        assert scale == 0.5 and scale16 == 0.5
+        assert torch.equal(flat, torch.arange(1000, dtype=torch.float32) * 3)      # sum over ranks
+        assert torch.equal(prm, torch.zeros(10))                                     # broadcast from rank 0
+        assert torch.equal(flat16, torch.full((64,), 3.0))
+        assert tmax == 2.0
+        assert seed == 1234 + rank
+
+
+def test_bench_cli_contract_help():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True)
+    assert r.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in r.stdout
