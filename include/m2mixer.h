@@ -24,7 +24,7 @@ extern "C" {
 
 #define M2M_ABI_VERSION 1
 #define M2M_MAX_BLOCKS 8      /* MixerBlocks per m2m_tower; longer towers are chained by the caller */
-#define M2M_ROWS_PER_WG 32    /* token rows one workgroup keeps on chip */
+#define M2M_ROWS_PER_WG 16    /* token rows one workgroup keeps on chip */
 
 #define M2M_PREC_BF16 0       /* bf16 operands, fp32 accumulate, fp32 residual stream / LayerNorm */
 #define M2M_PREC_F32 1        /* exact fp32 MFMA (parity mode: matches the reference CPU path to ~1e-5) */

@@ -19,7 +19,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 ABI_VERSION = 1
 MAX_BLOCKS = 8
-ROWS_PER_WG = 32
+ROWS_PER_WG = 16
 PREC_BF16, PREC_F32 = 0, 1
 PREC_BY_NAME = {"bf16": PREC_BF16, "fp32": PREC_F32, "f32": PREC_F32}
 

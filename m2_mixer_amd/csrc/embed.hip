@@ -9,6 +9,8 @@
 // straight from the packed NAT copy in global memory.
 #include "tile.h"
 
+#define EBM 32             // token rows per workgroup
+#define EMT (EBM / 16)
 #define EMB_KS 128          // k extent staged per step (floats)
 #define EMB_LD (EMB_KS + 4)
 #define EMB_KMAX 4096       // largest padded K the offset table holds (AV-MNIST audio 3136, MM-IMDb 3072)
@@ -39,35 +41,35 @@ __global__ __launch_bounds__(NTHREADS) void embed_fwd_kernel(const m2m_embed em,
     constexpr int DT = D / 16, KSB = EMB_KS / Pr::KB;     // k-blocks per stage
     constexpr int DPW = (DT + NWAVES - 1) / NWAVES;        // d-tiles per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* tile = reinterpret_cast<float*>(smem);          // [BM][EMB_LD] fp32
-    char* img = smem + BM * EMB_LD * 4;                    // packed NAT [mt][kb] of the stage
-    int* koff = reinterpret_cast<int*>(img + BM * EMB_KS * Pr::ESZ);   // [Kp rounded up to EMB_KS]
-    long* rbase = reinterpret_cast<long*>(koff + EMB_KMAX);            // [BM]
+    float* tile = reinterpret_cast<float*>(smem);          // [EBM][EMB_LD] fp32
+    char* img = smem + EBM * EMB_LD * 4;                    // packed NAT [mt][kb] of the stage
+    int* koff = reinterpret_cast<int*>(img + EBM * EMB_KS * Pr::ESZ);   // [Kp rounded up to EMB_KS]
+    long* rbase = reinterpret_cast<long*>(koff + EMB_KMAX);            // [EBM]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
     PatchGeom pg{em.Cin, em.H, em.W, em.ph, em.pw, em.W / em.pw, N, em.K};
-    const long m0 = (long)blockIdx.x * BM;
+    const long m0 = (long)blockIdx.x * EBM;
     const int nKB = em.Kp / Pr::KB;
     const int kext = (em.Kp + EMB_KS - 1) / EMB_KS * EMB_KS;
     for (int k = tid; k < kext; k += NTHREADS) koff[k] = patch_koff(pg, k);
-    if (tid < BM) rbase[tid] = patch_rowbase(pg, m0 + tid, M);
+    if (tid < EBM) rbase[tid] = patch_rowbase(pg, m0 + tid, M);
 
-    f32x4_t acc[MT][DPW];
+    f32x4_t acc[EMT][DPW];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < EMT; ++mt)
 #pragma unroll
         for (int j = 0; j < DPW; ++j) acc[mt][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     for (int k0 = 0; k0 < em.Kp; k0 += EMB_KS) {
         __syncthreads();
-        for (int idx = tid; idx < BM * EMB_KS; idx += NTHREADS) {
+        for (int idx = tid; idx < EBM * EMB_KS; idx += NTHREADS) {
             const int r = idx / EMB_KS, kk = idx % EMB_KS;
             const long rb = rbase[r];
             const int ko = koff[k0 + kk];
             tile[r * EMB_LD + kk] = (rb >= 0 && ko >= 0) ? in[rb + ko] : 0.f;
         }
         __syncthreads();
-        for (int slot = tid; slot < MT * KSB * 64; slot += NTHREADS) {
+        for (int slot = tid; slot < EMT * KSB * 64; slot += NTHREADS) {
             const int blk = slot >> 6;
             *reinterpret_cast<u32x4_t*>(img + slot * 16) =
                 gather_slot<P>(tile, EMB_LD, PACK_NAT, false, blk / KSB, blk % KSB, slot & 63);
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(NTHREADS) void embed_fwd_kernel(const m2m_embed em,
                 for (int kb = 0; kb < KSB && kb0 + kb < nKB; ++kb) {
                     const Frag w = ld_frag_global(em.wn, (long)dt * nKB + kb0 + kb, lane);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
+                    for (int mt = 0; mt < EMT; ++mt) {
                         const Frag a = ld_frag_lds(img, mt * KSB + kb, lane);
                         Pr::mma(acc[mt][j], a, w);
                     }
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(NTHREADS) void embed_fwd_kernel(const m2m_embed em,
             const int d = 16 * dt + il;
             const float bv = em.b[d];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < EMT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const long m = m0 + 16 * mt + 4 * g + r;
@@ -111,16 +113,16 @@ template <int P, int D>
 __global__ __launch_bounds__(NTHREADS) void embed_wgrad_kernel(const m2m_embed em, const float* __restrict__ in,
                                                                const float* __restrict__ dx0, long M, int N, int tiles_per_group) {
     typedef Prec<P> Pr;
-    constexpr int DT = D / 16, NKM = BM / Pr::KB, XLD = TileGeom<D>::XLD;
+    constexpr int DT = D / 16, NKM = EBM / Pr::KB, XLD = TileGeom<D>::XLD;
     constexpr int KC = 64, KCT = KC / 16, PLD = KC + 4;
     constexpr int DPW = (DT + NWAVES - 1) / NWAVES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* dxt = reinterpret_cast<float*>(smem);                  // [BM][XLD]   dx0 tile
-    float* pt = dxt + BM * XLD;                                    // [BM][PLD]   patch tile
-    char* aimg = reinterpret_cast<char*>(pt + BM * PLD);           // NAT X[i=d][k=m]  blocks [dt][kbm]
-    char* bimg = aimg + BM * D * Pr::ESZ;                          // NAT X[i=kk][k=m] blocks [kt][kbm]
-    int* koff = reinterpret_cast<int*>(bimg + BM * KC * Pr::ESZ);  // [KC]
-    long* rbase = reinterpret_cast<long*>(koff + KC);              // [BM]
+    float* dxt = reinterpret_cast<float*>(smem);                  // [EBM][XLD]   dx0 tile
+    float* pt = dxt + EBM * XLD;                                    // [EBM][PLD]   patch tile
+    char* aimg = reinterpret_cast<char*>(pt + EBM * PLD);           // NAT X[i=d][k=m]  blocks [dt][kbm]
+    char* bimg = aimg + EBM * D * Pr::ESZ;                          // NAT X[i=kk][k=m] blocks [kt][kbm]
+    int* koff = reinterpret_cast<int*>(bimg + EBM * KC * Pr::ESZ);  // [KC]
+    long* rbase = reinterpret_cast<long*>(koff + KC);              // [EBM]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
     PatchGeom pg{em.Cin, em.H, em.W, em.ph, em.pw, em.W / em.pw, N, em.K};
@@ -134,21 +136,21 @@ __global__ __launch_bounds__(NTHREADS) void embed_wgrad_kernel(const m2m_embed e
         for (int kt = 0; kt < KCT; ++kt) acc[j][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;                                               // bias gradient (k-chunk 0 only), thread d
 
-    const long ntiles = (M + BM - 1) / BM;
+    const long ntiles = (M + EBM - 1) / EBM;
     const long t_begin = (long)blockIdx.y * tiles_per_group;
     const long t_end = min(ntiles, t_begin + tiles_per_group);
     for (long tl = t_begin; tl < t_end; ++tl) {
-        const long m0 = tl * BM;
+        const long m0 = tl * EBM;
         __syncthreads();
-        if (tid < BM) rbase[tid] = patch_rowbase(pg, m0 + tid, M);
-        for (int idx = tid; idx < BM * (D / 4); idx += NTHREADS) {
+        if (tid < EBM) rbase[tid] = patch_rowbase(pg, m0 + tid, M);
+        for (int idx = tid; idx < EBM * (D / 4); idx += NTHREADS) {
             const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m0 + r < M) v = *reinterpret_cast<const float4*>(dx0 + (m0 + r) * D + c);
             *reinterpret_cast<float4*>(dxt + r * XLD + c) = v;
         }
         __syncthreads();
-        for (int idx = tid; idx < BM * KC; idx += NTHREADS) {
+        for (int idx = tid; idx < EBM * KC; idx += NTHREADS) {
             const int r = idx / KC, kk = idx % KC;
             const long rb = rbase[r];
             const int ko = koff[kk];
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(NTHREADS) void embed_wgrad_kernel(const m2m_embed e
         }
         if (blockIdx.x == 0 && tid < D) {
             float s = 0.f;
-            for (int r = 0; r < BM; ++r) s += dxt[r * XLD + tid];
+            for (int r = 0; r < EBM; ++r) s += dxt[r * XLD + tid];
             bsum += s;
         }
         __syncthreads();
@@ -221,11 +223,11 @@ template <int P, int D>
 static int launch_embed_fwd(const m2m_embed* e, const float* in, int B, float* x0, hipStream_t st) {
     const int N = (e->H / e->ph) * (e->W / e->pw);
     const long M = (long)B * N;
-    const size_t lds = (size_t)BM * EMB_LD * 4 + (size_t)BM * EMB_KS * Prec<P>::ESZ + EMB_KMAX * 4 + BM * 8;
+    const size_t lds = (size_t)EBM * EMB_LD * 4 + (size_t)EBM * EMB_KS * Prec<P>::ESZ + EMB_KMAX * 4 + EBM * 8;
     auto kern = embed_fwd_kernel<P, D>;
     static bool done = false;
     if (!done) { M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)((M + BM - 1) / BM)), dim3(NTHREADS), lds, st, *e, in, M, N, x0);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((M + EBM - 1) / EBM)), dim3(NTHREADS), lds, st, *e, in, M, N, x0);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -234,14 +236,14 @@ static int launch_embed_wgrad(const m2m_embed* e, const float* in, const float* 
     const int N = (e->H / e->ph) * (e->W / e->pw);
     const long M = (long)B * N;
     const int nchunks = (e->K + 63) / 64;
-    const long ntiles = (M + BM - 1) / BM;
+    const long ntiles = (M + EBM - 1) / EBM;
     long groups = (128 + nchunks - 1) / nchunks;           // ~128 workgroups; row groups add with atomics
     if (groups > ntiles / 4) groups = ntiles / 4;
     if (groups < 1) groups = 1;
     const int tpg = (int)((ntiles + groups - 1) / groups);
     groups = (ntiles + tpg - 1) / tpg;
-    const size_t lds = (size_t)BM * TileGeom<D>::XLD * 4 + (size_t)BM * 68 * 4 + (size_t)BM * D * Prec<P>::ESZ +
-                       (size_t)BM * 64 * Prec<P>::ESZ + 64 * 4 + BM * 8;
+    const size_t lds = (size_t)EBM * TileGeom<D>::XLD * 4 + (size_t)EBM * 68 * 4 + (size_t)EBM * D * Prec<P>::ESZ +
+                       (size_t)EBM * 64 * Prec<P>::ESZ + 64 * 4 + EBM * 8;
     auto kern = embed_wgrad_kernel<P, D>;
     static bool done = false;
     if (!done) { M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }

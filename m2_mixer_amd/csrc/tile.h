@@ -8,11 +8,14 @@
 #include "common.h"
 #include "../../include/m2mixer.h"
 
-#define BM 32
+#ifndef BM
+#define BM 16                      // token rows per workgroup of the chain kernels (16 or 32)
+#endif
 #define MT (BM / 16)
 #define NTHREADS 512
 #define NWAVES 8
-#define TPR (NTHREADS / BM)        // threads per row in the row-wise (LayerNorm) phases: 16
+#define TPR (NTHREADS / BM)        // threads per row in the row-wise (LayerNorm) phases: 32 (BM 16) / 16 (BM 32)
+#define WPAIR 32                   // rows of a weight-gradient tile: the packed operand images are laid out per 32 rows
 
 static __host__ __device__ __forceinline__ unsigned int m2m_mix32_hd(unsigned int x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
@@ -58,12 +61,13 @@ template <int D> struct TileGeom {
     static_assert(D % 32 == 0 && D >= 32, "hidden_dim must be a multiple of 32");
 };
 
-// column of element e (0..EPT-1) of row-thread j (0..TPR-1): float4 chunks interleaved over the 16
-// threads of a row (coalesced 256-byte segments); D == 32 degenerates to 2 contiguous columns.
+// column of element e (0..EPT-1) of row-thread j (0..TPR-1): float4 chunks interleaved over the TPR
+// threads of a row (coalesced segments); fewer than 4 elements per thread -> EPT contiguous columns.
 template <int D>
 static __device__ __forceinline__ int ln_col(int e, int j) {
-    if (D >= 64) return 64 * (e >> 2) + 4 * j + (e & 3);
-    return 2 * j + e;
+    constexpr int EPT = D / TPR;
+    if (EPT >= 4) return 4 * TPR * (e >> 2) + 4 * j + (e & 3);
+    return EPT * j + e;
 }
 
 // row statistics (mean, 1/std with biased variance, eps 1e-5) of one row held by TPR threads.
@@ -71,20 +75,24 @@ static __device__ __forceinline__ int ln_col(int e, int j) {
 template <int D>
 static __device__ __forceinline__ void row_stats(const float* src, bool valid, int j, float v[D / TPR], float& mean, float& rstd) {
     constexpr int EPT = D / TPR;
+    static_assert(EPT >= 1, "hidden_dim too small for this tile geometry");
     float s = 0.f;
-    if (D >= 64) {
+    if (EPT >= 4) {
 #pragma unroll
         for (int i = 0; i < EPT / 4; ++i) {
             float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid) q = *reinterpret_cast<const float4*>(src + 64 * i + 4 * j);
+            if (valid) q = *reinterpret_cast<const float4*>(src + 4 * TPR * i + 4 * j);
             v[4 * i + 0] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
             s += (q.x + q.y) + (q.z + q.w);
         }
-    } else {
+    } else if (EPT == 2) {
         float2 q = make_float2(0.f, 0.f);
         if (valid) q = *reinterpret_cast<const float2*>(src + 2 * j);
-        v[0] = q.x; v[1] = q.y;
+        v[0] = q.x; v[EPT - 1] = q.y;
         s = q.x + q.y;
+    } else {
+        v[0] = valid ? src[j] : 0.f;
+        s = v[0];
     }
     s = wave_sum_xor(s, TPR);
     mean = s * (1.0f / D);
@@ -145,14 +153,33 @@ static __device__ __forceinline__ void pack_tile_nat(const float* tile, char* im
             gather_slot<P>(tile, TileGeom<D>::XLD, PACK_NAT, false, blk / KD, blk % KD, slot & 63);
     }
 }
-// fp32 tile [BM][XLD] -> packed CHN image of the TRANSPOSE, X[i = d][k = m], blocks ordered [kb over m][dt]
+// fp32 tile [BM][XLD] -> this tile's part of the packed CHN image of the TRANSPOSE, X[i = d][k = m], m running
+// over a 32-row PAIR of tiles (blocks ordered [kb over the 32 rows][dt]); `pair_img` points at the pair's image,
+// `tile_in_pair` = 0/1 says which 16 rows this workgroup owns when BM == 16.
+//   bf16 (k-block = 32 rows): BM == 16 fills one 8-byte half of every 16-byte lane slot (elements 4h .. 4h+3).
+//   fp32 (k-block = 16 rows): BM == 16 fills k-block `tile_in_pair` whole.
 template <int P, int D>
-static __device__ __forceinline__ void pack_tile_chn_t(const float* tile, char* img, int tid) {
-    constexpr int DT = D / 16, NKM = BM / Prec<P>::KB;
-    _Pragma("unroll 1") for (int slot = tid; slot < NKM * DT * 64; slot += NTHREADS) {
-        const int blk = slot >> 6;
-        *reinterpret_cast<u32x4_t*>(img + slot * 16) =
-            gather_slot<P>(tile, TileGeom<D>::XLD, PACK_CHN, true, blk % DT, blk / DT, slot & 63);
+static __device__ __forceinline__ void pack_tile_chn_t(const float* tile, char* pair_img, int tile_in_pair, int tid) {
+    typedef Prec<P> Pr;
+    constexpr int DT = D / 16, XLD = TileGeom<D>::XLD;
+    if (BM >= Pr::KB) {                      // whole k-blocks
+        constexpr int NKM = BM / Pr::KB > 0 ? BM / Pr::KB : 1;
+        const int kb0 = tile_in_pair * NKM;
+        _Pragma("unroll 1") for (int slot = tid; slot < NKM * DT * 64; slot += NTHREADS) {
+            const int blk = slot >> 6;
+            *reinterpret_cast<u32x4_t*>(pair_img + (long)kb0 * DT * 1024 + slot * 16) =
+                gather_slot<P>(tile, XLD, PACK_CHN, true, blk % DT, blk / DT, slot & 63);
+        }
+    } else {                                 // bf16, 16 rows: half slots
+        _Pragma("unroll 1") for (int slot = tid; slot < DT * 64; slot += NTHREADS) {
+            const int dt = slot >> 6, lane = slot & 63, i = dt * 16 + (lane & 15), g = lane >> 4;
+            const float v0 = tile[(4 * g + 0) * XLD + i], v1 = tile[(4 * g + 1) * XLD + i];
+            const float v2 = tile[(4 * g + 2) * XLD + i], v3 = tile[(4 * g + 3) * XLD + i];
+            uint2 o;
+            o.x = pack_bf2(v0, v1);
+            o.y = pack_bf2(v2, v3);
+            *reinterpret_cast<uint2*>(pair_img + slot * 16 + tile_in_pair * 8) = o;
+        }
     }
 }
 

@@ -66,7 +66,7 @@ static __device__ __forceinline__ void ln_backward_tile(const float* xg, int R, 
     __syncthreads();
 }
 
-template <int P, int D, int NMAX, int TTMAX>
+template <int P, int D, int NMAX, int TG>
 __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw, int B, const float* __restrict__ d_out,
                                                              long d_out_ss, const float* __restrict__ d_pooled,
                                                              float* __restrict__ d_x0, long d_x0_ss, unsigned int seed,
@@ -96,7 +96,10 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
     const int ns = min(SPW, B - s0);
     const int R = ns * N;
     const long row0 = (long)s0 * N;
-    const long tile_off = (long)blockIdx.x * IMG_B;
+    const long tile_off = (long)blockIdx.x * IMG_B;                       // NAT images: consecutive BM-row tiles
+    constexpr int TPP = WPAIR / BM;                                         // chain tiles per 32-row pair
+    const long pair_off = (long)(blockIdx.x / TPP) * (WPAIR * D * Pr::ESZ); // CHN images: per 32-row pair
+    const int tile_in_pair = blockIdx.x % TPP;
     const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
 
     TIMER_START();
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
         }
         // pack dYd: NAT [m][d] (LDS image + global copy) and CHN [d][m] (global, for the weight gradients)
         pack_tile_nat<P, D>(ub, dyp, tid);
-        pack_tile_chn_t<P, D>(ub, reinterpret_cast<char*>(bk.dyt_chn) + tile_off, tid);
+        pack_tile_chn_t<P, D>(ub, reinterpret_cast<char*>(bk.dyt_chn) + pair_off, tile_in_pair, tid);
         __syncthreads();
         copy16(reinterpret_cast<char*>(bk.dy_nat) + tile_off, dyp, IMG_B, tid);
         // (C2) A = LN2(x_mid) -> fp32 tile (ub) -> packed images
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
         }
         __syncthreads();
         pack_tile_nat<P, D>(ub, at, tid);
-        pack_tile_chn_t<P, D>(ub, reinterpret_cast<char*>(bk.at_chn) + tile_off, tid);
+        pack_tile_chn_t<P, D>(ub, reinterpret_cast<char*>(bk.at_chn) + pair_off, tile_in_pair, tid);
         __syncthreads();
         copy16(reinterpret_cast<char*>(bk.a_nat) + tile_off, at, IMG_B, tid);
 
@@ -176,32 +179,61 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) dacc[mt][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         const int npairs = Cp >> 5;
-        for (int q = wave; q < npairs; q += NWAVES) {
-            Frag w1f[2][KD], w2f[2][KD];
+        Frag w1f[2][KD], w2f[2][KD];
+        if (wave < npairs) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int kb = 0; kb < KD; ++kb) {
-                    w1f[t][kb] = ld_frag_global(bk.w1n, (long)(2 * q + t) * KD + kb, lane);
-                    w2f[t][kb] = ld_frag_global(bk.w2tn, (long)(2 * q + t) * KD + kb, lane);
+                    w1f[t][kb] = ld_frag_global(bk.w1n, (long)(2 * wave + t) * KD + kb, lane);
+                    w2f[t][kb] = ld_frag_global(bk.w2tn, (long)(2 * wave + t) * KD + kb, lane);
                 }
+        }
+        for (int q = wave; q < npairs; q += NWAVES) {
             f32x4_t bias[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) bias[t] = *reinterpret_cast<const f32x4_t*>(bk.ch_b1p + 32 * q + 16 * t + 4 * g);
+            f32x4_t hacc[MT][2], gacc[MT][2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                hacc[mt][0] = bias[0];
+                hacc[mt][1] = bias[1];
+                gacc[mt][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                gacc[mt][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int kb = 0; kb < KD; ++kb) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const Frag a = ld_frag_lds(at, mt * KD + kb, lane);
+                    const Frag dy = ld_frag_lds(dyp, mt * KD + kb, lane);
+                    Pr::mma(hacc[mt][0], w1f[0][kb], a);
+                    Pr::mma(hacc[mt][1], w1f[1][kb], a);
+                    Pr::mma(gacc[mt][0], w2f[0][kb], dy);
+                    Pr::mma(gacc[mt][1], w2f[1][kb], dy);
+                }
+            }
+            // this step's W1^T fragments (third product) and the next step's W1 / W2^T fragments: in flight
+            // during the epilogue.  The scheduling barrier keeps the compiler from hoisting these loads above
+            // the MFMAs that still read the current fragments (which would double the live registers).
+            __builtin_amdgcn_sched_barrier(0);
+            Frag w3f[NF][DT];
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) w3f[f][dt] = ld_frag_global(bk.w1tc, (long)(q * NF + f) * DT + dt, lane);
+            if (q + NWAVES < npairs) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int kb = 0; kb < KD; ++kb) {
+                        w1f[t][kb] = ld_frag_global(bk.w1n, (long)(2 * (q + NWAVES) + t) * KD + kb, lane);
+                        w2f[t][kb] = ld_frag_global(bk.w2tn, (long)(2 * (q + NWAVES) + t) * KD + kb, lane);
+                    }
+            }
             Frag hf[MT][NF];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                f32x4_t hacc[2] = {bias[0], bias[1]};
-                f32x4_t gacc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-                for (int kb = 0; kb < KD; ++kb) {
-                    const Frag a = ld_frag_lds(at, mt * KD + kb, lane);
-                    const Frag dy = ld_frag_lds(dyp, mt * KD + kb, lane);
-                    Pr::mma(hacc[0], w1f[0][kb], a);
-                    Pr::mma(hacc[1], w1f[1][kb], a);
-                    Pr::mma(gacc[0], w2f[0][kb], dy);
-                    Pr::mma(gacc[1], w2f[1][kb], dy);
-                }
                 const unsigned int m = (unsigned int)(row0 + mt * 16 + il);
                 unsigned int word = 0xFFFFFFFFu;
                 if (half) word = drop_word_half(dr_ch, m, q, npairs);
@@ -212,23 +244,20 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float gl, dgl;
-                        gelu_grad_f(hacc[t][r], gl, dgl);
-                        const float v = gacc[t][r] * dgl * dr_ch.scale;
+                        gelu_grad_f(hacc[mt][t][r], gl, dgl);
+                        const float v = gacc[mt][t][r] * dgl * dr_ch.scale;
                         const bool k = half ? ((word >> (16 * t + 4 * g + r)) & 1u) : keep[r];
-                        gacc[t][r] = k ? v : 0.f;
+                        gacc[mt][t][r] = k ? v : 0.f;
                     }
                 }
-                Chain<P>::make(gacc[0], gacc[1], hf[mt]);
+                Chain<P>::make(gacc[mt][0], gacc[mt][1], hf[mt]);
             }
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {
+            for (int f = 0; f < NF; ++f)
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
-                    const Frag w = ld_frag_global(bk.w1tc, (long)(q * NF + f) * DT + dt, lane);
+                for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) Pr::mma(dacc[mt][dt], hf[mt][f], w);
-                }
-            }
+                    for (int mt = 0; mt < MT; ++mt) Pr::mma(dacc[mt][dt], hf[mt][f], w3f[f][dt]);
         }
         TIMER_MARK(g_tm_bwd, 2);   // C3 hidden-column loop (wave 0)
         __syncthreads();   // every wave is done reading the packed images that xh aliases
@@ -260,8 +289,9 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
         }
         __syncthreads();
         {
-            const int tg = tid & 7, pl = tid >> 3;
-            const int TT = T >> 3;
+            constexpr int TTMAX = 32 / TG;                 // hidden units per lane (T <= 32)
+            const int tg = tid % TG, pl = tid / TG;        // TG lanes share a column and split its T hidden units
+            const int TT = T / TG;
             float w1r[TTMAX][NMAX], w2r[NMAX][TTMAX], b1r[TTMAX];
             float aw1[TTMAX][NMAX], aw2[NMAX][TTMAX], ab1[TTMAX], ab2[NMAX];
 #pragma unroll
@@ -282,7 +312,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
             for (int n = 0; n < NMAX; ++n) ab2[n] = 0.f;
 
             const int npairs_tok = ns * D;
-            constexpr int PL = NTHREADS / 8;              // columns handled concurrently
+            constexpr int PL = NTHREADS / TG;             // columns handled concurrently
             const int iters = (npairs_tok + PL - 1) / PL;
             for (int it = 0; it < iters; ++it) {
                 const int p = it * PL + pl;
@@ -331,7 +361,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
 #pragma unroll
                 for (int n = 0; n < NMAX; ++n) {
                     if (n < N) {
-                        const float s = wave_sum_xor(du[n], 8);      // over the 8 lanes that share the column
+                        const float s = wave_sum_xor(du[n], TG);     // over the TG lanes that share the column
                         if (pv && tg == 0) {
                             ub[(sl * N + n) * XLD + d] = s;
                             ab2[n] += dv[n];
@@ -352,15 +382,14 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
                 if (tt < TT) {
                     const int t = tg * TT + tt;
                     float s = ab1[tt];
-                    s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-                    if (lane < 8) atomicAdd(red + 2 * T * N + t, s);
+                    for (int o = TG; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
+                    if (lane < TG) atomicAdd(red + 2 * T * N + t, s);
 #pragma unroll
                     for (int n = 0; n < NMAX; ++n) {
                         if (n < N) {
                             float a = aw1[tt][n], c = aw2[n][tt];
-                            a += __shfl_xor(a, 8, 64); a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
-                            c += __shfl_xor(c, 8, 64); c += __shfl_xor(c, 16, 64); c += __shfl_xor(c, 32, 64);
-                            if (lane < 8) {
+                            for (int o = TG; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+                            if (lane < TG) {
                                 atomicAdd(red + t * N + n, a);
                                 atomicAdd(red + T * N + n * T + t, c);
                             }
@@ -372,7 +401,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
             for (int n = 0; n < NMAX; ++n) {
                 if (n < N) {
                     float s = ab2[n];   // non-zero on tg == 0 lanes only
-                    s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+                    for (int o = TG; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
                     if (lane == 0) atomicAdd(red + 2 * T * N + T + n, s);
                 }
             }
@@ -433,14 +462,14 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
     }
 }
 
-template <int P, int D, int NMAX>
+template <int P, int D, int NMAX, int TG>
 static int launch_bwd(const m2m_tower* t, int B, const float* d_out, long d_out_ss, const float* d_pooled, float* d_x0,
                       long d_x0_ss, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
     const int SPW = BM / t->N;
     const int grid = (B + SPW - 1) / SPW;
     const size_t tile_b = (size_t)BM * TileGeom<D>::XLD * sizeof(float);
     const size_t lds = 2 * tile_b + 4 * SlabGeom<D>::FLOATS * sizeof(float) + BM * sizeof(float);
-    auto kern = tower_bwd_kernel<P, D, NMAX, 4>;
+    auto kern = tower_bwd_kernel<P, D, NMAX, TG>;
     static bool attr_done = false;
     if (!attr_done) {
         M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -458,8 +487,11 @@ extern "C" int m2m_tower_backward(const m2m_tower* t, int B, const float* d_out,
     if (int rc = m2m_check_tower(t, B)) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define M2M_BWD_CASE(PP, DD) \
-    if (t->prec == PP && t->D == DD) return t->N <= 4 ? launch_bwd<PP, DD, 4>(t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step, step_dev, st) \
-                                                      : launch_bwd<PP, DD, 8>(t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step, step_dev, st);
+    if (t->prec == PP && t->D == DD) {                                                                                          \
+        if (t->N <= 4) return launch_bwd<PP, DD, 4, 8>(t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step, step_dev, st);   \
+        if (t->T % 16 == 0) return launch_bwd<PP, DD, 8, 16>(t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step, step_dev, st); \
+        return launch_bwd<PP, DD, 8, 8>(t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step, step_dev, st);                \
+    }
     M2M_BWD_CASE(PREC_BF16, 32) M2M_BWD_CASE(PREC_BF16, 64) M2M_BWD_CASE(PREC_BF16, 128)
     M2M_BWD_CASE(PREC_F32, 32) M2M_BWD_CASE(PREC_F32, 64) M2M_BWD_CASE(PREC_F32, 128)
 #undef M2M_BWD_CASE

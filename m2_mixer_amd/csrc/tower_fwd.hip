@@ -176,7 +176,9 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw,
                     Pr::mma(hacc[mt][1], w1f[1][kb], a);
                 }
             }
-            // prefetch the next step's W1 fragments under the epilogue
+            // prefetch the next step's W1 fragments under the epilogue (scheduling barrier: do not hoist the
+            // loads above the MFMAs that still read the current fragments)
+            __builtin_amdgcn_sched_barrier(0);
             if (q + NWAVES < npairs) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t)

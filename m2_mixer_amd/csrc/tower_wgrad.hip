@@ -14,6 +14,9 @@
 #include "tile.h"
 #include <stdlib.h>
 
+#define WBM 32            // rows per streamed tile (= two 16-row tiles of the chain kernels when BM == 16)
+#define WMT (WBM / 16)
+
 TIMER_DECL(g_tm_wg);
 TIMER_READER(m2m_debug_timers_wgrad, g_tm_wg)
 
@@ -23,7 +26,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_wgrad_kernel(const m2m_tower t
                                                                const unsigned int* __restrict__ step_dev) {
     typedef Prec<P> Pr;
     constexpr int DT = D / 16, KD = D / Pr::KB, NF = Chain<P>::NF;
-    constexpr int IMG_B = BM * D * Pr::ESZ;
+    constexpr int IMG_B = WBM * D * Pr::ESZ;
     constexpr int STAGE_B = 4 * IMG_B;                      // A | dYd | A^T | dYd^T of one tile
     constexpr int NLD = STAGE_B / (NTHREADS * 16);          // 16-byte pieces per thread per tile
     static_assert(STAGE_B % (NTHREADS * 16) == 0, "tile stage must split evenly over the threads");
@@ -99,11 +102,10 @@ __global__ __launch_bounds__(NTHREADS) void tower_wgrad_kernel(const m2m_tower t
         const char* dyt_chn = cur + 3 * IMG_B;
         TIMER_MARK(g_tm_wg, 0);
         if (active) {
-            const unsigned int mrow0 = (unsigned int)tile * rows_per_tile;   // global token row of the tile's row 0
             // the tile's two 16-row sub-tiles chain into one k-block (bf16) / two (fp32)
             f32x4_t hact[2], dhp[2];                        // [row sub-tile]
 #pragma unroll
-            for (int u = 0; u < MT; ++u) {
+            for (int u = 0; u < WMT; ++u) {
                 f32x4_t hacc = f32x4_t{bias, bias, bias, bias};
                 f32x4_t gacc = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -116,7 +118,8 @@ __global__ __launch_bounds__(NTHREADS) void tower_wgrad_kernel(const m2m_tower t
                 // accumulator element r: row m = 16 u + 4 g + r, column c = 16 ct + il
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const unsigned int m = mrow0 + 16 * u + 4 * g + r;
+                    // sub-tile u of this tile is chain tile (tile * SUB + u / (BM/16)); its rows are sample-aligned
+                    const unsigned int m = (unsigned int)(tile * (WBM / BM) + (16 * u) / BM) * rows_per_tile + (16 * u) % BM + 4 * g + r;
                     float gl, dgl;
                     gelu_grad_f(hacc[r], gl, dgl);
                     bool keep = true;
@@ -191,8 +194,9 @@ __global__ __launch_bounds__(NTHREADS) void tower_wgrad_kernel(const m2m_tower t
 
 template <int P, int D>
 static int launch_wgrad(const m2m_tower* t, int B, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
-    const int SPW = BM / t->N;
-    const int ntiles = (B + SPW - 1) / SPW;
+    const int SPW = BM / t->N;                                  // samples per chain tile
+    const int nchain = (B + SPW - 1) / SPW;                     // chain tiles (BM rows each)
+    const int ntiles = (nchain * BM + WBM - 1) / WBM;           // streamed tiles (WBM rows each)
     const int nsl = ((t->Cp >> 4) + NWAVES - 1) / NWAVES;      // 128-column slices
     // Row groups trade parallelism against float-atomic traffic (every extra group re-adds the whole slice);
     // one group = single owner per element, no atomics.  Aim at >= ~96 workgroups per launch.
@@ -203,7 +207,7 @@ static int launch_wgrad(const m2m_tower* t, int B, unsigned int seed, unsigned i
     if (tpg < 4) tpg = 4;
     if (tpg > ntiles) tpg = ntiles;
     groups = (ntiles + tpg - 1) / tpg;
-    const size_t lds = (size_t)2 * 4 * BM * D * Prec<P>::ESZ;
+    const size_t lds = (size_t)2 * 4 * WBM * D * Prec<P>::ESZ;
     auto kern = tower_wgrad_kernel<P, D>;
     static bool attr_done = false;
     if (!attr_done) {

@@ -114,12 +114,16 @@ class TowerRuntime:
 
     # ---- activations saved for backward ---------------------------------------------------------------
     def ensure_buffers(self, B: int):
-        if B <= self._bufB:
+        """(Re)allocate the saved-activation buffers for batch B.  The packed operand images are laid out per
+        32-row pair of tiles and zero-filled: a ragged last pair must read as zeros in the weight-gradient pass,
+        so they are reallocated whenever B changes."""
+        if B == self._bufB:
             return
         spw = L.ROWS_PER_WG // self.N
         ntiles = (B + spw - 1) // spw
         esz = 2 if self.prec == L.PREC_BF16 else 4
-        img = ntiles * L.ROWS_PER_WG * self.D * esz
+        npairs = (ntiles * L.ROWS_PER_WG + 31) // 32
+        img = npairs * 32 * self.D * esz
         M = B * self.N
         for i in range(self.nblocks):
             bufs = {"x_in": torch.empty(M, self.D, device=self.device), "x_mid": torch.empty(M, self.D, device=self.device)}
