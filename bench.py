@@ -253,11 +253,6 @@ def profile_launches(eng, image, audio, labels, nsteps):
     E.heads_ce = timed("heads_ce", orig_heads, alg["heads"] * 3)
     try:
         for _ in range(nsteps):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            eng.flat_g.zero_()
-            e1.record()
-            spans.setdefault("zero_grad", {"events": [], "flops": 0})["events"].append((e0, e1))
             eng._forward(image, audio, labels, True, True)
             eng._backward(image, audio)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -265,7 +260,7 @@ def profile_launches(eng, image, audio, labels, nsteps):
             from m2_mixer_amd import _lib as L
             L.check(L.lib().m2m_adam_step(eng.flat_p.data_ptr(), eng.flat_g.data_ptr(), eng.flat_m.data_ptr(),
                                           eng.flat_v.data_ptr(), eng.n_params, eng.adam_state.data_ptr(), eng.betas[0],
-                                          eng.betas[1], eng.eps, eng.weight_decay, 1.0, L.stream_ptr()))
+                                          eng.betas[1], eng.eps, eng.weight_decay, -1.0, L.stream_ptr()))
             e1.record()
             spans.setdefault("adam", {"events": [], "flops": 0})["events"].append((e0, e1))
             L.check(L.lib().m2m_counter_add(eng.drop_step.data_ptr(), 1, L.stream_ptr()))

@@ -166,9 +166,9 @@ int m2m_heads_ce(const m2m_head* heads, int nheads, const int64_t* labels, int B
 /* state: device float[4] = {step (as float count), lr, unused, unused}; the kernel reads lr and the
  * step count from it, so a captured graph can be replayed while the host edits lr.  m2m_adam_step
  * increments state[0] on the stream before updating. */
-int m2m_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+int m2m_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   float* state, float beta1, float beta2, float eps, float weight_decay,
-                  float grad_scale, void* stream);
+                  float grad_scale, void* stream);   /* grad_scale < 0: scale by |grad_scale| and clear grad afterwards */
 
 /* *counter += delta on the stream (device uint32). */
 int m2m_counter_add(uint32_t* counter, uint32_t delta, void* stream);

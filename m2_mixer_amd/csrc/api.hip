@@ -161,9 +161,13 @@ extern "C" int m2m_pack_embed(const m2m_embed* e, void* stream) {
 // ---------------------------------------------------------------------------------------------------
 __global__ void adam_bump_kernel(float* state) { state[0] += 1.0f; }
 
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ gr, float* __restrict__ m,
+// gscale < 0 requests "consume": after the update the gradient element is cleared, so the next step starts from
+// zeroed gradients without a separate fill pass (|gscale| is the scale).
+__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ gr, float* __restrict__ m,
                             float* __restrict__ v, long n, const float* __restrict__ state, float b1, float b2,
-                            float eps, float wd, float gscale) {
+                            float eps, float wd, float gscale_in) {
+    const bool consume = gscale_in < 0.f;
+    const float gscale = consume ? -gscale_in : gscale_in;
     const float stepf = state[0], lr = state[1];
     const float bc1 = 1.0f - powf(b1, stepf);
     const float bc2 = 1.0f - powf(b2, stepf);
@@ -172,6 +176,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ gr,
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float g = gr[i] * gscale;
+        if (consume) gr[i] = 0.f;
         const float pv = p[i];
         if (wd != 0.f) g = __builtin_fmaf(wd, pv, g);
         const float mi = b1 * m[i] + (1.0f - b1) * g;
@@ -183,7 +188,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ gr,
     }
 }
 
-extern "C" int m2m_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
+extern "C" int m2m_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
                              float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, st, state);

@@ -60,32 +60,63 @@ __global__ __launch_bounds__(NTHREADS) void embed_fwd_kernel(const m2m_embed em,
 #pragma unroll
         for (int j = 0; j < DPW; ++j) acc[mt][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    for (int k0 = 0; k0 < em.Kp; k0 += EMB_KS) {
-        __syncthreads();
-        for (int idx = tid; idx < EBM * EMB_KS; idx += NTHREADS) {
+    // Software pipeline over EMB_KS-wide stages: the global loads of stage s+1 (this thread's patch elements and
+    // this wave's weight fragments) are issued before stage s is packed and multiplied, so their latency hides
+    // behind the LDS work and the MFMAs.  One workgroup owns its rows for the whole K: deterministic, no atomics.
+    constexpr int EPT = EBM * EMB_KS / NTHREADS;            // patch elements per thread per stage
+    float pre[EPT];
+    Frag wpre[DPW][KSB];
+    auto load_stage = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int idx = i * NTHREADS + tid;
             const int r = idx / EMB_KS, kk = idx % EMB_KS;
             const long rb = rbase[r];
             const int ko = koff[k0 + kk];
-            tile[r * EMB_LD + kk] = (rb >= 0 && ko >= 0) ? in[rb + ko] : 0.f;
+            pre[i] = (rb >= 0 && ko >= 0) ? in[rb + ko] : 0.f;
         }
+        const int kb0 = k0 / Pr::KB;
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) {
+            const int dt = wave + NWAVES * j;
+#pragma unroll
+            for (int kb = 0; kb < KSB; ++kb) {
+                wpre[j][kb].u = u32x4_t{0u, 0u, 0u, 0u};
+                if (dt < DT && kb0 + kb < nKB) wpre[j][kb] = ld_frag_global(em.wn, (long)dt * nKB + kb0 + kb, lane);
+            }
+        }
+    };
+    __syncthreads();                                         // offset tables ready
+    load_stage(0);
+    for (int k0 = 0; k0 < em.Kp; k0 += EMB_KS) {
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int idx = i * NTHREADS + tid;
+            tile[(idx / EMB_KS) * EMB_LD + idx % EMB_KS] = pre[i];
+        }
+        Frag wcur[DPW][KSB];
+#pragma unroll
+        for (int j = 0; j < DPW; ++j)
+#pragma unroll
+            for (int kb = 0; kb < KSB; ++kb) wcur[j][kb] = wpre[j][kb];
         __syncthreads();
+        if (k0 + EMB_KS < em.Kp) load_stage(k0 + EMB_KS);
         for (int slot = tid; slot < EMT * KSB * 64; slot += NTHREADS) {
             const int blk = slot >> 6;
             *reinterpret_cast<u32x4_t*>(img + slot * 16) =
                 gather_slot<P>(tile, EMB_LD, PACK_NAT, false, blk / KSB, blk % KSB, slot & 63);
         }
         __syncthreads();
-        const int kb0 = k0 / Pr::KB;
 #pragma unroll
         for (int j = 0; j < DPW; ++j) {
             const int dt = wave + NWAVES * j;
             if (dt < DT) {
-                for (int kb = 0; kb < KSB && kb0 + kb < nKB; ++kb) {
-                    const Frag w = ld_frag_global(em.wn, (long)dt * nKB + kb0 + kb, lane);
+#pragma unroll
+                for (int kb = 0; kb < KSB; ++kb) {
 #pragma unroll
                     for (int mt = 0; mt < EMT; ++mt) {
                         const Frag a = ld_frag_lds(img, mt * KSB + kb, lane);
-                        Pr::mma(acc[mt][j], a, w);
+                        Pr::mma(acc[mt][j], a, wcur[j][kb]);
                     }
                 }
             }

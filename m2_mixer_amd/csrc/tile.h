@@ -54,6 +54,43 @@ static __device__ __forceinline__ bool drop_keep_mc(const Drop& d, unsigned int 
     return drop_keep(d, m * Cp + c);
 }
 
+// Dropout mode of a launch (template parameter of the hot kernels, so the epilogues stay branch-free):
+//   DM_NONE  eval / p == 0        DM_HALF  p == 0.5 (one bit per element)        DM_GEN  any other p (16-bit draws)
+enum { DM_NONE = 0, DM_HALF = 1, DM_GEN = 2 };
+static inline int m2m_drop_mode(int training, float p) {
+    if (!training || p <= 0.f) return DM_NONE;
+    return m2m_drop_thr(p) == 32768u ? DM_HALF : DM_GEN;
+}
+// Keep-bits of the ncols (<= 32) elements of a token-site row `bd` (one (sample, channel) column): bit t = keep.
+template <int DM>
+static __device__ __forceinline__ unsigned int drop_row_bits(const Drop& d, unsigned int bd, int ncols) {
+    if (DM == DM_NONE) return 0xFFFFFFFFu;
+    if (DM == DM_HALF) return mix32(d.key ^ bd);
+    unsigned int bits = 0u;
+    for (int t = 0; t < ncols; ++t) bits |= (drop_keep(d, bd * ncols + t) ? 1u : 0u) << t;
+    return bits;
+}
+// Keep-bits of the 32 hidden columns [32 q, 32 q + 32) of token row m (channel-hidden site): bit c & 31.
+template <int DM>
+static __device__ __forceinline__ unsigned int drop_hidden_bits(const Drop& d, unsigned int m, unsigned int q, unsigned int Cp) {
+    if (DM == DM_NONE) return 0xFFFFFFFFu;
+    if (DM == DM_HALF) return drop_word_half(d, m, q, Cp >> 5);
+    unsigned int bits = 0u;
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {           // 16 hash words, two 16-bit draws each
+        const unsigned int w = mix32(d.key ^ ((m * Cp + 32 * q) / 2 + j));
+        bits |= (((w & 0xFFFFu) < d.thr) ? 1u : 0u) << (2 * j);
+        bits |= (((w >> 16) < d.thr) ? 1u : 0u) << (2 * j + 1);
+    }
+    return bits;
+}
+// one element of the channel-output / generic sites
+template <int DM>
+static __device__ __forceinline__ bool drop_keep_elem(const Drop& d, unsigned int idx) {
+    if (DM == DM_NONE) return true;
+    return drop_keep(d, idx);
+}
+
 template <int D> struct TileGeom {
     static constexpr int XLD = D + 4;          // padded fp32 row stride (floats)
     static constexpr int DT = D / 16;

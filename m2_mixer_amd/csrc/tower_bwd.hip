@@ -66,7 +66,7 @@ static __device__ __forceinline__ void ln_backward_tile(const float* xg, int R, 
     __syncthreads();
 }
 
-template <int P, int D, int NMAX, int TG>
+template <int P, int D, int NMAX, int TG, int DM>
 __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw, int B, const float* __restrict__ d_out,
                                                              long d_out_ss, const float* __restrict__ d_pooled,
                                                              float* __restrict__ d_x0, long d_x0_ss, unsigned int seed,
@@ -88,6 +88,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
     char* dyp = reinterpret_cast<char*>(slabs + 3 * SF);
     float* rstd_s = slabs + 4 * SF;                      // [BM]
     float* dasum = rstd_s + BM;                          // [BM][XLD] summed dA (row-major)
+    gtab_t* gtab = reinterpret_cast<gtab_t*>(dasum + TILE_F);   // [GELU_TAB_N] (bf16 mode only)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
     const int N = tw.N, T = tw.T, Cp = tw.Cp;
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
     const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
 
     TIMER_START();
+    if (Act<P>::USES_TABLE) gelu_tab_fill(gtab, tid, NTHREADS);
     // ---- upstream gradient of the tower output ----
     {
         const float invN = 1.0f / (float)N;
@@ -131,15 +133,13 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
         const Drop dr_to = make_drop(true, tw.p_drop, seed, step, site + 1);
         const Drop dr_ch = make_drop(true, tw.p_drop, seed, step, site + 2);
         const Drop dr_co = make_drop(true, tw.p_drop, seed, step, site + 3);
-        const bool dropping = dr_th.thr < 65536u;
-        const bool half = dr_th.thr == 32768u;
 
         // ================= channel mixing backward =================
         // (C1) dYd = dY * mask_out -> fp32 temp (ub)
         _Pragma("unroll 1") for (int idx = tid; idx < BM * D; idx += NTHREADS) {
             const int r = idx / D, d = idx % D;
             float v = dxs[r * XLD + d];
-            if (dropping) v = drop_keep(dr_co, (unsigned int)(row0 + r) * D + d) ? v * dr_co.scale : 0.f;
+            v = drop_keep_elem<DM>(dr_co, (unsigned int)(row0 + r) * D + d) ? v * dr_co.scale : 0.f;
             ub[r * XLD + d] = (r < R) ? v : 0.f;
         }
         __syncthreads();
@@ -235,19 +235,15 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const unsigned int m = (unsigned int)(row0 + mt * 16 + il);
-                unsigned int word = 0xFFFFFFFFu;
-                if (half) word = drop_word_half(dr_ch, m, q, npairs);
+                const unsigned int word = drop_hidden_bits<DM>(dr_ch, m, q, Cp) >> (4 * g);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    bool keep[4] = {true, true, true, true};
-                    if (dropping && !half) drop_keep4(dr_ch, m * (unsigned int)Cp + 32 * q + 16 * t + 4 * g, keep);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float gl, dgl;
-                        gelu_grad_f(hacc[mt][t][r], gl, dgl);
+                        Act<P>::gelu_grad(gtab, hacc[mt][t][r], gl, dgl);
                         const float v = gacc[mt][t][r] * dgl * dr_ch.scale;
-                        const bool k = half ? ((word >> (16 * t + 4 * g + r)) & 1u) : keep[r];
-                        gacc[mt][t][r] = k ? v : 0.f;
+                        gacc[mt][t][r] = ((word >> (16 * t + r)) & 1u) ? v : 0.f;
                     }
                 }
                 Chain<P>::make(gacc[mt][0], gacc[mt][1], hf[mt]);
@@ -320,21 +316,22 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
                 const int sl = pv ? p / D : 0, d = pv ? p % D : 0;
                 const unsigned int bd = (unsigned int)(s0 + sl) * D + d;
                 float un[NMAX], dv[NMAX], du[NMAX];
-                const unsigned int wth = half ? mix32(dr_th.key ^ bd) : 0u;
-                const unsigned int wto = half ? mix32(dr_to.key ^ bd) : 0u;
+                const unsigned int wth = drop_row_bits<DM>(dr_th, bd, T);     // keep-bits (all ones when dropout is off)
+                const unsigned int wto = drop_row_bits<DM>(dr_to, bd, N);
 #pragma unroll
                 for (int n = 0; n < NMAX; ++n) {
                     un[n] = 0.f; dv[n] = 0.f; du[n] = 0.f;
                     if (pv && n < N) {
                         un[n] = ub[(sl * N + n) * XLD + d];
-                        float v = dxs[(sl * N + n) * XLD + d];
-                        if (dropping) v = (half ? ((wto >> n) & 1u) : drop_keep(dr_to, bd * N + n)) ? v * dr_to.scale : 0.f;
-                        dv[n] = v;
+                        const float v = dxs[(sl * N + n) * XLD + d] * dr_to.scale;
+                        dv[n] = ((wto >> n) & 1u) ? v : 0.f;
                     }
                 }
+                // all TTMAX slots are computed unconditionally (weights of unused slots are zero, so they add
+                // nothing): straight-line code lets the TTMAX independent chains overlap their LDS latencies
 #pragma unroll
                 for (int tt = 0; tt < TTMAX; ++tt) {
-                    if (tt < TT) {
+                    {
                         const int t = tg * TT + tt;
                         float h = b1r[tt], dh = 0.f;
 #pragma unroll
@@ -343,10 +340,9 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
                             dh = __builtin_fmaf(w2r[n][tt], dv[n], dh);
                         }
                         float gl, dgl;
-                        gelu_grad_f(h, gl, dgl);
-                        bool keep = true;
-                        if (dropping) keep = half ? ((wth >> t) & 1u) : drop_keep(dr_th, bd * T + t);
-                        const float sc = dropping ? dr_th.scale : 1.0f;
+                        Act<P>::gelu_grad(gtab, h, gl, dgl);
+                        const bool keep = (wth >> (t & 31)) & 1u;
+                        const float sc = dr_th.scale;
                         const float hact = keep ? gl * sc : 0.f;
                         const float dhp = (keep && pv) ? dh * sc * dgl : 0.f;
                         ab1[tt] += dhp;
@@ -369,6 +365,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
                     }
                 }
             }
+            TIMER_MARK(g_tm_bwd, 4);   // T1: LN1 recompute + token MLP backward pair loop
             // reduce the token-weight gradients: over the 8 columns a wave handles at a time (shuffles), over the
             // 8 waves (LDS atomics into `red`, which reuses the dA tile), then ONE global atomic per value
             // per workgroup (the same ~300 addresses are hit by every workgroup of the launch).
@@ -381,14 +378,12 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
             for (int tt = 0; tt < TTMAX; ++tt) {
                 if (tt < TT) {
                     const int t = tg * TT + tt;
-                    float s = ab1[tt];
-                    for (int o = TG; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
+                    const float s = lane_class_sum(ab1[tt], TG);
                     if (lane < TG) atomicAdd(red + 2 * T * N + t, s);
 #pragma unroll
                     for (int n = 0; n < NMAX; ++n) {
                         if (n < N) {
-                            float a = aw1[tt][n], c = aw2[n][tt];
-                            for (int o = TG; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+                            const float a = lane_class_sum(aw1[tt][n], TG), c = lane_class_sum(aw2[n][tt], TG);
                             if (lane < TG) {
                                 atomicAdd(red + t * N + n, a);
                                 atomicAdd(red + T * N + n * T + t, c);
@@ -400,12 +395,12 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
 #pragma unroll
             for (int n = 0; n < NMAX; ++n) {
                 if (n < N) {
-                    float s = ab2[n];   // non-zero on tg == 0 lanes only
-                    for (int o = TG; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
+                    const float s = lane_class_sum(ab2[n], TG);   // non-zero on tg == 0 lanes only
                     if (lane == 0) atomicAdd(red + 2 * T * N + T + n, s);
                 }
             }
             __syncthreads();
+            TIMER_MARK(g_tm_bwd, 6);   // T1b: token-grad shuffles + LDS atomics
             for (int i = tid; i < nred; i += NTHREADS) {
                 float* dst = i < T * N ? bk.g_tok_w1 + i
                            : (i < 2 * T * N ? bk.g_tok_w2 + (i - T * N)
@@ -414,6 +409,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
             }
         }
         __syncthreads();
+        TIMER_MARK(g_tm_bwd, 7);       // T1c: global atomics of the token grads
         // (T2) LayerNorm-1 backward: dx_in = dx_mid + LN1'(dU); gamma/beta gradients
         {
             const int r = tid / TPR, j = tid % TPR;
@@ -462,14 +458,14 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
     }
 }
 
-template <int P, int D, int NMAX, int TG>
-static int launch_bwd(const m2m_tower* t, int B, const float* d_out, long d_out_ss, const float* d_pooled, float* d_x0,
+template <int P, int D, int NMAX, int TG, int DM>
+static int launch_bwd_dm(const m2m_tower* t, int B, const float* d_out, long d_out_ss, const float* d_pooled, float* d_x0,
                       long d_x0_ss, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
     const int SPW = BM / t->N;
     const int grid = (B + SPW - 1) / SPW;
     const size_t tile_b = (size_t)BM * TileGeom<D>::XLD * sizeof(float);
-    const size_t lds = 2 * tile_b + 4 * SlabGeom<D>::FLOATS * sizeof(float) + BM * sizeof(float);
-    auto kern = tower_bwd_kernel<P, D, NMAX, TG>;
+    const size_t lds = 2 * tile_b + 4 * SlabGeom<D>::FLOATS * sizeof(float) + BM * sizeof(float) + GELU_TAB_N * 16;
+    auto kern = tower_bwd_kernel<P, D, NMAX, TG, DM>;
     static bool attr_done = false;
     if (!attr_done) {
         M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -478,6 +474,16 @@ static int launch_bwd(const m2m_tower* t, int B, const float* d_out, long d_out_
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, st, *t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step, step_dev);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+template <int P, int D, int NMAX, int TG>
+static int launch_bwd(const m2m_tower* t, int B, const float* d_out, long d_out_ss, const float* d_pooled, float* d_x0,
+                      long d_x0_ss, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
+    switch (m2m_drop_mode(1, t->p_drop)) {
+        case DM_NONE: return launch_bwd_dm<P, D, NMAX, TG, DM_NONE>(t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step, step_dev, st);
+        case DM_HALF: return launch_bwd_dm<P, D, NMAX, TG, DM_HALF>(t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step, step_dev, st);
+        default:      return launch_bwd_dm<P, D, NMAX, TG, DM_GEN>(t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step, step_dev, st);
+    }
 }
 
 int m2m_check_tower(const m2m_tower* t, int B);

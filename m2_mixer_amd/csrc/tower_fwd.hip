@@ -17,7 +17,7 @@
 TIMER_DECL(g_tm_fwd);
 TIMER_READER(m2m_debug_timers_fwd, g_tm_fwd)
 
-template <int P, int D, int NMAX>
+template <int P, int D, int NMAX, int DM>
 __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw, const float* __restrict__ x0,
                                                              long x0_ss, int B, float* __restrict__ out, long out_ss,
                                                              float* __restrict__ pooled, int training,
@@ -36,6 +36,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw,
     char* at = reinterpret_cast<char*>(slabs + 4 * SlabGeom<D>::FLOATS);   // packed A image   BM*D*ESZ bytes
     float* tokw = reinterpret_cast<float*>(at + BM * D * Pr::ESZ);   // [T <= 32][TW_LD]
     float* tokb2 = tokw + 32 * TW_LD;                             // [NMAX]
+    gtab_t* gtab = reinterpret_cast<gtab_t*>(tokb2 + 8);          // [GELU_TAB_N] (bf16 mode only)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
     const int N = tw.N, T = tw.T, Cp = tw.Cp;
@@ -47,6 +48,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw,
     const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
 
     TIMER_START();
+    if (Act<P>::USES_TABLE) gelu_tab_fill(gtab, tid, NTHREADS);
     // ---- load the input tile (rows >= R are zero) ----
     _Pragma("unroll 1") for (int idx = tid; idx < BM * (D / 4); idx += NTHREADS) {
         const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
@@ -63,8 +65,6 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw,
         const Drop dr_to = make_drop(training, tw.p_drop, seed, step, site + 1);
         const Drop dr_ch = make_drop(training, tw.p_drop, seed, step, site + 2);
         const Drop dr_co = make_drop(training, tw.p_drop, seed, step, site + 3);
-        const bool dropping = dr_th.thr < 65536u;
-        const bool half = dr_th.thr == 32768u;
 
         // ---- save block input, LN1 -> ub; token-MLP weights -> LDS (zero-padded to NMAX tokens) ----
         //   tokw[t][0..NMAX) = W1[t][n]   tokw[t][NMAX..2NMAX) = W2[n][t]   tokw[t][2NMAX] = b1[t]
@@ -97,25 +97,24 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw,
                 un[n] = (n < N) ? ub[(sl * N + n) * XLD + d] : 0.f;
                 o[n] = tokb2[n];
             }
-            // p == 0.5: one 32-bit word per column decides all T (<= 32) hidden units / all N outputs
-            const unsigned int wth = half ? mix32(dr_th.key ^ bd) : 0u;
-            const unsigned int wto = half ? mix32(dr_to.key ^ bd) : 0u;
+            // keep-bits of this column's T hidden units / N outputs (all ones when dropout is off): no branches below
+            const unsigned int wth = drop_row_bits<DM>(dr_th, bd, T);
+            const unsigned int wto = drop_row_bits<DM>(dr_to, bd, N);
+#pragma unroll 4
             for (int t = 0; t < T; ++t) {
                 const float* wr = tokw + t * TW_LD;
                 float h = wr[2 * NMAX];
 #pragma unroll
                 for (int n = 0; n < NMAX; ++n) h = __builtin_fmaf(wr[n], un[n], h);
-                h = gelu_f(h);
-                if (dropping) h = (half ? ((wth >> t) & 1u) : drop_keep(dr_th, bd * T + t)) ? h * dr_th.scale : 0.f;
+                h = Act<P>::gelu(gtab, h) * dr_th.scale;
+                h = ((wth >> t) & 1u) ? h : 0.f;
 #pragma unroll
                 for (int n = 0; n < NMAX; ++n) o[n] = __builtin_fmaf(wr[NMAX + n], h, o[n]);
             }
 #pragma unroll
             for (int n = 0; n < NMAX; ++n) {
                 if (n < N) {
-                    float v = o[n];
-                    if (dropping) v = (half ? ((wto >> n) & 1u) : drop_keep(dr_to, bd * N + n)) ? v * dr_to.scale : 0.f;
-                    xs[(sl * N + n) * XLD + d] += v;
+                    xs[(sl * N + n) * XLD + d] += ((wto >> n) & 1u) ? o[n] * dr_to.scale : 0.f;
                 }
             }
         }
@@ -191,17 +190,13 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw,
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const unsigned int m = (unsigned int)(row0 + mt * 16 + il);
-                unsigned int word = 0xFFFFFFFFu;
-                if (half) word = drop_word_half(dr_ch, m, q, npairs);
+                const unsigned int word = drop_hidden_bits<DM>(dr_ch, m, q, Cp) >> (4 * g);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    bool keep[4] = {true, true, true, true};
-                    if (dropping && !half) drop_keep4(dr_ch, m * (unsigned int)Cp + 32 * q + 16 * t + 4 * g, keep);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float v = gelu_f(hacc[mt][t][r]) * dr_ch.scale;
-                        const bool k = half ? ((word >> (16 * t + 4 * g + r)) & 1u) : keep[r];
-                        hacc[mt][t][r] = k ? v : 0.f;
+                        const float v = Act<P>::gelu(gtab, hacc[mt][t][r]) * dr_ch.scale;
+                        hacc[mt][t][r] = ((word >> (16 * t + r)) & 1u) ? v : 0.f;
                     }
                 }
                 Chain<P>::make(hacc[mt][0], hacc[mt][1], hf[mt]);
@@ -222,7 +217,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw,
             const int d = idx / BM, r = idx % BM;
             if (r < R) {
                 float v = slab_sum<D>(slabs, r, d) + bk.ch_b2[d];
-                if (dropping) v = drop_keep(dr_co, (unsigned int)(row0 + r) * D + d) ? v * dr_co.scale : 0.f;
+                v = drop_keep_elem<DM>(dr_co, (unsigned int)(row0 + r) * D + d) ? v * dr_co.scale : 0.f;
                 xs[r * XLD + d] += v;
             }
         }
@@ -262,16 +257,16 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw,
 
 template <int P, int D>
 static size_t fwd_lds_bytes() {
-    return (size_t)(BM * TileGeom<D>::XLD + 4 * SlabGeom<D>::FLOATS) * sizeof(float) + (size_t)BM * D * Prec<P>::ESZ + (32 * 20 + 8) * sizeof(float);
+    return (size_t)(BM * TileGeom<D>::XLD + 4 * SlabGeom<D>::FLOATS) * sizeof(float) + (size_t)BM * D * Prec<P>::ESZ + (32 * 20 + 8) * sizeof(float) + GELU_TAB_N * 16;
 }
 
-template <int P, int D, int NMAX>
-static int launch_fwd(const m2m_tower* t, const float* x0, long x0_ss, int B, float* out, long out_ss, float* pooled,
+template <int P, int D, int NMAX, int DM>
+static int launch_fwd_dm(const m2m_tower* t, const float* x0, long x0_ss, int B, float* out, long out_ss, float* pooled,
                       int training, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
     const int SPW = BM / t->N;
     const int grid = (B + SPW - 1) / SPW;
     const size_t lds = fwd_lds_bytes<P, D>();
-    auto kern = tower_fwd_kernel<P, D, NMAX>;
+    auto kern = tower_fwd_kernel<P, D, NMAX, DM>;
     static bool attr_done = false;
     if (!attr_done) {
         M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -280,6 +275,16 @@ static int launch_fwd(const m2m_tower* t, const float* x0, long x0_ss, int B, fl
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, st, *t, x0, x0_ss, B, out, out_ss, pooled, training, seed, step, step_dev);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+template <int P, int D, int NMAX>
+static int launch_fwd(const m2m_tower* t, const float* x0, long x0_ss, int B, float* out, long out_ss, float* pooled,
+                      int training, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
+    switch (m2m_drop_mode(training, t->p_drop)) {
+        case DM_NONE: return launch_fwd_dm<P, D, NMAX, DM_NONE>(t, x0, x0_ss, B, out, out_ss, pooled, training, seed, step, step_dev, st);
+        case DM_HALF: return launch_fwd_dm<P, D, NMAX, DM_HALF>(t, x0, x0_ss, B, out, out_ss, pooled, training, seed, step, step_dev, st);
+        default:      return launch_fwd_dm<P, D, NMAX, DM_GEN>(t, x0, x0_ss, B, out, out_ss, pooled, training, seed, step, step_dev, st);
+    }
 }
 
 int m2m_check_tower(const m2m_tower* t, int B);

@@ -20,7 +20,7 @@
 TIMER_DECL(g_tm_wg);
 TIMER_READER(m2m_debug_timers_wgrad, g_tm_wg)
 
-template <int P, int D>
+template <int P, int D, int DM>
 __global__ __launch_bounds__(NTHREADS) void tower_wgrad_kernel(const m2m_tower tw, int ntiles, int tiles_per_group,
                                                                int rows_per_tile, unsigned int seed, unsigned int step_host,
                                                                const unsigned int* __restrict__ step_dev) {
@@ -33,6 +33,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_wgrad_kernel(const m2m_tower t
     static_assert(IMG_B % (NTHREADS * 16) == 0 || (NTHREADS * 16) % IMG_B == 0, "piece never straddles two images");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    gtab_t* gtab = reinterpret_cast<gtab_t*>(smem + 2 * STAGE_B);     // [GELU_TAB_N] (bf16 mode only)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
     const m2m_block& bk = tw.blk[blockIdx.y];
@@ -44,8 +45,6 @@ __global__ __launch_bounds__(NTHREADS) void tower_wgrad_kernel(const m2m_tower t
     const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
     const unsigned int site = tw.site_base + 4u * blockIdx.y;
     const Drop dr_ch = make_drop(true, tw.p_drop, seed, step, site + 2);
-    const bool dropping = dr_ch.thr < 65536u;
-    const bool half = dr_ch.thr == 32768u;
 
     Frag w1f[KD], w2f[KD];
     f32x4_t dw1[DT], dw2[DT];
@@ -84,6 +83,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_wgrad_kernel(const m2m_tower t
         *reinterpret_cast<u32x4_t*>((buf_) + (i * NTHREADS + tid) * 16) = pre[i];
 
     TIMER_START();
+    if (Act<P>::USES_TABLE) gelu_tab_fill(gtab, tid, NTHREADS);
     const int t_begin = blockIdx.z * tiles_per_group;
     const int t_end = min(ntiles, t_begin + tiles_per_group);
     if (t_begin < t_end) {
@@ -121,10 +121,8 @@ __global__ __launch_bounds__(NTHREADS) void tower_wgrad_kernel(const m2m_tower t
                     // sub-tile u of this tile is chain tile (tile * SUB + u / (BM/16)); its rows are sample-aligned
                     const unsigned int m = (unsigned int)(tile * (WBM / BM) + (16 * u) / BM) * rows_per_tile + (16 * u) % BM + 4 * g + r;
                     float gl, dgl;
-                    gelu_grad_f(hacc[r], gl, dgl);
-                    bool keep = true;
-                    if (half) keep = (drop_word_half(dr_ch, m, q, npairs) >> (16 * tq + il)) & 1u;
-                    else if (dropping) keep = drop_keep(dr_ch, m * (unsigned int)Cp + 16 * ct + il);
+                    Act<P>::gelu_grad(gtab, hacc[r], gl, dgl);
+                    const bool keep = (drop_hidden_bits<DM>(dr_ch, m, q, Cp) >> (16 * tq + il)) & 1u;
                     const float hv = keep ? gl * dr_ch.scale : 0.f;
                     const float dv = keep ? gacc[r] * dgl * dr_ch.scale : 0.f;
                     hact[u][r] = hv;
@@ -192,8 +190,8 @@ __global__ __launch_bounds__(NTHREADS) void tower_wgrad_kernel(const m2m_tower t
     TIMER_MARK(g_tm_wg, 4);        // result write-out
 }
 
-template <int P, int D>
-static int launch_wgrad(const m2m_tower* t, int B, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
+template <int P, int D, int DM>
+static int launch_wgrad_dm(const m2m_tower* t, int B, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
     const int SPW = BM / t->N;                                  // samples per chain tile
     const int nchain = (B + SPW - 1) / SPW;                     // chain tiles (BM rows each)
     const int ntiles = (nchain * BM + WBM - 1) / WBM;           // streamed tiles (WBM rows each)
@@ -207,8 +205,8 @@ static int launch_wgrad(const m2m_tower* t, int B, unsigned int seed, unsigned i
     if (tpg < 4) tpg = 4;
     if (tpg > ntiles) tpg = ntiles;
     groups = (ntiles + tpg - 1) / tpg;
-    const size_t lds = (size_t)2 * 4 * WBM * D * Prec<P>::ESZ;
-    auto kern = tower_wgrad_kernel<P, D>;
+    const size_t lds = (size_t)2 * 4 * WBM * D * Prec<P>::ESZ + GELU_TAB_N * 16;
+    auto kern = tower_wgrad_kernel<P, D, DM>;
     static bool attr_done = false;
     if (!attr_done) {
         M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -217,6 +215,15 @@ static int launch_wgrad(const m2m_tower* t, int B, unsigned int seed, unsigned i
     hipLaunchKernelGGL(kern, dim3(nsl, t->nblocks, groups), dim3(NTHREADS), lds, st, *t, ntiles, tpg, SPW * t->N, seed, step, step_dev);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+template <int P, int D>
+static int launch_wgrad(const m2m_tower* t, int B, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
+    switch (m2m_drop_mode(1, t->p_drop)) {
+        case DM_NONE: return launch_wgrad_dm<P, D, DM_NONE>(t, B, seed, step, step_dev, st);
+        case DM_HALF: return launch_wgrad_dm<P, D, DM_HALF>(t, B, seed, step, step_dev, st);
+        default:      return launch_wgrad_dm<P, D, DM_GEN>(t, B, seed, step, step_dev, st);
+    }
 }
 
 int m2m_check_tower(const m2m_tower* t, int B);

@@ -188,10 +188,22 @@ class AVMnistEngine:
         self.adam_state[1] = lr
 
     def pack(self):
-        for t in (self.t_img, self.t_aud, self.t_fus):
-            t.pack(force=True)
-        for e in (self.e_img, self.e_aud):
-            e.pack(force=True)
+        """Rebuild the packed MFMA-operand copies from the fp32 masters (three independent launches + two tiny ones:
+        spread over the side streams)."""
+        main = torch.cuda.current_stream()
+        s_a = self.s_aud if self.concurrent else main
+        s_f = self.s_fus if self.concurrent else main
+        s_a.wait_stream(main)
+        s_f.wait_stream(main)
+        with torch.cuda.stream(s_a):
+            self.t_aud.pack(force=True)
+            self.e_aud.pack(force=True)
+        with torch.cuda.stream(s_f):
+            self.t_fus.pack(force=True)
+        self.t_img.pack(force=True)
+        self.e_img.pack(force=True)
+        main.wait_stream(s_a)
+        main.wait_stream(s_f)
 
     # ---- one training step (enqueue only; no host synchronisation) ----------------------------------------
     def _forward(self, image, audio, labels, training: bool, with_grad: bool):
@@ -242,16 +254,17 @@ class AVMnistEngine:
         main.wait_stream(s_f)
 
     def forward_backward(self, image, audio, labels):
-        """zero grads -> forward (dropout on) -> multi-head loss -> backward; gradients land in flat_g."""
-        self.flat_g.zero_()
+        """forward (dropout on) -> multi-head loss -> backward; gradients are ADDED into flat_g, which must be
+        zero on entry: it is cleared at construction and again by every optimizer_step (the Adam kernel clears
+        each element it consumes), so no separate fill pass is needed."""
         self._forward(image, audio, labels, True, True)
         self._backward(image, audio)
 
     def optimizer_step(self, grad_scale: float = 1.0):
         L.check(L.lib().m2m_adam_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
                                       self.flat_v.data_ptr(), self.n_params, self.adam_state.data_ptr(),
-                                      self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale,
-                                      L.stream_ptr()), "adam_step")
+                                      self.betas[0], self.betas[1], self.eps, self.weight_decay, -abs(grad_scale),
+                                      L.stream_ptr()), "adam_step")          # negative scale: clear the gradients too
         L.check(L.lib().m2m_counter_add(self.drop_step.data_ptr(), 1, L.stream_ptr()), "counter_add")
         self.pack()
 

@@ -250,13 +250,16 @@ def t_engine():
             di, da, dl = image.to(dev), audio.to(dev), labels.to(dev)
             for step in range(2):
                 ro = O.avmnist_train_step(image, audio, labels, params, cfg, state, lr=1e-2)
-                eng.train_step(di, da, dl)
+                eng.forward_backward(di, da, dl)
+                torch.cuda.synchronize()
+                gsnap = {k: v.clone() for k, v in eng.grads.items()}
+                eng.optimizer_step()
                 torch.cuda.synchronize()
                 print(f"  {size} {prec} step{step}: loss {float(eng.losses[3]):.6f} vs {float(ro['loss']):.6f}  "
                       f"logits {rel(eng.logits[2], ro['logits'])} img {rel(eng.logits[0], ro['image_logits'])} "
                       f"preds eq {bool((eng.preds[2].cpu() == ro['preds']).all())}")
                 if step == 0:
-                    worst = sorted(((rel(eng.grads[k], g)[0] / (float(g.abs().max()) + 1e-9), k, rel(eng.grads[k], g)) for k, g in ro["grads"].items()
+                    worst = sorted(((rel(gsnap[k], g)[0] / (float(g.abs().max()) + 1e-9), k, rel(gsnap[k], g)) for k, g in ro["grads"].items()
                                     if not k.endswith("token_mix.2.net.3.bias")), reverse=True)[:5]
                     for w in worst:
                         print(f"      grad {w[1]:55s} err {w[2][0]:.3e} ref max {w[2][1]:.3e}")

@@ -18,7 +18,7 @@ import bench                                   # noqa: E402
 lib = L.lib()
 NAMES = {
     "fwd": ["load/save/LN1", "token mix", "save/LN2/pack", "column loop", "reduce+residual", "final LN/out"],
-    "bwd": ["upstream+LNf bwd", "C1+C2 pack", "C3 column loop", "C4+C5 reduce/LN2bwd", "T1 token bwd", "T2 LN1 bwd"],
+    "bwd": ["upstream+LNf bwd", "C1+C2 pack", "C3 column loop", "C4+C5 reduce/LN2bwd", "T1 token pair loop", "T2 LN1 bwd + colsums", "T1b shuffles+LDS atomics", "T1c global atomics"],
     "wgrad": ["tile load", "recompute+elementwise mb0", "grad GEMMs mb0", "recompute+elementwise mb1", "grad GEMMs mb1", "-", "write-out"],
 }
 

@@ -147,7 +147,7 @@ def test_avmnist_step_fp32_vs_reference_golden(size, B, seed, dev):
     shapes = G.avmnist_shapes(cfg)
     eng.load_state_dict(dict(G.make_params(shapes, seed)))
     image, audio, labels = (t.to(dev) for t in G.avmnist_batch(B, seed + 1, cfg))
-    eng.train_step(image, audio, labels)
+    eng.forward_backward(image, audio, labels)          # gradients are consumed (cleared) by optimizer_step: look first
     torch.cuda.synchronize()
     check(gold, "step0//logits", eng.logits[2], FP32_ATOL)
     check(gold, "step0//image_logits", eng.logits[0], FP32_ATOL)
@@ -159,6 +159,8 @@ def test_avmnist_step_fp32_vs_reference_golden(size, B, seed, dev):
     assert np.array_equal(eng.preds[1].cpu().numpy(), gold["step0//preds_audio"])
     for k in shapes:
         check(gold, f"grad//{k}", eng.grads[k], 1e-4, 1e-3, what="grad ")
+    eng.optimizer_step()
+    assert float(eng.flat_g.abs().max()) == 0.0, "Adam must leave the gradient buffer cleared"
     # second step goes through the Adam update
     eng.train_step(image, audio, labels)
     torch.cuda.synchronize()
@@ -177,7 +179,7 @@ def test_avmnist_step_bf16_vs_oracle(size, B, dev):
     params = dict(G.make_params(shapes, 7))
     eng.load_state_dict(params)
     image, audio, labels = G.avmnist_batch(B, 8, cfg)
-    eng.train_step(image.to(dev), audio.to(dev), labels.to(dev))
+    eng.forward_backward(image.to(dev), audio.to(dev), labels.to(dev))
     torch.cuda.synchronize()
     ref = O.avmnist_train_step(image, audio, labels, params, cfg, {}, lr=1e-2)
     assert abserr(eng.logits[2], ref["logits"]) < BF16_REL
@@ -242,21 +244,24 @@ def test_full_size_properties(dev):
     o2 = small.evaluate(image[:64].contiguous(), audio[:64].contiguous(), labels[:64].contiguous())
     assert torch.equal(o2["logits"], l1[:64]), "a sample's logits must not depend on the rest of the batch"
     assert torch.isfinite(l1).all()
-    # eager vs graph: same parameters, same dropout counter -> identical losses and gradients
+    # eager vs graph: same parameters, same Adam state, same dropout counter -> same losses and same updated weights
     a = AVMnistEngine(cfg, B, device=dev, precision="bf16", lr=1e-3, seed=42)
     a.load_state_dict(eng.state_dict())
-    a.forward_backward(image, audio, labels)
+    a.train_step(image, audio, labels)
     torch.cuda.synchronize()
-    ga, la = a.flat_g.clone(), a.losses.clone()
-    b = AVMnistEngine(cfg, B, device=dev, precision="bf16", lr=0.0, seed=42)
+    la, pa = a.losses.clone(), a.flat_p.clone()
+    b = AVMnistEngine(cfg, B, device=dev, precision="bf16", lr=1e-3, seed=42)
+    replay = b.capture(image, audio, labels)          # capture runs warm-up steps: rewind the state afterwards
     b.load_state_dict(eng.state_dict())
-    replay = b.capture(image, audio, labels)          # lr = 0: the two warm-up steps leave the weights unchanged
-    b.drop_step.zero_()
+    b.flat_m.zero_(); b.flat_v.zero_(); b.flat_g.zero_(); b.adam_state[0] = 0.0; b.drop_step.zero_()
     replay()
     torch.cuda.synchronize()
     assert torch.allclose(b.losses, la, rtol=0, atol=1e-5)
-    # float atomics make the order of a few small sums non-deterministic: compare with a tight tolerance
-    assert relerr(b.flat_g, ga) < 1e-4
+    # float atomics make the order of a few small sums non-deterministic: Adam's first step is lr * sign(g)-like,
+    # so compare the update direction statistically rather than bit for bit
+    agree = float(((b.flat_p - eng.flat_p).sign() == (pa - eng.flat_p).sign()).float().mean())
+    assert agree > 0.999, agree
+    assert float(b.flat_g.abs().max()) == 0.0
     # losses are sane for random init: each head near ln(10)
     assert all(abs(float(v) - np.log(10)) < 0.5 for v in la[:3])
 
