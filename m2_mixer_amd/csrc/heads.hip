@@ -36,13 +36,16 @@ __global__ __launch_bounds__(NTHREADS) void heads_ce_kernel(const HeadArgs ha, c
     }
     for (int idx = tid; idx < K * D; idx += NTHREADS) wl[(idx / D) * DL + idx % D] = hd.w[idx];
     __syncthreads();
-    // logits
-    for (int idx = tid; idx < HEAD_S * K; idx += NTHREADS) {
-        const int s = idx / K, k = idx % K;
-        float a = hd.b[k];
-        for (int d = 0; d < D; ++d) a = __builtin_fmaf(pl[s * DL + d], wl[k * DL + d], a);
-        lg[s * HEAD_MAXK + k] = a;
-        if (s < ns) logits_out[((long)hI * B + s0 + s) * K + k] = a;
+    // logits: 4 adjacent lanes split each D-long dot product
+    for (int idx = tid >> 2; idx < HEAD_S * K; idx += NTHREADS / 4) {
+        const int s = idx / K, k = idx % K, part = tid & 3;
+        float a = 0.f;
+        for (int d = part; d < D; d += 4) a = __builtin_fmaf(pl[s * DL + d], wl[k * DL + d], a);
+        a = wave_sum_xor(a, 4) + hd.b[k];
+        if (part == 0) {
+            lg[s * HEAD_MAXK + k] = a;
+            if (s < ns) logits_out[((long)hI * B + s0 + s) * K + k] = a;
+        }
     }
     __syncthreads();
     // softmax / loss / prediction / dlogits, one thread per sample

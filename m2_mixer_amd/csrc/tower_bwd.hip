@@ -89,6 +89,10 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
     float* rstd_s = slabs + 4 * SF;                      // [BM]
     float* dasum = rstd_s + BM;                          // [BM][XLD] summed dA (row-major)
     gtab_t* gtab = reinterpret_cast<gtab_t*>(dasum + TILE_F);   // [GELU_TAB_N] (bf16 mode only)
+    constexpr int RED_LD = ((32 / TG) * (1 + 2 * NMAX) + NMAX) * TG;   // token-grad slots per wave
+    float* red = reinterpret_cast<float*>(gtab + GELU_TAB_N);    // [NWAVES][RED_LD]
+    constexpr int TW_LD = 2 * NMAX + 4;
+    float* tokw = red + NWAVES * RED_LD;                         // [32][TW_LD] zero-padded token-MLP weights
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
     const int N = tw.N, T = tw.T, Cp = tw.Cp;
@@ -269,7 +273,18 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
 
         TIMER_MARK(g_tm_bwd, 3);   // C4 + C5: reduction, LN2 backward
         // ================= token mixing backward =================
-        // (T1) xhat1 -> xh, U = LN1(x_in) -> ub, rstd -> rstd_s
+        // (T1) xhat1 -> xh, U = LN1(x_in) -> ub, rstd -> rstd_s; token-MLP weights -> LDS, zero-padded:
+        //   tokw[t][0..NMAX) = W1[t][n]   tokw[t][NMAX..2NMAX) = W2[n][t]   tokw[t][2NMAX] = b1[t]   (t < 32)
+        _Pragma("unroll 1") for (int idx = tid; idx < 32 * TW_LD; idx += NTHREADS) {
+            const int t = idx / TW_LD, j = idx % TW_LD;
+            float v = 0.f;
+            if (t < T) {
+                if (j < NMAX) { if (j < N) v = bk.tok_w1[t * N + j]; }
+                else if (j < 2 * NMAX) { if (j - NMAX < N) v = bk.tok_w2[(j - NMAX) * T + t]; }
+                else if (j == 2 * NMAX) v = bk.tok_b1[t];
+            }
+            tokw[idx] = v;
+        }
         {
             const int r = tid / TPR, j = tid % TPR;
             float v[D / TPR], mean, rstd;
@@ -290,16 +305,17 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
             const int TT = T / TG;
             float w1r[TTMAX][NMAX], w2r[NMAX][TTMAX], b1r[TTMAX];
             float aw1[TTMAX][NMAX], aw2[NMAX][TTMAX], ab1[TTMAX], ab2[NMAX];
+            // this lane's hidden units from the zero-padded LDS copy of the token weights (rows t >= T and
+            // columns n >= N are zero, so unused slots contribute nothing and need no guards)
 #pragma unroll
             for (int tt = 0; tt < TTMAX; ++tt) {
-                const int t = tg * TT + tt;
-                b1r[tt] = (tt < TT) ? bk.tok_b1[t] : 0.f;
+                const float* wr = tokw + ((tg * TT + tt) & 31) * TW_LD;
+                b1r[tt] = (tt < TT) ? wr[2 * NMAX] : 0.f;
                 ab1[tt] = 0.f;
 #pragma unroll
                 for (int n = 0; n < NMAX; ++n) {
-                    const bool ok = (tt < TT) && (n < N);
-                    w1r[tt][n] = ok ? bk.tok_w1[t * N + n] : 0.f;
-                    w2r[n][tt] = ok ? bk.tok_w2[n * T + t] : 0.f;
+                    w1r[tt][n] = (tt < TT) ? wr[n] : 0.f;
+                    w2r[n][tt] = (tt < TT) ? wr[NMAX + n] : 0.f;
                     aw1[tt][n] = 0.f;
                     aw2[n][tt] = 0.f;
                 }
@@ -366,46 +382,46 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
                 }
             }
             TIMER_MARK(g_tm_bwd, 4);   // T1: LN1 recompute + token MLP backward pair loop
-            // reduce the token-weight gradients: over the 8 columns a wave handles at a time (shuffles), over the
-            // 8 waves (LDS atomics into `red`, which reuses the dA tile), then ONE global atomic per value
-            // per workgroup (the same ~300 addresses are hit by every workgroup of the launch).
-            //   red layout: [0, T*N) dW1[t][n] | [T*N, 2TN) dW2[n][t] | [2TN, 2TN+T) db1[t] | [2TN+T, +N) db2[n]
-            float* red = dasum;
-            const int nred = 2 * T * N + T + N;
-            for (int i = tid; i < nred; i += NTHREADS) red[i] = 0.f;
-            __syncthreads();
+            // reduce the token-weight gradients: over the columns a wave handles concurrently (VALU cross-lane
+            // sums), over the 8 waves (per-wave LDS slots written in REGISTER order -- slot (k, tg) at k*TG + tg
+            // from one base address, so no per-value address arithmetic stays live), then ONE global atomic
+            // per value per workgroup (the same ~300 addresses are hit by every workgroup of the launch).
+            //   k = tt*KS: db1[t] | tt*KS + 1 + n: dW1[t][n] | tt*KS + 1 + NMAX + n: dW2[n][t] | TTMAX*KS + n: db2[n]
+            constexpr int KS = 1 + 2 * NMAX;
+            float* myred = red + wave * RED_LD + tg;          // lanes >= TG of a wave never store
 #pragma unroll
             for (int tt = 0; tt < TTMAX; ++tt) {
-                if (tt < TT) {
-                    const int t = tg * TT + tt;
-                    const float s = lane_class_sum(ab1[tt], TG);
-                    if (lane < TG) atomicAdd(red + 2 * T * N + t, s);
+                const float s = lane_class_sum(ab1[tt], TG);
+                if (lane < TG) myred[(tt * KS) * TG] = s;
 #pragma unroll
-                    for (int n = 0; n < NMAX; ++n) {
-                        if (n < N) {
-                            const float a = lane_class_sum(aw1[tt][n], TG), c = lane_class_sum(aw2[n][tt], TG);
-                            if (lane < TG) {
-                                atomicAdd(red + t * N + n, a);
-                                atomicAdd(red + T * N + n * T + t, c);
-                            }
-                        }
+                for (int n = 0; n < NMAX; ++n) {
+                    const float a = lane_class_sum(aw1[tt][n], TG), c = lane_class_sum(aw2[n][tt], TG);
+                    if (lane < TG) {
+                        myred[(tt * KS + 1 + n) * TG] = a;
+                        myred[(tt * KS + 1 + NMAX + n) * TG] = c;
                     }
                 }
             }
 #pragma unroll
             for (int n = 0; n < NMAX; ++n) {
-                if (n < N) {
-                    const float s = lane_class_sum(ab2[n], TG);   // non-zero on tg == 0 lanes only
-                    if (lane == 0) atomicAdd(red + 2 * T * N + T + n, s);
-                }
+                const float s = lane_class_sum(ab2[n], TG);   // non-zero on tg == 0 lanes only
+                if (lane < TG) myred[(TTMAX * KS + n) * TG] = s;
             }
             __syncthreads();
-            TIMER_MARK(g_tm_bwd, 6);   // T1b: token-grad shuffles + LDS atomics
+            TIMER_MARK(g_tm_bwd, 6);   // T1b: token-grad cross-lane sums + per-wave LDS slots
+            const int nred = 2 * T * N + T + N;
             for (int i = tid; i < nred; i += NTHREADS) {
-                float* dst = i < T * N ? bk.g_tok_w1 + i
-                           : (i < 2 * T * N ? bk.g_tok_w2 + (i - T * N)
-                           : (i < 2 * T * N + T ? bk.g_tok_b1 + (i - 2 * T * N) : bk.g_tok_b2 + (i - 2 * T * N - T)));
-                atomicAdd(dst, red[i]);
+                int t, k;
+                float* dst;
+                if (i < T * N)              { t = i / N; k = 1 + i % N; dst = bk.g_tok_w1 + i; }
+                else if (i < 2 * T * N)     { const int j = i - T * N; t = j % T; k = 1 + NMAX + j / T; dst = bk.g_tok_w2 + j; }
+                else if (i < 2 * T * N + T) { t = i - 2 * T * N; k = 0; dst = bk.g_tok_b1 + t; }
+                else                        { t = -1; k = i - 2 * T * N - T; dst = bk.g_tok_b2 + k; }
+                const int slot = t < 0 ? (TTMAX * KS + k) * TG : ((t % TT) * KS + k) * TG + t / TT;
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < NWAVES; ++w) v += red[w * RED_LD + slot];
+                atomicAdd(dst, v);
             }
         }
         __syncthreads();
@@ -464,7 +480,8 @@ static int launch_bwd_dm(const m2m_tower* t, int B, const float* d_out, long d_o
     const int SPW = BM / t->N;
     const int grid = (B + SPW - 1) / SPW;
     const size_t tile_b = (size_t)BM * TileGeom<D>::XLD * sizeof(float);
-    const size_t lds = 2 * tile_b + 4 * SlabGeom<D>::FLOATS * sizeof(float) + BM * sizeof(float) + GELU_TAB_N * 16;
+    const size_t lds = 2 * tile_b + 4 * SlabGeom<D>::FLOATS * sizeof(float) + BM * sizeof(float) + GELU_TAB_N * 16 +
+                       (size_t)NWAVES * ((32 / TG) * (1 + 2 * NMAX) + NMAX) * TG * sizeof(float) + 32 * (2 * NMAX + 4) * sizeof(float);
     auto kern = tower_bwd_kernel<P, D, NMAX, TG, DM>;
     static bool attr_done = false;
     if (!attr_done) {
