@@ -196,9 +196,10 @@ static int launch_wgrad_dm(const m2m_tower* t, int B, unsigned int seed, unsigne
     const int nchain = (B + SPW - 1) / SPW;                     // chain tiles (BM rows each)
     const int ntiles = (nchain * BM + WBM - 1) / WBM;           // streamed tiles (WBM rows each)
     const int nsl = ((t->Cp >> 4) + NWAVES - 1) / NWAVES;      // 128-column slices
-    // Row groups trade parallelism against float-atomic traffic (every extra group re-adds the whole slice);
-    // one group = single owner per element, no atomics.  Aim at >= ~96 workgroups per launch.
-    int groups = (96 + nsl * t->nblocks - 1) / (nsl * t->nblocks);
+    // Row groups trade parallelism against float-atomic traffic (every extra group re-adds the whole slice) and,
+    // measured on M2-Mixer-B, against fitting the three towers' launches (100 + 100 + 50 workgroups) on the 256 CUs
+    // in ONE round: one group (single owner per element, no atomics) whenever the launch has >= 32 workgroups.
+    int groups = (32 + nsl * t->nblocks - 1) / (nsl * t->nblocks);
     if (const char* e = getenv("M2M_WGRAD_GROUPS")) groups = atoi(e);
     if (groups < 1) groups = 1;
     int tpg = (ntiles + groups - 1) / groups;

@@ -239,25 +239,25 @@ class AVMnistEngine:
         main = torch.cuda.current_stream()
         s_a = self.s_aud if self.concurrent else main
         s_f = self.s_fus if self.concurrent else main
+        # The two tower backward chains fill the chip (128 + 128 workgroups): nothing else runs beside them.
+        # All weight-gradient launches (three towers, two embeddings) follow, spread over three streams.
         s_a.wait_stream(main)
-        s_f.wait_stream(main)
         with torch.cuda.stream(s_a):
             self.t_aud.backward(B, d_aud_half, fs, self.dpool_aud, self.dx0_aud, self.Na * D, self.seed, 0, sd)
             ev_aud = torch.cuda.Event()
             ev_aud.record()
-            self.t_aud.wgrad(B, self.seed, 0, sd)
         self.t_img.backward(B, self.d_fused, fs, self.dpool_img, self.dx0_img, self.Ni * D, self.seed, 0, sd)
-        ev_img = torch.cuda.Event()
-        ev_img.record()
-        self.t_img.wgrad(B, self.seed, 0, sd)
-        with torch.cuda.stream(s_f):                        # fusion weight gradients need only the fusion backward;
-            self.t_fus.wgrad(B, self.seed, 0, sd)           # the embedding weight gradients only the towers' d_x0
-            if self.concurrent:
-                s_f.wait_event(ev_aud)
+        if self.concurrent:
+            main.wait_event(ev_aud)                         # both chains done
+        s_a.wait_stream(main)
+        s_f.wait_stream(main)
+        with torch.cuda.stream(s_a):
+            self.t_aud.wgrad(B, self.seed, 0, sd)
             self.e_aud.wgrad(audio, self.dx0_aud, B)
-            if self.concurrent:
-                s_f.wait_event(ev_img)
-            self.e_img.wgrad(image, self.dx0_img, B)
+        with torch.cuda.stream(s_f):
+            self.t_fus.wgrad(B, self.seed, 0, sd)
+        self.t_img.wgrad(B, self.seed, 0, sd)
+        self.e_img.wgrad(image, self.dx0_img, B)
         main.wait_stream(s_a)
         main.wait_stream(s_f)
 
