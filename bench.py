@@ -260,7 +260,7 @@ def profile_launches(eng, image, audio, labels, nsteps):
             from m2_mixer_amd import _lib as L
             L.check(L.lib().m2m_adam_step(eng.flat_p.data_ptr(), eng.flat_g.data_ptr(), eng.flat_m.data_ptr(),
                                           eng.flat_v.data_ptr(), eng.n_params, eng.adam_state.data_ptr(), eng.betas[0],
-                                          eng.betas[1], eng.eps, eng.weight_decay, -1.0, L.stream_ptr()))
+                                          eng.betas[1], eng.eps, eng.weight_decay, -1.0, 1, L.stream_ptr()))
             e1.record()
             spans.setdefault("adam", {"events": [], "flops": 0})["events"].append((e0, e1))
             L.check(L.lib().m2m_counter_add(eng.drop_step.data_ptr(), 1, L.stream_ptr()))

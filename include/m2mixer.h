@@ -164,11 +164,13 @@ int m2m_heads_ce(const m2m_head* heads, int nheads, const int64_t* labels, int B
 
 /* ---- optimizer (torch.optim.Adam as configured at models/avmnist.py:413-415) ---------------------- */
 /* state: device float[4] = {step (as float count), lr, unused, unused}; the kernel reads lr and the
- * step count from it, so a captured graph can be replayed while the host edits lr.  m2m_adam_step
- * increments state[0] on the stream before updating. */
+ * step count from it, so a captured graph can be replayed while the host edits lr.  With bump_step != 0
+ * state[0] is incremented on the stream first; a step may be applied as several calls over disjoint
+ * segments of the flat buffers (bump once, n == 0 allowed), e.g. per tower as its gradients complete. */
 int m2m_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   float* state, float beta1, float beta2, float eps, float weight_decay,
-                  float grad_scale, void* stream);   /* grad_scale < 0: scale by |grad_scale| and clear grad afterwards */
+                  float grad_scale, int bump_step, void* stream);
+                  /* grad_scale < 0: scale by |grad_scale| and clear grad afterwards */
 
 /* *counter += delta on the stream (device uint32). */
 int m2m_counter_add(uint32_t* counter, uint32_t delta, void* stream);

@@ -189,9 +189,11 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ gr, float
 }
 
 extern "C" int m2m_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
-                             float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
+                             float beta1, float beta2, float eps, float weight_decay, float grad_scale, int bump_step,
+                             void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, st, state);
+    if (bump_step) hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, st, state);
+    if (n <= 0) return 0;
     const int threads = 256;
     long grid = ceil_div(n, threads);
     if (grid > 2048) grid = 2048;

@@ -102,6 +102,16 @@ class AVMnistEngine:
             self.params[k] = self.flat_p[off:off + cnt].view(shp)
             self.grads[k] = self.flat_g[off:off + cnt].view(shp)
             off += cnt
+        # contiguous segments of the flat buffers: [image tower | audio tower | fusion tower + heads]
+        bounds, off = {}, 0
+        for k, shp in self.shapes.items():
+            seg = "image" if k.startswith("image_mixer.") else ("audio" if k.startswith("audio_mixer.") else "fusion")
+            cnt = int(torch.Size(shp).numel())
+            lo, hi = bounds.get(seg, (off, off))
+            bounds[seg] = (min(lo, off), off + cnt)
+            off += cnt
+        self.segments = bounds
+        assert bounds["image"][1] == bounds["audio"][0] and bounds["audio"][1] == bounds["fusion"][0] and bounds["fusion"][1] == n
         self.adam_state = torch.tensor([0.0, lr, 0.0, 0.0], device=dev)     # [step, lr, -, -]
         self.drop_step = torch.zeros(1, dtype=torch.int32, device=dev)       # device-side dropout step counter
         self.seed = seed & 0xFFFFFFFF
@@ -230,7 +240,16 @@ class AVMnistEngine:
                               g_b=Gr[key + "bias"], d_pooled=dp if with_grad else None, weight=self.head_weights[name]))
         heads_ce(heads, labels, B, D, self.K, out=(self.logits, self.losses, self.preds))
 
-    def _backward(self, image, audio):
+    def _adam(self, lo: int, hi: int, grad_scale: float, bump: bool):
+        n = hi - lo
+        off = lo * 4
+        L.check(L.lib().m2m_adam_step(self.flat_p.data_ptr() + off, self.flat_g.data_ptr() + off, self.flat_m.data_ptr() + off,
+                                      self.flat_v.data_ptr() + off, n, self.adam_state.data_ptr(), self.betas[0], self.betas[1],
+                                      self.eps, self.weight_decay, -abs(grad_scale), int(bump), L.stream_ptr()), "adam_step")
+
+    def _backward(self, image, audio, fused_update: bool = False):
+        """Backward of the whole model.  fused_update: also apply Adam + re-pack per tower as soon as that tower's
+        gradients are complete (single-GPU path; with a gradient all-reduce the update is a separate phase)."""
         B, D = self.B, self.D
         fs = self.Nf * D
         sd = self.drop_step
@@ -249,17 +268,32 @@ class AVMnistEngine:
         self.t_img.backward(B, self.d_fused, fs, self.dpool_img, self.dx0_img, self.Ni * D, self.seed, 0, sd)
         if self.concurrent:
             main.wait_event(ev_aud)                         # both chains done
+        if fused_update:
+            self._adam(0, 0, 1.0, True)                     # advance the Adam step counter once
         s_a.wait_stream(main)
         s_f.wait_stream(main)
         with torch.cuda.stream(s_a):
             self.t_aud.wgrad(B, self.seed, 0, sd)
             self.e_aud.wgrad(audio, self.dx0_aud, B)
+            if fused_update:
+                self._adam(*self.segments["audio"], 1.0, False)
+                self.t_aud.pack(force=True)
+                self.e_aud.pack(force=True)
         with torch.cuda.stream(s_f):
             self.t_fus.wgrad(B, self.seed, 0, sd)
+            if fused_update:
+                self._adam(*self.segments["fusion"], 1.0, False)
+                self.t_fus.pack(force=True)
         self.t_img.wgrad(B, self.seed, 0, sd)
         self.e_img.wgrad(image, self.dx0_img, B)
+        if fused_update:
+            self._adam(*self.segments["image"], 1.0, False)
+            self.t_img.pack(force=True)
+            self.e_img.pack(force=True)
         main.wait_stream(s_a)
         main.wait_stream(s_f)
+        if fused_update:
+            L.check(L.lib().m2m_counter_add(self.drop_step.data_ptr(), 1, L.stream_ptr()), "counter_add")
 
     def forward_backward(self, image, audio, labels):
         """forward (dropout on) -> multi-head loss -> backward; gradients are ADDED into flat_g, which must be
@@ -268,20 +302,25 @@ class AVMnistEngine:
         self._forward(image, audio, labels, True, True)
         self._backward(image, audio)
 
+    def fused_step(self, image, audio, labels):
+        """forward + backward + Adam + re-pack with the per-tower updates overlapped with the remaining
+        weight-gradient work (no gradient exchange: single-GPU training)."""
+        self._forward(image, audio, labels, True, True)
+        self._backward(image, audio, fused_update=True)
+        return self.losses
+
     def optimizer_step(self, grad_scale: float = 1.0):
-        L.check(L.lib().m2m_adam_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
-                                      self.flat_v.data_ptr(), self.n_params, self.adam_state.data_ptr(),
-                                      self.betas[0], self.betas[1], self.eps, self.weight_decay, -abs(grad_scale),
-                                      L.stream_ptr()), "adam_step")          # negative scale: clear the gradients too
+        self._adam(0, self.n_params, grad_scale, True)                        # negative scale inside: clears the gradients
         L.check(L.lib().m2m_counter_add(self.drop_step.data_ptr(), 1, L.stream_ptr()), "counter_add")
         self.pack()
 
     def train_step(self, image, audio, labels, grad_sync=None):
         """One optimisation step.  grad_sync: optional callable(flat_grad) doing the data-parallel
         all-reduce (parallel.GradSync); it returns the factor the summed gradient must be scaled by."""
+        if grad_sync is None:
+            return self.fused_step(image, audio, labels)
         self.forward_backward(image, audio, labels)
-        scale = grad_sync(self.flat_g) if grad_sync is not None else 1.0
-        self.optimizer_step(scale)
+        self.optimizer_step(grad_sync(self.flat_g))
         return self.losses
 
     @torch.no_grad()
@@ -301,17 +340,20 @@ class AVMnistEngine:
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
+            scale = 1.0
             for _ in range(2):                       # warm-up: lazy inits (LDS attributes, allocations) happen here
-                self.forward_backward(si, sa, sl)
-                scale = grad_sync(self.flat_g) if grad_sync is not None else 1.0
-                self.optimizer_step(scale)
+                if grad_sync is None:
+                    self.fused_step(si, sa, sl)
+                else:
+                    self.forward_backward(si, sa, sl)
+                    scale = grad_sync(self.flat_g)
+                    self.optimizer_step(scale)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g1 = torch.cuda.CUDAGraph()
         if grad_sync is None:
             with torch.cuda.graph(g1):
-                self.forward_backward(si, sa, sl)
-                self.optimizer_step()
+                self.fused_step(si, sa, sl)
             graphs = (g1,)
         else:
             g2 = torch.cuda.CUDAGraph()

@@ -228,7 +228,7 @@ def t_heads_adam():
         opt.step()
         gd = (g * (it + 1)).to(dev)
         L.check(L.lib().m2m_adam_step(pd.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, state.data_ptr(),
-                                      0.9, 0.999, 1e-8, 0.0, 1.0, L.stream_ptr()))
+                                      0.9, 0.999, 1e-8, 0.0, 1.0, 1, L.stream_ptr()))
     torch.cuda.synchronize()
     print("  adam 3 steps err", rel(pd, pt.detach()))
 
