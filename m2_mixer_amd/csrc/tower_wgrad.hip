@@ -200,6 +200,14 @@ static int launch_wgrad_dm(const m2m_tower* t, int B, unsigned int seed, unsigne
     // measured on M2-Mixer-B, against fitting the three towers' launches (100 + 100 + 50 workgroups) on the 256 CUs
     // in ONE round: one group (single owner per element, no atomics) whenever the launch has >= 32 workgroups.
     int groups = (32 + nsl * t->nblocks - 1) / (nsl * t->nblocks);
+    // Cutting the launch with few, long workgroups (the fusion tower: 50 x 128 tiles) into row groups so that it
+    // back-fills free CUs was measured and LOST (atomic traffic + contention: 612k -> 593k samples/s at 32-tile
+    // groups); kept as an opt-in knob.
+    if (nsl * t->nblocks <= 64 && ntiles > 64) {
+        int tgt = 0;
+        if (const char* e = getenv("M2M_WGRAD_SMALL_TILES")) tgt = atoi(e);
+        if (tgt > 0) groups = (ntiles + tgt - 1) / tgt;
+    }
     if (const char* e = getenv("M2M_WGRAD_GROUPS")) groups = atoi(e);
     if (groups < 1) groups = 1;
     int tpg = (ntiles + groups - 1) / groups;
