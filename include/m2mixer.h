@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define M2M_ABI_VERSION 1
+#define M2M_ABI_VERSION 2
 #define M2M_MAX_BLOCKS 8      /* MixerBlocks per m2m_tower; longer towers are chained by the caller */
 #define M2M_ROWS_PER_WG 16    /* token rows one workgroup keeps on chip */
 
@@ -64,7 +64,12 @@ typedef struct m2m_block {
 } m2m_block;
 
 /* A stack of MixerBlocks + optional final LayerNorm: the body of MLPMixer / FusionMixer /
- * MLPMixerNoPatching (reference: modules/mixer.py:125-132, :158-162, :182-186). */
+ * MLPMixerNoPatching (reference: modules/mixer.py:125-132, :158-162, :182-186).
+ * Two execution paths behind the same entry points:
+ *   fused (N <= 8, D <= 128): one launch walks all blocks with the token rows of whole samples resident on chip;
+ *   wide  (N <= 128, D <= 256; MIMIC N = 24/25, MM-IMDb N = 40/80, D = 256): per block one token-mixing launch
+ *         (a workgroup owns 64 (sample, channel) columns) and one channel-mixing launch (16 token rows per
+ *         workgroup, same MFMA code as the fused path), the residual stream passing through x_in / x_mid / ws_*. */
 typedef struct m2m_tower {
     int32_t prec;          /* M2M_PREC_*                                       */
     int32_t D, N, T, C;    /* hidden_dim, num_patch, token_dim, channel_dim    */
@@ -78,6 +83,8 @@ typedef struct m2m_tower {
     float* g_lnf_w;
     float* g_lnf_b;
     float* x_final;        /* saved input of the final LayerNorm (B*N, D) */
+    float* ws_a;           /* two (B*N, D) fp32 workspaces; required only on the wide path (N > 8 or D > 128), where  */
+    float* ws_b;           /* token mixing and channel mixing are separate launches and hand the stream over in HBM */
     m2m_block blk[M2M_MAX_BLOCKS];
 } m2m_tower;
 

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("M2M_LIB_PATH", os.path.join(_HERE, "libm2mixer.so"))   # override: diagnostic builds
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_BLOCKS = 8
 ROWS_PER_WG = 16
 PREC_BF16, PREC_F32 = 0, 1
@@ -42,7 +42,7 @@ class Tower(C.Structure):
                 ("Cp", C.c_int32), ("nblocks", C.c_int32), ("has_final_ln", C.c_int32),
                 ("p_drop", C.c_float), ("site_base", C.c_uint32),
                 ("lnf_w", _fp), ("lnf_b", _fp), ("g_lnf_w", _fp), ("g_lnf_b", _fp), ("x_final", _fp),
-                ("blk", Block * MAX_BLOCKS)]
+                ("ws_a", _fp), ("ws_b", _fp), ("blk", Block * MAX_BLOCKS)]
 
 
 class Embed(C.Structure):

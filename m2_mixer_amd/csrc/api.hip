@@ -23,8 +23,10 @@ int m2m_check_tower(const m2m_tower* t, int B) {
     if (!t) { m2m_set_error("null tower", __FILE__, __LINE__); return -1; }
     if (t->prec != PREC_BF16 && t->prec != PREC_F32) { m2m_set_error("bad prec", __FILE__, __LINE__); return -1; }
     if (t->nblocks < 0 || t->nblocks > M2M_MAX_BLOCKS) { m2m_set_error("nblocks out of range", __FILE__, __LINE__); return -1; }
-    if (t->N < 1 || t->N > 8) { m2m_set_error("num_patch N must be in [1, 8] in this build", __FILE__, __LINE__); return -1; }
-    if (t->T < 8 || t->T > 32 || (t->T % 8) != 0) { m2m_set_error("token_dim T must be a multiple of 8, <= 32 in this build", __FILE__, __LINE__); return -1; }
+    if (t->D != 32 && t->D != 64 && t->D != 128 && t->D != 256) { m2m_set_error("hidden_dim D must be 32, 64, 128 or 256 in this build", __FILE__, __LINE__); return -1; }
+    if (t->N < 1 || t->N > 128) { m2m_set_error("num_patch N must be in [1, 128] in this build", __FILE__, __LINE__); return -1; }
+    if (t->T < 1 || t->T > 32) { m2m_set_error("token_dim T must be in [1, 32] in this build", __FILE__, __LINE__); return -1; }
+    if (!m2m_is_wide(t) && (t->T % 8) != 0) { m2m_set_error("token_dim T must be a multiple of 8 on the fused path (N <= 8)", __FILE__, __LINE__); return -1; }
     if (t->Cp % 32 != 0 || t->Cp < t->C || t->C < 1) { m2m_set_error("Cp must be C rounded up to a multiple of 32", __FILE__, __LINE__); return -1; }
     if (B < 1) { m2m_set_error("B < 1", __FILE__, __LINE__); return -1; }
     if ((int64_t)B * t->N * (int64_t)t->Cp >= (1LL << 32)) { m2m_set_error("B*N*Cp exceeds the 32-bit dropout counter", __FILE__, __LINE__); return -1; }
@@ -237,7 +239,10 @@ __global__ void dropout_mask_kernel(unsigned int key, unsigned int thr, long n, 
     if (i < n) {
         Drop d; d.key = key; d.thr = thr; d.scale = 1.f;
         bool k;
-        if (mode == 1) k = (mix32(key ^ (unsigned int)(i / cols)) >> (unsigned int)(i % cols)) & 1u;
+        if (mode == 1) {
+            const unsigned int row = (unsigned int)(i / cols), col = (unsigned int)(i % cols), nw = (cols + 31u) >> 5;
+            k = (mix32(key ^ (row * nw + (col >> 5))) >> (col & 31u)) & 1u;
+        }
         else if (mode == 2) k = drop_keep_mc(d, (unsigned int)(i / cols), (unsigned int)(i % cols), cols);
         else k = drop_keep(d, (unsigned int)i);
         mask[i] = k ? 1 : 0;

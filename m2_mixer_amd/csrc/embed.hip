@@ -287,8 +287,8 @@ extern "C" int m2m_embed_forward(const m2m_embed* e, const float* input, int B, 
     if (int rc = check_embed(e, B)) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define M2M_EF_CASE(PP, DD) if (e->prec == PP && e->D == DD) return launch_embed_fwd<PP, DD>(e, input, B, x0, st);
-    M2M_EF_CASE(PREC_BF16, 32) M2M_EF_CASE(PREC_BF16, 64) M2M_EF_CASE(PREC_BF16, 128)
-    M2M_EF_CASE(PREC_F32, 32) M2M_EF_CASE(PREC_F32, 64) M2M_EF_CASE(PREC_F32, 128)
+    M2M_EF_CASE(PREC_BF16, 32) M2M_EF_CASE(PREC_BF16, 64) M2M_EF_CASE(PREC_BF16, 128) M2M_EF_CASE(PREC_BF16, 256)
+    M2M_EF_CASE(PREC_F32, 32) M2M_EF_CASE(PREC_F32, 64) M2M_EF_CASE(PREC_F32, 128) M2M_EF_CASE(PREC_F32, 256)
 #undef M2M_EF_CASE
     m2m_set_error("embed_forward: unsupported (prec, D)", __FILE__, __LINE__);
     return -1;
@@ -298,8 +298,8 @@ extern "C" int m2m_embed_wgrad(const m2m_embed* e, const float* input, const flo
     if (int rc = check_embed(e, B)) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define M2M_EW_CASE(PP, DD) if (e->prec == PP && e->D == DD) return launch_embed_wgrad<PP, DD>(e, input, d_x0, B, st);
-    M2M_EW_CASE(PREC_BF16, 32) M2M_EW_CASE(PREC_BF16, 64) M2M_EW_CASE(PREC_BF16, 128)
-    M2M_EW_CASE(PREC_F32, 32) M2M_EW_CASE(PREC_F32, 64) M2M_EW_CASE(PREC_F32, 128)
+    M2M_EW_CASE(PREC_BF16, 32) M2M_EW_CASE(PREC_BF16, 64) M2M_EW_CASE(PREC_BF16, 128) M2M_EW_CASE(PREC_BF16, 256)
+    M2M_EW_CASE(PREC_F32, 32) M2M_EW_CASE(PREC_F32, 64) M2M_EW_CASE(PREC_F32, 128) M2M_EW_CASE(PREC_F32, 256)
 #undef M2M_EW_CASE
     m2m_set_error("embed_wgrad: unsupported (prec, D)", __FILE__, __LINE__);
     return -1;

@@ -1,9 +1,10 @@
 // Per-workgroup token-tile helpers shared by the forward / backward / weight-gradient tower kernels.
 //
 // A workgroup (512 threads = 8 waves, two per SIMD so that the VALU-heavy GELU / dropout epilogues of
-// one wave overlap the MFMA and load latency of its partner) owns BM = 32 token rows = SPW whole
-// samples of N tokens (token mixing couples the N tokens of a sample, channel mixing is row-wise),
-// keeps the fp32 residual stream of those rows in LDS for the whole tower and streams the weights past it.
+// one wave overlap the MFMA and load latency of its partner) owns BM = 16 token rows: on the fused path SPW whole
+// samples of N tokens (token mixing couples the N tokens of a sample, channel mixing is row-wise), on the wide
+// path (kernels instantiated with NMAX == 0: channel mixing only) any 16 consecutive rows.  It keeps the fp32
+// residual stream of those rows in LDS for the whole launch and streams the weights past it.
 #pragma once
 #include "common.h"
 #include "../../include/m2mixer.h"
@@ -70,6 +71,17 @@ static __device__ __forceinline__ unsigned int drop_row_bits(const Drop& d, unsi
     for (int t = 0; t < ncols; ++t) bits |= (drop_keep(d, bd * ncols + t) ? 1u : 0u) << t;
     return bits;
 }
+// Wide path (ncols may exceed 32): keep-bit of column idx of token-site row bd.  Agrees with drop_row_bits for
+// ncols <= 32 (one word per row); longer rows take ceil(ncols / 32) consecutive words.
+template <int DM>
+static __device__ __forceinline__ bool drop_row_keep(const Drop& d, unsigned int bd, unsigned int ncols, unsigned int idx) {
+    if (DM == DM_NONE) return true;
+    if (DM == DM_HALF) {
+        const unsigned int nw = (ncols + 31u) >> 5;
+        return (mix32(d.key ^ (bd * nw + (idx >> 5))) >> (idx & 31u)) & 1u;
+    }
+    return drop_keep(d, bd * ncols + idx);
+}
 // Keep-bits of the 32 hidden columns [32 q, 32 q + 32) of token row m (channel-hidden site): bit c & 31.
 template <int DM>
 static __device__ __forceinline__ unsigned int drop_hidden_bits(const Drop& d, unsigned int m, unsigned int q, unsigned int Cp) {
@@ -90,6 +102,9 @@ static __device__ __forceinline__ bool drop_keep_elem(const Drop& d, unsigned in
     if (DM == DM_NONE) return true;
     return drop_keep(d, idx);
 }
+
+// Which execution path a tower takes (see include/m2mixer.h): fused = whole samples per workgroup.
+static inline bool m2m_is_wide(const m2m_tower* t) { return t->N > 8 || t->D > 128; }
 
 template <int D> struct TileGeom {
     static constexpr int XLD = D + 4;          // padded fp32 row stride (floats)

@@ -1,0 +1,494 @@
+// Wide path of a tower (N > 8 tokens per sample or D > 128: MIMIC N = 24 / 25, MM-IMDb N = 40 / 80, D = 256).
+//
+// A sample no longer fits one 16-row workgroup tile, so each MixerBlock (modules/mixer.py:42-47) runs as
+//   forward : token_fwd (x -> x_mid = x + token_mix(x))         then the channel-mixing launch of tower_fwd.hip
+//   backward: the channel-mixing launch of tower_bwd.hip         then token_bwd_cols + ln1_bwd_rows
+// with the fp32 residual / gradient stream handed over through x_in / x_mid / ws_a / ws_b.
+//
+// Token mixing couples the N tokens of one (sample, channel) COLUMN and nothing else, so the token kernels give
+// every lane one column: a workgroup is ONE wave = 64 columns (64 channels of a sample; two samples when D = 32).
+// LayerNorm-1 needs row statistics over all D channels: the wave first computes mean / rstd of its samples' N rows
+// (workgroups sharing a sample repeat that; the rows come from L2), then each lane walks its column.
+// The token MLP (N x T, T <= 32) runs on the VALU with the weights broadcast from LDS; h[t] lives in registers.
+#include "tile.h"
+
+#define TW_COLS 64                 // columns (lanes) per workgroup
+#define TW_TMAX 32                 // token_dim upper bound (h[] registers)
+#define TW_LDW (TW_COLS + 1)       // padded row stride of the per-column LDS tiles
+
+int m2m_chain_forward_rows(const m2m_tower* t, const float* x0, long x0_ss, int B, float* out, long out_ss, int training,
+                           unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st);
+int m2m_chain_backward_rows(const m2m_tower* t, int B, const float* d_out, long d_out_ss, const float* d_pooled, float* d_x0,
+                            long d_x0_ss, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st);
+
+// ---- shared prologue: token weights -> LDS, LayerNorm-1 row statistics of this workgroup's samples -------------
+//   w1s[n][t] = W1[t][n], w2s[n][t] = W2[n][t] (t padded to 32 with zeros), b1s[32], b2s[N]
+//   stats[(sl * N + n) * 2 + {0, 1}] = mean, rstd of row n of local sample sl
+struct TokGeom {
+    int chunks;      // 64-column chunks per sample (D / 64, at least 1)
+    int spw;         // samples per workgroup (2 when D == 32)
+};
+static __host__ __device__ __forceinline__ TokGeom tok_geom(int D) {
+    TokGeom g;
+    g.chunks = D >= TW_COLS ? D / TW_COLS : 1;
+    g.spw = D >= TW_COLS ? 1 : TW_COLS / D;
+    return g;
+}
+static __host__ __device__ __forceinline__ size_t tok_lds_floats(int N, int spw) { return (size_t)2 * N * TW_TMAX + TW_TMAX + N + 2 * spw * N; }
+
+static __device__ __forceinline__ void tok_stage_weights(const m2m_block& bk, int N, int T, float* w1s, float* w2s, float* b1s,
+                                                         float* b2s, int lane) {
+    for (int i = lane; i < N * TW_TMAX; i += TW_COLS) {
+        const int n = i / TW_TMAX, t = i % TW_TMAX;
+        w1s[i] = t < T ? bk.tok_w1[t * N + n] : 0.f;
+        w2s[i] = t < T ? bk.tok_w2[n * T + t] : 0.f;
+    }
+    if (lane < TW_TMAX) b1s[lane] = lane < T ? bk.tok_b1[lane] : 0.f;
+    for (int n = lane; n < N; n += TW_COLS) b2s[n] = bk.tok_b2[n];
+}
+// one wave: statistics of `rows` rows; row r lives at src + (r / N) * ss + (r % N) * D  (r counted from sample s_first)
+static __device__ __forceinline__ void tok_row_stats(const float* __restrict__ src, long ss, int s_first, int rows, int N, int D,
+                                                     float* stats, int lane) {
+    for (int r = 0; r < rows; ++r) {
+        const float* row = src + (long)(s_first + r / N) * ss + (long)(r % N) * D;
+        float v[4], s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = c < D ? row[c] : 0.f;
+            s += v[i];
+        }
+        s = wave_sum_xor(s, 64);
+        const float mean = s / (float)D;
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = lane + 64 * i;
+            const float dlt = c < D ? v[i] - mean : 0.f;
+            s2 = __builtin_fmaf(dlt, dlt, s2);
+        }
+        s2 = wave_sum_xor(s2, 64);
+        const float vv = s2 / (float)D + 1e-5f;
+        float rstd = __builtin_amdgcn_rsqf(vv);
+        rstd = rstd * (1.5f - 0.5f * vv * rstd * rstd);
+        if (lane == 0) { stats[2 * r] = mean; stats[2 * r + 1] = rstd; }
+    }
+}
+
+// ---- forward: x_mid = x + Dropout(W2 Dropout(GELU(W1 LN1(x)^T + b1)) + b2)^T  (modules/mixer.py:30-35, :43) ------
+template <int P, int DM>
+__global__ __launch_bounds__(TW_COLS) void token_fwd_kernel(const m2m_tower tw, int b, const float* __restrict__ src, long src_ss,
+                                                            int B, float* __restrict__ x_mid, float* __restrict__ save_x_in,
+                                                            int training, unsigned int seed, unsigned int step_host,
+                                                            const unsigned int* __restrict__ step_dev) {
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    const int N = tw.N, T = tw.T, D = tw.D;
+    const TokGeom tg = tok_geom(D);
+    float* w1s = smf;
+    float* w2s = w1s + N * TW_TMAX;
+    float* b1s = w2s + N * TW_TMAX;
+    float* b2s = b1s + TW_TMAX;
+    float* stats = b2s + N;
+    gtab_t* gtab = reinterpret_cast<gtab_t*>(smf + ((tok_lds_floats(N, tg.spw) + 3) & ~(size_t)3));
+
+    const int lane = threadIdx.x;
+    const m2m_block& bk = tw.blk[b];
+    const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
+    const unsigned int site = tw.site_base + 4u * b;
+    const Drop dr_th = make_drop(training, tw.p_drop, seed, step, site + 0);
+    const Drop dr_to = make_drop(training, tw.p_drop, seed, step, site + 1);
+
+    const int s_first = (blockIdx.x / tg.chunks) * tg.spw;
+    const int chunk = blockIdx.x % tg.chunks;
+    const int ns = min(tg.spw, B - s_first);
+    if (Act<P>::USES_TABLE) gelu_tab_fill(gtab, lane, TW_COLS);
+    tok_stage_weights(bk, N, T, w1s, w2s, b1s, b2s, lane);
+    tok_row_stats(src, src_ss, s_first, ns * N, N, D, stats, lane);
+    __syncthreads();
+
+    const int sl = D >= TW_COLS ? 0 : lane / D;
+    const int d = D >= TW_COLS ? chunk * TW_COLS + lane : lane % D;
+    if (sl >= ns) return;
+    const int s = s_first + sl;
+    const unsigned int bd = (unsigned int)s * D + d;
+    const float gam = bk.ln1_w[d], bet = bk.ln1_b[d];
+    const float* col = src + (long)s * src_ss + d;
+    const float* st = stats + 2 * sl * N;
+
+    float h[TW_TMAX];
+#pragma unroll
+    for (int t = 0; t < TW_TMAX; ++t) h[t] = b1s[t];
+    for (int n = 0; n < N; ++n) {
+        const float u = (col[(long)n * D] - st[2 * n]) * st[2 * n + 1] * gam + bet;
+        const float4* wr = reinterpret_cast<const float4*>(w1s + n * TW_TMAX);
+#pragma unroll
+        for (int t4 = 0; t4 < TW_TMAX / 4; ++t4) {
+            const float4 w = wr[t4];
+            h[4 * t4 + 0] = __builtin_fmaf(w.x, u, h[4 * t4 + 0]);
+            h[4 * t4 + 1] = __builtin_fmaf(w.y, u, h[4 * t4 + 1]);
+            h[4 * t4 + 2] = __builtin_fmaf(w.z, u, h[4 * t4 + 2]);
+            h[4 * t4 + 3] = __builtin_fmaf(w.w, u, h[4 * t4 + 3]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TW_TMAX; ++t) {
+        if (t < T) {
+            const float v = Act<P>::gelu(gtab, h[t]) * dr_th.scale;
+            h[t] = drop_row_keep<DM>(dr_th, bd, T, t) ? v : 0.f;
+        } else {
+            h[t] = 0.f;
+        }
+    }
+    for (int n = 0; n < N; ++n) {
+        const float4* wr = reinterpret_cast<const float4*>(w2s + n * TW_TMAX);
+        float o0 = b2s[n], o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#pragma unroll
+        for (int t4 = 0; t4 < TW_TMAX / 4; ++t4) {
+            const float4 w = wr[t4];
+            o0 = __builtin_fmaf(w.x, h[4 * t4 + 0], o0);
+            o1 = __builtin_fmaf(w.y, h[4 * t4 + 1], o1);
+            o2 = __builtin_fmaf(w.z, h[4 * t4 + 2], o2);
+            o3 = __builtin_fmaf(w.w, h[4 * t4 + 3], o3);
+        }
+        const float o = (o0 + o1) + (o2 + o3);
+        const float xv = col[(long)n * D];
+        const long off = ((long)s * N + n) * D + d;
+        if (save_x_in) save_x_in[off] = xv;
+        x_mid[off] = xv + (drop_row_keep<DM>(dr_to, bd, N, n) ? o * dr_to.scale : 0.f);
+    }
+}
+
+// ---- backward, column part: dU (gradient wrt LN1 output) + token-MLP parameter gradients --------------------------
+//   g_mid : gradient wrt x_mid (dense rows);  x_in : saved block input (dense rows);  du_out : receives dU (dense rows)
+template <int P, int DM>
+__global__ __launch_bounds__(TW_COLS) void token_bwd_cols_kernel(const m2m_tower tw, int b, const float* __restrict__ g_mid, int B,
+                                                                 float* __restrict__ du_out, unsigned int seed,
+                                                                 unsigned int step_host, const unsigned int* __restrict__ step_dev) {
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    const int N = tw.N, T = tw.T, D = tw.D;
+    const TokGeom tg = tok_geom(D);
+    float* w1s = smf;
+    float* w2s = w1s + N * TW_TMAX;
+    float* b1s = w2s + N * TW_TMAX;
+    float* b2s = b1s + TW_TMAX;
+    float* stats = b2s + N;
+    gtab_t* gtab = reinterpret_cast<gtab_t*>(smf + ((tok_lds_floats(N, tg.spw) + 3) & ~(size_t)3));
+    float* us = reinterpret_cast<float*>(gtab + GELU_TAB_N);   // [N][TW_LDW]  LN1 output of each column
+    float* dvs = us + N * TW_LDW;                               // [N][TW_LDW]  masked upstream gradient
+    float* hs = dvs + N * TW_LDW;                               // [32][TW_LDW] hidden activation (after dropout)
+    float* dhs = hs + TW_TMAX * TW_LDW;                         // [32][TW_LDW] gradient wrt the hidden pre-activation
+
+    const int lane = threadIdx.x;
+    const m2m_block& bk = tw.blk[b];
+    const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
+    const unsigned int site = tw.site_base + 4u * b;
+    const Drop dr_th = make_drop(true, tw.p_drop, seed, step, site + 0);
+    const Drop dr_to = make_drop(true, tw.p_drop, seed, step, site + 1);
+
+    const int s_first = (blockIdx.x / tg.chunks) * tg.spw;
+    const int chunk = blockIdx.x % tg.chunks;
+    const int ns = min(tg.spw, B - s_first);
+    if (Act<P>::USES_TABLE) gelu_tab_fill(gtab, lane, TW_COLS);
+    tok_stage_weights(bk, N, T, w1s, w2s, b1s, b2s, lane);
+    tok_row_stats(bk.x_in, (long)N * D, s_first, ns * N, N, D, stats, lane);
+    __syncthreads();
+
+    const int sl = D >= TW_COLS ? 0 : lane / D;
+    const int d = D >= TW_COLS ? chunk * TW_COLS + lane : lane % D;
+    const bool pv = sl < ns;
+    const int s = s_first + (pv ? sl : 0);
+    const unsigned int bd = (unsigned int)s * D + d;
+    const float gam = bk.ln1_w[d], bet = bk.ln1_b[d];
+    const long col0 = (long)s * N * D + d;
+    const float* st = stats + 2 * (pv ? sl : 0) * N;
+
+    float h[TW_TMAX], dh[TW_TMAX];
+#pragma unroll
+    for (int t = 0; t < TW_TMAX; ++t) { h[t] = b1s[t]; dh[t] = 0.f; }
+    for (int n = 0; n < N; ++n) {
+        float u = 0.f, dv = 0.f;
+        if (pv) {
+            u = (bk.x_in[col0 + (long)n * D] - st[2 * n]) * st[2 * n + 1] * gam + bet;
+            const float gv = g_mid[col0 + (long)n * D] * dr_to.scale;
+            dv = drop_row_keep<DM>(dr_to, bd, N, n) ? gv : 0.f;
+        }
+        us[n * TW_LDW + lane] = u;
+        dvs[n * TW_LDW + lane] = dv;
+        const float4* wr1 = reinterpret_cast<const float4*>(w1s + n * TW_TMAX);
+        const float4* wr2 = reinterpret_cast<const float4*>(w2s + n * TW_TMAX);
+#pragma unroll
+        for (int t4 = 0; t4 < TW_TMAX / 4; ++t4) {
+            const float4 a = wr1[t4], c = wr2[t4];
+            h[4 * t4 + 0] = __builtin_fmaf(a.x, u, h[4 * t4 + 0]);
+            h[4 * t4 + 1] = __builtin_fmaf(a.y, u, h[4 * t4 + 1]);
+            h[4 * t4 + 2] = __builtin_fmaf(a.z, u, h[4 * t4 + 2]);
+            h[4 * t4 + 3] = __builtin_fmaf(a.w, u, h[4 * t4 + 3]);
+            dh[4 * t4 + 0] = __builtin_fmaf(c.x, dv, dh[4 * t4 + 0]);
+            dh[4 * t4 + 1] = __builtin_fmaf(c.y, dv, dh[4 * t4 + 1]);
+            dh[4 * t4 + 2] = __builtin_fmaf(c.z, dv, dh[4 * t4 + 2]);
+            dh[4 * t4 + 3] = __builtin_fmaf(c.w, dv, dh[4 * t4 + 3]);
+        }
+    }
+    // hidden activation and gradient wrt the pre-activation; dh[] is reused for the latter
+#pragma unroll
+    for (int t = 0; t < TW_TMAX; ++t) {
+        float hact = 0.f, dhp = 0.f;
+        if (t < T) {
+            float gl, dgl;
+            Act<P>::gelu_grad(gtab, h[t], gl, dgl);
+            const bool keep = pv && drop_row_keep<DM>(dr_th, bd, T, t);
+            hact = keep ? gl * dr_th.scale : 0.f;
+            dhp = keep ? dh[t] * dr_th.scale * dgl : 0.f;
+        }
+        dh[t] = dhp;
+        hs[t * TW_LDW + lane] = hact;
+        dhs[t * TW_LDW + lane] = dhp;
+    }
+    // dU[n] = sum_t W1[t][n] dHpre[t]
+    if (pv) {
+        for (int n = 0; n < N; ++n) {
+            const float4* wr = reinterpret_cast<const float4*>(w1s + n * TW_TMAX);
+            float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#pragma unroll
+            for (int t4 = 0; t4 < TW_TMAX / 4; ++t4) {
+                const float4 w = wr[t4];
+                o0 = __builtin_fmaf(w.x, dh[4 * t4 + 0], o0);
+                o1 = __builtin_fmaf(w.y, dh[4 * t4 + 1], o1);
+                o2 = __builtin_fmaf(w.z, dh[4 * t4 + 2], o2);
+                o3 = __builtin_fmaf(w.w, dh[4 * t4 + 3], o3);
+            }
+            du_out[col0 + (long)n * D] = (o0 + o1) + (o2 + o3);
+        }
+    }
+    __syncthreads();
+    // parameter gradients: each lane owns (n, t) pairs and sums over the workgroup's 64 columns (fixed order),
+    // then one float atomic per value per workgroup
+    for (int p = lane; p < N * T; p += TW_COLS) {
+        const int n = p / T, t = p % T;
+        const float* ur = us + n * TW_LDW;
+        const float* vr = dvs + n * TW_LDW;
+        const float* hr = hs + t * TW_LDW;
+        const float* gr = dhs + t * TW_LDW;
+        float a = 0.f, c = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < TW_COLS; ++k) {
+            a = __builtin_fmaf(gr[k], ur[k], a);         // dW1[t][n] += dHpre[t] U[n]
+            c = __builtin_fmaf(vr[k], hr[k], c);         // dW2[n][t] += dV[n] Hact[t]
+        }
+        atomicAdd(bk.g_tok_w1 + t * N + n, a);
+        atomicAdd(bk.g_tok_w2 + n * T + t, c);
+    }
+    if (lane < T) {
+        const float* gr = dhs + lane * TW_LDW;
+        float a = 0.f;
+        for (int k = 0; k < TW_COLS; ++k) a += gr[k];
+        atomicAdd(bk.g_tok_b1 + lane, a);
+    }
+    for (int n = lane; n < N; n += TW_COLS) {
+        const float* vr = dvs + n * TW_LDW;
+        float a = 0.f;
+        for (int k = 0; k < TW_COLS; ++k) a += vr[k];
+        atomicAdd(bk.g_tok_b2 + n, a);
+    }
+}
+
+// ---- backward, row part: dx_in = g_mid + LN1'(dU); gamma / beta gradients ------------------------------------------
+// 4 waves, each walks rows (row = wave, wave + 4, ...) of the workgroup's LN_ROWS rows; a lane holds columns lane + 64 i.
+#define LN_ROWS 32
+// `dst` may alias `du` (dense, in place): a row's dU is read before its result is written.
+__global__ __launch_bounds__(256) void ln1_bwd_rows_kernel(const float* __restrict__ x_in, const float* __restrict__ g_mid,
+                                                           const float* du, const float* __restrict__ gamma,
+                                                           long rows, int N, int D, float* dst, long dst_ss,
+                                                           float* __restrict__ g_w, float* __restrict__ g_b) {
+    __shared__ float acc_w[4][256], acc_b[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float gw[4] = {0.f, 0.f, 0.f, 0.f}, gb[4] = {0.f, 0.f, 0.f, 0.f}, gm[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gm[i] = (lane + 64 * i) < D ? gamma[lane + 64 * i] : 0.f;
+    const long r0 = (long)blockIdx.x * LN_ROWS;
+    for (int rr = wave; rr < LN_ROWS; rr += 4) {
+        const long r = r0 + rr;
+        if (r >= rows) break;
+        const float* xr = x_in + r * D;
+        float v[4], u[4], s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = c < D ? xr[c] : 0.f;
+            u[i] = c < D ? du[r * D + c] : 0.f;
+            s += v[i];
+        }
+        s = wave_sum_xor(s, 64);
+        const float mean = s / (float)D;
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = c < D ? v[i] - mean : 0.f;
+            s2 = __builtin_fmaf(v[i], v[i], s2);
+        }
+        s2 = wave_sum_xor(s2, 64);
+        const float vv = s2 / (float)D + 1e-5f;
+        float rstd = __builtin_amdgcn_rsqf(vv);
+        rstd = rstd * (1.5f - 0.5f * vv * rstd * rstd);
+        float gsum = 0.f, gxsum = 0.f, gg[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] *= rstd;                                 // xhat
+            gg[i] = u[i] * gm[i];
+            gsum += gg[i];
+            gxsum = __builtin_fmaf(gg[i], v[i], gxsum);
+            gw[i] = __builtin_fmaf(u[i], v[i], gw[i]);
+            gb[i] += u[i];
+        }
+        gsum = wave_sum_xor(gsum, 64) / (float)D;
+        gxsum = wave_sum_xor(gxsum, 64) / (float)D;
+        float* orow = dst + (r / N) * dst_ss + (r % N) * D;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = lane + 64 * i;
+            if (c < D) orow[c] = g_mid[r * D + c] + rstd * (gg[i] - gsum - v[i] * gxsum);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc_w[wave][lane + 64 * i] = gw[i]; acc_b[wave][lane + 64 * i] = gb[i]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        atomicAdd(g_w + c, (acc_w[0][c] + acc_w[1][c]) + (acc_w[2][c] + acc_w[3][c]));
+        atomicAdd(g_b + c, (acc_b[0][c] + acc_b[1][c]) + (acc_b[2][c] + acc_b[3][c]));
+    }
+}
+
+// pooled[s][d] = mean over the N tokens of out[s]  (x.mean(dim=1), models/avmnist.py:271-272)
+__global__ void token_mean_kernel(const float* __restrict__ out, long out_ss, int B, int N, int D, float* __restrict__ pooled) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * D) return;
+    const long s = i / D, d = i % D;
+    float a = 0.f;
+    for (int n = 0; n < N; ++n) a += out[s * out_ss + (long)n * D + d];
+    pooled[i] = a * (1.0f / (float)N);
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+static m2m_tower block_view(const m2m_tower* t, int b) {
+    m2m_tower v = *t;
+    v.nblocks = 1;
+    v.blk[0] = t->blk[b];
+    v.site_base = t->site_base + 4u * (unsigned int)b;
+    v.has_final_ln = (b == t->nblocks - 1) ? t->has_final_ln : 0;
+    return v;
+}
+
+template <int P, int DM>
+static int launch_token_fwd(const m2m_tower* t, int b, const float* src, long src_ss, int B, float* x_mid, float* save_x_in,
+                            int training, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
+    const TokGeom g = tok_geom(t->D);
+    const int grid = ((B + g.spw - 1) / g.spw) * g.chunks;
+    const size_t lds = ((tok_lds_floats(t->N, g.spw) + 3) & ~(size_t)3) * sizeof(float) + GELU_TAB_N * 16;
+    hipLaunchKernelGGL((token_fwd_kernel<P, DM>), dim3(grid), dim3(TW_COLS), lds, st, *t, b, src, src_ss, B, x_mid, save_x_in,
+                       training, seed, step, step_dev);
+    M2M_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+template <int P, int DM>
+static int launch_token_bwd(const m2m_tower* t, int b, const float* g_mid, int B, float* du, unsigned int seed, unsigned int step,
+                            const unsigned int* step_dev, hipStream_t st) {
+    const TokGeom g = tok_geom(t->D);
+    const int grid = ((B + g.spw - 1) / g.spw) * g.chunks;
+    const size_t lds = ((tok_lds_floats(t->N, g.spw) + 3) & ~(size_t)3) * sizeof(float) + GELU_TAB_N * 16 +
+                       (size_t)(2 * t->N + 2 * TW_TMAX) * TW_LDW * sizeof(float);
+    auto kern = token_bwd_cols_kernel<P, DM>;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(TW_COLS), lds, st, *t, b, g_mid, B, du, seed, step, step_dev);
+    M2M_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+#define M2M_TOK_DISPATCH(FN, training_, ...)                                                        \
+    do {                                                                                            \
+        const int dm_ = m2m_drop_mode(training_, t->p_drop);                                       \
+        if (t->prec == PREC_BF16) {                                                                 \
+            if (dm_ == DM_NONE) return FN<PREC_BF16, DM_NONE>(__VA_ARGS__);                        \
+            if (dm_ == DM_HALF) return FN<PREC_BF16, DM_HALF>(__VA_ARGS__);                        \
+            return FN<PREC_BF16, DM_GEN>(__VA_ARGS__);                                             \
+        }                                                                                           \
+        if (dm_ == DM_NONE) return FN<PREC_F32, DM_NONE>(__VA_ARGS__);                             \
+        if (dm_ == DM_HALF) return FN<PREC_F32, DM_HALF>(__VA_ARGS__);                             \
+        return FN<PREC_F32, DM_GEN>(__VA_ARGS__);                                                  \
+    } while (0)
+
+static int token_fwd(const m2m_tower* t, int b, const float* src, long src_ss, int B, float* x_mid, float* save_x_in, int training,
+                     unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
+    M2M_TOK_DISPATCH(launch_token_fwd, training, t, b, src, src_ss, B, x_mid, save_x_in, training, seed, step, step_dev, st);
+}
+static int token_bwd(const m2m_tower* t, int b, const float* g_mid, int B, float* du, unsigned int seed, unsigned int step,
+                     const unsigned int* step_dev, hipStream_t st) {
+    M2M_TOK_DISPATCH(launch_token_bwd, 1, t, b, g_mid, B, du, seed, step, step_dev, st);
+}
+
+int m2m_forward_wide(const m2m_tower* t, const float* x0, long x0_ss, int B, float* out, long out_ss, float* pooled,
+                     int training, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
+    const long dense = (long)t->N * t->D;
+    if (!t->ws_a || !t->ws_b) { m2m_set_error("wide path (N > 8 or D > 128) needs the ws_a / ws_b workspaces", __FILE__, __LINE__); return -1; }
+    if (t->nblocks == 0) {      // final LayerNorm only
+        m2m_tower v = *t;
+        if (int rc = m2m_chain_forward_rows(&v, x0, x0_ss, B, out, out_ss, training, seed, step, step_dev, st)) return rc;
+    }
+    const float* src = x0;
+    long src_ss = x0_ss;
+    for (int b = 0; b < t->nblocks; ++b) {
+        const m2m_block& bk = t->blk[b];
+        const bool last = b == t->nblocks - 1;
+        // training: the saved activations ARE the stream (x_in[b] -> x_mid[b] -> x_in[b+1]); eval: the two workspaces
+        float* mid = training ? bk.x_mid : t->ws_a;
+        float* save = (training && src != bk.x_in) ? bk.x_in : nullptr;
+        if (int rc = token_fwd(t, b, src, src_ss, B, mid, save, training, seed, step, step_dev, st)) return rc;
+        float* nxt = last ? out : (training ? t->blk[b + 1].x_in : t->ws_b);
+        const long nxt_ss = last ? out_ss : dense;
+        const m2m_tower v = block_view(t, b);
+        if (int rc = m2m_chain_forward_rows(&v, mid, dense, B, nxt, nxt_ss, training, seed, step, step_dev, st)) return rc;
+        src = nxt;
+        src_ss = nxt_ss;
+    }
+    if (pooled) {
+        const long n = (long)B * t->D;
+        hipLaunchKernelGGL(token_mean_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, out_ss, B, t->N, t->D, pooled);
+        M2M_CHECK_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+int m2m_backward_wide(const m2m_tower* t, int B, const float* d_out, long d_out_ss, const float* d_pooled, float* d_x0,
+                      long d_x0_ss, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
+    const long dense = (long)t->N * t->D;
+    const long rows = (long)B * t->N;
+    if (!t->ws_a || !t->ws_b) { m2m_set_error("wide path (N > 8 or D > 128) needs the ws_a / ws_b workspaces", __FILE__, __LINE__); return -1; }
+    if (t->nblocks == 0) {
+        m2m_tower v = *t;
+        return m2m_chain_backward_rows(&v, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step, step_dev, st);
+    }
+    const float* up = d_out;
+    long up_ss = d_out_ss;
+    const float* up_pooled = d_pooled;
+    for (int b = t->nblocks - 1; b >= 0; --b) {
+        const m2m_block& bk = t->blk[b];
+        const m2m_tower v = block_view(t, b);
+        // gradient wrt x_mid -> ws_b
+        if (int rc = m2m_chain_backward_rows(&v, B, up, up_ss, up_pooled, t->ws_b, dense, seed, step, step_dev, st)) return rc;
+        // dU -> ws_a, token parameter gradients
+        if (int rc = token_bwd(t, b, t->ws_b, B, t->ws_a, seed, step, step_dev, st)) return rc;
+        // gradient wrt the block input -> ws_a in place (row-local), or the caller's buffer for the first block
+        float* dst = b > 0 ? t->ws_a : d_x0;
+        const long dst_ss = b > 0 ? dense : d_x0_ss;
+        hipLaunchKernelGGL(ln1_bwd_rows_kernel, dim3((unsigned)((rows + LN_ROWS - 1) / LN_ROWS)), dim3(256), 0, st, bk.x_in, t->ws_b,
+                           t->ws_a, bk.ln1_w, rows, t->N, t->D, dst, dst_ss, bk.g_ln1_w, bk.g_ln1_b);
+        M2M_CHECK_HIP(hipGetLastError());
+        up = t->ws_a;
+        up_ss = dense;
+        up_pooled = nullptr;
+    }
+    return 0;
+}

@@ -74,6 +74,8 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
     typedef Prec<P> Pr;
     typedef TileGeom<D> G;
     constexpr int XLD = G::XLD, DT = G::DT, KD = D / Pr::KB, NF = Chain<P>::NF;
+    constexpr bool TOK = NMAX > 0;                      // false: wide path, channel mixing only (rows independent)
+    constexpr int NM = TOK ? NMAX : 1;
     constexpr int TILE_F = BM * XLD;                    // floats in one fp32 tile
     constexpr int IMG_B = BM * D * Pr::ESZ;             // bytes of one packed 64-row image
 
@@ -89,18 +91,18 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
     float* rstd_s = slabs + 4 * SF;                      // [BM]
     float* dasum = rstd_s + BM;                          // [BM][XLD] summed dA (row-major)
     gtab_t* gtab = reinterpret_cast<gtab_t*>(dasum + TILE_F);   // [GELU_TAB_N] (bf16 mode only)
-    constexpr int RED_LD = ((32 / TG) * (1 + 2 * NMAX) + NMAX) * TG;   // token-grad slots per wave
+    constexpr int RED_LD = ((32 / TG) * (1 + 2 * NM) + NM) * TG;       // token-grad slots per wave
     float* red = reinterpret_cast<float*>(gtab + GELU_TAB_N);    // [NWAVES][RED_LD]
-    constexpr int TW_LD = 2 * NMAX + 4;
+    constexpr int TW_LD = 2 * NM + 4;
     float* tokw = red + NWAVES * RED_LD;                         // [32][TW_LD] zero-padded token-MLP weights
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
     const int N = tw.N, T = tw.T, Cp = tw.Cp;
-    const int SPW = BM / N;
+    const int SPW = TOK ? BM / N : 0;
     const int s0 = blockIdx.x * SPW;
-    const int ns = min(SPW, B - s0);
-    const int R = ns * N;
-    const long row0 = (long)s0 * N;
+    const int ns = TOK ? min(SPW, B - s0) : 0;
+    const long row0 = TOK ? (long)s0 * N : (long)blockIdx.x * BM;
+    const int R = TOK ? ns * N : (int)min((long)BM, (long)B * N - row0);
     const long tile_off = (long)blockIdx.x * IMG_B;                       // NAT images: consecutive BM-row tiles
     constexpr int TPP = WPAIR / BM;                                         // chain tiles per 32-row pair
     const long pair_off = (long)(blockIdx.x / TPP) * (WPAIR * D * Pr::ESZ); // CHN images: per 32-row pair
@@ -116,9 +118,10 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
             const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < R) {
-                if (d_out) v = *reinterpret_cast<const float4*>(d_out + (long)(s0 + r / N) * d_out_ss + (long)(r % N) * D + c);
+                const long gr = row0 + r, gs = gr / N;
+                if (d_out) v = *reinterpret_cast<const float4*>(d_out + gs * d_out_ss + (gr % N) * D + c);
                 if (d_pooled) {
-                    const float4 p = *reinterpret_cast<const float4*>(d_pooled + (long)(s0 + r / N) * D + c);
+                    const float4 p = *reinterpret_cast<const float4*>(d_pooled + gs * D + c);
                     v.x += p.x * invN; v.y += p.y * invN; v.z += p.z * invN; v.w += p.w * invN;
                 }
             }
@@ -272,6 +275,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
         ln_backward_tile<D>(bk.x_mid + row0 * D, R, dasum, bk.ln2_w, dxs, true, xh, bk.g_ln2_w, bk.g_ln2_b, tid);
 
         TIMER_MARK(g_tm_bwd, 3);   // C4 + C5: reduction, LN2 backward
+        if constexpr (TOK) {
         // ================= token mixing backward =================
         // (T1) xhat1 -> xh, U = LN1(x_in) -> ub, rstd -> rstd_s; token-MLP weights -> LDS, zero-padded:
         //   tokw[t][0..NMAX) = W1[t][n]   tokw[t][NMAX..2NMAX) = W2[n][t]   tokw[t][2NMAX] = b1[t]   (t < 32)
@@ -464,12 +468,14 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
         }
         __syncthreads();
         TIMER_MARK(g_tm_bwd, 5);   // T2: LN1 backward
+        }   // TOK
     }
 
     // ---- gradient wrt the tower input ----
     _Pragma("unroll 1") for (int idx = tid; idx < R * (D / 4); idx += NTHREADS) {
         const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
-        *reinterpret_cast<float4*>(d_x0 + (long)(s0 + r / N) * d_x0_ss + (long)(r % N) * D + c) =
+        const long gr = row0 + r;
+        *reinterpret_cast<float4*>(d_x0 + (gr / N) * d_x0_ss + (gr % N) * D + c) =
             *reinterpret_cast<const float4*>(dxs + r * XLD + c);
     }
 }
@@ -477,11 +483,12 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
 template <int P, int D, int NMAX, int TG, int DM>
 static int launch_bwd_dm(const m2m_tower* t, int B, const float* d_out, long d_out_ss, const float* d_pooled, float* d_x0,
                       long d_x0_ss, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
-    const int SPW = BM / t->N;
-    const int grid = (B + SPW - 1) / SPW;
+    constexpr int NM = NMAX > 0 ? NMAX : 1;
+    const int SPW = NMAX > 0 ? BM / t->N : 1;
+    const int grid = NMAX > 0 ? (B + SPW - 1) / SPW : (int)(((long)B * t->N + BM - 1) / BM);
     const size_t tile_b = (size_t)BM * TileGeom<D>::XLD * sizeof(float);
     const size_t lds = 2 * tile_b + 4 * SlabGeom<D>::FLOATS * sizeof(float) + BM * sizeof(float) + GELU_TAB_N * 16 +
-                       (size_t)NWAVES * ((32 / TG) * (1 + 2 * NMAX) + NMAX) * TG * sizeof(float) + 32 * (2 * NMAX + 4) * sizeof(float);
+                       (size_t)NWAVES * ((32 / TG) * (1 + 2 * NM) + NM) * TG * sizeof(float) + 32 * (2 * NM + 4) * sizeof(float);
     auto kern = tower_bwd_kernel<P, D, NMAX, TG, DM>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -504,11 +511,26 @@ static int launch_bwd(const m2m_tower* t, int B, const float* d_out, long d_out_
 }
 
 int m2m_check_tower(const m2m_tower* t, int B);
+int m2m_backward_wide(const m2m_tower* t, int B, const float* d_out, long d_out_ss, const float* d_pooled, float* d_x0,
+                      long d_x0_ss, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st);
+
+// Backward of the channel-mixing half of ONE block (+ final LayerNorm if the view has it) over B*N independent rows.
+int m2m_chain_backward_rows(const m2m_tower* t, int B, const float* d_out, long d_out_ss, const float* d_pooled, float* d_x0,
+                            long d_x0_ss, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
+#define M2M_BWDR_CASE(PP, DD) \
+    if (t->prec == PP && t->D == DD) return launch_bwd<PP, DD, 0, 8>(t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step, step_dev, st);
+    M2M_BWDR_CASE(PREC_BF16, 32) M2M_BWDR_CASE(PREC_BF16, 64) M2M_BWDR_CASE(PREC_BF16, 128) M2M_BWDR_CASE(PREC_BF16, 256)
+    M2M_BWDR_CASE(PREC_F32, 32) M2M_BWDR_CASE(PREC_F32, 64) M2M_BWDR_CASE(PREC_F32, 128) M2M_BWDR_CASE(PREC_F32, 256)
+#undef M2M_BWDR_CASE
+    m2m_set_error("tower_backward (wide): unsupported (prec, D)", __FILE__, __LINE__);
+    return -1;
+}
 
 extern "C" int m2m_tower_backward(const m2m_tower* t, int B, const float* d_out, int64_t d_out_ss, const float* d_pooled,
                                   float* d_x0, int64_t d_x0_ss, uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream) {
     if (int rc = m2m_check_tower(t, B)) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (m2m_is_wide(t)) return m2m_backward_wide(t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step, step_dev, st);
 #define M2M_BWD_CASE(PP, DD) \
     if (t->prec == PP && t->D == DD) {                                                                                          \
         if (t->N <= 4) return launch_bwd<PP, DD, 4, 8>(t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step, step_dev, st);   \

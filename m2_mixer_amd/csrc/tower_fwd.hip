@@ -26,7 +26,9 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw,
     typedef Prec<P> Pr;
     typedef TileGeom<D> G;
     constexpr int XLD = G::XLD, DT = G::DT, KD = D / Pr::KB, NF = Chain<P>::NF;
-    constexpr int TW_LD = 2 * NMAX + 4;                          // token-weight row: W1 | W2^T | b1 | pad
+    constexpr bool TOK = NMAX > 0;                               // false: wide path, channel mixing only (rows independent)
+    constexpr int NM = TOK ? NMAX : 1;
+    constexpr int TW_LD = 2 * NM + 4;                            // token-weight row: W1 | W2^T | b1 | pad
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xs = reinterpret_cast<float*>(smem);                  // residual stream  [BM][XLD]
@@ -35,16 +37,16 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw,
     static_assert(SlabGeom<D>::FLOATS >= BM * XLD, "scratch tile must fit in slab 0");
     char* at = reinterpret_cast<char*>(slabs + 4 * SlabGeom<D>::FLOATS);   // packed A image   BM*D*ESZ bytes
     float* tokw = reinterpret_cast<float*>(at + BM * D * Pr::ESZ);   // [T <= 32][TW_LD]
-    float* tokb2 = tokw + 32 * TW_LD;                             // [NMAX]
+    float* tokb2 = tokw + 32 * TW_LD;                             // [NM]
     gtab_t* gtab = reinterpret_cast<gtab_t*>(tokb2 + 8);          // [GELU_TAB_N] (bf16 mode only)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
     const int N = tw.N, T = tw.T, Cp = tw.Cp;
-    const int SPW = BM / N;
+    const int SPW = TOK ? BM / N : 0;
     const int s0 = blockIdx.x * SPW;
-    const int ns = min(SPW, B - s0);
-    const int R = ns * N;
-    const long row0 = (long)s0 * N;                              // first global token row of this tile
+    const int ns = TOK ? min(SPW, B - s0) : 0;
+    const long row0 = TOK ? (long)s0 * N : (long)blockIdx.x * BM;   // first global token row of this tile
+    const int R = TOK ? ns * N : (int)min((long)BM, (long)B * N - row0);
     const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
 
     TIMER_START();
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw,
     _Pragma("unroll 1") for (int idx = tid; idx < BM * (D / 4); idx += NTHREADS) {
         const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < R) v = *reinterpret_cast<const float4*>(x0 + (long)(s0 + r / N) * x0_ss + (long)(r % N) * D + c);
+        if (r < R) { const long gr = row0 + r; v = *reinterpret_cast<const float4*>(x0 + (gr / N) * x0_ss + (gr % N) * D + c); }
         *reinterpret_cast<float4*>(xs + r * XLD + c) = v;
     }
     __syncthreads();
@@ -66,6 +68,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw,
         const Drop dr_ch = make_drop(training, tw.p_drop, seed, step, site + 2);
         const Drop dr_co = make_drop(training, tw.p_drop, seed, step, site + 3);
 
+        if constexpr (TOK) {
         // ---- save block input, LN1 -> ub; token-MLP weights -> LDS (zero-padded to NMAX tokens) ----
         //   tokw[t][0..NMAX) = W1[t][n]   tokw[t][NMAX..2NMAX) = W2[n][t]   tokw[t][2NMAX] = b1[t]
         if (training) {
@@ -120,9 +123,10 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw,
         }
         __syncthreads();
         TIMER_MARK(g_tm_fwd, 1);   // token mixing
+        }   // TOK
 
-        // ---- save x_mid, LN2 -> packed operand image ----
-        if (training) {
+        // ---- save x_mid, LN2 -> packed operand image (wide path: the input IS the saved x_mid) ----
+        if (training && TOK) {
             _Pragma("unroll 1") for (int idx = tid; idx < R * (D / 4); idx += NTHREADS) {
                 const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
                 *reinterpret_cast<float4*>(bk.x_mid + (row0 + r) * D + c) = *reinterpret_cast<const float4*>(xs + r * XLD + c);
@@ -240,10 +244,11 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw,
     }
     _Pragma("unroll 1") for (int idx = tid; idx < R * (D / 4); idx += NTHREADS) {
         const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
-        *reinterpret_cast<float4*>(out + (long)(s0 + r / N) * out_ss + (long)(r % N) * D + c) =
+        const long gr = row0 + r;
+        *reinterpret_cast<float4*>(out + (gr / N) * out_ss + (gr % N) * D + c) =
             *reinterpret_cast<const float4*>(res + r * XLD + c);
     }
-    if (pooled) {
+    if (TOK && pooled) {
         const float inv = 1.0f / (float)N;
         _Pragma("unroll 1") for (int p = tid; p < ns * D; p += NTHREADS) {
             const int sl = p / D, d = p % D;
@@ -263,8 +268,8 @@ static size_t fwd_lds_bytes() {
 template <int P, int D, int NMAX, int DM>
 static int launch_fwd_dm(const m2m_tower* t, const float* x0, long x0_ss, int B, float* out, long out_ss, float* pooled,
                       int training, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
-    const int SPW = BM / t->N;
-    const int grid = (B + SPW - 1) / SPW;
+    const int SPW = NMAX > 0 ? BM / t->N : 1;
+    const int grid = NMAX > 0 ? (B + SPW - 1) / SPW : (int)(((long)B * t->N + BM - 1) / BM);
     const size_t lds = fwd_lds_bytes<P, D>();
     auto kern = tower_fwd_kernel<P, D, NMAX, DM>;
     static bool attr_done = false;
@@ -288,11 +293,27 @@ static int launch_fwd(const m2m_tower* t, const float* x0, long x0_ss, int B, fl
 }
 
 int m2m_check_tower(const m2m_tower* t, int B);
+int m2m_forward_wide(const m2m_tower* t, const float* x0, long x0_ss, int B, float* out, long out_ss, float* pooled,
+                     int training, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st);
+
+// Channel-mixing half of ONE block (+ final LayerNorm if the view has it) over B*N independent rows: the wide path's
+// per-block launch.  `view` is a one-block copy of the tower (token parameters unused).
+int m2m_chain_forward_rows(const m2m_tower* t, const float* x0, long x0_ss, int B, float* out, long out_ss, int training,
+                           unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
+#define M2M_FWDR_CASE(PP, DD) \
+    if (t->prec == PP && t->D == DD) return launch_fwd<PP, DD, 0>(t, x0, x0_ss, B, out, out_ss, nullptr, training, seed, step, step_dev, st);
+    M2M_FWDR_CASE(PREC_BF16, 32) M2M_FWDR_CASE(PREC_BF16, 64) M2M_FWDR_CASE(PREC_BF16, 128) M2M_FWDR_CASE(PREC_BF16, 256)
+    M2M_FWDR_CASE(PREC_F32, 32) M2M_FWDR_CASE(PREC_F32, 64) M2M_FWDR_CASE(PREC_F32, 128) M2M_FWDR_CASE(PREC_F32, 256)
+#undef M2M_FWDR_CASE
+    m2m_set_error("tower_forward (wide): unsupported (prec, D)", __FILE__, __LINE__);
+    return -1;
+}
 
 extern "C" int m2m_tower_forward(const m2m_tower* t, const float* x0, int64_t x0_ss, int B, float* out, int64_t out_ss,
                                  float* pooled, int training, uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream) {
     if (int rc = m2m_check_tower(t, B)) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (m2m_is_wide(t)) return m2m_forward_wide(t, x0, x0_ss, B, out, out_ss, pooled, training, seed, step, step_dev, st);
 #define M2M_FWD_CASE(PP, DD) \
     if (t->prec == PP && t->D == DD) return t->N <= 4 ? launch_fwd<PP, DD, 4>(t, x0, x0_ss, B, out, out_ss, pooled, training, seed, step, step_dev, st) \
                                                       : launch_fwd<PP, DD, 8>(t, x0, x0_ss, B, out, out_ss, pooled, training, seed, step, step_dev, st);

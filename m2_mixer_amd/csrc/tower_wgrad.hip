@@ -20,6 +20,11 @@
 TIMER_DECL(g_tm_wg);
 TIMER_READER(m2m_debug_timers_wgrad, g_tm_wg)
 
+template <int P, int D>
+static constexpr int wgrad_stages() {
+    return (2 * 4 * WBM * D * Prec<P>::ESZ + (Act<P>::USES_TABLE ? GELU_TAB_N * 16 : 0)) <= 160 * 1024 ? 2 : 1;
+}
+
 template <int P, int D, int DM>
 __global__ __launch_bounds__(NTHREADS) void tower_wgrad_kernel(const m2m_tower tw, int ntiles, int tiles_per_group,
                                                                int rows_per_tile, unsigned int seed, unsigned int step_host,
@@ -29,11 +34,12 @@ __global__ __launch_bounds__(NTHREADS) void tower_wgrad_kernel(const m2m_tower t
     constexpr int IMG_B = WBM * D * Pr::ESZ;
     constexpr int STAGE_B = 4 * IMG_B;                      // A | dYd | A^T | dYd^T of one tile
     constexpr int NLD = STAGE_B / (NTHREADS * 16);          // 16-byte pieces per thread per tile
+    constexpr int NST = wgrad_stages<P, D>();               // 2: double-buffered LDS stage; 1 when two would not fit (fp32, D = 256)
     static_assert(STAGE_B % (NTHREADS * 16) == 0, "tile stage must split evenly over the threads");
     static_assert(IMG_B % (NTHREADS * 16) == 0 || (NTHREADS * 16) % IMG_B == 0, "piece never straddles two images");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    gtab_t* gtab = reinterpret_cast<gtab_t*>(smem + 2 * STAGE_B);     // [GELU_TAB_N] (bf16 mode only)
+    gtab_t* gtab = reinterpret_cast<gtab_t*>(smem + NST * STAGE_B);   // [GELU_TAB_N] (bf16 mode only)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
     const m2m_block& bk = tw.blk[blockIdx.y];
@@ -92,8 +98,8 @@ __global__ __launch_bounds__(NTHREADS) void tower_wgrad_kernel(const m2m_tower t
     }
     __syncthreads();
     for (int tile = t_begin; tile < t_end; ++tile) {
-        char* cur = smem + ((tile - t_begin) & 1) * STAGE_B;
-        char* nxt = smem + (((tile - t_begin) & 1) ^ 1) * STAGE_B;
+        char* cur = smem + (NST == 2 ? ((tile - t_begin) & 1) * STAGE_B : 0);
+        char* nxt = smem + (NST == 2 ? (((tile - t_begin) & 1) ^ 1) * STAGE_B : 0);
         const bool more = tile + 1 < t_end;
         if (more) { STAGE_LOAD(tile + 1) }                   // in flight during this tile's math
         const char* a_nat = cur;
@@ -148,6 +154,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_wgrad_kernel(const m2m_tower t
             }
             TIMER_MARK(g_tm_wg, 2);
         }
+        if (NST == 1) __syncthreads();                       // single stage: everyone is done reading before the overwrite
         if (more) { STAGE_STORE(nxt) }
         __syncthreads();
         TIMER_MARK(g_tm_wg, 3);
@@ -192,8 +199,9 @@ __global__ __launch_bounds__(NTHREADS) void tower_wgrad_kernel(const m2m_tower t
 
 template <int P, int D, int DM>
 static int launch_wgrad_dm(const m2m_tower* t, int B, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
-    const int SPW = BM / t->N;                                  // samples per chain tile
-    const int nchain = (B + SPW - 1) / SPW;                     // chain tiles (BM rows each)
+    const bool wide = m2m_is_wide(t);                           // wide path: chain tiles are any BM consecutive rows
+    const int SPW = wide ? 1 : BM / t->N;                       // samples per chain tile
+    const int nchain = wide ? (int)(((long)B * t->N + BM - 1) / BM) : (B + SPW - 1) / SPW;   // chain tiles (BM rows each)
     const int ntiles = (nchain * BM + WBM - 1) / WBM;           // streamed tiles (WBM rows each)
     const int nsl = ((t->Cp >> 4) + NWAVES - 1) / NWAVES;      // 128-column slices
     // Row groups trade parallelism against float-atomic traffic (every extra group re-adds the whole slice) and,
@@ -214,14 +222,15 @@ static int launch_wgrad_dm(const m2m_tower* t, int B, unsigned int seed, unsigne
     if (tpg < 4) tpg = 4;
     if (tpg > ntiles) tpg = ntiles;
     groups = (ntiles + tpg - 1) / tpg;
-    const size_t lds = (size_t)2 * 4 * WBM * D * Prec<P>::ESZ + GELU_TAB_N * 16;
+    const size_t lds = (size_t)wgrad_stages<P, D>() * 4 * WBM * D * Prec<P>::ESZ + GELU_TAB_N * 16;
+    const int rows_per_tile = wide ? BM : SPW * t->N;
     auto kern = tower_wgrad_kernel<P, D, DM>;
     static bool attr_done = false;
     if (!attr_done) {
         M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(nsl, t->nblocks, groups), dim3(NTHREADS), lds, st, *t, ntiles, tpg, SPW * t->N, seed, step, step_dev);
+    hipLaunchKernelGGL(kern, dim3(nsl, t->nblocks, groups), dim3(NTHREADS), lds, st, *t, ntiles, tpg, rows_per_tile, seed, step, step_dev);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -242,8 +251,8 @@ extern "C" int m2m_tower_wgrad(const m2m_tower* t, int B, uint32_t seed, uint32_
     if (t->nblocks == 0) return 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define M2M_WG_CASE(PP, DD) if (t->prec == PP && t->D == DD) return launch_wgrad<PP, DD>(t, B, seed, step, step_dev, st);
-    M2M_WG_CASE(PREC_BF16, 32) M2M_WG_CASE(PREC_BF16, 64) M2M_WG_CASE(PREC_BF16, 128)
-    M2M_WG_CASE(PREC_F32, 32) M2M_WG_CASE(PREC_F32, 64) M2M_WG_CASE(PREC_F32, 128)
+    M2M_WG_CASE(PREC_BF16, 32) M2M_WG_CASE(PREC_BF16, 64) M2M_WG_CASE(PREC_BF16, 128) M2M_WG_CASE(PREC_BF16, 256)
+    M2M_WG_CASE(PREC_F32, 32) M2M_WG_CASE(PREC_F32, 64) M2M_WG_CASE(PREC_F32, 128) M2M_WG_CASE(PREC_F32, 256)
 #undef M2M_WG_CASE
     m2m_set_error("tower_wgrad: unsupported (prec, D)", __FILE__, __LINE__);
     return -1;

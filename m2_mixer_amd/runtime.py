@@ -58,7 +58,10 @@ class TowerRuntime:
         self._param_versions: List[int] = []
         self._packed_for: Optional[List[int]] = None
         self._bufB = 0
+        self._wsB = 0
         self.device = None
+        # wide path (include/m2mixer.h): token mixing and channel mixing are separate launches
+        self.wide = N > 8 or D > 128
 
     # ---- parameters --------------------------------------------------------------------------------
     def bind_params(self, blocks: Sequence[Dict[str, torch.Tensor]], lnf: Optional[Sequence[torch.Tensor]]):
@@ -119,8 +122,11 @@ class TowerRuntime:
         so they are reallocated whenever B changes."""
         if B == self._bufB:
             return
-        spw = L.ROWS_PER_WG // self.N
-        ntiles = (B + spw - 1) // spw
+        if self.wide:
+            ntiles = (B * self.N + L.ROWS_PER_WG - 1) // L.ROWS_PER_WG
+        else:
+            spw = L.ROWS_PER_WG // self.N
+            ntiles = (B + spw - 1) // spw
         esz = 2 if self.prec == L.PREC_BF16 else 4
         npairs = (ntiles * L.ROWS_PER_WG + 31) // 32
         img = npairs * 32 * self.D * esz
@@ -136,6 +142,15 @@ class TowerRuntime:
         self.desc.x_final = xf.data_ptr()
         self._keep["x_final"] = xf
         self._bufB = B
+
+    def ensure_workspace(self, B: int):
+        """The wide path's two (B*N, D) stream buffers (needed in eval too)."""
+        if not self.wide or B == self._wsB:
+            return
+        ws = torch.empty(2, B * self.N, self.D, device=self.device)
+        self.desc.ws_a, self.desc.ws_b = ws[0].data_ptr(), ws[1].data_ptr()
+        self._keep["ws"] = ws
+        self._wsB = B
 
     # ---- gradients -----------------------------------------------------------------------------------
     def grad_numel(self) -> int:
@@ -178,6 +193,7 @@ class TowerRuntime:
                 step_dev: Optional[torch.Tensor] = None):
         if training:
             self.ensure_buffers(B)
+        self.ensure_workspace(B)
         L.check(L.lib().m2m_tower_forward(C.byref(self.desc), x0.data_ptr(), x0_ss, B, out.data_ptr(), out_ss,
                                           L.ptr(pooled), int(training), seed & 0xFFFFFFFF, step & 0xFFFFFFFF,
                                           L.ptr(step_dev), L.stream_ptr()), "tower_forward")

@@ -56,7 +56,9 @@ def run_block(case, B, prec, dev, p_drop=0.0, seed=0):
     return blk, p, x, dy, y, xg
 
 
-GPU_BLOCK_CASES = [(ci, c) for ci, c in enumerate(G.BLOCK_CASES) if c[0] <= 8 and c[1] <= 128]
+# every block shape of SURVEY.md section 8c(i): N <= 8 runs on the fused path, the MIMIC / MM-IMDb shapes
+# (N = 24, 25, 40, 80; D = 256) on the wide path
+GPU_BLOCK_CASES = list(enumerate(G.BLOCK_CASES))
 
 
 @pytest.mark.parametrize("ci,case", GPU_BLOCK_CASES)
@@ -97,7 +99,7 @@ def test_block_bf16_vs_oracle(ci, case, dev):
 
 
 @pytest.mark.parametrize("p_drop", [0.5, 0.1])
-@pytest.mark.parametrize("case", [(4, 128, 32, 3072), (8, 32, 16, 256)])
+@pytest.mark.parametrize("case", [(4, 128, 32, 3072), (8, 32, 16, 256), (24, 64, 16, 64), (40, 256, 16, 512)])
 def test_block_dropout_masks_match_oracle(case, p_drop, dev):
     """Training-mode dropout: export the keep-masks the kernels regenerate (forward, backward and the
     weight-gradient pass all recompute them) and feed them to the oracle: every output and gradient
@@ -202,26 +204,28 @@ def test_module_path_towers_and_no_patching(dev):
     cfg = G.MIMIC_H["time"]
     shapes = G.tower_shapes("", cfg, cfg["num_patch"], "proj")
     params = G.make_params(shapes, 5)
-    tower = MM.get_block_by_name(block_type="MLPMixerNoPatching", in_channels=1, **{**cfg, "num_patch": 8}, dropout=0.0).to(dev)
-    # N = 24 is outside this build's N <= 8: the library must refuse, not compute something else
-    big = MM.get_block_by_name(block_type="MLPMixerNoPatching", in_channels=1, **cfg, dropout=0.0).to(dev)
-    with pytest.raises(RuntimeError, match="num_patch"):
-        big(torch.zeros(2, 24, 12, device=dev))
-    shapes8 = G.tower_shapes("", {**cfg, "num_patch": 8}, 8, "proj")
-    params8 = G.make_params(shapes8, 5)
-    tower.load_state_dict(params8)
-    x = torch.randn(9, 8, 12)
-    y = tower(x.to(dev))                       # the tower input is data: no gradient is produced for it
-    y.square().sum().backward()
-    leaves = {k: v.clone().requires_grad_(True) for k, v in params8.items()}
-    yo = O.mlp_mixer_no_patching(x, leaves, "", 1)
-    yo.square().sum().backward()
-    assert abserr(y, yo) < FP32_ATOL
-    for k, prm in tower.named_parameters():
-        if k.endswith("token_mix.2.net.3.bias"):      # exactly-zero true gradient (the next LayerNorm removes it): noise only
-            assert float(prm.grad.abs().max()) < 1e-3
-            continue
-        assert relerr(prm.grad, leaves[k].grad) < 1e-3, k
+    for N in (8, cfg["num_patch"]):              # fused path (N = 8) and the MIMIC time tower as configured (N = 24: wide path)
+        cfgN = {**cfg, "num_patch": N}
+        tower = MM.get_block_by_name(block_type="MLPMixerNoPatching", in_channels=1, **cfgN, dropout=0.0).to(dev)
+        paramsN = G.make_params(G.tower_shapes("", cfgN, N, "proj"), 5)
+        tower.load_state_dict(paramsN)
+        x = torch.randn(9, N, 12)
+        y = tower(x.to(dev))                       # the tower input is data: no gradient is produced for it
+        y.square().sum().backward()
+        leaves = {k: v.clone().requires_grad_(True) for k, v in paramsN.items()}
+        yo = O.mlp_mixer_no_patching(x, leaves, "", 1)
+        yo.square().sum().backward()
+        assert abserr(y, yo) < FP32_ATOL
+        for k, prm in tower.named_parameters():
+            if k.endswith("token_mix.2.net.3.bias"):      # exactly-zero true gradient (the next LayerNorm removes it): noise only
+                assert float(prm.grad.abs().max()) < 1e-3
+                continue
+            assert relerr(prm.grad, leaves[k].grad) < 1e-3, (N, k)
+        # eval forward (no saved activations: the wide path streams through its workspaces)
+        tower.eval()
+        with torch.no_grad():
+            ye = tower(x.to(dev))
+        assert abserr(ye, yo) < FP32_ATOL
 
 
 def test_full_size_properties(dev):
@@ -290,8 +294,14 @@ def test_training_reduces_loss_bf16(dev):
 def test_unsupported_shapes_are_refused(dev):
     from m2_mixer_amd import modules as MM
     blk = MM.MixerBlock(48, 4, 16, 64).to(dev)          # hidden_dim 48 has no kernel instantiation
-    with pytest.raises(RuntimeError, match="unsupported"):
+    with pytest.raises(RuntimeError, match="hidden_dim"):
         blk(torch.zeros(2, 4, 48, device=dev))
-    blk = MM.MixerBlock(32, 4, 12, 64).to(dev)          # token_dim must be a multiple of 8
+    blk = MM.MixerBlock(32, 4, 12, 64).to(dev)          # token_dim must be a multiple of 8 on the fused path
     with pytest.raises(RuntimeError, match="token_dim"):
         blk(torch.zeros(2, 4, 32, device=dev))
+    blk = MM.MixerBlock(32, 200, 16, 64).to(dev)        # more tokens than the wide path's LDS tiles hold
+    with pytest.raises(RuntimeError, match="num_patch"):
+        blk(torch.zeros(2, 200, 32, device=dev))
+    blk = MM.MixerBlock(32, 24, 40, 64).to(dev)         # token_dim above the register budget of the token kernels
+    with pytest.raises(RuntimeError, match="token_dim"):
+        blk(torch.zeros(2, 24, 32, device=dev))

@@ -39,10 +39,10 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_struct_layouts_match_header(lib):
     import ctypes as C
-    # m2m_block: 12 params + 5 packed + 12 grads + 6 saved pointers; m2m_tower header is 40 bytes then 5 pointers
+    # m2m_block: 12 params + 5 packed + 12 grads + 6 saved pointers; m2m_tower header is 40 bytes then 7 pointers
     assert C.sizeof(lib.Block) == 35 * 8
-    assert C.sizeof(lib.Tower) == 40 + 5 * 8 + lib.MAX_BLOCKS * C.sizeof(lib.Block)
-    assert lib.Tower.blk.offset == 80
+    assert C.sizeof(lib.Tower) == 40 + 7 * 8 + lib.MAX_BLOCKS * C.sizeof(lib.Block)
+    assert lib.Tower.blk.offset == 96
     assert C.sizeof(lib.Embed) == 40 + 5 * 8
     assert C.sizeof(lib.Head) == 6 * 8 + 8
 
