@@ -155,9 +155,9 @@ def main():
 
     if args.no_graph:
         def step():
-            eng.train_step(image, audio, labels, sync)
+            eng.train_step(image, audio, labels, grad_sync=sync)
     else:
-        replay = eng.capture(image, audio, labels, sync)
+        replay = eng.capture(image, audio, labels, grad_sync=sync)
 
         def step():
             replay()

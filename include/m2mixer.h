@@ -169,6 +169,35 @@ typedef struct m2m_head {
 int m2m_heads_ce(const m2m_head* heads, int nheads, const int64_t* labels, int B, int D, int K,
                  float* logits, float* losses, int32_t* preds, void* stream);
 
+/* BCEWithLogitsLoss(pos_weight) variant (models/mmimdb.py:47-50, :115-133): targets (B, K) float multi-hot,
+ * pos_weight (K); per-head loss = mean over all B*K elements; preds (nheads, B, K) int32 = sigmoid(logits) > 0.5. */
+int m2m_heads_bce(const m2m_head* heads, int nheads, const float* targets, const float* pos_weight, int B, int D, int K,
+                  float* logits, float* losses, int32_t* preds, void* stream);
+
+/* ---- plain MLP tower (modules/mlp.py:4-27; the MIMIC `static` modality, models/mimic.py:98) ------- */
+#define M2M_MLP_MAX_LAYERS 4
+/* num_blocks x (Linear -> ReLU -> Dropout(p)) followed, if has_out, by an output Linear.  nlayers counts every Linear;
+ * dims[i] -> dims[i+1] is layer i (reference state-dict keys module_list.{3*i}.weight/bias, output layer at 3*num_blocks). */
+typedef struct m2m_mlp {
+    int32_t nlayers;
+    int32_t has_out;                         /* 1: the last Linear has no ReLU / Dropout after it */
+    int32_t dims[M2M_MLP_MAX_LAYERS + 1];    /* widths, each <= 128 */
+    float p_drop;
+    uint32_t site_base;                      /* dropout stream of layer i = site_base + i */
+    const float* w[M2M_MLP_MAX_LAYERS];      /* (dims[i+1], dims[i]) */
+    const float* b[M2M_MLP_MAX_LAYERS];
+    float* g_w[M2M_MLP_MAX_LAYERS];          /* gradients, accumulated with += */
+    float* g_b[M2M_MLP_MAX_LAYERS];
+    float* act[M2M_MLP_MAX_LAYERS];          /* saved outputs of the hidden layers (B, dims[i+1]) for backward */
+} m2m_mlp;
+/* out: sample b at out + b*out_sample_stride (lets the result be token 0 of a fused buffer, models/mimic.py:102);
+ * out_dense (B, dims[nlayers]) or NULL: a second dense copy (input of the modality's own head, models/mimic.py:106). */
+int m2m_mlp_forward(const m2m_mlp* m, const float* x, int B, float* out, int64_t out_sample_stride, float* out_dense,
+                    int training, uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream);
+/* gradient wrt the output = d_out (strided, or NULL) + d_out_dense (or NULL); accumulates g_w / g_b.  The input is data. */
+int m2m_mlp_backward(const m2m_mlp* m, const float* x, int B, const float* d_out, int64_t d_out_sample_stride,
+                     const float* d_out_dense, void* stream);
+
 /* ---- optimizer (torch.optim.Adam as configured at models/avmnist.py:413-415) ---------------------- */
 /* state: device float[4] = {step (as float count), lr, unused, unused}; the kernel reads lr and the
  * step count from it, so a captured graph can be replayed while the host edits lr.  With bump_step != 0

@@ -58,6 +58,17 @@ class Head(C.Structure):
                 ("weight", C.c_float)]
 
 
+MLP_MAX_LAYERS = 4
+
+
+class Mlp(C.Structure):
+    """m2m_mlp"""
+    _fields_ = [("nlayers", C.c_int32), ("has_out", C.c_int32), ("dims", C.c_int32 * (MLP_MAX_LAYERS + 1)),
+                ("p_drop", C.c_float), ("site_base", C.c_uint32),
+                ("w", _fp * MLP_MAX_LAYERS), ("b", _fp * MLP_MAX_LAYERS), ("g_w", _fp * MLP_MAX_LAYERS),
+                ("g_b", _fp * MLP_MAX_LAYERS), ("act", _fp * MLP_MAX_LAYERS)]
+
+
 # name -> (restype, argtypes); every symbol include/m2mixer.h declares
 SIGNATURES = {
     "m2m_abi_version": (C.c_int, []),
@@ -75,6 +86,10 @@ SIGNATURES = {
     "m2m_counter_add": (C.c_int, [_fp, C.c_uint32, _fp]),
     "m2m_embed_wgrad": (C.c_int, [C.POINTER(Embed), _fp, _fp, C.c_int, _fp]),
     "m2m_heads_ce": (C.c_int, [C.POINTER(Head), C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp]),
+    "m2m_heads_bce": (C.c_int, [C.POINTER(Head), C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp]),
+    "m2m_mlp_forward": (C.c_int, [C.POINTER(Mlp), _fp, C.c_int, _fp, C.c_int64, _fp, C.c_int, C.c_uint32, C.c_uint32,
+                                  _fp, _fp]),
+    "m2m_mlp_backward": (C.c_int, [C.POINTER(Mlp), _fp, C.c_int, _fp, C.c_int64, _fp, _fp]),
     "m2m_adam_step": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, _fp, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_float, C.c_int, _fp]),
     "m2m_dropout_mask": (C.c_int, [C.POINTER(Tower), C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, _fp, _fp]),

@@ -4,6 +4,8 @@
 // classifier_fusion = StandardClassifier (mean over tokens -> Linear, modules/classification.py:89-90),
 // three nn.CrossEntropyLoss() (mean), loss = (w Lf + ow Li + ow La) * 3, preds = softmax(.).argmax(1).
 // The token means ("pooled") are produced by the tower forward kernel; this kernel consumes them.
+// BCE = true is the MM-IMDb variant (models/mmimdb.py:47-50, :115-133): nn.BCEWithLogitsLoss(pos_weight) with mean
+// reduction over all B*K elements per head, preds = sigmoid(logits) > 0.5 per label.
 #include "tile.h"
 
 #define HEAD_S 64       // samples per workgroup
@@ -14,9 +16,13 @@ struct HeadArgs {
     m2m_head h[HEAD_MAXH];
 };
 
-__global__ __launch_bounds__(NTHREADS) void heads_ce_kernel(const HeadArgs ha, const int64_t* __restrict__ labels, int B, int D,
-                                                            int K, float* __restrict__ logits_out, float* __restrict__ losses,
-                                                            int32_t* __restrict__ preds, int nheads) {
+template <bool BCE>
+__global__ __launch_bounds__(NTHREADS) void heads_kernel(const HeadArgs ha, const void* __restrict__ labels_v,
+                                                         const float* __restrict__ pos_weight, int B, int D,
+                                                         int K, float* __restrict__ logits_out, float* __restrict__ losses,
+                                                         int32_t* __restrict__ preds, int nheads) {
+    const int64_t* labels = reinterpret_cast<const int64_t*>(labels_v);       // CE: class index (B)
+    const float* targets = reinterpret_cast<const float*>(labels_v);          // BCE: multi-hot (B, K)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int DL = D + 1;
     float* pl = reinterpret_cast<float*>(smem);          // pooled tile [HEAD_S][DL]
@@ -51,7 +57,20 @@ __global__ __launch_bounds__(NTHREADS) void heads_ce_kernel(const HeadArgs ha, c
     // softmax / loss / prediction / dlogits, one thread per sample
     if (tid < HEAD_S) {
         float term = 0.f;
-        if (tid < ns) {
+        if (BCE && tid < ns) {
+            const int s = tid;
+            const float scale = hd.weight / ((float)B * (float)K);
+            for (int k = 0; k < K; ++k) {
+                const float x = lg[s * HEAD_MAXK + k], y = targets[(long)(s0 + s) * K + k], pw = pos_weight[k];
+                // log sigmoid(x) = min(x, 0) - log1p(exp(-|x|));  log(1 - sigmoid(x)) = log sigmoid(x) - x
+                const float ls = __builtin_fminf(x, 0.f) - log1pf(__expf(-__builtin_fabsf(x)));
+                term -= pw * y * ls + (1.f - y) * (ls - x);
+                const float sg = 1.0f / (1.0f + __expf(-x));
+                lg[s * HEAD_MAXK + k] = scale * ((1.f - y) * sg - pw * y * (1.f - sg));
+                preds[((long)hI * B + s0 + s) * K + k] = x > 0.f ? 1 : 0;
+            }
+            term /= (float)K;
+        } else if (tid < ns) {
             const int s = tid;
             const int y = (int)labels[s0 + s];
             float mx = lg[s * HEAD_MAXK];
@@ -108,10 +127,11 @@ __global__ void zero_floats_kernel(float* p, int n) {
     if ((int)threadIdx.x < n) p[threadIdx.x] = 0.f;
 }
 
-extern "C" int m2m_heads_ce(const m2m_head* heads, int nheads, const int64_t* labels, int B, int D, int K, float* logits,
-                            float* losses, int32_t* preds, void* stream) {
-    if (!heads || nheads < 1 || nheads > HEAD_MAXH || K < 2 || K > HEAD_MAXK || D < 1 || D > 512 || B < 1) {
-        m2m_set_error("heads_ce: unsupported (nheads<=4, K<=32, D<=512)", __FILE__, __LINE__);
+template <bool BCE>
+static int launch_heads(const m2m_head* heads, int nheads, const void* labels, const float* pos_weight, int B, int D, int K,
+                        float* logits, float* losses, int32_t* preds, void* stream) {
+    if (!heads || nheads < 1 || nheads > HEAD_MAXH || K < 2 || K > HEAD_MAXK || D < 1 || D > 256 || B < 1) {
+        m2m_set_error("heads: unsupported (nheads<=4, K<=32, D<=256)", __FILE__, __LINE__);
         return -1;
     }
     HeadArgs ha;
@@ -121,8 +141,19 @@ extern "C" int m2m_heads_ce(const m2m_head* heads, int nheads, const int64_t* la
     hipLaunchKernelGGL(zero_floats_kernel, dim3(1), dim3(64), 0, st, losses, nheads + 1);
     const size_t lds = sizeof(float) * ((size_t)HEAD_S * (D + 1) + (size_t)HEAD_MAXK * (D + 1) + HEAD_S * HEAD_MAXK + HEAD_S);
     static bool done = false;
-    if (!done) { M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(heads_ce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); done = true; }
-    hipLaunchKernelGGL(heads_ce_kernel, dim3((B + HEAD_S - 1) / HEAD_S, nheads), dim3(NTHREADS), lds, st, ha, labels, B, D, K, logits, losses, preds, nheads);
+    if (!done) { M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(heads_kernel<BCE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); done = true; }
+    hipLaunchKernelGGL(heads_kernel<BCE>, dim3((B + HEAD_S - 1) / HEAD_S, nheads), dim3(NTHREADS), lds, st, ha, labels, pos_weight, B, D, K, logits, losses, preds, nheads);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+extern "C" int m2m_heads_ce(const m2m_head* heads, int nheads, const int64_t* labels, int B, int D, int K, float* logits,
+                            float* losses, int32_t* preds, void* stream) {
+    return launch_heads<false>(heads, nheads, labels, nullptr, B, D, K, logits, losses, preds, stream);
+}
+
+extern "C" int m2m_heads_bce(const m2m_head* heads, int nheads, const float* targets, const float* pos_weight, int B, int D, int K,
+                             float* logits, float* losses, int32_t* preds, void* stream) {
+    if (!targets || !pos_weight) { m2m_set_error("heads_bce: targets and pos_weight are required", __FILE__, __LINE__); return -1; }
+    return launch_heads<true>(heads, nheads, targets, pos_weight, B, D, K, logits, losses, preds, stream);
 }

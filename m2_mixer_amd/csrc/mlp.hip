@@ -1,0 +1,164 @@
+// Plain MLP tower: num_blocks x (Linear -> ReLU -> Dropout) + optional output Linear  (reference: modules/mlp.py:4-27;
+// the MIMIC `static` modality, models/mimic.py:98: 5 -> 64 -> 64 -> 64, ~8.5 kMAC per sample).
+//
+// The work is tiny and the widths are <= 128, so both passes are exact-fp32 VALU kernels: a workgroup owns
+// MLP_S samples, keeps the activations of the current layer in LDS and the layer's weights (transposed, padded)
+// beside them.  Backward needs no mask regeneration: the saved layer output is relu(z) * keep * scale, which is
+// non-zero exactly where the gradient passes, so dz = d_out * scale * [out != 0].
+#include "tile.h"
+
+#define MLP_S 32           // samples per workgroup
+#define MLP_T 256          // threads
+#define MLP_MAXW 128       // widest layer (LDS: activations + one layer's weights)
+
+static __device__ __forceinline__ Drop mlp_drop(const m2m_mlp& m, int layer, int training, unsigned int seed, unsigned int step) {
+    return make_drop(training != 0, m.p_drop, seed, step, m.site_base + (unsigned int)layer);
+}
+
+__global__ __launch_bounds__(MLP_T) void mlp_fwd_kernel(const m2m_mlp m, const float* __restrict__ x, int B, float* __restrict__ out,
+                                                        long out_ss, float* __restrict__ out2, int training, unsigned int seed,
+                                                        unsigned int step_host, const unsigned int* __restrict__ step_dev) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* a0 = sm;                                   // [MLP_S][MLP_MAXW + 1]
+    float* a1 = a0 + MLP_S * (MLP_MAXW + 1);
+    float* wt = a1 + MLP_S * (MLP_MAXW + 1);          // [din][dout + 1]  (transposed weights of the current layer)
+    const int tid = threadIdx.x;
+    const int s0 = blockIdx.x * MLP_S;
+    const int ns = min(MLP_S, B - s0);
+    const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
+    constexpr int LD = MLP_MAXW + 1;
+
+    for (int i = tid; i < MLP_S * m.dims[0]; i += MLP_T) {
+        const int s = i / m.dims[0], k = i % m.dims[0];
+        a0[s * LD + k] = s < ns ? x[(long)(s0 + s) * m.dims[0] + k] : 0.f;
+    }
+    float* cur = a0;
+    float* nxt = a1;
+    for (int l = 0; l < m.nlayers; ++l) {
+        const int din = m.dims[l], dout = m.dims[l + 1];
+        const bool hidden = l < m.nlayers - m.has_out;
+        const Drop dr = mlp_drop(m, l, training && hidden, seed, step);
+        __syncthreads();
+        for (int i = tid; i < din * dout; i += MLP_T) { const int j = i / din, k = i % din; wt[k * (dout + 1) + j] = m.w[l][i]; }
+        __syncthreads();
+        for (int i = tid; i < MLP_S * dout; i += MLP_T) {
+            const int s = i / dout, j = i % dout;
+            float acc = m.b[l][j];
+            for (int k = 0; k < din; ++k) acc = __builtin_fmaf(cur[s * LD + k], wt[k * (dout + 1) + j], acc);
+            if (hidden) {
+                acc = acc > 0.f ? acc : 0.f;
+                acc = drop_keep(dr, (unsigned int)(s0 + s) * dout + j) ? acc * dr.scale : 0.f;
+                if (training && s < ns) m.act[l][(long)(s0 + s) * dout + j] = acc;
+            }
+            nxt[s * LD + j] = acc;
+        }
+        float* t = cur; cur = nxt; nxt = t;
+    }
+    __syncthreads();
+    const int dl = m.dims[m.nlayers];
+    for (int i = tid; i < ns * dl; i += MLP_T) {
+        const int s = i / dl, j = i % dl;
+        const float v = cur[s * LD + j];
+        out[(long)(s0 + s) * out_ss + j] = v;
+        if (out2) out2[(long)(s0 + s) * dl + j] = v;
+    }
+}
+
+__global__ __launch_bounds__(MLP_T) void mlp_bwd_kernel(const m2m_mlp m, const float* __restrict__ x, int B,
+                                                        const float* __restrict__ d_out, long d_out_ss,
+                                                        const float* __restrict__ d_out2) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int LD = MLP_MAXW + 1;
+    float* g0 = sm;                                   // gradient wrt the current layer's output [MLP_S][LD]
+    float* g1 = g0 + MLP_S * LD;                      // gradient wrt its input
+    float* ain = g1 + MLP_S * LD;                     // the layer's input activations [MLP_S][LD]
+    float* wl = ain + MLP_S * LD;                     // weights [dout][din + 1]
+    const int tid = threadIdx.x;
+    const int s0 = blockIdx.x * MLP_S;
+    const int ns = min(MLP_S, B - s0);
+    const float scale = 65536.0f / (float)m2m_drop_thr(m.p_drop);
+
+    const int dl = m.dims[m.nlayers];
+    for (int i = tid; i < MLP_S * dl; i += MLP_T) {
+        const int s = i / dl, j = i % dl;
+        float v = 0.f;
+        if (s < ns) {
+            if (d_out) v = d_out[(long)(s0 + s) * d_out_ss + j];
+            if (d_out2) v += d_out2[(long)(s0 + s) * dl + j];
+        }
+        g0[s * LD + j] = v;
+    }
+    float* gc = g0;
+    float* gn = g1;
+    for (int l = m.nlayers - 1; l >= 0; --l) {
+        const int din = m.dims[l], dout = m.dims[l + 1];
+        const bool hidden = l < m.nlayers - m.has_out;
+        const float* inp = l == 0 ? x : m.act[l - 1];
+        __syncthreads();
+        for (int i = tid; i < dout * din; i += MLP_T) wl[(i / din) * (din + 1) + i % din] = m.w[l][i];
+        for (int i = tid; i < MLP_S * din; i += MLP_T) {
+            const int s = i / din, k = i % din;
+            ain[s * LD + k] = s < ns ? inp[(long)(s0 + s) * din + k] : 0.f;
+        }
+        if (hidden) {                                  // through Dropout and ReLU
+            for (int i = tid; i < MLP_S * dout; i += MLP_T) {
+                const int s = i / dout, j = i % dout;
+                const float o = s < ns ? m.act[l][(long)(s0 + s) * dout + j] : 0.f;
+                gc[s * LD + j] = o != 0.f ? gc[s * LD + j] * scale : 0.f;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < dout * din; i += MLP_T) {      // dW[j][k] += sum_s dz[s][j] in[s][k]
+            const int j = i / din, k = i % din;
+            float a = 0.f;
+            for (int s = 0; s < MLP_S; ++s) a = __builtin_fmaf(gc[s * LD + j], ain[s * LD + k], a);
+            atomicAdd(m.g_w[l] + i, a);
+        }
+        for (int j = tid; j < dout; j += MLP_T) {
+            float a = 0.f;
+            for (int s = 0; s < MLP_S; ++s) a += gc[s * LD + j];
+            atomicAdd(m.g_b[l] + j, a);
+        }
+        if (l > 0) {
+            for (int i = tid; i < MLP_S * din; i += MLP_T) {  // d_in[s][k] = sum_j dz[s][j] W[j][k]
+                const int s = i / din, k = i % din;
+                float a = 0.f;
+                for (int j = 0; j < dout; ++j) a = __builtin_fmaf(gc[s * LD + j], wl[j * (din + 1) + k], a);
+                gn[s * LD + k] = a;
+            }
+        }
+        float* t = gc; gc = gn; gn = t;
+    }
+}
+
+static int check_mlp(const m2m_mlp* m, int B) {
+    if (!m || B < 1) { m2m_set_error("mlp: bad argument", __FILE__, __LINE__); return -1; }
+    if (m->nlayers < 1 || m->nlayers > M2M_MLP_MAX_LAYERS) { m2m_set_error("mlp: nlayers out of range", __FILE__, __LINE__); return -1; }
+    for (int i = 0; i <= m->nlayers; ++i)
+        if (m->dims[i] < 1 || m->dims[i] > MLP_MAXW) { m2m_set_error("mlp: layer widths must be in [1, 128]", __FILE__, __LINE__); return -1; }
+    return 0;
+}
+
+extern "C" int m2m_mlp_forward(const m2m_mlp* m, const float* x, int B, float* out, int64_t out_sample_stride, float* out_dense,
+                               int training, uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream) {
+    if (int rc = check_mlp(m, B)) return rc;
+    const size_t lds = sizeof(float) * ((size_t)2 * MLP_S * (MLP_MAXW + 1) + (size_t)MLP_MAXW * (MLP_MAXW + 1));
+    static bool done = false;
+    if (!done) { M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); done = true; }
+    hipLaunchKernelGGL(mlp_fwd_kernel, dim3((B + MLP_S - 1) / MLP_S), dim3(MLP_T), lds, reinterpret_cast<hipStream_t>(stream), *m, x, B,
+                       out, (long)out_sample_stride, out_dense, training, seed, step, step_dev);
+    M2M_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int m2m_mlp_backward(const m2m_mlp* m, const float* x, int B, const float* d_out, int64_t d_out_sample_stride,
+                                const float* d_out_dense, void* stream) {
+    if (int rc = check_mlp(m, B)) return rc;
+    const size_t lds = sizeof(float) * ((size_t)3 * MLP_S * (MLP_MAXW + 1) + (size_t)MLP_MAXW * (MLP_MAXW + 1));
+    static bool done = false;
+    if (!done) { M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); done = true; }
+    hipLaunchKernelGGL(mlp_bwd_kernel, dim3((B + MLP_S - 1) / MLP_S), dim3(MLP_T), lds, reinterpret_cast<hipStream_t>(stream), *m, x, B,
+                       d_out, (long)d_out_sample_stride, d_out_dense);
+    M2M_CHECK_HIP(hipGetLastError());
+    return 0;
+}

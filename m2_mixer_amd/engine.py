@@ -1,92 +1,116 @@
-"""Fused AV-MNIST M2-Mixer training engine: the whole `shared_step` + backward + Adam of
-AVMnistMixerMultiLoss (reference: models/avmnist.py:236-312, :413-422) as a fixed sequence of
-libm2mixer launches over flat fp32 parameter / gradient / Adam-state buffers.
+"""Fused M2-Mixer training engines: the whole `shared_step` + backward + Adam of the reference's multi-loss
+LightningModules as a fixed sequence of libm2mixer launches over flat fp32 parameter / gradient / Adam-state buffers.
+
+  AVMnistEngine   AVMnistMixerMultiLoss   models/avmnist.py:236-312, :413-422   (two patch towers, CE, total x3)
+  MMIMDBEngine    MMIMDBMixerMultiLoss    models/mmimdb.py:96-147               (two patch towers, BCE(pos_weight), plain sum)
+  MimicEngine     MimicMixerMultiLoss     models/mimic.py:93-142                (static MLP + time tower, CE, no x3)
 
 What changes relative to the module path (modules/mixer.py + torch autograd):
-  * parameters are views into ONE flat buffer (names = the reference's state-dict keys, creation
-    order of models/avmnist.py:181-191), gradients into ONE flat buffer -> one memset, one RCCL
-    all-reduce, one Adam launch;
-  * the image / audio towers write their outputs straight into the halves of the fused (B, Ni+Na, D)
-    buffer (ConcatFusion costs nothing) and hand the token means to the heads kernel;
-  * the three heads, their cross-entropies and gradients are one launch;
+  * parameters are views into ONE flat buffer (names = the reference's state-dict keys, in the reference's creation
+    order), gradients into ONE flat buffer -> no memset (Adam clears what it consumes), one RCCL all-reduce;
+  * the two modality towers write their outputs straight into their parts of the fused (B, N1+N2, D) buffer
+    (ConcatFusion costs nothing) and hand the token means to the heads kernel;
+  * the three heads, their losses and gradients are one launch;
+  * each tower's Adam update + operand re-pack follows its own weight gradients on its own HIP stream;
   * the step can be captured into a hipGraph (torch.cuda.CUDAGraph); the dropout step counter, the Adam
     step counter and the learning rate live in device memory so replays stay correct.
 """
 from __future__ import annotations
 
 from collections import OrderedDict
-from typing import Dict, Optional
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
 from . import _lib as L
 from . import config
-from .runtime import BLOCK_FIELDS, BLOCK_KEYS, EmbedRuntime, TowerRuntime, block_param_shapes, heads_ce
+from .runtime import (BLOCK_FIELDS, BLOCK_KEYS, EmbedRuntime, MlpRuntime, TowerRuntime, block_param_shapes, heads_bce,
+                      heads_ce)
 
 
 def _num_patch(c: dict) -> int:
     return (c["image_size"][0] // c["patch_size"]) * (c["image_size"][1] // c["patch_size"])
 
 
-def avmnist_param_shapes(cfg: dict) -> "OrderedDict[str, tuple]":
-    """state-dict key -> shape in the reference's creation order (models/avmnist.py:181-191)."""
+def _tower_shapes(s: "OrderedDict[str, tuple]", prefix: str, c: dict, N: int, embed: Optional[str]):
+    D = c["hidden_dim"]
+    if embed == "patch":
+        s[prefix + "to_patch_embedding.0.weight"] = (D, c["in_channels"], c["patch_size"], c["patch_size"])
+        s[prefix + "to_patch_embedding.0.bias"] = (D,)
+    elif embed == "proj":
+        s[prefix + "proj.weight"] = (c["proj_dim"], c["embedding_dim"])
+        s[prefix + "proj.bias"] = (c["proj_dim"],)
+    shapes = block_param_shapes(D, N, c["token_dim"], c["channel_dim"])
+    for i in range(c["num_mixers"]):
+        for f in BLOCK_FIELDS:
+            s[f"{prefix}mixer_blocks.{i}.{BLOCK_KEYS[f]}"] = shapes[f]
+    s[prefix + "layer_norm.weight"] = (D,)
+    s[prefix + "layer_norm.bias"] = (D,)
+
+
+def _head_shapes(s, names: Sequence[str], dims: Sequence[int], K: int):
+    for n, d in zip(names, dims):
+        key = "classifier_fusion.classifer." if n == "fusion" else f"classifier_{n}."     # sic: classification.py:87
+        s[key + "weight"] = (K, d)
+        s[key + "bias"] = (K,)
+
+
+def two_tower_param_shapes(cfg: dict, mods: Tuple[str, str]) -> "OrderedDict[str, tuple]":
+    """state-dict key -> shape in the reference's creation order (models/avmnist.py:181-191, models/mmimdb.py:35-45)."""
     s: "OrderedDict[str, tuple]" = OrderedDict()
-    ni, na = _num_patch(cfg["image"]), _num_patch(cfg["audio"])
-
-    def tower(prefix, c, N, patch):
-        D = c["hidden_dim"]
-        if patch:
-            s[prefix + "to_patch_embedding.0.weight"] = (D, c["in_channels"], c["patch_size"], c["patch_size"])
-            s[prefix + "to_patch_embedding.0.bias"] = (D,)
-        shapes = block_param_shapes(D, N, c["token_dim"], c["channel_dim"])
-        for i in range(c["num_mixers"]):
-            for f in BLOCK_FIELDS:
-                s[f"{prefix}mixer_blocks.{i}.{BLOCK_KEYS[f]}"] = shapes[f]
-        s[prefix + "layer_norm.weight"] = (D,)
-        s[prefix + "layer_norm.bias"] = (D,)
-
-    tower("image_mixer.", cfg["image"], ni, True)
-    tower("audio_mixer.", cfg["audio"], na, True)
-    tower("fusion_mixer.", cfg["multimodal"], ni + na, False)
-    K = cfg["num_classes"]
-    s["classifier_image.weight"] = (K, cfg["image"]["hidden_dim"])
-    s["classifier_image.bias"] = (K,)
-    s["classifier_audio.weight"] = (K, cfg["audio"]["hidden_dim"])
-    s["classifier_audio.bias"] = (K,)
-    s["classifier_fusion.classifer.weight"] = (K, cfg["multimodal"]["hidden_dim"])
-    s["classifier_fusion.classifer.bias"] = (K,)
+    a, b = mods
+    na, nb = _num_patch(cfg[a]), _num_patch(cfg[b])
+    _tower_shapes(s, f"{a}_mixer.", cfg[a], na, "patch")
+    _tower_shapes(s, f"{b}_mixer.", cfg[b], nb, "patch")
+    _tower_shapes(s, "fusion_mixer.", cfg["multimodal"], na + nb, None)
+    _head_shapes(s, (a, b, "fusion"), (cfg[a]["hidden_dim"], cfg[b]["hidden_dim"], cfg["multimodal"]["hidden_dim"]),
+                 cfg["num_classes"])
     return s
 
 
-class AVMnistEngine:
-    """cfg: {'dropout', 'num_classes', 'image': {...}, 'audio': {...}, 'multimodal': {...}} with the keys of
-    cfg/avmnist/avmnist_m2-mixer_*.yml (model.modalities.*)."""
+def avmnist_param_shapes(cfg: dict) -> "OrderedDict[str, tuple]":
+    return two_tower_param_shapes(cfg, ("image", "audio"))
 
-    def __init__(self, cfg: dict, batch_size: int, device="cuda:0", precision: Optional[str] = None,
-                 lr: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                 fusion_loss_weight: float = 1.0 / 3, seed: int = 42, init: bool = True):
+
+def mimic_param_shapes(cfg: dict) -> "OrderedDict[str, tuple]":
+    """Creation order of models/mimic.py:39-49: time_mixer, static_extractor, fusion_mixer, three classifiers."""
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    t, st = cfg["time"], cfg["static"]
+    _tower_shapes(s, "time_mixer.", t, t["num_patch"], "proj")
+    for i in range(st["num_blocks"]):
+        s[f"static_extractor.module_list.{3 * i}.weight"] = (st["hidden_dim"], st["input_dim"] if i == 0 else st["hidden_dim"])
+        s[f"static_extractor.module_list.{3 * i}.bias"] = (st["hidden_dim"],)
+    k = 3 * st["num_blocks"]
+    s[f"static_extractor.module_list.{k}.weight"] = (st["output_dim"], st["hidden_dim"])
+    s[f"static_extractor.module_list.{k}.bias"] = (st["output_dim"],)
+    _tower_shapes(s, "fusion_mixer.", cfg["multimodal"], 1 + t["num_patch"], None)
+    _head_shapes(s, ("static", "time", "fusion"), (st["output_dim"], t["hidden_dim"], cfg["multimodal"]["hidden_dim"]),
+                 cfg["num_classes"])
+    return s
+
+
+def _is_layer_norm(k: str) -> bool:
+    return ("layer_norm." in k) or k.endswith("token_mix.0.weight") or k.endswith("token_mix.0.bias") \
+        or k.endswith("channel_mix.0.weight") or k.endswith("channel_mix.0.bias")
+
+
+class _FlatEngine:
+    """Flat parameter / gradient / Adam buffers, the optimizer, data-parallel hooks and hipGraph capture.
+    Subclasses supply `shapes`, `_segment_of(key)`, `_build()`, `_forward(...)`, `_backward(...)`, `pack()`."""
+
+    SEGMENTS: Tuple[str, ...] = ()
+
+    def __init__(self, cfg: dict, batch_size: int, device, precision, lr, betas, eps, weight_decay, seed, init):
         self.cfg, self.B = cfg, int(batch_size)
         self.device = torch.device(device)
         if self.device.type != "cuda":
-            raise RuntimeError("AVMnistEngine runs on the GPU only (MI355X); there is no CPU path")
+            raise RuntimeError(f"{type(self).__name__} runs on the GPU only (MI355X); there is no CPU path")
         L.lib()  # fail loudly if the HIP library is absent
         self.prec = config.prec_id(precision)
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.p_drop = float(cfg.get("dropout", 0.0))
-        ci, ca, cm = cfg["image"], cfg["audio"], cfg["multimodal"]
-        self.D = ci["hidden_dim"]
-        if not (ca["hidden_dim"] == self.D == cm["hidden_dim"]):
-            raise RuntimeError("image / audio / fusion hidden_dim must agree (ConcatFusion on dim 1)")
-        self.Ni, self.Na = _num_patch(ci), _num_patch(ca)
-        self.Nf = self.Ni + self.Na
         self.K = cfg["num_classes"]
-        w = fusion_loss_weight
-        ow = (1 - w) / 2
-        # loss = (w Lf + ow Li + ow La) * 3      (models/avmnist.py:289-290)
-        self.head_weights = {"image": 3 * ow, "audio": 3 * ow, "fusion": 3 * w}
-
-        # ---- flat parameter / gradient / Adam buffers ----
-        self.shapes = avmnist_param_shapes(cfg)
+        self.shapes = self._param_shapes(cfg)
         n = sum(int(torch.Size(s).numel()) for s in self.shapes.values())
         self.n_params = n
         dev = self.device
@@ -96,74 +120,59 @@ class AVMnistEngine:
         self.flat_v = torch.zeros(n, device=dev)
         self.params: Dict[str, torch.Tensor] = OrderedDict()
         self.grads: Dict[str, torch.Tensor] = OrderedDict()
+        bounds: Dict[str, Tuple[int, int]] = {}
         off = 0
         for k, shp in self.shapes.items():
             cnt = int(torch.Size(shp).numel())
             self.params[k] = self.flat_p[off:off + cnt].view(shp)
             self.grads[k] = self.flat_g[off:off + cnt].view(shp)
-            off += cnt
-        # contiguous segments of the flat buffers: [image tower | audio tower | fusion tower + heads]
-        bounds, off = {}, 0
-        for k, shp in self.shapes.items():
-            seg = "image" if k.startswith("image_mixer.") else ("audio" if k.startswith("audio_mixer.") else "fusion")
-            cnt = int(torch.Size(shp).numel())
+            seg = self._segment_of(k)
             lo, hi = bounds.get(seg, (off, off))
-            bounds[seg] = (min(lo, off), off + cnt)
+            if hi != off:
+                raise AssertionError(f"segment {seg} is not contiguous in the flat buffer")
+            bounds[seg] = (lo, off + cnt)
             off += cnt
+        # contiguous segments of the flat buffers, one per tower (the last one also holds the heads)
         self.segments = bounds
-        assert bounds["image"][1] == bounds["audio"][0] and bounds["audio"][1] == bounds["fusion"][0] and bounds["fusion"][1] == n
         self.adam_state = torch.tensor([0.0, lr, 0.0, 0.0], device=dev)     # [step, lr, -, -]
         self.drop_step = torch.zeros(1, dtype=torch.int32, device=dev)       # device-side dropout step counter
         self.seed = seed & 0xFFFFFFFF
         if init:
             self.reset_parameters(seed)
-
-        # ---- towers ----
-        def make_tower(prefix, c, N, site):
-            rt = TowerRuntime(self.D, N, c["token_dim"], c["channel_dim"], c["num_mixers"], True, self.p_drop,
-                              self.prec, site)
-            blocks = [{f: self.params[f"{prefix}mixer_blocks.{i}.{BLOCK_KEYS[f]}"] for f in BLOCK_FIELDS}
-                      for i in range(c["num_mixers"])]
-            rt.bind_params(blocks, (self.params[prefix + "layer_norm.weight"], self.params[prefix + "layer_norm.bias"]))
-            rt.bind_grad_tensors([{f: self.grads[f"{prefix}mixer_blocks.{i}.{BLOCK_KEYS[f]}"] for f in BLOCK_FIELDS}
-                                  for i in range(c["num_mixers"])],
-                                 (self.grads[prefix + "layer_norm.weight"], self.grads[prefix + "layer_norm.bias"]))
-            rt.ensure_buffers(self.B)
-            return rt
-
-        self.t_img = make_tower("image_mixer.", ci, self.Ni, 0)
-        self.t_aud = make_tower("audio_mixer.", ca, self.Na, 1024)
-        self.t_fus = make_tower("fusion_mixer.", cm, self.Nf, 2048)
-
-        def make_embed(prefix, c):
-            e = EmbedRuntime(c["in_channels"], c["image_size"][0], c["image_size"][1], c["patch_size"], c["patch_size"],
-                             self.D, self.prec)
-            e.bind_params(self.params[prefix + "to_patch_embedding.0.weight"], self.params[prefix + "to_patch_embedding.0.bias"])
-            e.bind_grads(self.grads[prefix + "to_patch_embedding.0.weight"], self.grads[prefix + "to_patch_embedding.0.bias"])
-            return e
-
-        self.e_img = make_embed("image_mixer.", ci)
-        self.e_aud = make_embed("audio_mixer.", ca)
-
-        # ---- workspaces ----
-        B, D = self.B, self.D
-        f = lambda *s: torch.zeros(*s, device=dev)
-        self.x0_img, self.x0_aud = f(B * self.Ni, D), f(B * self.Na, D)
-        self.fused, self.fus_out = f(B, self.Nf, D), f(B, self.Nf, D)
-        self.pool_img, self.pool_aud, self.pool_fus = f(B, D), f(B, D), f(B, D)
-        self.dpool_img, self.dpool_aud, self.dpool_fus = f(B, D), f(B, D), f(B, D)
-        self.d_fused = f(B, self.Nf, D)
-        self.dx0_img, self.dx0_aud = f(B * self.Ni, D), f(B * self.Na, D)
-        self.logits = f(3, B, self.K)
-        self.losses = f(4)
-        self.preds = torch.zeros(3, B, dtype=torch.int32, device=dev)
+        self.logits = torch.zeros(3, self.B, self.K, device=dev)
+        self.losses = torch.zeros(4, device=dev)
         self._graph = None
         self._static = None
-        # the audio tower / the fusion weight gradients run beside the image tower on side streams
-        self.s_aud = torch.cuda.Stream(device=dev)
+        # the second modality / the fusion weight gradients run beside the first modality on side streams
+        self.s_b = torch.cuda.Stream(device=dev)
         self.s_fus = torch.cuda.Stream(device=dev)
         self.concurrent = True
+        self._build()
         self.pack()
+
+    # ---- helpers for subclasses ----------------------------------------------------------------------------
+    def _make_tower(self, prefix: str, c: dict, N: int, site: int) -> TowerRuntime:
+        rt = TowerRuntime(c["hidden_dim"], N, c["token_dim"], c["channel_dim"], c["num_mixers"], True, self.p_drop,
+                          self.prec, site)
+        nb = c["num_mixers"]
+        blocks = [{f: self.params[f"{prefix}mixer_blocks.{i}.{BLOCK_KEYS[f]}"] for f in BLOCK_FIELDS} for i in range(nb)]
+        rt.bind_params(blocks, (self.params[prefix + "layer_norm.weight"], self.params[prefix + "layer_norm.bias"]))
+        rt.bind_grad_tensors([{f: self.grads[f"{prefix}mixer_blocks.{i}.{BLOCK_KEYS[f]}"] for f in BLOCK_FIELDS}
+                              for i in range(nb)],
+                             (self.grads[prefix + "layer_norm.weight"], self.grads[prefix + "layer_norm.bias"]))
+        rt.ensure_buffers(self.B)
+        rt.ensure_workspace(self.B)
+        return rt
+
+    def _head(self, name: str, pooled, d_pooled, weight: float, with_grad: bool) -> dict:
+        key = "classifier_fusion.classifer." if name == "fusion" else f"classifier_{name}."
+        P, Gr = self.params, self.grads
+        return dict(pooled=pooled, w=P[key + "weight"], b=P[key + "bias"], g_w=Gr[key + "weight"], g_b=Gr[key + "bias"],
+                    d_pooled=d_pooled if with_grad else None, weight=weight)
+
+    def _streams(self):
+        main = torch.cuda.current_stream()
+        return main, (self.s_b if self.concurrent else main), (self.s_fus if self.concurrent else main)
 
     # ---- parameters --------------------------------------------------------------------------------------
     def reset_parameters(self, seed: int = 42):
@@ -171,9 +180,7 @@ class AVMnistEngine:
         drawn on the CPU generator under `seed` in creation order (run.py:32 seeds 42)."""
         gen = torch.Generator().manual_seed(seed)
         for k, shp in self.shapes.items():
-            is_ln = ("layer_norm." in k) or k.endswith("token_mix.0.weight") or k.endswith("token_mix.0.bias") \
-                or k.endswith("channel_mix.0.weight") or k.endswith("channel_mix.0.bias")
-            if is_ln:
+            if _is_layer_norm(k):
                 v = torch.ones(shp) if k.endswith("weight") else torch.zeros(shp)
             else:
                 wshape = self.shapes[k[:-4] + "weight"] if k.endswith("bias") else shp
@@ -197,49 +204,7 @@ class AVMnistEngine:
     def set_lr(self, lr: float):
         self.adam_state[1] = lr
 
-    def pack(self):
-        """Rebuild the packed MFMA-operand copies from the fp32 masters (three independent launches + two tiny ones:
-        spread over the side streams)."""
-        main = torch.cuda.current_stream()
-        s_a = self.s_aud if self.concurrent else main
-        s_f = self.s_fus if self.concurrent else main
-        s_a.wait_stream(main)
-        s_f.wait_stream(main)
-        with torch.cuda.stream(s_a):
-            self.t_aud.pack(force=True)
-            self.e_aud.pack(force=True)
-        with torch.cuda.stream(s_f):
-            self.t_fus.pack(force=True)
-        self.t_img.pack(force=True)
-        self.e_img.pack(force=True)
-        main.wait_stream(s_a)
-        main.wait_stream(s_f)
-
-    # ---- one training step (enqueue only; no host synchronisation) ----------------------------------------
-    def _forward(self, image, audio, labels, training: bool, with_grad: bool):
-        B, D = self.B, self.D
-        sd = self.drop_step if training else None
-        fs = self.Nf * D
-        aud_half = self.fused.view(-1)[self.Ni * D:]
-        main = torch.cuda.current_stream()
-        side = self.s_aud if self.concurrent else main
-        side.wait_stream(main)
-        with torch.cuda.stream(side):                       # audio tower beside the image tower
-            self.e_aud.forward(audio, B, self.x0_aud)
-            self.t_aud.forward(self.x0_aud, self.Na * D, B, aud_half, fs, self.pool_aud, training, self.seed, 0, sd)
-        self.e_img.forward(image, B, self.x0_img)
-        self.t_img.forward(self.x0_img, self.Ni * D, B, self.fused, fs, self.pool_img, training, self.seed, 0, sd)
-        main.wait_stream(side)
-        self.t_fus.forward(self.fused, fs, B, self.fus_out, fs, self.pool_fus, training, self.seed, 0, sd)
-        P, Gr = self.params, self.grads
-        heads = []
-        for name, pooled, dp, key in (("image", self.pool_img, self.dpool_img, "classifier_image."),
-                                      ("audio", self.pool_aud, self.dpool_aud, "classifier_audio."),
-                                      ("fusion", self.pool_fus, self.dpool_fus, "classifier_fusion.classifer.")):
-            heads.append(dict(pooled=pooled, w=P[key + "weight"], b=P[key + "bias"], g_w=Gr[key + "weight"],
-                              g_b=Gr[key + "bias"], d_pooled=dp if with_grad else None, weight=self.head_weights[name]))
-        heads_ce(heads, labels, B, D, self.K, out=(self.logits, self.losses, self.preds))
-
+    # ---- optimizer -------------------------------------------------------------------------------------------
     def _adam(self, lo: int, hi: int, grad_scale: float, bump: bool):
         n = hi - lo
         off = lo * 4
@@ -247,105 +212,52 @@ class AVMnistEngine:
                                       self.flat_v.data_ptr() + off, n, self.adam_state.data_ptr(), self.betas[0], self.betas[1],
                                       self.eps, self.weight_decay, -abs(grad_scale), int(bump), L.stream_ptr()), "adam_step")
 
-    def _backward(self, image, audio, fused_update: bool = False):
-        """Backward of the whole model.  fused_update: also apply Adam + re-pack per tower as soon as that tower's
-        gradients are complete (single-GPU path; with a gradient all-reduce the update is a separate phase)."""
-        B, D = self.B, self.D
-        fs = self.Nf * D
-        sd = self.drop_step
-        self.t_fus.backward(B, None, 0, self.dpool_fus, self.d_fused, fs, self.seed, 0, sd)
-        d_aud_half = self.d_fused.view(-1)[self.Ni * D:]
-        main = torch.cuda.current_stream()
-        s_a = self.s_aud if self.concurrent else main
-        s_f = self.s_fus if self.concurrent else main
-        # The two tower backward chains fill the chip (128 + 128 workgroups): nothing else runs beside them.
-        # All weight-gradient launches (three towers, two embeddings) follow, spread over three streams.
-        s_a.wait_stream(main)
-        with torch.cuda.stream(s_a):
-            self.t_aud.backward(B, d_aud_half, fs, self.dpool_aud, self.dx0_aud, self.Na * D, self.seed, 0, sd)
-            ev_aud = torch.cuda.Event()
-            ev_aud.record()
-        self.t_img.backward(B, self.d_fused, fs, self.dpool_img, self.dx0_img, self.Ni * D, self.seed, 0, sd)
-        if self.concurrent:
-            main.wait_event(ev_aud)                         # both chains done
-        if fused_update:
-            self._adam(0, 0, 1.0, True)                     # advance the Adam step counter once
-        s_a.wait_stream(main)
-        s_f.wait_stream(main)
-        with torch.cuda.stream(s_a):
-            self.t_aud.wgrad(B, self.seed, 0, sd)
-            self.e_aud.wgrad(audio, self.dx0_aud, B)
-            if fused_update:
-                self._adam(*self.segments["audio"], 1.0, False)
-                self.t_aud.pack(force=True)
-                self.e_aud.pack(force=True)
-        with torch.cuda.stream(s_f):
-            self.t_fus.wgrad(B, self.seed, 0, sd)
-            if fused_update:
-                self._adam(*self.segments["fusion"], 1.0, False)
-                self.t_fus.pack(force=True)
-        self.t_img.wgrad(B, self.seed, 0, sd)
-        self.e_img.wgrad(image, self.dx0_img, B)
-        if fused_update:
-            self._adam(*self.segments["image"], 1.0, False)
-            self.t_img.pack(force=True)
-            self.e_img.pack(force=True)
-        main.wait_stream(s_a)
-        main.wait_stream(s_f)
-        if fused_update:
-            L.check(L.lib().m2m_counter_add(self.drop_step.data_ptr(), 1, L.stream_ptr()), "counter_add")
+    def _bump_dropout(self):
+        L.check(L.lib().m2m_counter_add(self.drop_step.data_ptr(), 1, L.stream_ptr()), "counter_add")
 
-    def forward_backward(self, image, audio, labels):
+    def forward_backward(self, *batch):
         """forward (dropout on) -> multi-head loss -> backward; gradients are ADDED into flat_g, which must be
         zero on entry: it is cleared at construction and again by every optimizer_step (the Adam kernel clears
         each element it consumes), so no separate fill pass is needed."""
-        self._forward(image, audio, labels, True, True)
-        self._backward(image, audio)
+        self._forward(*batch, training=True, with_grad=True)
+        self._backward(*batch[:-1])
 
-    def fused_step(self, image, audio, labels):
+    def fused_step(self, *batch):
         """forward + backward + Adam + re-pack with the per-tower updates overlapped with the remaining
         weight-gradient work (no gradient exchange: single-GPU training)."""
-        self._forward(image, audio, labels, True, True)
-        self._backward(image, audio, fused_update=True)
+        self._forward(*batch, training=True, with_grad=True)
+        self._backward(*batch[:-1], fused_update=True)
         return self.losses
 
     def optimizer_step(self, grad_scale: float = 1.0):
         self._adam(0, self.n_params, grad_scale, True)                        # negative scale inside: clears the gradients
-        L.check(L.lib().m2m_counter_add(self.drop_step.data_ptr(), 1, L.stream_ptr()), "counter_add")
+        self._bump_dropout()
         self.pack()
 
-    def train_step(self, image, audio, labels, grad_sync=None):
+    def train_step(self, *batch, grad_sync=None):
         """One optimisation step.  grad_sync: optional callable(flat_grad) doing the data-parallel
         all-reduce (parallel.GradSync); it returns the factor the summed gradient must be scaled by."""
         if grad_sync is None:
-            return self.fused_step(image, audio, labels)
-        self.forward_backward(image, audio, labels)
+            return self.fused_step(*batch)
+        self.forward_backward(*batch)
         self.optimizer_step(grad_sync(self.flat_g))
         return self.losses
 
-    @torch.no_grad()
-    def evaluate(self, image, audio, labels):
-        """validation/test step: dropout off (models/avmnist.py shared_step in eval mode)."""
-        self._forward(image, audio, labels, False, False)
-        return {"logits": self.logits[2], "image_logits": self.logits[0], "audio_logits": self.logits[1],
-                "loss_image": self.losses[0], "loss_audio": self.losses[1], "loss_fusion": self.losses[2],
-                "loss": self.losses[3], "preds": self.preds[2], "preds_image": self.preds[0], "preds_audio": self.preds[1]}
-
     # ---- hipGraph capture -----------------------------------------------------------------------------------
-    def capture(self, image, audio, labels, grad_sync=None):
-        """Capture train_step on static input buffers; returns a callable replay(image, audio, labels).
+    def capture(self, *batch, grad_sync=None):
+        """Capture train_step on static input buffers; returns a callable replay(*batch).
         With a grad_sync the step is captured as two graphs with the all-reduce between them."""
-        self._static = (image.clone(), audio.clone(), labels.clone())
-        si, sa, sl = self._static
+        self._static = tuple(t.clone() for t in batch)
+        st = self._static
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             scale = 1.0
             for _ in range(2):                       # warm-up: lazy inits (LDS attributes, allocations) happen here
                 if grad_sync is None:
-                    self.fused_step(si, sa, sl)
+                    self.fused_step(*st)
                 else:
-                    self.forward_backward(si, sa, sl)
+                    self.forward_backward(*st)
                     scale = grad_sync(self.flat_g)
                     self.optimizer_step(scale)
         torch.cuda.current_stream().wait_stream(s)
@@ -353,22 +265,21 @@ class AVMnistEngine:
         g1 = torch.cuda.CUDAGraph()
         if grad_sync is None:
             with torch.cuda.graph(g1):
-                self.fused_step(si, sa, sl)
+                self.fused_step(*st)
             graphs = (g1,)
         else:
             g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
-                self.forward_backward(si, sa, sl)
+                self.forward_backward(*st)
             with torch.cuda.graph(g2):
                 self.optimizer_step(scale)
             graphs = (g1, g2)
         self._graph = graphs
 
-        def replay(image=None, audio=None, labels=None):
-            if image is not None:
-                si.copy_(image, non_blocking=True)
-                sa.copy_(audio, non_blocking=True)
-                sl.copy_(labels, non_blocking=True)
+        def replay(*new_batch):
+            if new_batch and new_batch[0] is not None:
+                for dst, src in zip(st, new_batch):
+                    dst.copy_(src, non_blocking=True)
             graphs[0].replay()
             if grad_sync is not None:
                 grad_sync(self.flat_g)
@@ -376,3 +287,315 @@ class AVMnistEngine:
             return self.losses
 
         return replay
+
+
+class _TwoTowerEngine(_FlatEngine):
+    """Two MLPMixer towers (patch embedding) -> ConcatFusion(dim=1) -> FusionMixer -> three heads."""
+
+    MODS: Tuple[str, str] = ("image", "audio")
+
+    def _param_shapes(self, cfg):
+        return two_tower_param_shapes(cfg, self.MODS)
+
+    def _segment_of(self, k: str) -> str:
+        a, b = self.MODS
+        return a if k.startswith(f"{a}_mixer.") else (b if k.startswith(f"{b}_mixer.") else "fusion")
+
+    def _build(self):
+        a, b = self.MODS
+        cfg = self.cfg
+        ca, cb, cm = cfg[a], cfg[b], cfg["multimodal"]
+        self.D = ca["hidden_dim"]
+        if not (cb["hidden_dim"] == self.D == cm["hidden_dim"]):
+            raise RuntimeError("both towers and the fusion mixer must share hidden_dim (ConcatFusion on dim 1)")
+        self.Na, self.Nb = _num_patch(ca), _num_patch(cb)
+        self.Nf = self.Na + self.Nb
+        self.t_a = self._make_tower(f"{a}_mixer.", ca, self.Na, 0)
+        self.t_b = self._make_tower(f"{b}_mixer.", cb, self.Nb, 1024)
+        self.t_fus = self._make_tower("fusion_mixer.", cm, self.Nf, 2048)
+
+        def make_embed(prefix, c):
+            e = EmbedRuntime(c["in_channels"], c["image_size"][0], c["image_size"][1], c["patch_size"], c["patch_size"],
+                             self.D, self.prec)
+            e.bind_params(self.params[prefix + "to_patch_embedding.0.weight"], self.params[prefix + "to_patch_embedding.0.bias"])
+            e.bind_grads(self.grads[prefix + "to_patch_embedding.0.weight"], self.grads[prefix + "to_patch_embedding.0.bias"])
+            return e
+
+        self.e_a = make_embed(f"{a}_mixer.", ca)
+        self.e_b = make_embed(f"{b}_mixer.", cb)
+        B, D, dev = self.B, self.D, self.device
+        f = lambda *s: torch.zeros(*s, device=dev)
+        self.x0_a, self.x0_b = f(B * self.Na, D), f(B * self.Nb, D)
+        self.fused, self.fus_out = f(B, self.Nf, D), f(B, self.Nf, D)
+        self.pool_a, self.pool_b, self.pool_fus = f(B, D), f(B, D), f(B, D)
+        self.dpool_a, self.dpool_b, self.dpool_fus = f(B, D), f(B, D), f(B, D)
+        self.d_fused = f(B, self.Nf, D)
+        self.dx0_a, self.dx0_b = f(B * self.Na, D), f(B * self.Nb, D)
+        self.preds = torch.zeros(self._preds_shape(), dtype=torch.int32, device=dev)
+
+    def _preds_shape(self):
+        return (3, self.B)
+
+    def pack(self):
+        """Rebuild the packed MFMA-operand copies from the fp32 masters (three independent launches + two tiny ones:
+        spread over the side streams)."""
+        main, s_b, s_f = self._streams()
+        s_b.wait_stream(main)
+        s_f.wait_stream(main)
+        with torch.cuda.stream(s_b):
+            self.t_b.pack(force=True)
+            self.e_b.pack(force=True)
+        with torch.cuda.stream(s_f):
+            self.t_fus.pack(force=True)
+        self.t_a.pack(force=True)
+        self.e_a.pack(force=True)
+        main.wait_stream(s_b)
+        main.wait_stream(s_f)
+
+    def _loss_heads(self, heads, labels):
+        raise NotImplementedError
+
+    # ---- one training step (enqueue only; no host synchronisation) ----------------------------------------
+    def _forward(self, xa, xb, labels, training: bool, with_grad: bool):
+        B, D = self.B, self.D
+        sd = self.drop_step if training else None
+        fs = self.Nf * D
+        b_part = self.fused.view(-1)[self.Na * D:]
+        main, side, _ = self._streams()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):                       # second tower beside the first
+            self.e_b.forward(xb, B, self.x0_b)
+            self.t_b.forward(self.x0_b, self.Nb * D, B, b_part, fs, self.pool_b, training, self.seed, 0, sd)
+        self.e_a.forward(xa, B, self.x0_a)
+        self.t_a.forward(self.x0_a, self.Na * D, B, self.fused, fs, self.pool_a, training, self.seed, 0, sd)
+        main.wait_stream(side)
+        self.t_fus.forward(self.fused, fs, B, self.fus_out, fs, self.pool_fus, training, self.seed, 0, sd)
+        a, b = self.MODS
+        hw = self.head_weights
+        heads = [self._head(a, self.pool_a, self.dpool_a, hw[a], with_grad),
+                 self._head(b, self.pool_b, self.dpool_b, hw[b], with_grad),
+                 self._head("fusion", self.pool_fus, self.dpool_fus, hw["fusion"], with_grad)]
+        self._loss_heads(heads, labels)
+
+    def _backward(self, xa, xb, fused_update: bool = False):
+        """Backward of the whole model.  fused_update: also apply Adam + re-pack per tower as soon as that tower's
+        gradients are complete (single-GPU path; with a gradient all-reduce the update is a separate phase)."""
+        B, D = self.B, self.D
+        fs = self.Nf * D
+        sd = self.drop_step
+        a, b = self.MODS
+        self.t_fus.backward(B, None, 0, self.dpool_fus, self.d_fused, fs, self.seed, 0, sd)
+        d_b_part = self.d_fused.view(-1)[self.Na * D:]
+        main, s_b, s_f = self._streams()
+        # The two tower backward chains fill the chip (128 + 128 workgroups): nothing else runs beside them.
+        # All weight-gradient launches (three towers, two embeddings) follow, spread over three streams.
+        s_b.wait_stream(main)
+        with torch.cuda.stream(s_b):
+            self.t_b.backward(B, d_b_part, fs, self.dpool_b, self.dx0_b, self.Nb * D, self.seed, 0, sd)
+            ev_b = torch.cuda.Event()
+            ev_b.record()
+        self.t_a.backward(B, self.d_fused, fs, self.dpool_a, self.dx0_a, self.Na * D, self.seed, 0, sd)
+        if self.concurrent:
+            main.wait_event(ev_b)                           # both chains done
+        if fused_update:
+            self._adam(0, 0, 1.0, True)                     # advance the Adam step counter once
+        s_b.wait_stream(main)
+        s_f.wait_stream(main)
+        with torch.cuda.stream(s_b):
+            self.t_b.wgrad(B, self.seed, 0, sd)
+            self.e_b.wgrad(xb, self.dx0_b, B)
+            if fused_update:
+                self._adam(*self.segments[b], 1.0, False)
+                self.t_b.pack(force=True)
+                self.e_b.pack(force=True)
+        with torch.cuda.stream(s_f):
+            self.t_fus.wgrad(B, self.seed, 0, sd)
+            if fused_update:
+                self._adam(*self.segments["fusion"], 1.0, False)
+                self.t_fus.pack(force=True)
+        self.t_a.wgrad(B, self.seed, 0, sd)
+        self.e_a.wgrad(xa, self.dx0_a, B)
+        if fused_update:
+            self._adam(*self.segments[a], 1.0, False)
+            self.t_a.pack(force=True)
+            self.e_a.pack(force=True)
+        main.wait_stream(s_b)
+        main.wait_stream(s_f)
+        if fused_update:
+            self._bump_dropout()
+
+    @torch.no_grad()
+    def evaluate(self, xa, xb, labels):
+        """validation/test step: dropout off (the reference's shared_step under model.eval())."""
+        self._forward(xa, xb, labels, False, False)
+        a, b = self.MODS
+        return {"logits": self.logits[2], f"{a}_logits": self.logits[0], f"{b}_logits": self.logits[1],
+                f"loss_{a}": self.losses[0], f"loss_{b}": self.losses[1], "loss_fusion": self.losses[2],
+                "loss": self.losses[3], "preds": self.preds[2], f"preds_{a}": self.preds[0], f"preds_{b}": self.preds[1]}
+
+
+class AVMnistEngine(_TwoTowerEngine):
+    """cfg: {'dropout', 'num_classes', 'image': {...}, 'audio': {...}, 'multimodal': {...}} with the keys of
+    cfg/avmnist/avmnist_m2-mixer_*.yml (model.modalities.*)."""
+
+    MODS = ("image", "audio")
+
+    def __init__(self, cfg: dict, batch_size: int, device="cuda:0", precision: Optional[str] = None,
+                 lr: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 fusion_loss_weight: float = 1.0 / 3, seed: int = 42, init: bool = True):
+        w = fusion_loss_weight
+        ow = (1 - w) / 2
+        # loss = (w Lf + ow Li + ow La) * 3      (models/avmnist.py:289-290)
+        self.head_weights = {"image": 3 * ow, "audio": 3 * ow, "fusion": 3 * w}
+        super().__init__(cfg, batch_size, device, precision, lr, betas, eps, weight_decay, seed, init)
+
+    def _loss_heads(self, heads, labels):
+        heads_ce(heads, labels, self.B, self.D, self.K, out=(self.logits, self.losses, self.preds))
+
+    # names kept from the first engine revision (bench.py, tests, INTEGRATION.md)
+    t_img = property(lambda self: self.t_a)
+    t_aud = property(lambda self: self.t_b)
+    e_img = property(lambda self: self.e_a)
+    e_aud = property(lambda self: self.e_b)
+    s_aud = property(lambda self: self.s_b)
+    Ni = property(lambda self: self.Na)
+    x0_img = property(lambda self: self.x0_a)
+
+
+class MMIMDBEngine(_TwoTowerEngine):
+    """cfg: {'dropout', 'num_classes', 'pos_weight': [K], 'image': {...}, 'text': {...}, 'multimodal': {...}} with the
+    keys of cfg/mmimdb/mmimdb_3loss.yml.  Loss = BCE_image + BCE_text + BCE_fusion (models/mmimdb.py:115-123),
+    preds = sigmoid(logits) > 0.5 (:128-133); labels are (B, K) multi-hot floats."""
+
+    MODS = ("image", "text")
+
+    def __init__(self, cfg: dict, batch_size: int, device="cuda:0", precision: Optional[str] = None,
+                 lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 seed: int = 42, init: bool = True):
+        self.head_weights = {"image": 1.0, "text": 1.0, "fusion": 1.0}
+        super().__init__(cfg, batch_size, device, precision, lr, betas, eps, weight_decay, seed, init)
+        self.pos_weight = torch.tensor(cfg["pos_weight"], dtype=torch.float32, device=self.device)
+        if self.pos_weight.numel() != self.K:
+            raise RuntimeError("pos_weight needs one entry per class")
+
+    def _preds_shape(self):
+        return (3, self.B, self.K)
+
+    def _loss_heads(self, heads, labels):
+        heads_bce(heads, labels, self.pos_weight, self.B, self.D, self.K, out=(self.logits, self.losses, self.preds))
+
+
+class MimicEngine(_FlatEngine):
+    """cfg: {'dropout', 'num_classes', 'time': {...}, 'static': {...}, 'multimodal': {...}} with the keys of
+    cfg/mimic/mimic_m2-mixer_H.yml.  static (B, 5) -> MLP -> one token; time (B, 24, 12) -> Linear proj -> MixerBlocks;
+    fused = cat(static token, time tokens) (models/mimic.py:98-103); loss = w Lf + ow Ls + ow Lt (:115-121, no x3)."""
+
+    def __init__(self, cfg: dict, batch_size: int, device="cuda:0", precision: Optional[str] = None,
+                 lr: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 fusion_loss_weight: float = 1.0 / 3, seed: int = 42, init: bool = True):
+        w = fusion_loss_weight
+        ow = (1 - w) / 2
+        self.head_weights = {"static": ow, "time": ow, "fusion": w}
+        super().__init__(cfg, batch_size, device, precision, lr, betas, eps, weight_decay, seed, init)
+
+    def _param_shapes(self, cfg):
+        return mimic_param_shapes(cfg)
+
+    def _segment_of(self, k: str) -> str:
+        return "time" if k.startswith("time_mixer.") else ("static" if k.startswith("static_extractor.") else "fusion")
+
+    def _build(self):
+        cfg = self.cfg
+        ct, cs, cm = cfg["time"], cfg["static"], cfg["multimodal"]
+        self.D = ct["hidden_dim"]
+        if not (ct["proj_dim"] == self.D == cm["hidden_dim"] == cs["output_dim"]):
+            raise RuntimeError("time hidden_dim / proj_dim, static output_dim and fusion hidden_dim must agree")
+        self.Nt = ct["num_patch"]
+        self.Nf = 1 + self.Nt
+        self.t_time = self._make_tower("time_mixer.", ct, self.Nt, 0)
+        self.t_fus = self._make_tower("fusion_mixer.", cm, self.Nf, 2048)
+        # (B, N, K) rows == a (B, 1, N, K) image cut into (1, K) patches
+        self.e_time = EmbedRuntime(1, self.Nt, ct["embedding_dim"], 1, ct["embedding_dim"], self.D, self.prec)
+        self.e_time.bind_params(self.params["time_mixer.proj.weight"], self.params["time_mixer.proj.bias"])
+        self.e_time.bind_grads(self.grads["time_mixer.proj.weight"], self.grads["time_mixer.proj.bias"])
+        nb = cs["num_blocks"]
+        keys = [f"static_extractor.module_list.{3 * i}." for i in range(nb)] + [f"static_extractor.module_list.{3 * nb}."]
+        self.mlp = MlpRuntime([cs["input_dim"]] + [cs["hidden_dim"]] * nb + [cs["output_dim"]], True, self.p_drop, 4096)
+        self.mlp.bind([(self.params[k + "weight"], self.params[k + "bias"]) for k in keys],
+                      [(self.grads[k + "weight"], self.grads[k + "bias"]) for k in keys], self.B)
+        B, D, dev = self.B, self.D, self.device
+        f = lambda *s: torch.zeros(*s, device=dev)
+        self.x0_time = f(B * self.Nt, D)
+        self.fused, self.fus_out = f(B, self.Nf, D), f(B, self.Nf, D)
+        self.pool_static, self.pool_time, self.pool_fus = f(B, D), f(B, D), f(B, D)
+        self.dpool_static, self.dpool_time, self.dpool_fus = f(B, D), f(B, D), f(B, D)
+        self.d_fused = f(B, self.Nf, D)
+        self.dx0_time = f(B * self.Nt, D)
+        self.preds = torch.zeros(3, B, dtype=torch.int32, device=dev)
+
+    def pack(self):
+        main, s_b, s_f = self._streams()
+        s_f.wait_stream(main)
+        with torch.cuda.stream(s_f):
+            self.t_fus.pack(force=True)
+        self.t_time.pack(force=True)
+        self.e_time.pack(force=True)
+        main.wait_stream(s_f)
+
+    def _forward(self, static, time, labels, training: bool, with_grad: bool):
+        B, D = self.B, self.D
+        sd = self.drop_step if training else None
+        fs = self.Nf * D
+        time_part = self.fused.view(-1)[D:]                 # tokens 1..Nt of every sample
+        main, side, _ = self._streams()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):                       # the static MLP beside the time tower: token 0 + its head's input
+            self.mlp.forward(static, B, self.fused, fs, self.pool_static, training, self.seed, 0, sd)
+        self.e_time.forward(time, B, self.x0_time)
+        self.t_time.forward(self.x0_time, self.Nt * D, B, time_part, fs, self.pool_time, training, self.seed, 0, sd)
+        main.wait_stream(side)
+        self.t_fus.forward(self.fused, fs, B, self.fus_out, fs, self.pool_fus, training, self.seed, 0, sd)
+        hw = self.head_weights
+        heads = [self._head("static", self.pool_static, self.dpool_static, hw["static"], with_grad),
+                 self._head("time", self.pool_time, self.dpool_time, hw["time"], with_grad),
+                 self._head("fusion", self.pool_fus, self.dpool_fus, hw["fusion"], with_grad)]
+        heads_ce(heads, labels, B, D, self.K, out=(self.logits, self.losses, self.preds))
+
+    def _backward(self, static, time, fused_update: bool = False):
+        B, D = self.B, self.D
+        fs = self.Nf * D
+        sd = self.drop_step
+        self.t_fus.backward(B, None, 0, self.dpool_fus, self.d_fused, fs, self.seed, 0, sd)
+        d_time_part = self.d_fused.view(-1)[D:]
+        main, s_b, s_f = self._streams()
+        if fused_update:
+            self._adam(0, 0, 1.0, True)                     # advance the Adam step counter once
+        s_b.wait_stream(main)
+        s_f.wait_stream(main)
+        with torch.cuda.stream(s_b):                        # static MLP: gradient of token 0 + of its own head
+            self.mlp.backward(static, B, self.d_fused, fs, self.dpool_static)
+            if fused_update:
+                self._adam(*self.segments["static"], 1.0, False)
+        with torch.cuda.stream(s_f):
+            self.t_fus.wgrad(B, self.seed, 0, sd)
+            if fused_update:
+                self._adam(*self.segments["fusion"], 1.0, False)
+                self.t_fus.pack(force=True)
+        self.t_time.backward(B, d_time_part, fs, self.dpool_time, self.dx0_time, self.Nt * D, self.seed, 0, sd)
+        self.t_time.wgrad(B, self.seed, 0, sd)
+        self.e_time.wgrad(time, self.dx0_time, B)
+        if fused_update:
+            self._adam(*self.segments["time"], 1.0, False)
+            self.t_time.pack(force=True)
+            self.e_time.pack(force=True)
+        main.wait_stream(s_b)
+        main.wait_stream(s_f)
+        if fused_update:
+            self._bump_dropout()
+
+    @torch.no_grad()
+    def evaluate(self, static, time, labels):
+        self._forward(static, time, labels, False, False)
+        return {"logits": self.logits[2], "logits_static": self.logits[0], "logits_time": self.logits[1],
+                "loss_static": self.losses[0], "loss_time": self.losses[1], "loss_fusion": self.losses[2],
+                "loss": self.losses[3], "preds": self.preds[2]}

@@ -266,15 +266,90 @@ class EmbedRuntime:
                 "embed_wgrad")
 
 
-def heads_ce(heads: Sequence[dict], labels: torch.Tensor, B: int, D: int, K: int, out=None):
-    """heads: dicts with pooled, w, b, g_w, g_b, d_pooled (tensors or None) and weight.
-    Returns logits (nh, B, K), losses (nh + 1), preds (nh, B) int32 (written into `out` if given)."""
+class MlpRuntime:
+    """m2m_mlp: num_blocks x (Linear -> ReLU -> Dropout) + output Linear (modules/mlp.py:4-27)."""
+
+    def __init__(self, dims: Sequence[int], has_out: bool, p_drop: float, site_base: int = 0):
+        nl = len(dims) - 1
+        if nl < 1 or nl > L.MLP_MAX_LAYERS:
+            raise RuntimeError(f"MLP: 1..{L.MLP_MAX_LAYERS} Linear layers supported, got {nl}")
+        self.dims, self.nlayers, self.has_out = list(dims), nl, bool(has_out)
+        self.desc = L.Mlp()
+        d = self.desc
+        d.nlayers, d.has_out, d.p_drop, d.site_base = nl, int(self.has_out), float(p_drop), site_base
+        for i, w in enumerate(dims):
+            d.dims[i] = int(w)
+        self._keep: Dict[str, object] = {}
+        self._B = 0
+
+    def bind(self, params: Sequence[tuple], grads: Optional[Sequence[tuple]], B: int):
+        """params / grads: [(weight, bias)] per Linear, weight (dims[i+1], dims[i])."""
+        for i, (w, b) in enumerate(params):
+            _check_tensor(w, (self.dims[i + 1], self.dims[i]), f"mlp layer {i} weight")
+            _check_tensor(b, (self.dims[i + 1],), f"mlp layer {i} bias")
+            self.desc.w[i], self.desc.b[i] = w.data_ptr(), b.data_ptr()
+        if grads is not None:
+            for i, (gw, gb) in enumerate(grads):
+                self.desc.g_w[i], self.desc.g_b[i] = gw.data_ptr(), gb.data_ptr()
+        self._keep["params"], self._keep["grads"] = list(params), grads
+        self.ensure_buffers(B, params[0][0].device)
+
+    def ensure_buffers(self, B: int, device):
+        if B == self._B:
+            return
+        acts = [torch.zeros(B, self.dims[i + 1], device=device) for i in range(self.nlayers)]
+        for i, a in enumerate(acts):
+            self.desc.act[i] = a.data_ptr()
+        self._keep["act"] = acts
+        self._B = B
+
+    def forward(self, x: torch.Tensor, B: int, out: torch.Tensor, out_ss: int, out_dense: Optional[torch.Tensor],
+                training: bool, seed: int, step: int, step_dev: Optional[torch.Tensor] = None):
+        _check_tensor(x, (B, self.dims[0]), "mlp input")
+        self.ensure_buffers(B, x.device)
+        L.check(L.lib().m2m_mlp_forward(C.byref(self.desc), x.data_ptr(), B, out.data_ptr(), out_ss, L.ptr(out_dense),
+                                        int(training), seed & 0xFFFFFFFF, step & 0xFFFFFFFF, L.ptr(step_dev),
+                                        L.stream_ptr()), "mlp_forward")
+
+    def backward(self, x: torch.Tensor, B: int, d_out: Optional[torch.Tensor], d_out_ss: int,
+                 d_out_dense: Optional[torch.Tensor]):
+        L.check(L.lib().m2m_mlp_backward(C.byref(self.desc), x.data_ptr(), B, L.ptr(d_out), d_out_ss, L.ptr(d_out_dense),
+                                         L.stream_ptr()), "mlp_backward")
+
+
+def _head_array(heads: Sequence[dict]):
     nh = len(heads)
     arr = (L.Head * nh)()
     for i, h in enumerate(heads):
         arr[i].pooled, arr[i].w, arr[i].b = h["pooled"].data_ptr(), h["w"].data_ptr(), h["b"].data_ptr()
         arr[i].g_w, arr[i].g_b, arr[i].d_pooled = L.ptr(h.get("g_w")), L.ptr(h.get("g_b")), L.ptr(h.get("d_pooled"))
         arr[i].weight = float(h["weight"])
+    return arr
+
+
+def heads_bce(heads: Sequence[dict], targets: torch.Tensor, pos_weight: torch.Tensor, B: int, D: int, K: int, out=None):
+    """BCEWithLogitsLoss(pos_weight) heads (models/mmimdb.py:47-50): targets (B, K) float32 multi-hot.
+    Returns logits (nh, B, K), losses (nh + 1), preds (nh, B, K) int32."""
+    nh = len(heads)
+    arr = _head_array(heads)
+    _check_tensor(targets, (B, K), "BCE targets")
+    dev = targets.device
+    if out is not None:
+        logits, losses, preds = out
+    else:
+        logits = torch.empty(nh, B, K, device=dev)
+        losses = torch.empty(nh + 1, device=dev)
+        preds = torch.empty(nh, B, K, dtype=torch.int32, device=dev)
+    L.check(L.lib().m2m_heads_bce(arr, nh, targets.data_ptr(), pos_weight.data_ptr(), B, D, K, logits.data_ptr(),
+                                  losses.data_ptr(), preds.data_ptr(), L.stream_ptr()), "heads_bce")
+    return logits, losses, preds
+
+
+def heads_ce(heads: Sequence[dict], labels: torch.Tensor, B: int, D: int, K: int, out=None):
+    """heads: dicts with pooled, w, b, g_w, g_b, d_pooled (tensors or None) and weight.
+    Returns logits (nh, B, K), losses (nh + 1), preds (nh, B) int32 (written into `out` if given)."""
+    nh = len(heads)
+    arr = _head_array(heads)
     dev = labels.device
     if out is not None:
         logits, losses, preds = out

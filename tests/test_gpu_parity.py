@@ -305,3 +305,149 @@ def test_unsupported_shapes_are_refused(dev):
     blk = MM.MixerBlock(32, 24, 40, 64).to(dev)         # token_dim above the register budget of the token kernels
     with pytest.raises(RuntimeError, match="token_dim"):
         blk(torch.zeros(2, 24, 32, device=dev))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# MIMIC-H and MM-IMDb: the wide tower path, the static MLP,
+# BCE heads -- whole training step against the vectors recorded from the reference
+# ---------------------------------------------------------------------------------------------------------------
+def test_mimic_step_fp32_vs_reference_golden(dev):
+    from m2_mixer_amd.engine import MimicEngine
+    gold = load("mimic_H.npz")
+    cfg = dict(G.MIMIC_H, dropout=0.0)
+    B = 6
+    eng = MimicEngine(cfg, B, device=dev, precision="fp32", lr=1e-2, init=False)
+    shapes = G.mimic_shapes(cfg)
+    assert list(eng.shapes.keys()) == list(shapes.keys()) and eng.n_params == int(gold["n_params"])
+    eng.load_state_dict(dict(G.make_params(shapes, 31)))
+    static, time, labels = (t.to(dev) for t in G.mimic_batch(B, 32, cfg))
+    eng.forward_backward(static, time, labels)
+    torch.cuda.synchronize()
+    check(gold, "logits", eng.logits[2], FP32_ATOL)
+    check(gold, "logits_static", eng.logits[0], FP32_ATOL)
+    check(gold, "logits_time", eng.logits[1], FP32_ATOL)
+    for i, k in enumerate(("loss_static", "loss_time", "loss_fusion", "loss")):
+        check(gold, k, eng.losses[i], FP32_ATOL)
+    check(gold, "time_tokens", eng.fused[:, 1:, :], FP32_ATOL)
+    check(gold, "fusion_tokens", eng.fus_out, FP32_ATOL)
+    for k in shapes:
+        check(gold, f"grad//{k}", eng.grads[k], 1e-4, 1e-3, what="grad ")
+    # the update itself: one Adam step moves every parameter with a non-zero gradient by ~lr
+    before = eng.flat_p.clone()
+    eng.optimizer_step()
+    torch.cuda.synchronize()
+    assert float(eng.flat_g.abs().max()) == 0.0
+    assert float((eng.flat_p - before).abs().max()) <= 1e-2 * 1.001
+
+
+def test_mmimdb_step_fp32_vs_reference_golden(dev):
+    from m2_mixer_amd.engine import MMIMDBEngine
+    gold = load("mmimdb.npz")
+    cfg = dict(G.MMIMDB, dropout=0.0)
+    B = 3
+    eng = MMIMDBEngine(cfg, B, device=dev, precision="fp32", lr=1e-3, init=False)
+    shapes = G.mmimdb_shapes(cfg)
+    assert list(eng.shapes.keys()) == list(shapes.keys()) and eng.n_params == int(gold["n_params"])
+    eng.load_state_dict(dict(G.make_params(shapes, 51)))
+    image, text, labels = (t.to(dev) for t in G.mmimdb_batch(B, 52, cfg))
+    eng.forward_backward(image, text, labels)
+    torch.cuda.synchronize()
+    check(gold, "logits", eng.logits[2], FP32_ATOL)
+    check(gold, "image_logits", eng.logits[0], FP32_ATOL)
+    check(gold, "text_logits", eng.logits[1], FP32_ATOL)
+    for i, k in enumerate(("loss_image", "loss_text", "loss_fusion", "loss")):
+        check(gold, k, eng.losses[i], FP32_ATOL)
+    assert np.array_equal(eng.preds[2].cpu().numpy(), gold["preds"])
+    for k in shapes:
+        check(gold, f"grad//{k}", eng.grads[k], 1e-4, 1e-3, what="grad ")
+
+
+@pytest.mark.parametrize("task", ["mimic", "mmimdb"])
+def test_wide_models_bf16_vs_oracle_and_training(task, dev):
+    """bf16 mode on the wide path against the oracle (dropout off), then a captured training run with the configs'
+    dropout on (p = 0.3: 16-bit-draw masks; p = 0.5: one-bit masks) must overfit one batch."""
+    from m2_mixer_amd.engine import MimicEngine, MMIMDBEngine
+    if task == "mimic":
+        cfg, B = dict(G.MIMIC_H), 40
+        shapes = G.mimic_shapes(cfg)
+        batch = G.mimic_batch(B, 5, cfg)
+        mk = lambda c, lr: MimicEngine(c, B, device=dev, precision="bf16", lr=lr, init=False)
+        fwd = lambda p: O.mimic_forward(*batch, p, cfg)
+        names = ("logits_static", "logits_time", "logits")
+    else:
+        cfg, B = dict(G.MMIMDB), 6
+        shapes = G.mmimdb_shapes(cfg)
+        batch = G.mmimdb_batch(B, 5, cfg)
+        mk = lambda c, lr: MMIMDBEngine(c, B, device=dev, precision="bf16", lr=lr, init=False)
+        fwd = lambda p: O.mmimdb_forward(*batch, p, cfg, torch.tensor(cfg["pos_weight"]))
+        names = ("image_logits", "text_logits", "logits")
+    params = dict(G.make_params(shapes, 9))
+    eng = mk(dict(cfg, dropout=0.0), 1e-3)
+    eng.load_state_dict(params)
+    gb = tuple(t.to(dev) for t in batch)
+    eng.forward_backward(*gb)
+    torch.cuda.synchronize()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = fwd(leaves)
+    ref["loss"].backward()
+    for i, k in enumerate(names):
+        assert abserr(eng.logits[i], ref[k]) < BF16_REL * max(1.0, float(ref[k].detach().abs().max())), k
+    assert abs(float(eng.losses[3]) - float(ref["loss"])) < 2e-2 * max(1.0, abs(float(ref["loss"])))
+    for k, leaf in leaves.items():
+        if k.endswith("token_mix.2.net.3.bias"):      # exactly-zero true gradient
+            continue
+        assert relerr(eng.grads[k], leaf.grad) < 6e-2, k
+    # training with dropout on
+    eng = mk(cfg, 2e-3)
+    eng.load_state_dict(params)
+    first = float(eng.evaluate(*gb)["loss"])
+    replay = eng.capture(*gb)
+    for _ in range(300):
+        replay()
+    torch.cuda.synchronize()
+    last = float(eng.evaluate(*gb)["loss"])
+    assert np.isfinite(last) and last < 0.85 * first, (first, last)
+
+
+def test_static_mlp_dropout_consistency(dev):
+    """The MIMIC static MLP (Linear-ReLU-Dropout x2 + Linear) with dropout on: forward equals the oracle under the
+    masks the kernel drew (read back from the saved activations), backward equals autograd through those masks."""
+    from m2_mixer_amd.runtime import MlpRuntime
+    cs = G.MIMIC_H["static"]
+    B, p_drop = 97, 0.3
+    shapes = {k: v for k, v in G.mimic_shapes(G.MIMIC_H).items() if k.startswith("static_extractor.")}
+    params = {k: v.to(dev) for k, v in G.make_params(shapes, 3).items()}
+    grads = {k: torch.zeros_like(v) for k, v in params.items()}
+    keys = [f"static_extractor.module_list.{i}." for i in (0, 3, 6)]
+    rt = MlpRuntime([cs["input_dim"], cs["hidden_dim"], cs["hidden_dim"], cs["output_dim"]], True, p_drop, 77)
+    rt.bind([(params[k + "weight"], params[k + "bias"]) for k in keys], [(grads[k + "weight"], grads[k + "bias"]) for k in keys], B)
+    x = torch.randn(B, cs["input_dim"], device=dev)
+    out = torch.zeros(B, 3, cs["output_dim"], device=dev)            # strided destination: token 0 of a (B, 3, D) buffer
+    dense = torch.zeros(B, cs["output_dim"], device=dev)
+    rt.forward(x, B, out, 3 * cs["output_dim"], dense, True, 123, 1)
+    torch.cuda.synchronize()
+    acts = [a.cpu() for a in rt._keep["act"][:2]]
+    thr = round((1 - p_drop) * 65536)
+    scale = 65536.0 / thr
+    leaves = {k[len("static_extractor."):]: v.detach().cpu().clone().requires_grad_(True) for k, v in params.items()}
+    h = x.cpu()
+    keep_rates = []
+    for i, a in enumerate(acts):
+        z = torch.relu(h @ leaves[f"module_list.{3 * i}.weight"].T + leaves[f"module_list.{3 * i}.bias"])
+        mask = (a != 0).float()
+        keep_rates.append(float(mask[z.detach() > 1e-6].mean()))
+        h = z * mask * scale
+        assert abserr(a, h) < 1e-4
+    yo = h @ leaves["module_list.6.weight"].T + leaves["module_list.6.bias"]
+    assert abserr(dense, yo) < 1e-4 and torch.equal(out[:, 0, :], dense) and float(out[:, 1:, :].abs().max()) == 0.0
+    assert all(abs(r - thr / 65536) < 0.05 for r in keep_rates), keep_rates
+    d1, d2 = torch.randn(B, 3, cs["output_dim"], device=dev), torch.randn(B, cs["output_dim"], device=dev)
+    rt.backward(x, B, d1, 3 * cs["output_dim"], d2)
+    torch.cuda.synchronize()
+    (yo * (d1[:, 0, :] + d2).cpu()).sum().backward()
+    for k, g in grads.items():
+        assert relerr(g, leaves[k[len("static_extractor."):]].grad) < 1e-4, k
+    # eval: no dropout
+    rt.forward(x, B, out, 3 * cs["output_dim"], dense, False, 123, 2)
+    ye = O.mlp(x.cpu(), {k: v.cpu() for k, v in params.items()}, "static_extractor.", 2, True)
+    assert abserr(dense, ye) < 1e-4
