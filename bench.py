@@ -249,10 +249,12 @@ def profile_launches(eng, image, audio, labels, nsteps):
         patch(e, "forward", f"embed_fwd[{tname}]", alg[tname]["embed"])
         patch(e, "wgrad", f"embed_wgrad[{tname}]", alg[tname]["embed"])
     import m2_mixer_amd.engine as E
-    orig_heads = E.heads_ce
+    orig_heads, orig_twg = E.heads_ce, E.towers_wgrad
     E.heads_ce = timed("heads_ce", orig_heads, alg["heads"] * 3)
+    E.towers_wgrad = timed("towers_wgrad[all]", orig_twg, sum(alg[t]["channel"] for t in ("image", "audio", "fusion")))
     try:
         for _ in range(nsteps):
+            eng._prologue()
             eng._forward(image, audio, labels, True, True)
             eng._backward(image, audio)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -260,16 +262,15 @@ def profile_launches(eng, image, audio, labels, nsteps):
             from m2_mixer_amd import _lib as L
             L.check(L.lib().m2m_adam_step(eng.flat_p.data_ptr(), eng.flat_g.data_ptr(), eng.flat_m.data_ptr(),
                                           eng.flat_v.data_ptr(), eng.n_params, eng.adam_state.data_ptr(), eng.betas[0],
-                                          eng.betas[1], eng.eps, eng.weight_decay, -1.0, 1, L.stream_ptr()))
+                                          eng.betas[1], eng.eps, eng.weight_decay, -1.0, 0, L.stream_ptr()))
             e1.record()
             spans.setdefault("adam", {"events": [], "flops": 0})["events"].append((e0, e1))
-            L.check(L.lib().m2m_counter_add(eng.drop_step.data_ptr(), 1, L.stream_ptr()))
             eng.pack()
         torch.cuda.synchronize()
     finally:
         for obj, attr, orig in saved:
             setattr(obj, attr, orig)
-        E.heads_ce = orig_heads
+        E.heads_ce, E.towers_wgrad = orig_heads, orig_twg
         eng.concurrent = was_concurrent
     out = {}
     for name, sp in spans.items():

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define M2M_ABI_VERSION 2
+#define M2M_ABI_VERSION 5
 #define M2M_MAX_BLOCKS 8      /* MixerBlocks per m2m_tower; longer towers are chained by the caller */
 #define M2M_ROWS_PER_WG 16    /* token rows one workgroup keeps on chip */
 
@@ -56,11 +56,12 @@ typedef struct m2m_block {
     /* activations saved by forward(training) for backward: (B*N, D) fp32 each */
     float* x_in;          /* block input                                */
     float* x_mid;         /* after the token-mixing residual            */
-    /* packed operands written by m2m_tower_backward for m2m_tower_wgrad (per 64-row tile) */
-    void* a_nat;          /* LN2(x_mid)          NAT [i=m][k=d] */
-    void* at_chn;         /* LN2(x_mid)^T        CHN [i=d][k=m] */
-    void* dy_nat;         /* d(channel MLP out)  NAT [i=m][k=d] */
-    void* dyt_chn;        /* its transpose       CHN [i=d][k=m] */
+    /* packed operands written by m2m_tower_backward for m2m_tower_wgrad, laid out per 32-row pair of tiles
+     * (k = token row m inside the pair, CHN order): */
+    void* at_chn;         /* LN2(x_mid)^T                    [pair][dt][lane]   i = d, k = m           (rows x D elements)  */
+    void* dyt_chn;        /* d(channel MLP out)^T            [pair][dt][lane]   i = d, k = m                                */
+    void* h_chn;          /* hidden activation^T  (after GELU + dropout)   [ct][pair][lane]   i = c, k = m   (rows x Cp)    */
+    void* dh_chn;         /* gradient wrt the hidden pre-activation ^T      [ct][pair][lane]   i = c, k = m   (rows x Cp)    */
 } m2m_block;
 
 /* A stack of MixerBlocks + optional final LayerNorm: the body of MLPMixer / FusionMixer /
@@ -142,13 +143,19 @@ int m2m_tower_forward(const m2m_tower* t, const float* x0, int64_t x0_sample_str
  *   d_out / d_out_sample_stride : gradient wrt the tower output tokens, or NULL
  *   d_pooled (B, D)             : gradient wrt `pooled`, or NULL (adds d_pooled/N to every token)
  *   d_x0 / d_x0_sample_stride   : gradient wrt the tower input tokens (written)
- * Accumulates the LayerNorm, token-mixing and ch_b2 gradients; writes the packed operands that
- * m2m_tower_wgrad needs for the channel-mixing weight gradients. */
+ * Accumulates the LayerNorm, token-mixing and ch_b2 gradients; writes the packed operands (at_chn, dyt_chn, h_chn,
+ * dh_chn) that m2m_tower_wgrad contracts into the channel-mixing weight gradients. */
 int m2m_tower_backward(const m2m_tower* t, int B, const float* d_out, int64_t d_out_sample_stride,
                        const float* d_pooled, float* d_x0, int64_t d_x0_sample_stride,
                        uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream);
-/* g_ch_w1, g_ch_b1, g_ch_w2 of every block (hidden activations recomputed, never stored). */
+/* g_ch_w1, g_ch_b1, g_ch_w2 of every block: two contractions over all token rows, streaming the bf16 (fp32 in parity
+ * mode) operands m2m_tower_backward stored.  seed / step are accepted for ABI symmetry (dropout is already applied). */
 int m2m_tower_wgrad(const m2m_tower* t, int B, uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream);
+/* The same for up to 4 towers (same precision and hidden_dim) in ONE launch: the towers of a model finish their backward
+ * chains together, and one launch lets the hardware balance all their workgroups over the chip.  `dev_towers[i]` is a
+ * device-resident byte copy of *towers[i] (kernel arguments are limited to 4 KiB; the caller refreshes the copy whenever
+ * a pointer in the descriptor changes, outside any graph capture). */
+int m2m_towers_wgrad(const m2m_tower* const* towers, const m2m_tower* const* dev_towers, int ntowers, int B, void* stream);
 /* g_w += d_x0^T patches(input), g_b += column sums of d_x0. */
 int m2m_embed_wgrad(const m2m_embed* e, const float* input, const float* d_x0, int B, void* stream);
 
@@ -167,12 +174,14 @@ typedef struct m2m_head {
     float weight;         /* coefficient of this head's mean loss in the total */
 } m2m_head;
 int m2m_heads_ce(const m2m_head* heads, int nheads, const int64_t* labels, int B, int D, int K,
-                 float* logits, float* losses, int32_t* preds, void* stream);
+                 float* logits, float* losses, int32_t* preds, int zero_losses, void* stream);
+                 /* losses are accumulated over workgroups: zero_losses != 0 clears them first (one more tiny launch);
+                  * 0 when the caller already did (m2m_step_prologue) */
 
 /* BCEWithLogitsLoss(pos_weight) variant (models/mmimdb.py:47-50, :115-133): targets (B, K) float multi-hot,
  * pos_weight (K); per-head loss = mean over all B*K elements; preds (nheads, B, K) int32 = sigmoid(logits) > 0.5. */
 int m2m_heads_bce(const m2m_head* heads, int nheads, const float* targets, const float* pos_weight, int B, int D, int K,
-                  float* logits, float* losses, int32_t* preds, void* stream);
+                  float* logits, float* losses, int32_t* preds, int zero_losses, void* stream);
 
 /* ---- plain MLP tower (modules/mlp.py:4-27; the MIMIC `static` modality, models/mimic.py:98) ------- */
 #define M2M_MLP_MAX_LAYERS 4
@@ -207,6 +216,10 @@ int m2m_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
                   float* state, float beta1, float beta2, float eps, float weight_decay,
                   float grad_scale, int bump_step, void* stream);
                   /* grad_scale < 0: scale by |grad_scale| and clear grad afterwards */
+
+/* Head of a training step, ONE launch: adam_state[0] += 1 (the step count m2m_adam_step reads), *drop_counter += 1
+ * (the step_dev of the tower calls), losses[0 .. nlosses) = 0.  Any pointer may be NULL. */
+int m2m_step_prologue(float* adam_state, uint32_t* drop_counter, float* losses, int nlosses, void* stream);
 
 /* *counter += delta on the stream (device uint32). */
 int m2m_counter_add(uint32_t* counter, uint32_t delta, void* stream);

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("M2M_LIB_PATH", os.path.join(_HERE, "libm2mixer.so"))   # override: diagnostic builds
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 2
+ABI_VERSION = 5
 MAX_BLOCKS = 8
 ROWS_PER_WG = 16
 PREC_BF16, PREC_F32 = 0, 1
@@ -32,7 +32,7 @@ class Block(C.Structure):
               "ch_w1", "ch_b1", "ch_w2", "ch_b2"]
     PACKED = ["w1n", "w2c", "w2tn", "w1tc", "ch_b1p"]
     GRADS = ["g_" + p for p in PARAMS]
-    SAVED = ["x_in", "x_mid", "a_nat", "at_chn", "dy_nat", "dyt_chn"]
+    SAVED = ["x_in", "x_mid", "at_chn", "dyt_chn", "h_chn", "dh_chn"]
     _fields_ = [(n, _fp) for n in PARAMS + PACKED + GRADS + SAVED]
 
 
@@ -83,10 +83,12 @@ SIGNATURES = {
     "m2m_tower_backward": (C.c_int, [C.POINTER(Tower), C.c_int, _fp, C.c_int64, _fp, _fp, C.c_int64,
                                      C.c_uint32, C.c_uint32, _fp, _fp]),
     "m2m_tower_wgrad": (C.c_int, [C.POINTER(Tower), C.c_int, C.c_uint32, C.c_uint32, _fp, _fp]),
+    "m2m_towers_wgrad": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.POINTER(_fp), C.c_int, C.c_int, _fp]),
     "m2m_counter_add": (C.c_int, [_fp, C.c_uint32, _fp]),
     "m2m_embed_wgrad": (C.c_int, [C.POINTER(Embed), _fp, _fp, C.c_int, _fp]),
-    "m2m_heads_ce": (C.c_int, [C.POINTER(Head), C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp]),
-    "m2m_heads_bce": (C.c_int, [C.POINTER(Head), C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp]),
+    "m2m_heads_ce": (C.c_int, [C.POINTER(Head), C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, C.c_int, _fp]),
+    "m2m_step_prologue": (C.c_int, [_fp, _fp, _fp, C.c_int, _fp]),
+    "m2m_heads_bce": (C.c_int, [C.POINTER(Head), C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, C.c_int, _fp]),
     "m2m_mlp_forward": (C.c_int, [C.POINTER(Mlp), _fp, C.c_int, _fp, C.c_int64, _fp, C.c_int, C.c_uint32, C.c_uint32,
                                   _fp, _fp]),
     "m2m_mlp_backward": (C.c_int, [C.POINTER(Mlp), _fp, C.c_int, _fp, C.c_int64, _fp, _fp]),

@@ -205,6 +205,21 @@ extern "C" int m2m_adam_step(float* param, float* grad, float* exp_avg, float* e
     return 0;
 }
 
+// One tiny launch at the head of a training step instead of three scattered through it (each tiny kernel costs
+// 3-9 us on the critical path of a replayed graph): Adam step count += 1, dropout step counter += 1, losses = 0.
+__global__ void step_prologue_kernel(float* adam_state, unsigned int* drop_counter, float* losses, int nlosses) {
+    const int t = threadIdx.x;
+    if (t == 0 && adam_state) adam_state[0] += 1.0f;
+    if (t == 1 && drop_counter) *drop_counter += 1u;
+    if (losses && t < nlosses) losses[t] = 0.f;
+}
+extern "C" int m2m_step_prologue(float* adam_state, uint32_t* drop_counter, float* losses, int nlosses, void* stream) {
+    if (nlosses < 0 || nlosses > 64) { m2m_set_error("step_prologue: nlosses must be in [0, 64]", __FILE__, __LINE__); return -1; }
+    hipLaunchKernelGGL(step_prologue_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), adam_state, drop_counter, losses, nlosses);
+    M2M_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 __global__ void counter_add_kernel(unsigned int* c, unsigned int d) { *c += d; }
 extern "C" int m2m_counter_add(uint32_t* counter, uint32_t delta, void* stream) {
     hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream), counter, delta);

@@ -129,7 +129,7 @@ __global__ void zero_floats_kernel(float* p, int n) {
 
 template <bool BCE>
 static int launch_heads(const m2m_head* heads, int nheads, const void* labels, const float* pos_weight, int B, int D, int K,
-                        float* logits, float* losses, int32_t* preds, void* stream) {
+                        float* logits, float* losses, int32_t* preds, int zero_losses, void* stream) {
     if (!heads || nheads < 1 || nheads > HEAD_MAXH || K < 2 || K > HEAD_MAXK || D < 1 || D > 256 || B < 1) {
         m2m_set_error("heads: unsupported (nheads<=4, K<=32, D<=256)", __FILE__, __LINE__);
         return -1;
@@ -138,7 +138,7 @@ static int launch_heads(const m2m_head* heads, int nheads, const void* labels, c
     for (int i = 0; i < nheads; ++i) ha.h[i] = heads[i];
     for (int i = nheads; i < HEAD_MAXH; ++i) ha.h[i] = heads[0];
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(zero_floats_kernel, dim3(1), dim3(64), 0, st, losses, nheads + 1);
+    if (zero_losses) hipLaunchKernelGGL(zero_floats_kernel, dim3(1), dim3(64), 0, st, losses, nheads + 1);
     const size_t lds = sizeof(float) * ((size_t)HEAD_S * (D + 1) + (size_t)HEAD_MAXK * (D + 1) + HEAD_S * HEAD_MAXK + HEAD_S);
     static bool done = false;
     if (!done) { M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(heads_kernel<BCE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); done = true; }
@@ -148,12 +148,12 @@ static int launch_heads(const m2m_head* heads, int nheads, const void* labels, c
 }
 
 extern "C" int m2m_heads_ce(const m2m_head* heads, int nheads, const int64_t* labels, int B, int D, int K, float* logits,
-                            float* losses, int32_t* preds, void* stream) {
-    return launch_heads<false>(heads, nheads, labels, nullptr, B, D, K, logits, losses, preds, stream);
+                            float* losses, int32_t* preds, int zero_losses, void* stream) {
+    return launch_heads<false>(heads, nheads, labels, nullptr, B, D, K, logits, losses, preds, zero_losses, stream);
 }
 
 extern "C" int m2m_heads_bce(const m2m_head* heads, int nheads, const float* targets, const float* pos_weight, int B, int D, int K,
-                             float* logits, float* losses, int32_t* preds, void* stream) {
+                             float* logits, float* losses, int32_t* preds, int zero_losses, void* stream) {
     if (!targets || !pos_weight) { m2m_set_error("heads_bce: targets and pos_weight are required", __FILE__, __LINE__); return -1; }
-    return launch_heads<true>(heads, nheads, targets, pos_weight, B, D, K, logits, losses, preds, stream);
+    return launch_heads<true>(heads, nheads, targets, pos_weight, B, D, K, logits, losses, preds, zero_losses, stream);
 }

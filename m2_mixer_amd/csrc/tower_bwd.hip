@@ -11,7 +11,8 @@
 //                    accumulated in registers and reduced once per block.
 // Small parameter gradients (LayerNorm, token MLP, ch_b2) are added to the fp32 gradient buffers with
 // float atomics.  The channel-mixing WEIGHT gradients need a reduction over all rows and are left to
-// tower_wgrad.hip; this kernel writes the packed operand tiles (A, A^T, dYd, dYd^T) it needs.
+// tower_wgrad.hip; this kernel writes the operands it contracts: A^T, dYd^T per token tile and, per hidden column
+// tile, Hact^T and dHpre^T (the hidden activation and its gradient leave the chip ONCE, in operand precision, here).
 #include "tile.h"
 
 TIMER_DECL(g_tm_bwd);
@@ -160,7 +161,6 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
         pack_tile_nat<P, D>(ub, dyp, tid);
         pack_tile_chn_t<P, D>(ub, reinterpret_cast<char*>(bk.dyt_chn) + pair_off, tile_in_pair, tid);
         __syncthreads();
-        copy16(reinterpret_cast<char*>(bk.dy_nat) + tile_off, dyp, IMG_B, tid);
         // (C2) A = LN2(x_mid) -> fp32 tile (ub) -> packed images
         {
             const int r = tid / TPR, j = tid % TPR;
@@ -176,7 +176,6 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
         pack_tile_nat<P, D>(ub, at, tid);
         pack_tile_chn_t<P, D>(ub, reinterpret_cast<char*>(bk.at_chn) + pair_off, tile_in_pair, tid);
         __syncthreads();
-        copy16(reinterpret_cast<char*>(bk.a_nat) + tile_off, at, IMG_B, tid);
 
         TIMER_MARK(g_tm_bwd, 1);   // C1 + C2: dYd, A, packing, global copies
         // (C3) hidden-column loop
@@ -186,6 +185,9 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) dacc[mt][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         const int npairs = Cp >> 5;
+        // identity block of the transposing MFMA (bf16): lane (g, il) is non-zero iff g == il >> 2, at element il & 3
+        const unsigned int id_sel = (g == (il >> 2)) ? ((il & 1) ? 0x3F800000u : 0x00003F80u) : 0u;
+        const unsigned int id_a = (il & 2) ? 0u : id_sel, id_b = (il & 2) ? id_sel : 0u;
         Frag w1f[2][KD], w2f[2][KD];
         if (wave < npairs) {
 #pragma unroll
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
                         w2f[t][kb] = ld_frag_global(bk.w2tn, (long)(2 * (q + NWAVES) + t) * KD + kb, lane);
                     }
             }
-            Frag hf[MT][NF];
+            Frag hf[MT][NF], af[MT][NF];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const unsigned int m = (unsigned int)(row0 + mt * 16 + il);
@@ -249,11 +251,47 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
                     for (int r = 0; r < 4; ++r) {
                         float gl, dgl;
                         Act<P>::gelu_grad(gtab, hacc[mt][t][r], gl, dgl);
+                        const bool keep = (word >> (16 * t + r)) & 1u;
                         const float v = gacc[mt][t][r] * dgl * dr_ch.scale;
-                        gacc[mt][t][r] = ((word >> (16 * t + r)) & 1u) ? v : 0.f;
+                        gacc[mt][t][r] = keep ? v : 0.f;
+                        hacc[mt][t][r] = keep ? gl * dr_ch.scale : 0.f;
                     }
                 }
-                Chain<P>::make(gacc[mt][0], gacc[mt][1], hf[mt]);
+                Chain<P>::make(gacc[mt][0], gacc[mt][1], hf[mt]);     // dHpre: operand of dA += dHpre W1
+                Chain<P>::make(hacc[mt][0], hacc[mt][1], af[mt]);     // Hact : only stored, for the weight gradients
+            }
+            // Operands of the weight-gradient pass: dHpre^T and Hact^T with k = token row.  The accumulators hold
+            // [c in registers][m across lanes]; an MFMA against an identity block turns them ([m][c] as the A operand,
+            // chained k order) into [m in registers][c across lanes] = exactly the layout that pass consumes, exact in
+            // the operand precision.  The MFMA pipe is mostly idle here, so the transpose is nearly free.
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int u = BM == 16 ? tile_in_pair : mt;        // 16-row half of the 32-row pair
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    Frag id;
+                    if (P == PREC_BF16) id.u = t == 0 ? u32x4_t{id_a, id_b, 0u, 0u} : u32x4_t{0u, 0u, id_a, id_b};
+                    else id.f = f32x4_t{4 * g + 0 == il ? 1.f : 0.f, 4 * g + 1 == il ? 1.f : 0.f, 4 * g + 2 == il ? 1.f : 0.f, 4 * g + 3 == il ? 1.f : 0.f};
+                    f32x4_t od = f32x4_t{0.f, 0.f, 0.f, 0.f}, oa = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    Pr::mma(od, hf[mt][P == PREC_BF16 ? 0 : t], id);
+                    Pr::mma(oa, af[mt][P == PREC_BF16 ? 0 : t], id);
+                    // od[r] = dHpre[m = 16u + 4g + r][c = 32q + 16t + il]
+                    const long frag = (long)(2 * q + t) * ((gridDim.x + TPP - 1) / TPP) + (blockIdx.x / TPP);   // [column tile][pair]: a column tile's stream is contiguous
+                    // streamed out once and read once by the weight-gradient pass: non-temporal, so that the 100 MB per
+                    // launch do not evict the weights the other workgroups of this XCD keep re-reading from its L2
+                    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+                    if (P == PREC_BF16) {
+                        const long off = frag * 1024 + u * 512 + lane * 8;       // each 16-row half is 512 contiguous bytes
+                        __builtin_nontemporal_store(u32x2_t{pack_bf2(od[0], od[1]), pack_bf2(od[2], od[3])},
+                                                    reinterpret_cast<u32x2_t*>(reinterpret_cast<char*>(bk.dh_chn) + off));
+                        __builtin_nontemporal_store(u32x2_t{pack_bf2(oa[0], oa[1]), pack_bf2(oa[2], oa[3])},
+                                                    reinterpret_cast<u32x2_t*>(reinterpret_cast<char*>(bk.h_chn) + off));
+                    } else {
+                        const long off = (frag * 2 + u) * 1024 + lane * 16;
+                        __builtin_nontemporal_store(od, reinterpret_cast<f32x4_t*>(reinterpret_cast<char*>(bk.dh_chn) + off));
+                        __builtin_nontemporal_store(oa, reinterpret_cast<f32x4_t*>(reinterpret_cast<char*>(bk.h_chn) + off));
+                    }
+                }
             }
 #pragma unroll
             for (int f = 0; f < NF; ++f)

@@ -2,171 +2,218 @@
 //
 //   dW1[c][d] = sum_m dHpre[m][c] A[m][d]      dW2[d][c] = sum_m dYd[m][d] Hact[m][c]      db1[c] = sum_m dHpre[m][c]
 //
-// The contraction runs over ALL token rows, so the roles flip relative to the forward/backward chain:
-// a workgroup owns 128 hidden columns of one block (each of its 8 waves 16; the wave's W1 / W2^T
-// fragments and its 16x128 slices of dW1 and dW2^T stay in registers: 2 waves per SIMD need <= 256 VGPRs) and streams the 32-row operand
-// tiles that tower_bwd.hip wrote (A, A^T, dYd, dYd^T, already in packed MFMA order) through a
-// double-buffered LDS stage (global loads of tile t+1 are issued before tile t is computed and written
-// to LDS after it).  Per tile it recomputes Hpre = A W1^T + b1 and dHact = dYd W2 (hidden activations
-// are never stored), applies GELU / GELU' / dropout on the accumulators and chains them (k = row
-// index) into the two products.  With one row group (the default when the launch already has enough
-// workgroups) every result element has a single owner and is written without atomics.
+// The contraction runs over ALL token rows, so the roles flip relative to the forward/backward chain: a workgroup of
+// FOUR waves owns 128 hidden columns of one block (each wave 32 = two 16-column tiles; the wave's 32x128 slices of dW1
+// and dW2^T stay in registers) and streams the operands tower_bwd.hip stored, 32 token rows per step:
+//   A^T, dYd^T   (D x 32, shared by the whole workgroup)  -> double-buffered LDS stage; each ds_read_b128 fragment feeds
+//                                                            both column tiles of the wave (two MFMAs per LDS read);
+//   dHpre^T, Hact^T (this wave's 32 x 32)                  -> straight from global into registers.
+// Nothing is recomputed.  Two such workgroups share a CU (<= 256 VGPRs, 32 KiB LDS each): while one sits at its
+// per-tile barrier or waits for loads the other computes, and together with the register ring (WG_DEPTH tiles of
+// loads in flight per workgroup, counted s_waitcnt) that covers the memory latency.
+// With one row group every result element has a single owner and is written without atomics; two groups add onto the
+// zeroed gradient with float atomics (a + b == b + a: still bit-deterministic).
 #include "tile.h"
 #include <stdlib.h>
+#include <string.h>
 
 #define WBM 32            // rows per streamed tile (= two 16-row tiles of the chain kernels when BM == 16)
-#define WMT (WBM / 16)
+#ifndef WG_RING_MAX
+#define WG_RING_MAX 24    // VGPR budget of one tile in flight that still allows a second one (register ring depth 2)
+#endif
+#define WG_WAVES 4
+#ifndef WG_MINWAVES
+#define WG_MINWAVES 2
+#endif
+#define WG_THREADS (WG_WAVES * 64)
 
 TIMER_DECL(g_tm_wg);
 TIMER_READER(m2m_debug_timers_wgrad, g_tm_wg)
 
+template <int P, int D> struct WgradGeom {
+    static constexpr int NF = Chain<P>::NF;
+#ifdef WG_CPW_FORCE
+    static constexpr int CPW = WG_CPW_FORCE;
+#else
+    static constexpr int CPW = (P == PREC_BF16 && D <= 128) ? 2 : 1;                 // 16-column tiles per wave
+#endif
+    static constexpr int IMG_B = WBM * D * Prec<P>::ESZ;
+    static constexpr int STAGE_B = 2 * IMG_B;                                          // A^T | dYd^T of one tile
+    static constexpr int NLD = (STAGE_B + WG_THREADS * 16 - 1) / (WG_THREADS * 16);   // 16-byte pieces per thread per tile
+    // token tiles per step (= per barrier).  Measured on M2-Mixer-B: 4 tiles per step with one workgroup per CU (the next
+    // step's 128 KiB of loads in flight in up to 512 VGPRs) was SLOWER (230 vs 160 us for the three towers) than one
+    // tile per step with two workgroups per CU, so 1 is the default; the knob stays for other shapes.
+#ifdef WG_TPS_FORCE
+    static constexpr int TPS = (P == PREC_BF16 && D <= 128) ? WG_TPS_FORCE : 1;
+#else
+    static constexpr int TPS = 1;
+#endif
+    static constexpr int RING_REGS = NLD * 4 + CPW * 2 * NF * 4;                      // VGPRs of one tile in flight
+    static constexpr int DEPTH = (TPS == 1 && RING_REGS <= WG_RING_MAX) ? 2 : 1;      // steps of loads in flight
+    static constexpr int COLS = WG_WAVES * CPW * 16;                                   // hidden columns per workgroup
+    static constexpr int MINWAVES = TPS > 1 ? 1 : 2;                                   // waves per SIMD the kernel is built for
+    static_assert(TPS == 1 || DEPTH == 1, "multi-tile steps use a ring of one step");
+};
+
+// One workgroup's share: column slice `slice` of block `bk`, token tiles [group * tiles_per_group, ...).
 template <int P, int D>
-static constexpr int wgrad_stages() {
-    return (2 * 4 * WBM * D * Prec<P>::ESZ + (Act<P>::USES_TABLE ? GELU_TAB_N * 16 : 0)) <= 160 * 1024 ? 2 : 1;
-}
-
-template <int P, int D, int DM>
-__global__ __launch_bounds__(NTHREADS) void tower_wgrad_kernel(const m2m_tower tw, int ntiles, int tiles_per_group,
-                                                               int rows_per_tile, unsigned int seed, unsigned int step_host,
-                                                               const unsigned int* __restrict__ step_dev) {
+static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, int C, int slice, int group, bool single,
+                                                  int ntiles, int tiles_per_group, char* smem) {
     typedef Prec<P> Pr;
-    constexpr int DT = D / 16, KD = D / Pr::KB, NF = Chain<P>::NF;
-    constexpr int IMG_B = WBM * D * Pr::ESZ;
-    constexpr int STAGE_B = 4 * IMG_B;                      // A | dYd | A^T | dYd^T of one tile
-    constexpr int NLD = STAGE_B / (NTHREADS * 16);          // 16-byte pieces per thread per tile
-    constexpr int NST = wgrad_stages<P, D>();               // 2: double-buffered LDS stage; 1 when two would not fit (fp32, D = 256)
-    static_assert(STAGE_B % (NTHREADS * 16) == 0, "tile stage must split evenly over the threads");
-    static_assert(IMG_B % (NTHREADS * 16) == 0 || (NTHREADS * 16) % IMG_B == 0, "piece never straddles two images");
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    gtab_t* gtab = reinterpret_cast<gtab_t*>(smem + NST * STAGE_B);   // [GELU_TAB_N] (bf16 mode only)
+    typedef WgradGeom<P, D> G;
+    constexpr int DT = D / 16, NF = G::NF, CPW = G::CPW, IMG_B = G::IMG_B, STAGE_B = G::STAGE_B, NLD = G::NLD, DEPTH = G::DEPTH,
+                  TPS = G::TPS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
-    const m2m_block& bk = tw.blk[blockIdx.y];
-    const int Cp = tw.Cp, C = tw.C;
-    const int npairs = Cp >> 5;
-    const int ct = blockIdx.x * NWAVES + wave;              // this wave's 16-column tile
-    const bool active = ct < (Cp >> 4);
-    const int q = ct >> 1, tq = ct & 1;                     // pair / half of the pair (dropout word addressing)
-    const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
-    const unsigned int site = tw.site_base + 4u * blockIdx.y;
-    const Drop dr_ch = make_drop(true, tw.p_drop, seed, step, site + 2);
+    const int nct = Cp >> 4;
+    const int ct0 = (slice * WG_WAVES + wave) * CPW;        // this wave's first 16-column tile
 
-    Frag w1f[KD], w2f[KD];
-    f32x4_t dw1[DT], dw2[DT];
-    float db1 = 0.f;
+    f32x4_t dw1[CPW][DT], dw2[CPW][DT], db1[CPW];
 #pragma unroll
-    for (int kb = 0; kb < KD; ++kb) {
-        w1f[kb].u = u32x4_t{0u, 0u, 0u, 0u};
-        w2f[kb].u = u32x4_t{0u, 0u, 0u, 0u};
-        if (active) {
-            w1f[kb] = ld_frag_global(bk.w1n, (long)ct * KD + kb, lane);
-            w2f[kb] = ld_frag_global(bk.w2tn, (long)ct * KD + kb, lane);
+    for (int j = 0; j < CPW; ++j) {
+        db1[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            dw1[j][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            dw2[j][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
     }
-    const float bias = active ? bk.ch_b1p[16 * ct + il] : 0.f;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        dw1[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        dw2[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    }
+    Frag ones;
+    if (P == PREC_BF16) ones.u = u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    else ones.f = f32x4_t{1.f, 1.f, 1.f, 1.f};
 
-    // the four packed images of a tile, as NLD 16-byte pieces per thread
-    const char* src_a = reinterpret_cast<const char*>(bk.a_nat);
-    const char* src_dy = reinterpret_cast<const char*>(bk.dy_nat);
     const char* src_at = reinterpret_cast<const char*>(bk.at_chn);
     const char* src_dyt = reinterpret_cast<const char*>(bk.dyt_chn);
-    u32x4_t pre[NLD];
-#define STAGE_LOAD(tile_)                                                                          \
-    _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                              \
-        const int o = (i * NTHREADS + tid) * 16;                                                   \
-        const int img = o / IMG_B, oo = o % IMG_B;                                                 \
-        const char* sp = img == 0 ? src_a : (img == 1 ? src_dy : (img == 2 ? src_at : src_dyt));   \
-        pre[i] = *reinterpret_cast<const u32x4_t*>(sp + (long)(tile_) * IMG_B + oo);               \
-    }
-#define STAGE_STORE(buf_)                                                                          \
-    _Pragma("unroll") for (int i = 0; i < NLD; ++i)                                                \
-        *reinterpret_cast<u32x4_t*>((buf_) + (i * NTHREADS + tid) * 16) = pre[i];
-
+    // One tile's worth of loads in flight: this thread's pieces of the shared stage + this wave's own fragments.
+    struct Pre {
+        u32x4_t st[TPS][NLD];
+        Frag h[TPS][CPW][NF], d[TPS][CPW][NF];
+    };
+    // Every load below is unconditional (indices clamped into range, a few redundant loads at the tail): with a fixed
+    // number of loads per step the compiler can place counted s_waitcnt vmcnt(N) and really keep DEPTH tiles in flight;
+    // any guard around a load makes it fall back to vmcnt(0) at the top of the loop.
     TIMER_START();
-    if (Act<P>::USES_TABLE) gelu_tab_fill(gtab, tid, NTHREADS);
-    const int t_begin = blockIdx.z * tiles_per_group;
-    const int t_end = min(ntiles, t_begin + tiles_per_group);
-    if (t_begin < t_end) {
-        STAGE_LOAD(t_begin)
-        STAGE_STORE(smem)
-    }
-    __syncthreads();
-    for (int tile = t_begin; tile < t_end; ++tile) {
-        char* cur = smem + (NST == 2 ? ((tile - t_begin) & 1) * STAGE_B : 0);
-        char* nxt = smem + (NST == 2 ? (((tile - t_begin) & 1) ^ 1) * STAGE_B : 0);
-        const bool more = tile + 1 < t_end;
-        if (more) { STAGE_LOAD(tile + 1) }                   // in flight during this tile's math
-        const char* a_nat = cur;
-        const char* dy_nat = cur + IMG_B;
-        const char* at_chn = cur + 2 * IMG_B;
-        const char* dyt_chn = cur + 3 * IMG_B;
-        TIMER_MARK(g_tm_wg, 0);
-        if (active) {
-            // the tile's two 16-row sub-tiles chain into one k-block (bf16) / two (fp32)
-            f32x4_t hact[2], dhp[2];                        // [row sub-tile]
+    int ctl[CPW];                                           // column tiles past the end (last slice) shadow the last one
 #pragma unroll
-            for (int u = 0; u < WMT; ++u) {
-                f32x4_t hacc = f32x4_t{bias, bias, bias, bias};
-                f32x4_t gacc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < CPW; ++j) ctl[j] = min(ct0 + j, nct - 1);
+    auto tile_load = [&](Pre& p, int tile0, int t_end) {
 #pragma unroll
-                for (int kb = 0; kb < KD; ++kb) {
-                    const Frag a = ld_frag_lds(a_nat, u * KD + kb, lane);
-                    const Frag dy = ld_frag_lds(dy_nat, u * KD + kb, lane);
-                    Pr::mma(hacc, a, w1f[kb]);
-                    Pr::mma(gacc, dy, w2f[kb]);
-                }
-                // accumulator element r: row m = 16 u + 4 g + r, column c = 16 ct + il
+        for (int u = 0; u < TPS; ++u) {
+            const int tile = min(tile0 + u, t_end - 1);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    // sub-tile u of this tile is chain tile (tile * SUB + u / (BM/16)); its rows are sample-aligned
-                    const unsigned int m = (unsigned int)(tile * (WBM / BM) + (16 * u) / BM) * rows_per_tile + (16 * u) % BM + 4 * g + r;
-                    float gl, dgl;
-                    Act<P>::gelu_grad(gtab, hacc[r], gl, dgl);
-                    const bool keep = (drop_hidden_bits<DM>(dr_ch, m, q, Cp) >> (16 * tq + il)) & 1u;
-                    const float hv = keep ? gl * dr_ch.scale : 0.f;
-                    const float dv = keep ? gacc[r] * dgl * dr_ch.scale : 0.f;
-                    hact[u][r] = hv;
-                    dhp[u][r] = dv;
-                    db1 += dv;
-                }
+            for (int i = 0; i < NLD; ++i) {
+                const int o = min((i * WG_THREADS + tid) * 16, STAGE_B - 16);
+                const char* sp = o < IMG_B ? src_at : src_dyt;
+                p.st[u][i] = *reinterpret_cast<const u32x4_t*>(sp + (long)tile * IMG_B + (o < IMG_B ? o : o - IMG_B));
             }
-            TIMER_MARK(g_tm_wg, 1);
-            {
-                Frag hf[NF], df[NF];
-                Chain<P>::make(hact[0], hact[1], hf);
-                Chain<P>::make(dhp[0], dhp[1], df);
 #pragma unroll
-                for (int f = 0; f < NF; ++f) {
+            for (int j = 0; j < CPW; ++j) {
 #pragma unroll
-                    for (int dt = 0; dt < DT; ++dt) {
-                        const Frag at = ld_frag_lds(at_chn, f * DT + dt, lane);
-                        const Frag dyt = ld_frag_lds(dyt_chn, f * DT + dt, lane);
-                        Pr::mma(dw1[dt], df[f], at);
-                        Pr::mma(dw2[dt], hf[f], dyt);
+                for (int f = 0; f < NF; ++f) {               // NF 1-KiB blocks each
+                    const long blk = ((long)ctl[j] * ntiles + tile) * NF + f;      // [column tile][pair][f]: contiguous per wave
+                    if (P == PREC_BF16) {                    // stored as two 512-byte halves [h][lane][8 bytes]
+                        const char* ph = reinterpret_cast<const char*>(bk.h_chn) + blk * 1024 + lane * 8;
+                        const char* pd = reinterpret_cast<const char*>(bk.dh_chn) + blk * 1024 + lane * 8;
+                        // read exactly once: non-temporal, so the stream does not evict the A^T / dYd^T tiles that the
+                        // other column slices of this block re-read from L2
+                        typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+                        const u32x2_t h0 = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(ph));
+                        const u32x2_t h1 = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(ph + 512));
+                        const u32x2_t d0 = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(pd));
+                        const u32x2_t d1 = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(pd + 512));
+                        p.h[u][j][f].u = u32x4_t{h0[0], h0[1], h1[0], h1[1]};
+                        p.d[u][j][f].u = u32x4_t{d0[0], d0[1], d1[0], d1[1]};
+                    } else {
+                        p.h[u][j][f].u = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(bk.h_chn) + blk * 1024 + lane * 16));
+                        p.d[u][j][f].u = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(bk.dh_chn) + blk * 1024 + lane * 16));
                     }
                 }
             }
-            TIMER_MARK(g_tm_wg, 2);
         }
-        if (NST == 1) __syncthreads();                       // single stage: everyone is done reading before the overwrite
-        if (more) { STAGE_STORE(nxt) }
+    };
+    // Consume the step (TPS tiles from `tile0`) held in p, then refill p with the step DEPTH ahead.  One barrier per step:
+    // the stage written in step i (buffer i & 1) was last read in step i - 2, and every wave has passed the barrier of
+    // step i - 1 since.
+    auto step = [&](Pre& p, int tile0, int t_end, int i) {
+        char* buf = smem + (i & 1) * (TPS * STAGE_B);
+#pragma unroll
+        for (int u = 0; u < TPS; ++u) {
+            char* cur = buf + u * STAGE_B;
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int o = (k * WG_THREADS + tid) * 16;
+                if (o < STAGE_B) {
+                    if (P == PREC_BF16) {
+                        // global block = [h][lane][8 B]; this 16-byte piece holds half h of lanes 2j, 2j + 1 -> 16-byte lane slots
+                        const int blk = o >> 10, h = (o >> 9) & 1, jj = (o & 511) >> 4;
+                        char* dst = cur + blk * 1024 + (2 * jj) * 16 + h * 8;
+                        *reinterpret_cast<uint2*>(dst) = make_uint2(p.st[u][k][0], p.st[u][k][1]);
+                        *reinterpret_cast<uint2*>(dst + 16) = make_uint2(p.st[u][k][2], p.st[u][k][3]);
+                    } else {
+                        *reinterpret_cast<u32x4_t*>(cur + o) = p.st[u][k];
+                    }
+                }
+            }
+        }
+        Frag hf[TPS][CPW][NF], df[TPS][CPW][NF];
+#pragma unroll
+        for (int u = 0; u < TPS; ++u)
+#pragma unroll
+            for (int j = 0; j < CPW; ++j)
+#pragma unroll
+                for (int f = 0; f < NF; ++f) { hf[u][j][f] = p.h[u][j][f]; df[u][j][f] = p.d[u][j][f]; }
+        TIMER_MARK(g_tm_wg, 0);    // wait for this step's loads + stage write
+        tile_load(p, min(tile0 + DEPTH * TPS, t_end - 1), t_end);
+        TIMER_MARK(g_tm_wg, 1);    // issue of the refill loads
         __syncthreads();
-        TIMER_MARK(g_tm_wg, 3);
-    }
-#undef STAGE_LOAD
-#undef STAGE_STORE
+        TIMER_MARK(g_tm_wg, 2);    // barrier
+#pragma unroll
+        for (int u = 0; u < TPS; ++u) {
+            if (TPS > 1 && tile0 + u >= t_end) break;
+            const char* cur = buf + u * STAGE_B;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const Frag at = ld_frag_lds(cur, f * DT + dt, lane);
+                    const Frag dyt = ld_frag_lds(cur + IMG_B, f * DT + dt, lane);
+#pragma unroll
+                    for (int j = 0; j < CPW; ++j) {
+                        Pr::mma(dw1[j][dt], df[u][j][f], at);
+                        Pr::mma(dw2[j][dt], hf[u][j][f], dyt);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < CPW; ++j) Pr::mma(db1[j], df[u][j][f], ones);   // every column = sum over the tile's rows of dHpre[.][c]
+            }
+        }
+        TIMER_MARK(g_tm_wg, 3);    // LDS reads + MFMAs
+    };
 
-    if (!active) return;
-    const bool single = gridDim.z == 1;
-    // ---- results: dw1[dt][r] = dW1[c = 16ct + 4g + r][d = 16dt + il]; dw2 likewise = dW2[d][c] ----
-    {
-        const int c0 = 16 * ct + 4 * g;
+    const int t_begin = group * tiles_per_group;
+    const int t_end = min(ntiles, t_begin + tiles_per_group);
+    if (t_begin >= t_end) return;
+    Pre p[DEPTH];
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) tile_load(p[k], min(t_begin + k * TPS, t_end - 1), t_end);
+    int tile = t_begin, it = 0;
+    if (DEPTH == 1) {
+        for (; tile < t_end; tile += TPS) step(p[0], tile, t_end, it++);
+    } else {
+        for (; tile + DEPTH <= t_end; tile += DEPTH) {       // full trips: straight-line, fixed load count
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) step(p[k], tile + k, t_end, it++);
+        }
+#pragma unroll
+        for (int k = 0; k + 1 < DEPTH; ++k)
+            if (tile + k < t_end) step(p[k], tile + k, t_end, it++);
+    }
+
+    // ---- results: dw1[j][dt][r] = dW1[c = 16 ct + 4g + r][d = 16dt + il]; dw2 likewise = dW2[d][c] ----
+#pragma unroll
+    for (int j = 0; j < CPW; ++j) {
+        if (ct0 + j >= nct) continue;
+        const int c0 = 16 * (ct0 + j) + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const int d = 16 * dt + il;
@@ -174,74 +221,138 @@ __global__ __launch_bounds__(NTHREADS) void tower_wgrad_kernel(const m2m_tower t
             for (int r = 0; r < 4; ++r) {
                 if (c0 + r < C) {
                     float* p1 = bk.g_ch_w1 + (long)(c0 + r) * D + d;
-                    if (single) *p1 += dw1[dt][r]; else atomicAdd(p1, dw1[dt][r]);
+                    if (single) *p1 += dw1[j][dt][r]; else atomicAdd(p1, dw1[j][dt][r]);
                 }
             }
             float* p2 = bk.g_ch_w2 + (long)d * C + c0;      // four consecutive c of row d
             if (single && c0 + 3 < C && (C & 3) == 0) {
                 float4 o = *reinterpret_cast<float4*>(p2);
-                o.x += dw2[dt][0]; o.y += dw2[dt][1]; o.z += dw2[dt][2]; o.w += dw2[dt][3];
+                o.x += dw2[j][dt][0]; o.y += dw2[j][dt][1]; o.z += dw2[j][dt][2]; o.w += dw2[j][dt][3];
                 *reinterpret_cast<float4*>(p2) = o;
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (c0 + r < C) { if (single) p2[r] += dw2[dt][r]; else atomicAdd(p2 + r, dw2[dt][r]); }
+                    if (c0 + r < C) { if (single) p2[r] += dw2[j][dt][r]; else atomicAdd(p2 + r, dw2[j][dt][r]); }
             }
         }
-        float s = db1;
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
-        const int c = 16 * ct + il;
-        if (g == 0 && c < C) { if (single) bk.g_ch_b1[c] += s; else atomicAdd(bk.g_ch_b1 + c, s); }
+        // db1[r] = sum_m dHpre[m][c0 + r], identical in all 16 columns: column 0 writes
+        if (il == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (c0 + r < C) { if (single) bk.g_ch_b1[c0 + r] += db1[j][r]; else atomicAdd(bk.g_ch_b1 + c0 + r, db1[j][r]); }
+        }
     }
     TIMER_MARK(g_tm_wg, 4);        // result write-out
 }
 
-template <int P, int D, int DM>
-static int launch_wgrad_dm(const m2m_tower* t, int B, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
+template <int P, int D>
+__global__ __launch_bounds__(WG_THREADS, (WgradGeom<P, D>::MINWAVES)) void tower_wgrad_kernel(const m2m_tower tw, int ntiles, int tiles_per_group) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    wgrad_body<P, D>(tw.blk[blockIdx.y], tw.Cp, tw.C, blockIdx.x, blockIdx.z, gridDim.z == 1, ntiles, tiles_per_group, smem);
+}
+
+// Several towers in ONE launch (blockIdx.y = job = (tower, block)): the three towers of a model finish their backward
+// chains at about the same time, and one launch lets the hardware dispatcher balance their ~480 workgroups over the chip
+// instead of three launches on three queues of a replayed graph racing (and sometimes serialising) each other.
+// The descriptors are device-resident copies (kernel arguments are limited to 4 KiB, one m2m_tower is 2.4 KiB).
+#define WG_MAX_TOWERS 4
+#define WG_MAX_JOBS 32
+struct WgradGroupArgs {
+    const m2m_tower* tw[WG_MAX_TOWERS];
+    int ntiles[WG_MAX_TOWERS], tpg[WG_MAX_TOWERS], groups[WG_MAX_TOWERS], nsl[WG_MAX_TOWERS];
+    unsigned char job_tower[WG_MAX_JOBS], job_block[WG_MAX_JOBS];
+};
+template <int P, int D>
+__global__ __launch_bounds__(WG_THREADS, (WgradGeom<P, D>::MINWAVES)) void tower_wgrad_group_kernel(const WgradGroupArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = a.job_tower[blockIdx.y];
+    if ((int)blockIdx.x >= a.nsl[t] || (int)blockIdx.z >= a.groups[t]) return;
+    const m2m_tower& tw = *a.tw[t];
+    wgrad_body<P, D>(tw.blk[a.job_block[blockIdx.y]], tw.Cp, tw.C, blockIdx.x, blockIdx.z, a.groups[t] == 1, a.ntiles[t],
+                     a.tpg[t], smem);
+}
+
+struct WgradPlan { int ntiles, nsl, groups, tpg; };
+template <int P, int D>
+static WgradPlan wgrad_plan(const m2m_tower* t, int B);
+
+template <int P, int D>
+static int launch_wgrad(const m2m_tower* t, int B, hipStream_t st) {
+    const WgradPlan pl = wgrad_plan<P, D>(t, B);
+    const size_t lds = (size_t)2 * WgradGeom<P, D>::TPS * WgradGeom<P, D>::STAGE_B;
+    auto kern = tower_wgrad_kernel<P, D>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(pl.nsl, t->nblocks, pl.groups), dim3(WG_THREADS), lds, st, *t, pl.ntiles, pl.tpg);
+    M2M_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int P, int D>
+static int launch_wgrad_group(const m2m_tower* const* host, const m2m_tower* const* dev, int n, int B, hipStream_t st) {
+    WgradGroupArgs a;
+    memset(&a, 0, sizeof(a));
+    int njobs = 0, max_nsl = 1, max_groups = 1;
+    // longest workgroups first (most token tiles per workgroup): they are dispatched first and the short ones back-fill
+    int order[WG_MAX_TOWERS];
+    WgradPlan pl[WG_MAX_TOWERS];
+    for (int i = 0; i < n; ++i) { order[i] = i; pl[i] = wgrad_plan<P, D>(host[i], B); }
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j)
+            if (pl[order[j]].tpg > pl[order[i]].tpg) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+    for (int k = 0; k < n; ++k) {
+        const int i = order[k];
+        a.tw[i] = dev[i];
+        a.ntiles[i] = pl[i].ntiles; a.tpg[i] = pl[i].tpg; a.groups[i] = pl[i].groups; a.nsl[i] = pl[i].nsl;
+        if (pl[i].nsl > max_nsl) max_nsl = pl[i].nsl;
+        if (pl[i].groups > max_groups) max_groups = pl[i].groups;
+        for (int b = 0; b < host[i]->nblocks; ++b) {
+            if (njobs >= WG_MAX_JOBS) { m2m_set_error("towers_wgrad: more than 32 (tower, block) jobs", __FILE__, __LINE__); return -1; }
+            a.job_tower[njobs] = (unsigned char)i;
+            a.job_block[njobs] = (unsigned char)b;
+            ++njobs;
+        }
+    }
+    if (njobs == 0) return 0;
+    const size_t lds = (size_t)2 * WgradGeom<P, D>::TPS * WgradGeom<P, D>::STAGE_B;
+    auto kern = tower_wgrad_group_kernel<P, D>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(max_nsl, njobs, max_groups), dim3(WG_THREADS), lds, st, a);
+    M2M_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int P, int D>
+static WgradPlan wgrad_plan(const m2m_tower* t, int B) {
     const bool wide = m2m_is_wide(t);                           // wide path: chain tiles are any BM consecutive rows
     const int SPW = wide ? 1 : BM / t->N;                       // samples per chain tile
     const int nchain = wide ? (int)(((long)B * t->N + BM - 1) / BM) : (B + SPW - 1) / SPW;   // chain tiles (BM rows each)
     const int ntiles = (nchain * BM + WBM - 1) / WBM;           // streamed tiles (WBM rows each)
-    const int nsl = ((t->Cp >> 4) + NWAVES - 1) / NWAVES;      // 128-column slices
-    // Row groups trade parallelism against float-atomic traffic (every extra group re-adds the whole slice) and,
-    // measured on M2-Mixer-B, against fitting the three towers' launches (100 + 100 + 50 workgroups) on the 256 CUs
-    // in ONE round: one group (single owner per element, no atomics) whenever the launch has >= 32 workgroups.
-    int groups = (32 + nsl * t->nblocks - 1) / (nsl * t->nblocks);
-    // Cutting the launch with few, long workgroups (the fusion tower: 50 x 128 tiles) into row groups so that it
-    // back-fills free CUs was measured and LOST (atomic traffic + contention: 612k -> 593k samples/s at 32-tile
-    // groups); kept as an opt-in knob.
-    if (nsl * t->nblocks <= 64 && ntiles > 64) {
-        int tgt = 0;
-        if (const char* e = getenv("M2M_WGRAD_SMALL_TILES")) tgt = atoi(e);
-        if (tgt > 0) groups = (ntiles + tgt - 1) / tgt;
-    }
+    const int nsl = (t->Cp + WgradGeom<P, D>::COLS - 1) / WgradGeom<P, D>::COLS;   // column slices (128 or 64 columns)
+    // A workgroup streams its operands at the per-CU HBM rate (~27 GB/s), so the launch time is set by the bytes of its
+    // longest workgroup: rows are split into groups until a workgroup has at most 64 tiles (2048 rows) or the launch
+    // reaches ~128 workgroups.  Two groups add their partial results with float atomics onto the zeroed gradient:
+    // a + b == b + a, so the result stays bit-deterministic; more groups (only tiny launches) are not.
+    int groups = 1;
+    const int wgs = nsl * t->nblocks;
+    while (wgs * groups < 128 && (ntiles + groups - 1) / groups > 64) ++groups;
+    if (groups < (32 + wgs - 1) / wgs) groups = (32 + wgs - 1) / wgs;
     if (const char* e = getenv("M2M_WGRAD_GROUPS")) groups = atoi(e);
     if (groups < 1) groups = 1;
     int tpg = (ntiles + groups - 1) / groups;
     if (tpg < 4) tpg = 4;
     if (tpg > ntiles) tpg = ntiles;
     groups = (ntiles + tpg - 1) / tpg;
-    const size_t lds = (size_t)wgrad_stages<P, D>() * 4 * WBM * D * Prec<P>::ESZ + GELU_TAB_N * 16;
-    const int rows_per_tile = wide ? BM : SPW * t->N;
-    auto kern = tower_wgrad_kernel<P, D, DM>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(nsl, t->nblocks, groups), dim3(NTHREADS), lds, st, *t, ntiles, tpg, rows_per_tile, seed, step, step_dev);
-    M2M_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-
-template <int P, int D>
-static int launch_wgrad(const m2m_tower* t, int B, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
-    switch (m2m_drop_mode(1, t->p_drop)) {
-        case DM_NONE: return launch_wgrad_dm<P, D, DM_NONE>(t, B, seed, step, step_dev, st);
-        case DM_HALF: return launch_wgrad_dm<P, D, DM_HALF>(t, B, seed, step, step_dev, st);
-        default:      return launch_wgrad_dm<P, D, DM_GEN>(t, B, seed, step, step_dev, st);
-    }
+    WgradPlan pl;
+    pl.ntiles = ntiles; pl.nsl = nsl; pl.groups = groups; pl.tpg = tpg;
+    return pl;
 }
 
 int m2m_check_tower(const m2m_tower* t, int B);
@@ -250,10 +361,31 @@ extern "C" int m2m_tower_wgrad(const m2m_tower* t, int B, uint32_t seed, uint32_
     if (int rc = m2m_check_tower(t, B)) return rc;
     if (t->nblocks == 0) return 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define M2M_WG_CASE(PP, DD) if (t->prec == PP && t->D == DD) return launch_wgrad<PP, DD>(t, B, seed, step, step_dev, st);
+#define M2M_WG_CASE(PP, DD) if (t->prec == PP && t->D == DD) return launch_wgrad<PP, DD>(t, B, st);
     M2M_WG_CASE(PREC_BF16, 32) M2M_WG_CASE(PREC_BF16, 64) M2M_WG_CASE(PREC_BF16, 128) M2M_WG_CASE(PREC_BF16, 256)
     M2M_WG_CASE(PREC_F32, 32) M2M_WG_CASE(PREC_F32, 64) M2M_WG_CASE(PREC_F32, 128) M2M_WG_CASE(PREC_F32, 256)
 #undef M2M_WG_CASE
     m2m_set_error("tower_wgrad: unsupported (prec, D)", __FILE__, __LINE__);
+    return -1;
+}
+
+extern "C" int m2m_towers_wgrad(const m2m_tower* const* towers, const m2m_tower* const* dev_towers, int ntowers, int B,
+                                void* stream) {
+    if (!towers || !dev_towers || ntowers < 1 || ntowers > WG_MAX_TOWERS) { m2m_set_error("towers_wgrad: 1..4 towers", __FILE__, __LINE__); return -1; }
+    for (int i = 0; i < ntowers; ++i) {
+        if (int rc = m2m_check_tower(towers[i], B)) return rc;
+        if (!dev_towers[i]) { m2m_set_error("towers_wgrad: missing device-resident descriptor", __FILE__, __LINE__); return -1; }
+        if (towers[i]->prec != towers[0]->prec || towers[i]->D != towers[0]->D) {
+            m2m_set_error("towers_wgrad: the towers of one launch must share precision and hidden_dim", __FILE__, __LINE__);
+            return -1;
+        }
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const m2m_tower* t = towers[0];
+#define M2M_WGG_CASE(PP, DD) if (t->prec == PP && t->D == DD) return launch_wgrad_group<PP, DD>(towers, dev_towers, ntowers, B, st);
+    M2M_WGG_CASE(PREC_BF16, 32) M2M_WGG_CASE(PREC_BF16, 64) M2M_WGG_CASE(PREC_BF16, 128) M2M_WGG_CASE(PREC_BF16, 256)
+    M2M_WGG_CASE(PREC_F32, 32) M2M_WGG_CASE(PREC_F32, 64) M2M_WGG_CASE(PREC_F32, 128) M2M_WGG_CASE(PREC_F32, 256)
+#undef M2M_WGG_CASE
+    m2m_set_error("towers_wgrad: unsupported (prec, D)", __FILE__, __LINE__);
     return -1;
 }

@@ -25,7 +25,7 @@ import torch
 from . import _lib as L
 from . import config
 from .runtime import (BLOCK_FIELDS, BLOCK_KEYS, EmbedRuntime, MlpRuntime, TowerRuntime, block_param_shapes, heads_bce,
-                      heads_ce)
+                      heads_ce, towers_wgrad)
 
 
 def _num_patch(c: dict) -> int:
@@ -146,6 +146,7 @@ class _FlatEngine:
         # the second modality / the fusion weight gradients run beside the first modality on side streams
         self.s_b = torch.cuda.Stream(device=dev)
         self.s_fus = torch.cuda.Stream(device=dev)
+        self.s_emb = torch.cuda.Stream(device=dev)
         self.concurrent = True
         self._build()
         self.pack()
@@ -212,27 +213,30 @@ class _FlatEngine:
                                       self.flat_v.data_ptr() + off, n, self.adam_state.data_ptr(), self.betas[0], self.betas[1],
                                       self.eps, self.weight_decay, -abs(grad_scale), int(bump), L.stream_ptr()), "adam_step")
 
-    def _bump_dropout(self):
-        L.check(L.lib().m2m_counter_add(self.drop_step.data_ptr(), 1, L.stream_ptr()), "counter_add")
+    def _prologue(self):
+        """Head of a training step: Adam step count += 1, dropout counter += 1, losses = 0 -- one tiny launch."""
+        L.check(L.lib().m2m_step_prologue(self.adam_state.data_ptr(), self.drop_step.data_ptr(), self.losses.data_ptr(), 4,
+                                          L.stream_ptr()), "step_prologue")
 
     def forward_backward(self, *batch):
         """forward (dropout on) -> multi-head loss -> backward; gradients are ADDED into flat_g, which must be
         zero on entry: it is cleared at construction and again by every optimizer_step (the Adam kernel clears
         each element it consumes), so no separate fill pass is needed."""
+        self._prologue()
         self._forward(*batch, training=True, with_grad=True)
         self._backward(*batch[:-1])
 
     def fused_step(self, *batch):
         """forward + backward + Adam + re-pack with the per-tower updates overlapped with the remaining
         weight-gradient work (no gradient exchange: single-GPU training)."""
+        self._prologue()
         self._forward(*batch, training=True, with_grad=True)
         self._backward(*batch[:-1], fused_update=True)
         return self.losses
 
     def optimizer_step(self, grad_scale: float = 1.0):
-        self._adam(0, self.n_params, grad_scale, True)                        # negative scale inside: clears the gradients
-        self._bump_dropout()
-        self.pack()
+        self._adam(0, self.n_params, grad_scale, False)                       # negative scale inside: clears the gradients
+        self.pack()                                                            # (the step counters were advanced by _prologue)
 
     def train_step(self, *batch, grad_sync=None):
         """One optimisation step.  grad_sync: optional callable(flat_grad) doing the data-parallel
@@ -352,7 +356,7 @@ class _TwoTowerEngine(_FlatEngine):
         main.wait_stream(s_b)
         main.wait_stream(s_f)
 
-    def _loss_heads(self, heads, labels):
+    def _loss_heads(self, heads, labels, zero_losses):
         raise NotImplementedError
 
     # ---- one training step (enqueue only; no host synchronisation) ----------------------------------------
@@ -375,7 +379,7 @@ class _TwoTowerEngine(_FlatEngine):
         heads = [self._head(a, self.pool_a, self.dpool_a, hw[a], with_grad),
                  self._head(b, self.pool_b, self.dpool_b, hw[b], with_grad),
                  self._head("fusion", self.pool_fus, self.dpool_fus, hw["fusion"], with_grad)]
-        self._loss_heads(heads, labels)
+        self._loss_heads(heads, labels, not training)      # a training step's _prologue already cleared the losses
 
     def _backward(self, xa, xb, fused_update: bool = False):
         """Backward of the whole model.  fused_update: also apply Adam + re-pack per tower as soon as that tower's
@@ -386,43 +390,27 @@ class _TwoTowerEngine(_FlatEngine):
         a, b = self.MODS
         self.t_fus.backward(B, None, 0, self.dpool_fus, self.d_fused, fs, self.seed, 0, sd)
         d_b_part = self.d_fused.view(-1)[self.Na * D:]
-        main, s_b, s_f = self._streams()
-        # The two tower backward chains fill the chip (128 + 128 workgroups): nothing else runs beside them.
-        # All weight-gradient launches (three towers, two embeddings) follow, spread over three streams.
-        s_b.wait_stream(main)
-        with torch.cuda.stream(s_b):
-            self.t_b.backward(B, d_b_part, fs, self.dpool_b, self.dx0_b, self.Nb * D, self.seed, 0, sd)
-            ev_b = torch.cuda.Event()
-            ev_b.record()
-        self.t_a.backward(B, self.d_fused, fs, self.dpool_a, self.dx0_a, self.Na * D, self.seed, 0, sd)
-        if self.concurrent:
-            main.wait_event(ev_b)                           # both chains done
-        if fused_update:
-            self._adam(0, 0, 1.0, True)                     # advance the Adam step counter once
-        s_b.wait_stream(main)
-        s_f.wait_stream(main)
-        with torch.cuda.stream(s_b):
-            self.t_b.wgrad(B, self.seed, 0, sd)
+        main, s_a, _ = self._streams()
+        s_e = self.s_emb if self.concurrent else main
+        # The two tower chains fill the chip (128 + 128 workgroups) side by side; then ONE launch computes the channel-mixing
+        # weight gradients of all three towers (the hardware dispatcher balances their ~480 workgroups; three launches on
+        # three queues of a replayed graph raced and sometimes serialised each other), with the two patch-embedding
+        # gradients beside it.  Every side stream forks from and joins into `main` directly (a fork from a forked stream
+        # crashed hipGraph capture on ROCm 7.2).
+        s_a.wait_stream(main)
+        with torch.cuda.stream(s_a):
+            self.t_a.backward(B, self.d_fused, fs, self.dpool_a, self.dx0_a, self.Na * D, self.seed, 0, sd)
+        self.t_b.backward(B, d_b_part, fs, self.dpool_b, self.dx0_b, self.Nb * D, self.seed, 0, sd)
+        main.wait_stream(s_a)
+        s_e.wait_stream(main)
+        with torch.cuda.stream(s_e):                        # e_b reads the whole input of that modality (audio: 50 KB / sample)
             self.e_b.wgrad(xb, self.dx0_b, B)
-            if fused_update:
-                self._adam(*self.segments[b], 1.0, False)
-                self.t_b.pack(force=True)
-                self.e_b.pack(force=True)
-        with torch.cuda.stream(s_f):
-            self.t_fus.wgrad(B, self.seed, 0, sd)
-            if fused_update:
-                self._adam(*self.segments["fusion"], 1.0, False)
-                self.t_fus.pack(force=True)
-        self.t_a.wgrad(B, self.seed, 0, sd)
-        self.e_a.wgrad(xa, self.dx0_a, B)
+            self.e_a.wgrad(xa, self.dx0_a, B)
+        towers_wgrad([self.t_fus, self.t_a, self.t_b], B)
+        main.wait_stream(s_e)
         if fused_update:
-            self._adam(*self.segments[a], 1.0, False)
-            self.t_a.pack(force=True)
-            self.e_a.pack(force=True)
-        main.wait_stream(s_b)
-        main.wait_stream(s_f)
-        if fused_update:
-            self._bump_dropout()
+            self._adam(0, self.n_params, 1.0, False)
+            self.pack()
 
     @torch.no_grad()
     def evaluate(self, xa, xb, labels):
@@ -449,8 +437,8 @@ class AVMnistEngine(_TwoTowerEngine):
         self.head_weights = {"image": 3 * ow, "audio": 3 * ow, "fusion": 3 * w}
         super().__init__(cfg, batch_size, device, precision, lr, betas, eps, weight_decay, seed, init)
 
-    def _loss_heads(self, heads, labels):
-        heads_ce(heads, labels, self.B, self.D, self.K, out=(self.logits, self.losses, self.preds))
+    def _loss_heads(self, heads, labels, zero_losses):
+        heads_ce(heads, labels, self.B, self.D, self.K, out=(self.logits, self.losses, self.preds), zero_losses=zero_losses)
 
     # names kept from the first engine revision (bench.py, tests)
     t_img = property(lambda self: self.t_a)
@@ -481,8 +469,9 @@ class MMIMDBEngine(_TwoTowerEngine):
     def _preds_shape(self):
         return (3, self.B, self.K)
 
-    def _loss_heads(self, heads, labels):
-        heads_bce(heads, labels, self.pos_weight, self.B, self.D, self.K, out=(self.logits, self.losses, self.preds))
+    def _loss_heads(self, heads, labels, zero_losses):
+        heads_bce(heads, labels, self.pos_weight, self.B, self.D, self.K, out=(self.logits, self.losses, self.preds),
+                  zero_losses=zero_losses)
 
 
 class MimicEngine(_FlatEngine):
@@ -559,7 +548,7 @@ class MimicEngine(_FlatEngine):
         heads = [self._head("static", self.pool_static, self.dpool_static, hw["static"], with_grad),
                  self._head("time", self.pool_time, self.dpool_time, hw["time"], with_grad),
                  self._head("fusion", self.pool_fus, self.dpool_fus, hw["fusion"], with_grad)]
-        heads_ce(heads, labels, B, D, self.K, out=(self.logits, self.losses, self.preds))
+        heads_ce(heads, labels, B, D, self.K, out=(self.logits, self.losses, self.preds), zero_losses=not training)
 
     def _backward(self, static, time, fused_update: bool = False):
         B, D = self.B, self.D
@@ -568,8 +557,6 @@ class MimicEngine(_FlatEngine):
         self.t_fus.backward(B, None, 0, self.dpool_fus, self.d_fused, fs, self.seed, 0, sd)
         d_time_part = self.d_fused.view(-1)[D:]
         main, s_b, s_f = self._streams()
-        if fused_update:
-            self._adam(0, 0, 1.0, True)                     # advance the Adam step counter once
         s_b.wait_stream(main)
         s_f.wait_stream(main)
         with torch.cuda.stream(s_b):                        # static MLP: gradient of token 0 + of its own head
@@ -590,8 +577,6 @@ class MimicEngine(_FlatEngine):
             self.e_time.pack(force=True)
         main.wait_stream(s_b)
         main.wait_stream(s_f)
-        if fused_update:
-            self._bump_dropout()
 
     @torch.no_grad()
     def evaluate(self, static, time, labels):

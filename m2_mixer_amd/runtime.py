@@ -133,8 +133,10 @@ class TowerRuntime:
         M = B * self.N
         for i in range(self.nblocks):
             bufs = {"x_in": torch.empty(M, self.D, device=self.device), "x_mid": torch.empty(M, self.D, device=self.device)}
-            for k in ("a_nat", "at_chn", "dy_nat", "dyt_chn"):
+            for k in ("at_chn", "dyt_chn"):
                 bufs[k] = torch.zeros(img, dtype=torch.uint8, device=self.device)
+            for k in ("h_chn", "dh_chn"):           # hidden activation / its gradient, transposed: rows x Cp elements
+                bufs[k] = torch.zeros(npairs * 32 * self.Cp * esz, dtype=torch.uint8, device=self.device)
             for k, v in bufs.items():
                 setattr(self.desc.blk[i], k, v.data_ptr())
             self._keep[f"saved{i}"] = bufs
@@ -208,6 +210,16 @@ class TowerRuntime:
         L.check(L.lib().m2m_tower_wgrad(C.byref(self.desc), B, seed & 0xFFFFFFFF, step & 0xFFFFFFFF, L.ptr(step_dev),
                                         L.stream_ptr()), "tower_wgrad")
 
+    def device_desc(self) -> int:
+        """Device pointer of a byte copy of the descriptor (for the multi-tower launches, whose kernel arguments cannot
+        hold several 2.4 KiB descriptors).  Re-uploaded only when the descriptor changed -- never inside a graph capture:
+        the warm-up steps before a capture leave it current."""
+        raw = bytes(self.desc)
+        if self._keep.get("desc_bytes") != raw:
+            self._keep["desc_dev"] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+            self._keep["desc_bytes"] = raw
+        return self._keep["desc_dev"].data_ptr()
+
     def dropout_mask(self, blk: int, site: int, B: int, seed: int, step: int) -> torch.Tensor:
         """Keep-mask (uint8) of one dropout site in the kernels' index order (test hook)."""
         n = {0: B * self.D * self.T, 1: B * self.D * self.N, 2: B * self.N * self.Cp, 3: B * self.N * self.D}[site]
@@ -215,6 +227,14 @@ class TowerRuntime:
         L.check(L.lib().m2m_dropout_mask(C.byref(self.desc), blk, site, B, seed & 0xFFFFFFFF, step & 0xFFFFFFFF,
                                          m.data_ptr(), L.stream_ptr()), "dropout_mask")
         return m
+
+
+def towers_wgrad(towers: Sequence[TowerRuntime], B: int):
+    """Channel-mixing weight gradients of several towers (same precision / hidden_dim) in one launch."""
+    n = len(towers)
+    host = (C.POINTER(L.Tower) * n)(*[C.pointer(t.desc) for t in towers])
+    dev = (C.c_void_p * n)(*[t.device_desc() for t in towers])
+    L.check(L.lib().m2m_towers_wgrad(host, dev, n, B, L.stream_ptr()), "towers_wgrad")
 
 
 class EmbedRuntime:
@@ -327,7 +347,8 @@ def _head_array(heads: Sequence[dict]):
     return arr
 
 
-def heads_bce(heads: Sequence[dict], targets: torch.Tensor, pos_weight: torch.Tensor, B: int, D: int, K: int, out=None):
+def heads_bce(heads: Sequence[dict], targets: torch.Tensor, pos_weight: torch.Tensor, B: int, D: int, K: int, out=None,
+              zero_losses: bool = True):
     """BCEWithLogitsLoss(pos_weight) heads (models/mmimdb.py:47-50): targets (B, K) float32 multi-hot.
     Returns logits (nh, B, K), losses (nh + 1), preds (nh, B, K) int32."""
     nh = len(heads)
@@ -341,11 +362,11 @@ def heads_bce(heads: Sequence[dict], targets: torch.Tensor, pos_weight: torch.Te
         losses = torch.empty(nh + 1, device=dev)
         preds = torch.empty(nh, B, K, dtype=torch.int32, device=dev)
     L.check(L.lib().m2m_heads_bce(arr, nh, targets.data_ptr(), pos_weight.data_ptr(), B, D, K, logits.data_ptr(),
-                                  losses.data_ptr(), preds.data_ptr(), L.stream_ptr()), "heads_bce")
+                                  losses.data_ptr(), preds.data_ptr(), int(zero_losses), L.stream_ptr()), "heads_bce")
     return logits, losses, preds
 
 
-def heads_ce(heads: Sequence[dict], labels: torch.Tensor, B: int, D: int, K: int, out=None):
+def heads_ce(heads: Sequence[dict], labels: torch.Tensor, B: int, D: int, K: int, out=None, zero_losses: bool = True):
     """heads: dicts with pooled, w, b, g_w, g_b, d_pooled (tensors or None) and weight.
     Returns logits (nh, B, K), losses (nh + 1), preds (nh, B) int32 (written into `out` if given)."""
     nh = len(heads)
@@ -358,5 +379,5 @@ def heads_ce(heads: Sequence[dict], labels: torch.Tensor, B: int, D: int, K: int
         losses = torch.empty(nh + 1, device=dev)
         preds = torch.empty(nh, B, dtype=torch.int32, device=dev)
     L.check(L.lib().m2m_heads_ce(arr, nh, labels.data_ptr(), B, D, K, logits.data_ptr(), losses.data_ptr(),
-                                 preds.data_ptr(), L.stream_ptr()), "heads_ce")
+                                 preds.data_ptr(), int(zero_losses), L.stream_ptr()), "heads_ce")
     return logits, losses, preds

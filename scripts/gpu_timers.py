@@ -19,7 +19,7 @@ lib = L.lib()
 NAMES = {
     "fwd": ["load/save/LN1", "token mix", "save/LN2/pack", "column loop", "reduce+residual", "final LN/out"],
     "bwd": ["upstream+LNf bwd", "C1+C2 pack", "C3 column loop", "C4+C5 reduce/LN2bwd", "T1 token pair loop", "T2 LN1 bwd + colsums", "T1b shuffles+LDS atomics", "T1c global atomics"],
-    "wgrad": ["tile load", "recompute+elementwise mb0", "grad GEMMs mb0", "recompute+elementwise mb1", "grad GEMMs mb1", "-", "write-out"],
+    "wgrad": ["wait loads + stage write", "issue refill loads", "barrier", "LDS reads + MFMA", "write-out"],
 }
 
 
@@ -62,6 +62,12 @@ def main():
         torch.cuda.synchronize()
         t = read("wgrad") / n
         print(f"tower_wgrad[{name}] per launch (WG0): total {t.sum():.1f} us: " + ", ".join(f"{k} {v:.1f}" for k, v in zip(NAMES['wgrad'], t)))
+    from m2_mixer_amd.runtime import towers_wgrad
+    for _ in range(n):
+        towers_wgrad([eng.t_fus, eng.t_a, eng.t_b], B)
+    torch.cuda.synchronize()
+    t = read("wgrad") / n
+    print(f"towers_wgrad[all three] per launch (WG0): total {t.sum():.1f} us: " + ", ".join(f"{k} {v:.1f}" for k, v in zip(NAMES['wgrad'], t)))
 
 
 if __name__ == "__main__":

@@ -3,7 +3,7 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 names = [r['Kernel_Name'] for r in rows]
-adam = [i for i, n in enumerate(names) if n.startswith('counter_add_kernel')]   # one per training step
+adam = [i for i, n in enumerate(names) if n.startswith('step_prologue_kernel')]   # one per training step
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 seg = sorted(rows[adam[k]:adam[k + 1] + 1], key=lambda r: int(r['Start_Timestamp']))
 t0 = int(seg[0]['End_Timestamp'])

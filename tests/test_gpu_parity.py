@@ -392,7 +392,7 @@ def test_wide_models_bf16_vs_oracle_and_training(task, dev):
     ref["loss"].backward()
     for i, k in enumerate(names):
         assert abserr(eng.logits[i], ref[k]) < BF16_REL * max(1.0, float(ref[k].detach().abs().max())), k
-    assert abs(float(eng.losses[3]) - float(ref["loss"])) < 2e-2 * max(1.0, abs(float(ref["loss"])))
+    assert abs(float(eng.losses[3]) - float(ref["loss"].detach())) < 2e-2 * max(1.0, abs(float(ref["loss"].detach())))
     for k, leaf in leaves.items():
         if k.endswith("token_mix.2.net.3.bias"):      # exactly-zero true gradient
             continue
