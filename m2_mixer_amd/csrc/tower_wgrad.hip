@@ -210,36 +210,79 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, i
     }
 
     // ---- results: dw1[j][dt][r] = dW1[c = 16 ct + 4g + r][d = 16dt + il]; dw2 likewise = dW2[d][c] ----
+    // "+=" onto the caller's gradient.  Single owner (one row group): ALL loads of the old values first (they overlap
+    // each other; one dependent load-add-store at a time cost 40 % of the kernel), then the stores.  Two row groups:
+    // no-return float atomics (a + b == b + a: still bit-deterministic); measured 2x slower per byte than the batched
+    // read-modify-write, so only launches that need the split use them.
+    if (single) {
 #pragma unroll
-    for (int j = 0; j < CPW; ++j) {
-        if (ct0 + j >= nct) continue;
-        const int c0 = 16 * (ct0 + j) + 4 * g;
+        for (int j = 0; j < CPW; ++j) {
+            if (ct0 + j >= nct) continue;
+            const int c0 = 16 * (ct0 + j) + 4 * g;
+            const bool vec = c0 + 3 < C && (C & 3) == 0;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const int d = 16 * dt + il;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (c0 + r < C) {
-                    float* p1 = bk.g_ch_w1 + (long)(c0 + r) * D + d;
-                    if (single) *p1 += dw1[j][dt][r]; else atomicAdd(p1, dw1[j][dt][r]);
-                }
-            }
-            float* p2 = bk.g_ch_w2 + (long)d * C + c0;      // four consecutive c of row d
-            if (single && c0 + 3 < C && (C & 3) == 0) {
-                float4 o = *reinterpret_cast<float4*>(p2);
-                o.x += dw2[j][dt][0]; o.y += dw2[j][dt][1]; o.z += dw2[j][dt][2]; o.w += dw2[j][dt][3];
-                *reinterpret_cast<float4*>(p2) = o;
-            } else {
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = 16 * dt + il;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (c0 + r < C) { if (single) p2[r] += dw2[j][dt][r]; else atomicAdd(p2 + r, dw2[j][dt][r]); }
+                    if (c0 + r < C) dw1[j][dt][r] += bk.g_ch_w1[(long)(c0 + r) * D + d];
+                const float* p2 = bk.g_ch_w2 + (long)d * C + c0;    // four consecutive c of row d
+                if (vec) {
+                    dw2[j][dt] = dw2[j][dt] + *reinterpret_cast<const f32x4_t*>(p2);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (c0 + r < C) dw2[j][dt][r] += p2[r];
+                }
             }
         }
-        // db1[r] = sum_m dHpre[m][c0 + r], identical in all 16 columns: column 0 writes
-        if (il == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (c0 + r < C) { if (single) bk.g_ch_b1[c0 + r] += db1[j][r]; else atomicAdd(bk.g_ch_b1 + c0 + r, db1[j][r]); }
+        for (int j = 0; j < CPW; ++j) {
+            if (ct0 + j >= nct) continue;
+            const int c0 = 16 * (ct0 + j) + 4 * g;
+            const bool vec = c0 + 3 < C && (C & 3) == 0;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = 16 * dt + il;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c0 + r < C) bk.g_ch_w1[(long)(c0 + r) * D + d] = dw1[j][dt][r];
+                float* p2 = bk.g_ch_w2 + (long)d * C + c0;
+                if (vec) {
+                    *reinterpret_cast<f32x4_t*>(p2) = dw2[j][dt];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (c0 + r < C) p2[r] = dw2[j][dt][r];
+                }
+            }
+            if (il == 0) {                                  // db1[r] is identical in all 16 columns: column 0 writes
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c0 + r < C) bk.g_ch_b1[c0 + r] += db1[j][r];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < CPW; ++j) {
+            if (ct0 + j >= nct) continue;
+            const int c0 = 16 * (ct0 + j) + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = 16 * dt + il;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (c0 + r < C) {
+                        atomicAdd(bk.g_ch_w1 + (long)(c0 + r) * D + d, dw1[j][dt][r]);
+                        atomicAdd(bk.g_ch_w2 + (long)d * C + c0 + r, dw2[j][dt][r]);
+                    }
+                }
+            }
+            if (il == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c0 + r < C) atomicAdd(bk.g_ch_b1 + c0 + r, db1[j][r]);
+            }
         }
     }
     TIMER_MARK(g_tm_wg, 4);        // result write-out
