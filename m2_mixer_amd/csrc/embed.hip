@@ -34,36 +34,36 @@ static __device__ __forceinline__ long patch_rowbase(const PatchGeom& pg, long m
     return (b * pg.Cin * pg.H + gy * pg.ph) * (long)pg.W + gx * pg.pw;
 }
 
-template <int P, int D>
+template <int P, int D, int RB>
 __global__ __launch_bounds__(NTHREADS) void embed_fwd_kernel(const m2m_embed em, const float* __restrict__ in, long M, int N,
                                                              float* __restrict__ x0) {
     typedef Prec<P> Pr;
     constexpr int DT = D / 16, KSB = EMB_KS / Pr::KB;     // k-blocks per stage
     constexpr int DPW = (DT + NWAVES - 1) / NWAVES;        // d-tiles per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* tile = reinterpret_cast<float*>(smem);          // [EBM][EMB_LD] fp32
-    char* img = smem + EBM * EMB_LD * 4;                    // packed NAT [mt][kb] of the stage
-    int* koff = reinterpret_cast<int*>(img + EBM * EMB_KS * Pr::ESZ);   // [Kp rounded up to EMB_KS]
-    long* rbase = reinterpret_cast<long*>(koff + EMB_KMAX);            // [EBM]
+    float* tile = reinterpret_cast<float*>(smem);          // [RB][EMB_LD] fp32
+    char* img = smem + RB * EMB_LD * 4;                    // packed NAT [mt][kb] of the stage
+    int* koff = reinterpret_cast<int*>(img + RB * EMB_KS * Pr::ESZ);   // [Kp rounded up to EMB_KS]
+    long* rbase = reinterpret_cast<long*>(koff + EMB_KMAX);            // [RB]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
     PatchGeom pg{em.Cin, em.H, em.W, em.ph, em.pw, em.W / em.pw, N, em.K};
-    const long m0 = (long)blockIdx.x * EBM;
+    const long m0 = (long)blockIdx.x * RB;
     const int nKB = em.Kp / Pr::KB;
     const int kext = (em.Kp + EMB_KS - 1) / EMB_KS * EMB_KS;
     for (int k = tid; k < kext; k += NTHREADS) koff[k] = patch_koff(pg, k);
-    if (tid < EBM) rbase[tid] = patch_rowbase(pg, m0 + tid, M);
+    if (tid < RB) rbase[tid] = patch_rowbase(pg, m0 + tid, M);
 
-    f32x4_t acc[EMT][DPW];
+    f32x4_t acc[(RB / 16)][DPW];
 #pragma unroll
-    for (int mt = 0; mt < EMT; ++mt)
+    for (int mt = 0; mt < (RB / 16); ++mt)
 #pragma unroll
         for (int j = 0; j < DPW; ++j) acc[mt][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // Software pipeline over EMB_KS-wide stages: the global loads of stage s+1 (this thread's patch elements and
     // this wave's weight fragments) are issued before stage s is packed and multiplied, so their latency hides
     // behind the LDS work and the MFMAs.  One workgroup owns its rows for the whole K: deterministic, no atomics.
-    constexpr int EPT = EBM * EMB_KS / NTHREADS;            // patch elements per thread per stage
+    constexpr int EPT = RB * EMB_KS / NTHREADS;            // patch elements per thread per stage
     float pre[EPT];
     Frag wpre[DPW][KSB];
     auto load_stage = [&](int k0) {
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(NTHREADS) void embed_fwd_kernel(const m2m_embed em,
             for (int kb = 0; kb < KSB; ++kb) wcur[j][kb] = wpre[j][kb];
         __syncthreads();
         if (k0 + EMB_KS < em.Kp) load_stage(k0 + EMB_KS);
-        for (int slot = tid; slot < EMT * KSB * 64; slot += NTHREADS) {
+        for (int slot = tid; slot < (RB / 16) * KSB * 64; slot += NTHREADS) {
             const int blk = slot >> 6;
             *reinterpret_cast<u32x4_t*>(img + slot * 16) =
                 gather_slot<P>(tile, EMB_LD, PACK_NAT, false, blk / KSB, blk % KSB, slot & 63);
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(NTHREADS) void embed_fwd_kernel(const m2m_embed em,
 #pragma unroll
                 for (int kb = 0; kb < KSB; ++kb) {
 #pragma unroll
-                    for (int mt = 0; mt < EMT; ++mt) {
+                    for (int mt = 0; mt < (RB / 16); ++mt) {
                         const Frag a = ld_frag_lds(img, mt * KSB + kb, lane);
                         Pr::mma(acc[mt][j], a, wcur[j][kb]);
                     }
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(NTHREADS) void embed_fwd_kernel(const m2m_embed em,
             const int d = 16 * dt + il;
             const float bv = em.b[d];
 #pragma unroll
-            for (int mt = 0; mt < EMT; ++mt)
+            for (int mt = 0; mt < (RB / 16); ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const long m = m0 + 16 * mt + 4 * g + r;
@@ -254,11 +254,14 @@ template <int P, int D>
 static int launch_embed_fwd(const m2m_embed* e, const float* in, int B, float* x0, hipStream_t st) {
     const int N = (e->H / e->ph) * (e->W / e->pw);
     const long M = (long)B * N;
-    const size_t lds = (size_t)EBM * EMB_LD * 4 + (size_t)EBM * EMB_KS * Prec<P>::ESZ + EMB_KMAX * 4 + EBM * 8;
-    auto kern = embed_fwd_kernel<P, D>;
+    // 16 rows per workgroup: the audio embedding (2048 rows at batch 512, 50 KB of input per sample) sits at the head of
+    // the step's critical path, and 64 workgroups of 32 rows left three quarters of the chip idle
+    constexpr int RB = 16;
+    const size_t lds = (size_t)RB * EMB_LD * 4 + (size_t)RB * EMB_KS * Prec<P>::ESZ + EMB_KMAX * 4 + RB * 8;
+    auto kern = embed_fwd_kernel<P, D, RB>;
     static bool done = false;
     if (!done) { M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)((M + EBM - 1) / EBM)), dim3(NTHREADS), lds, st, *e, in, M, N, x0);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((M + RB - 1) / RB)), dim3(NTHREADS), lds, st, *e, in, M, N, x0);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
 }

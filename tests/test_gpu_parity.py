@@ -115,7 +115,8 @@ def test_block_dropout_masks_match_oracle(case, p_drop, dev):
     thr = round((1 - p_drop) * 65536)
     p_eff = 1 - thr / 65536            # keep probability is quantised to 16 bits; the kernels scale by 1/(1-p_eff)
     for k, m in masks.items():
-        assert abs(float(m.mean()) - (1 - p_eff)) < 0.03, (k, float(m.mean()))
+        tol = max(0.03, 5 * 0.5 / m.numel() ** 0.5)      # 5 sigma of a Bernoulli mean over the mask's elements
+        assert abs(float(m.mean()) - (1 - p_eff)) < tol, (k, float(m.mean()))
     leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
     xr = x.clone().requires_grad_(True)
     yo = O.mixer_block(xr, leaves, "", p_eff, masks)
