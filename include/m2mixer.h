@@ -60,8 +60,9 @@ typedef struct m2m_block {
      * (k = token row m inside the pair, CHN order): */
     void* at_chn;         /* LN2(x_mid)^T                    [pair][dt][lane]   i = d, k = m           (rows x D elements)  */
     void* dyt_chn;        /* d(channel MLP out)^T            [pair][dt][lane]   i = d, k = m                                */
-    void* h_chn;          /* hidden activation^T  (after GELU + dropout)   [ct][pair][lane]   i = c, k = m   (rows x Cp)    */
-    void* dh_chn;         /* gradient wrt the hidden pre-activation ^T      [ct][pair][lane]   i = c, k = m   (rows x Cp)    */
+    void* h_chn;          /* hidden activation^T (after GELU + dropout), i = c, k = m, rows x Cp elements.  bf16:
+                           * [ct / 2][pair][16-row half][lane][tile 2q: 4 elem | tile 2q+1: 4 elem]; fp32: [ct][pair][half][lane] */
+    void* dh_chn;         /* gradient wrt the hidden pre-activation ^T, same layout                                          */
 } m2m_block;
 
 /* A stack of MixerBlocks + optional final LayerNorm: the body of MLPMixer / FusionMixer /

@@ -267,29 +267,39 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int u = BM == 16 ? tile_in_pair : mt;        // 16-row half of the 32-row pair
+                const long npair = (gridDim.x + TPP - 1) / TPP, pair = blockIdx.x / TPP;
+                f32x4_t od[2], oa[2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     Frag id;
                     if (P == PREC_BF16) id.u = t == 0 ? u32x4_t{id_a, id_b, 0u, 0u} : u32x4_t{0u, 0u, id_a, id_b};
                     else id.f = f32x4_t{4 * g + 0 == il ? 1.f : 0.f, 4 * g + 1 == il ? 1.f : 0.f, 4 * g + 2 == il ? 1.f : 0.f, 4 * g + 3 == il ? 1.f : 0.f};
-                    f32x4_t od = f32x4_t{0.f, 0.f, 0.f, 0.f}, oa = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                    Pr::mma(od, hf[mt][P == PREC_BF16 ? 0 : t], id);
-                    Pr::mma(oa, af[mt][P == PREC_BF16 ? 0 : t], id);
-                    // od[r] = dHpre[m = 16u + 4g + r][c = 32q + 16t + il]
-                    const long frag = (long)(2 * q + t) * ((gridDim.x + TPP - 1) / TPP) + (blockIdx.x / TPP);   // [column tile][pair]: a column tile's stream is contiguous
-                    // streamed out once and read once by the weight-gradient pass: non-temporal, so that the 100 MB per
-                    // launch do not evict the weights the other workgroups of this XCD keep re-reading from its L2
-                    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
-                    if (P == PREC_BF16) {
-                        const long off = frag * 1024 + u * 512 + lane * 8;       // each 16-row half is 512 contiguous bytes
-                        __builtin_nontemporal_store(u32x2_t{pack_bf2(od[0], od[1]), pack_bf2(od[2], od[3])},
-                                                    reinterpret_cast<u32x2_t*>(reinterpret_cast<char*>(bk.dh_chn) + off));
-                        __builtin_nontemporal_store(u32x2_t{pack_bf2(oa[0], oa[1]), pack_bf2(oa[2], oa[3])},
-                                                    reinterpret_cast<u32x2_t*>(reinterpret_cast<char*>(bk.h_chn) + off));
-                    } else {
-                        const long off = (frag * 2 + u) * 1024 + lane * 16;
-                        __builtin_nontemporal_store(od, reinterpret_cast<f32x4_t*>(reinterpret_cast<char*>(bk.dh_chn) + off));
-                        __builtin_nontemporal_store(oa, reinterpret_cast<f32x4_t*>(reinterpret_cast<char*>(bk.h_chn) + off));
+                    od[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    oa[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    Pr::mma(od[t], hf[mt][P == PREC_BF16 ? 0 : t], id);
+                    Pr::mma(oa[t], af[mt][P == PREC_BF16 ? 0 : t], id);
+                    // od[t][r] = dHpre[m = 16u + 4g + r][c = 32q + 16t + il]
+                }
+                // streamed out once and read once by the weight-gradient pass: non-temporal, so that the 100 MB per
+                // launch do not evict the weights the other workgroups of this XCD keep re-reading from its L2
+                if (P == PREC_BF16) {
+                    // [column-tile pair q][32-row pair][16-row half u][lane][tile 2q: 4 bf16 | tile 2q+1: 4 bf16]: one full
+                    // 16-byte-per-lane store per operand and step (1 KiB contiguous), and the weight-gradient wave that owns
+                    // both column tiles reads it back with one 16-byte load per half
+                    const long off = (((long)q * npair + pair) * 2 + u) * 1024 + lane * 16;
+                    __builtin_nontemporal_store(u32x4_t{pack_bf2(od[0][0], od[0][1]), pack_bf2(od[0][2], od[0][3]),
+                                                        pack_bf2(od[1][0], od[1][1]), pack_bf2(od[1][2], od[1][3])},
+                                                reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(bk.dh_chn) + off));
+                    __builtin_nontemporal_store(u32x4_t{pack_bf2(oa[0][0], oa[0][1]), pack_bf2(oa[0][2], oa[0][3]),
+                                                        pack_bf2(oa[1][0], oa[1][1]), pack_bf2(oa[1][2], oa[1][3])},
+                                                reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(bk.h_chn) + off));
+                } else {
+                    // fp32: a 16-row half is a whole k-block: [column tile][32-row pair][half][lane][16 bytes]
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const long off = (((long)(2 * q + t) * npair + pair) * 2 + u) * 1024 + lane * 16;
+                        __builtin_nontemporal_store(od[t], reinterpret_cast<f32x4_t*>(reinterpret_cast<char*>(bk.dh_chn) + off));
+                        __builtin_nontemporal_store(oa[t], reinterpret_cast<f32x4_t*>(reinterpret_cast<char*>(bk.h_chn) + off));
                     }
                 }
             }

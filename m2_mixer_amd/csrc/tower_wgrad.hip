@@ -17,11 +17,21 @@
 #include <stdlib.h>
 #include <string.h>
 
+// address-space qualifier for pointers known to be global memory (device pass only; the host pass just parses)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define M2M_GLOBAL_AS __attribute__((address_space(1)))
+#else
+#define M2M_GLOBAL_AS
+#endif
+
 #define WBM 32            // rows per streamed tile (= two 16-row tiles of the chain kernels when BM == 16)
 #ifndef WG_RING_MAX
 #define WG_RING_MAX 24    // VGPR budget of one tile in flight that still allows a second one (register ring depth 2)
 #endif
 #define WG_WAVES 4
+#ifndef WG_LA
+#define WG_LA 4           // LDS fragments read ahead of their MFMAs
+#endif
 #ifndef WG_MINWAVES
 #define WG_MINWAVES 2
 #endif
@@ -82,8 +92,12 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, i
     if (P == PREC_BF16) ones.u = u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
     else ones.f = f32x4_t{1.f, 1.f, 1.f, 1.f};
 
-    const char* src_at = reinterpret_cast<const char*>(bk.at_chn);
-    const char* src_dyt = reinterpret_cast<const char*>(bk.dyt_chn);
+    // Explicit global address space: in the multi-tower launch the descriptor is read from memory, so the compiler
+    // cannot prove where its pointers point and would emit FLAT loads -- which also count on lgkmcnt, so that every wait
+    // for an LDS fragment would drain the global prefetch too.
+    typedef const M2M_GLOBAL_AS char* gptr_t;
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+    const gptr_t src_at = (gptr_t)bk.at_chn, src_dyt = (gptr_t)bk.dyt_chn, src_h = (gptr_t)bk.h_chn, src_dh = (gptr_t)bk.dh_chn;
     // One tile's worth of loads in flight: this thread's pieces of the shared stage + this wave's own fragments.
     struct Pre {
         u32x4_t st[TPS][NLD];
@@ -104,28 +118,43 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, i
             for (int i = 0; i < NLD; ++i) {
                 const int o = min((i * WG_THREADS + tid) * 16, STAGE_B - 16);
                 const char* sp = o < IMG_B ? src_at : src_dyt;
+#ifdef M2M_EXP_NOSTAGE
+                p.st[u][i] = u32x4_t{(unsigned)o, 1u, 2u, (unsigned)tile};
+#else
                 p.st[u][i] = *reinterpret_cast<const u32x4_t*>(sp + (long)tile * IMG_B + (o < IMG_B ? o : o - IMG_B));
+#endif
             }
+            if (P == PREC_BF16) {
+                // [column-tile pair][32-row pair][16-row half][lane][tile 2q: 8 B | tile 2q+1: 8 B]  (written by tower_bwd.hip)
+                // read exactly once: non-temporal, so the stream does not evict the A^T / dYd^T tiles that the other column
+                // slices of this block re-read from L2
+                const long blk = ((long)(ctl[0] >> 1) * ntiles + tile) * 2048 + lane * 16;
+                if (CPW == 2) {                              // the wave owns both tiles of the pair: one 16-byte load per half
+                    typedef const M2M_GLOBAL_AS u32x4_t* g4_t;
+                    const u32x4_t h0 = __builtin_nontemporal_load((g4_t)(src_h + blk)), h1 = __builtin_nontemporal_load((g4_t)(src_h + blk + 1024));
+                    const u32x4_t d0 = __builtin_nontemporal_load((g4_t)(src_dh + blk)), d1 = __builtin_nontemporal_load((g4_t)(src_dh + blk + 1024));
 #pragma unroll
-            for (int j = 0; j < CPW; ++j) {
+                    for (int j = 0; j < CPW; ++j) {
+                        p.h[u][j][0].u = u32x4_t{h0[2 * j], h0[2 * j + 1], h1[2 * j], h1[2 * j + 1]};
+                        p.d[u][j][0].u = u32x4_t{d0[2 * j], d0[2 * j + 1], d1[2 * j], d1[2 * j + 1]};
+                    }
+                } else {                                     // one tile of the pair: its 8-byte half of every lane slot
+                    typedef const M2M_GLOBAL_AS u32x2_t* g2_t;
+                    const long o = blk + (ctl[0] & 1) * 8;
+                    const u32x2_t h0 = __builtin_nontemporal_load((g2_t)(src_h + o)), h1 = __builtin_nontemporal_load((g2_t)(src_h + o + 1024));
+                    const u32x2_t d0 = __builtin_nontemporal_load((g2_t)(src_dh + o)), d1 = __builtin_nontemporal_load((g2_t)(src_dh + o + 1024));
+                    p.h[u][0][0].u = u32x4_t{h0[0], h0[1], h1[0], h1[1]};
+                    p.d[u][0][0].u = u32x4_t{d0[0], d0[1], d1[0], d1[1]};
+                }
+            } else {
+                typedef const M2M_GLOBAL_AS u32x4_t* g4_t;
 #pragma unroll
-                for (int f = 0; f < NF; ++f) {               // NF 1-KiB blocks each
-                    const long blk = ((long)ctl[j] * ntiles + tile) * NF + f;      // [column tile][pair][f]: contiguous per wave
-                    if (P == PREC_BF16) {                    // stored as two 512-byte halves [h][lane][8 bytes]
-                        const char* ph = reinterpret_cast<const char*>(bk.h_chn) + blk * 1024 + lane * 8;
-                        const char* pd = reinterpret_cast<const char*>(bk.dh_chn) + blk * 1024 + lane * 8;
-                        // read exactly once: non-temporal, so the stream does not evict the A^T / dYd^T tiles that the
-                        // other column slices of this block re-read from L2
-                        typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
-                        const u32x2_t h0 = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(ph));
-                        const u32x2_t h1 = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(ph + 512));
-                        const u32x2_t d0 = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(pd));
-                        const u32x2_t d1 = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(pd + 512));
-                        p.h[u][j][f].u = u32x4_t{h0[0], h0[1], h1[0], h1[1]};
-                        p.d[u][j][f].u = u32x4_t{d0[0], d0[1], d1[0], d1[1]};
-                    } else {
-                        p.h[u][j][f].u = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(bk.h_chn) + blk * 1024 + lane * 16));
-                        p.d[u][j][f].u = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(bk.dh_chn) + blk * 1024 + lane * 16));
+                for (int j = 0; j < CPW; ++j) {
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) {           // fp32: [column tile][32-row pair][half = k-block f][lane][16 B]
+                        const long blk = (((long)ctl[j] * ntiles + tile) * NF + f) * 1024 + lane * 16;
+                        p.h[u][j][f].u = __builtin_nontemporal_load((g4_t)(src_h + blk));
+                        p.d[u][j][f].u = __builtin_nontemporal_load((g4_t)(src_dh + blk));
                     }
                 }
             }
@@ -142,6 +171,9 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, i
 #pragma unroll
             for (int k = 0; k < NLD; ++k) {
                 const int o = (k * WG_THREADS + tid) * 16;
+#ifdef M2M_EXP_NOLDSWRITE
+                if (p.st[u][k][0] == 0x12345u)
+#endif
                 if (o < STAGE_B) {
                     if (P == PREC_BF16) {
                         // global block = [h][lane][8 B]; this 16-byte piece holds half h of lanes 2j, 2j + 1 -> 16-byte lane slots
@@ -171,20 +203,34 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, i
         for (int u = 0; u < TPS; ++u) {
             if (TPS > 1 && tile0 + u >= t_end) break;
             const char* cur = buf + u * STAGE_B;
+            // The shared operands come from LDS one 1-KiB fragment per (f, dt); with one wave per SIMD nothing else hides
+            // the ds_read latency, so the reads run WG_LA fragments ahead of the MFMAs that consume them (measured: the
+            // compiler's own distance of one made the loop LDS-latency-bound at 0.83 us per tile).
+            constexpr int NQ = NF * DT;
+            constexpr int LA = WG_LA < NQ ? WG_LA : NQ;
+            Frag aq[LA], dq[LA];
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {
+            for (int q = 0; q < LA; ++q) {
+                aq[q] = ld_frag_lds(cur, q, lane);
+                dq[q] = ld_frag_lds(cur + IMG_B, q, lane);
+            }
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
-                    const Frag at = ld_frag_lds(cur, f * DT + dt, lane);
-                    const Frag dyt = ld_frag_lds(cur + IMG_B, f * DT + dt, lane);
-#pragma unroll
-                    for (int j = 0; j < CPW; ++j) {
-                        Pr::mma(dw1[j][dt], df[u][j][f], at);
-                        Pr::mma(dw2[j][dt], hf[u][j][f], dyt);
-                    }
+            for (int q = 0; q < NQ; ++q) {
+                const int f = q / DT, dt = q % DT;
+                const Frag at = aq[q % LA], dyt = dq[q % LA];
+                if (q + LA < NQ) {
+                    aq[q % LA] = ld_frag_lds(cur, q + LA, lane);
+                    dq[q % LA] = ld_frag_lds(cur + IMG_B, q + LA, lane);
                 }
 #pragma unroll
-                for (int j = 0; j < CPW; ++j) Pr::mma(db1[j], df[u][j][f], ones);   // every column = sum over the tile's rows of dHpre[.][c]
+                for (int j = 0; j < CPW; ++j) {
+                    Pr::mma(dw1[j][dt], df[u][j][f], at);
+                    Pr::mma(dw2[j][dt], hf[u][j][f], dyt);
+                }
+                if (dt == DT - 1) {
+#pragma unroll
+                    for (int j = 0; j < CPW; ++j) Pr::mma(db1[j], df[u][j][f], ones);   // every column = sum over the tile's rows of dHpre[.][c]
+                }
             }
         }
         TIMER_MARK(g_tm_wg, 3);    // LDS reads + MFMAs
