@@ -20,6 +20,7 @@ CSRC = os.path.join(_HERE, "csrc")
 ABI_VERSION = 5
 MAX_BLOCKS = 8
 ROWS_PER_WG = 16
+HCHN_PAD = 4096          # >= the pad between operand streams the library uses (csrc/tile.h M2M_HCHN_PAD)
 PREC_BF16, PREC_F32 = 0, 1
 PREC_BY_NAME = {"bf16": PREC_BF16, "fp32": PREC_F32, "f32": PREC_F32}
 

@@ -103,6 +103,15 @@ static __device__ __forceinline__ bool drop_keep_elem(const Drop& d, unsigned in
     return drop_keep(d, idx);
 }
 
+// Byte stride between the operand streams (h_chn / dh_chn) of consecutive column-tile groups (a pair of 16-column tiles in
+// bf16, one tile in fp32): npair 2-KiB blocks plus a pad.  Without the pad the stride is a power of two (128 KiB at batch
+// 512), every column slice of the weight-gradient launch walks its stream in lockstep, and all of them hit the same L2
+// channel at the same time.
+#ifndef M2M_HCHN_PAD
+#define M2M_HCHN_PAD 2304
+#endif
+static __host__ __device__ __forceinline__ long m2m_hchn_stride(long npair) { return npair * 2048 + M2M_HCHN_PAD; }
+
 // Which execution path a tower takes (see include/m2mixer.h): fused = whole samples per workgroup.
 static inline bool m2m_is_wide(const m2m_tower* t) { return t->N > 8 || t->D > 128; }
 

@@ -286,7 +286,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
                     // [column-tile pair q][32-row pair][16-row half u][lane][tile 2q: 4 bf16 | tile 2q+1: 4 bf16]: one full
                     // 16-byte-per-lane store per operand and step (1 KiB contiguous), and the weight-gradient wave that owns
                     // both column tiles reads it back with one 16-byte load per half
-                    const long off = (((long)q * npair + pair) * 2 + u) * 1024 + lane * 16;
+                    const long off = (long)q * m2m_hchn_stride(npair) + (pair * 2 + u) * 1024 + lane * 16;
                     __builtin_nontemporal_store(u32x4_t{pack_bf2(od[0][0], od[0][1]), pack_bf2(od[0][2], od[0][3]),
                                                         pack_bf2(od[1][0], od[1][1]), pack_bf2(od[1][2], od[1][3])},
                                                 reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(bk.dh_chn) + off));
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
                     // fp32: a 16-row half is a whole k-block: [column tile][32-row pair][half][lane][16 bytes]
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
-                        const long off = (((long)(2 * q + t) * npair + pair) * 2 + u) * 1024 + lane * 16;
+                        const long off = (long)(2 * q + t) * m2m_hchn_stride(npair) + (pair * 2 + u) * 1024 + lane * 16;
                         __builtin_nontemporal_store(od[t], reinterpret_cast<f32x4_t*>(reinterpret_cast<char*>(bk.dh_chn) + off));
                         __builtin_nontemporal_store(oa[t], reinterpret_cast<f32x4_t*>(reinterpret_cast<char*>(bk.h_chn) + off));
                     }

@@ -61,7 +61,7 @@ template <int P, int D> struct WgradGeom {
     static constexpr int RING_REGS = NLD * 4 + CPW * 2 * NF * 4;                      // VGPRs of one tile in flight
     static constexpr int DEPTH = (TPS == 1 && RING_REGS <= WG_RING_MAX) ? 2 : 1;      // steps of loads in flight
     static constexpr int COLS = WG_WAVES * CPW * 16;                                   // hidden columns per workgroup
-    static constexpr int MINWAVES = TPS > 1 ? 1 : 2;                                   // waves per SIMD the kernel is built for
+    static constexpr int MINWAVES = TPS > 2 ? 1 : 2;                                   // waves per SIMD the kernel is built for
     static_assert(TPS == 1 || DEPTH == 1, "multi-tile steps use a ring of one step");
 };
 
@@ -117,18 +117,14 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, i
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
                 const int o = min((i * WG_THREADS + tid) * 16, STAGE_B - 16);
-                const char* sp = o < IMG_B ? src_at : src_dyt;
-#ifdef M2M_EXP_NOSTAGE
-                p.st[u][i] = u32x4_t{(unsigned)o, 1u, 2u, (unsigned)tile};
-#else
-                p.st[u][i] = *reinterpret_cast<const u32x4_t*>(sp + (long)tile * IMG_B + (o < IMG_B ? o : o - IMG_B));
-#endif
+                const gptr_t sp = o < IMG_B ? src_at : src_dyt;
+                p.st[u][i] = *(const M2M_GLOBAL_AS u32x4_t*)(sp + (long)tile * IMG_B + (o < IMG_B ? o : o - IMG_B));
             }
             if (P == PREC_BF16) {
                 // [column-tile pair][32-row pair][16-row half][lane][tile 2q: 8 B | tile 2q+1: 8 B]  (written by tower_bwd.hip)
                 // read exactly once: non-temporal, so the stream does not evict the A^T / dYd^T tiles that the other column
                 // slices of this block re-read from L2
-                const long blk = ((long)(ctl[0] >> 1) * ntiles + tile) * 2048 + lane * 16;
+                const long blk = (long)(ctl[0] >> 1) * m2m_hchn_stride(ntiles) + (long)tile * 2048 + lane * 16;
                 if (CPW == 2) {                              // the wave owns both tiles of the pair: one 16-byte load per half
                     typedef const M2M_GLOBAL_AS u32x4_t* g4_t;
                     const u32x4_t h0 = __builtin_nontemporal_load((g4_t)(src_h + blk)), h1 = __builtin_nontemporal_load((g4_t)(src_h + blk + 1024));
@@ -152,7 +148,7 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, i
                 for (int j = 0; j < CPW; ++j) {
 #pragma unroll
                     for (int f = 0; f < NF; ++f) {           // fp32: [column tile][32-row pair][half = k-block f][lane][16 B]
-                        const long blk = (((long)ctl[j] * ntiles + tile) * NF + f) * 1024 + lane * 16;
+                        const long blk = (long)ctl[j] * m2m_hchn_stride(ntiles) + ((long)tile * NF + f) * 1024 + lane * 16;
                         p.h[u][j][f].u = __builtin_nontemporal_load((g4_t)(src_h + blk));
                         p.d[u][j][f].u = __builtin_nontemporal_load((g4_t)(src_dh + blk));
                     }
@@ -171,9 +167,6 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, i
 #pragma unroll
             for (int k = 0; k < NLD; ++k) {
                 const int o = (k * WG_THREADS + tid) * 16;
-#ifdef M2M_EXP_NOLDSWRITE
-                if (p.st[u][k][0] == 0x12345u)
-#endif
                 if (o < STAGE_B) {
                     if (P == PREC_BF16) {
                         // global block = [h][lane][8 B]; this 16-byte piece holds half h of lanes 2j, 2j + 1 -> 16-byte lane slots

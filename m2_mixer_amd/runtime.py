@@ -136,7 +136,7 @@ class TowerRuntime:
             for k in ("at_chn", "dyt_chn"):
                 bufs[k] = torch.zeros(img, dtype=torch.uint8, device=self.device)
             for k in ("h_chn", "dh_chn"):           # hidden activation / its gradient, transposed: rows x Cp elements
-                bufs[k] = torch.zeros(npairs * 32 * self.Cp * esz, dtype=torch.uint8, device=self.device)
+                bufs[k] = torch.zeros((self.Cp // 16) * (npairs * 2048 + L.HCHN_PAD), dtype=torch.uint8, device=self.device)
             for k, v in bufs.items():
                 setattr(self.desc.blk[i], k, v.data_ptr())
             self._keep[f"saved{i}"] = bufs
