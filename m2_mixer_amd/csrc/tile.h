@@ -217,9 +217,9 @@ static __device__ __forceinline__ void pack_tile_nat(const float* tile, char* im
 // fp32 tile [BM][XLD] -> this tile's part of the packed CHN image of the TRANSPOSE, X[i = d][k = m], m running
 // over a 32-row PAIR of tiles (blocks ordered [kb over the 32 rows][dt]); `pair_img` points at the pair's image,
 // `tile_in_pair` = 0/1 says which 16 rows this workgroup owns when BM == 16.
-//   bf16 (k-block = 32 rows): BM == 16 owns elements 4h .. 4h+3 of every lane; in GLOBAL memory a block is stored as its
-//        two halves back to back, [h][lane][8 bytes], so that each workgroup writes 512 contiguous bytes (full lines);
-//        the weight-gradient kernel re-interleaves them into 16-byte lane slots when it stages / loads the block.
+//   bf16 (k-block = 32 rows): BM == 16 fills one 8-byte half of every 16-byte lane slot (elements 4h .. 4h+3).  These
+//        images are small (D x 32 elements per pair): the half-slot writes cost nothing measurable, and the 16-byte slot
+//        layout lets the weight-gradient kernel stage a block with plain conflict-free 16-byte LDS writes.
 //   fp32 (k-block = 16 rows): BM == 16 fills k-block `tile_in_pair` whole.
 template <int P, int D>
 static __device__ __forceinline__ void pack_tile_chn_t(const float* tile, char* pair_img, int tile_in_pair, int tid) {
@@ -241,7 +241,7 @@ static __device__ __forceinline__ void pack_tile_chn_t(const float* tile, char* 
             uint2 o;
             o.x = pack_bf2(v0, v1);
             o.y = pack_bf2(v2, v3);
-            *reinterpret_cast<uint2*>(pair_img + dt * 1024 + tile_in_pair * 512 + lane * 8) = o;
+            *reinterpret_cast<uint2*>(pair_img + slot * 16 + tile_in_pair * 8) = o;
         }
     }
 }

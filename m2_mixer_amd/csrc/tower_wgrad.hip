@@ -61,6 +61,8 @@ template <int P, int D> struct WgradGeom {
     static constexpr int RING_REGS = NLD * 4 + CPW * 2 * NF * 4;                      // VGPRs of one tile in flight
     static constexpr int DEPTH = (TPS == 1 && RING_REGS <= WG_RING_MAX) ? 2 : 1;      // steps of loads in flight
     static constexpr int COLS = WG_WAVES * CPW * 16;                                   // hidden columns per workgroup
+    static constexpr int TR_B = WG_WAVES * 16 * (D + 4) * 4;                          // dW1 write-out transpose: 16 x (D + 4) floats per wave
+    static constexpr int LDS_B = 2 * TPS * STAGE_B > TR_B ? 2 * TPS * STAGE_B : TR_B;  // dynamic LDS of the kernel
     static constexpr int MINWAVES = TPS > 2 ? 1 : 2;                                   // waves per SIMD the kernel is built for
     static_assert(TPS == 1 || DEPTH == 1, "multi-tile steps use a ring of one step");
 };
@@ -167,17 +169,7 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, i
 #pragma unroll
             for (int k = 0; k < NLD; ++k) {
                 const int o = (k * WG_THREADS + tid) * 16;
-                if (o < STAGE_B) {
-                    if (P == PREC_BF16) {
-                        // global block = [h][lane][8 B]; this 16-byte piece holds half h of lanes 2j, 2j + 1 -> 16-byte lane slots
-                        const int blk = o >> 10, h = (o >> 9) & 1, jj = (o & 511) >> 4;
-                        char* dst = cur + blk * 1024 + (2 * jj) * 16 + h * 8;
-                        *reinterpret_cast<uint2*>(dst) = make_uint2(p.st[u][k][0], p.st[u][k][1]);
-                        *reinterpret_cast<uint2*>(dst + 16) = make_uint2(p.st[u][k][2], p.st[u][k][3]);
-                    } else {
-                        *reinterpret_cast<u32x4_t*>(cur + o) = p.st[u][k];
-                    }
-                }
+                if (o < STAGE_B) *reinterpret_cast<u32x4_t*>(cur + o) = p.st[u][k];
             }
         }
         Frag hf[TPS][CPW][NF], df[TPS][CPW][NF];
@@ -254,6 +246,38 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, i
     // no-return float atomics (a + b == b + a: still bit-deterministic); measured 2x slower per byte than the batched
     // read-modify-write, so only launches that need the split use them.
     if (single) {
+        // dW1 rows are contiguous in memory (row c = D floats) but the accumulators hold d across lanes and c in registers:
+        // 4-byte accesses in four 64-byte segments per instruction cost 17 us per workgroup.  Transpose each 16 x D tile
+        // through the (now free) LDS stage so that the read-modify-write runs on whole rows, 16 bytes per lane.
+        constexpr int TLD = D + 4;                           // padded row (floats): the four g-groups land in different banks
+        __syncthreads();                                     // every wave is done reading the stage
+        float* tr = reinterpret_cast<float*>(smem) + wave * 16 * TLD;
+#pragma unroll
+        for (int j = 0; j < CPW; ++j) {
+            const int ct = ct0 + j;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tr[(4 * g + r) * TLD + 16 * dt + il] = dw1[j][dt][r];
+            // (one wave: LDS accesses of a wave complete in order, no barrier needed)
+            if (ct < nct) {
+                constexpr int PER = 16 * D / (64 * 4);       // float4 pieces per lane
+                f32x4_t v[PER];
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    const int idx = i * 64 + lane, row = idx / (D / 4), c4 = idx % (D / 4);
+                    v[i] = *reinterpret_cast<const f32x4_t*>(tr + row * TLD + 4 * c4);
+                    const int c = 16 * ct + row;
+                    if (c < C) v[i] = v[i] + *reinterpret_cast<const f32x4_t*>(bk.g_ch_w1 + (long)c * D + 4 * c4);
+                }
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    const int idx = i * 64 + lane, row = idx / (D / 4), c4 = idx % (D / 4);
+                    const int c = 16 * ct + row;
+                    if (c < C) *reinterpret_cast<f32x4_t*>(bk.g_ch_w1 + (long)c * D + 4 * c4) = v[i];
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < CPW; ++j) {
             if (ct0 + j >= nct) continue;
@@ -262,9 +286,6 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, i
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 const int d = 16 * dt + il;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (c0 + r < C) dw1[j][dt][r] += bk.g_ch_w1[(long)(c0 + r) * D + d];
                 const float* p2 = bk.g_ch_w2 + (long)d * C + c0;    // four consecutive c of row d
                 if (vec) {
                     dw2[j][dt] = dw2[j][dt] + *reinterpret_cast<const f32x4_t*>(p2);
@@ -283,9 +304,6 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, i
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 const int d = 16 * dt + il;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (c0 + r < C) bk.g_ch_w1[(long)(c0 + r) * D + d] = dw1[j][dt][r];
                 float* p2 = bk.g_ch_w2 + (long)d * C + c0;
                 if (vec) {
                     *reinterpret_cast<f32x4_t*>(p2) = dw2[j][dt];
@@ -361,7 +379,7 @@ static WgradPlan wgrad_plan(const m2m_tower* t, int B);
 template <int P, int D>
 static int launch_wgrad(const m2m_tower* t, int B, hipStream_t st) {
     const WgradPlan pl = wgrad_plan<P, D>(t, B);
-    const size_t lds = (size_t)2 * WgradGeom<P, D>::TPS * WgradGeom<P, D>::STAGE_B;
+    const size_t lds = (size_t)WgradGeom<P, D>::LDS_B;
     auto kern = tower_wgrad_kernel<P, D>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -399,7 +417,7 @@ static int launch_wgrad_group(const m2m_tower* const* host, const m2m_tower* con
         }
     }
     if (njobs == 0) return 0;
-    const size_t lds = (size_t)2 * WgradGeom<P, D>::TPS * WgradGeom<P, D>::STAGE_B;
+    const size_t lds = (size_t)WgradGeom<P, D>::LDS_B;
     auto kern = tower_wgrad_group_kernel<P, D>;
     static bool attr_done = false;
     if (!attr_done) {
