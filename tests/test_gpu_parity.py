@@ -488,3 +488,91 @@ def test_data_parallel_step_path_matches_fused_step(dev):
     da, db = a.flat_p - p0, b.flat_p - p0
     assert float((da - db).abs().max()) <= 2e-3 * 3 * 0.51      # a few sign flips of ~0 gradients at most (lr = 1e-3, 3 steps)
     assert float((da.sign() == db.sign()).float().mean()) > 0.995
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the callers: Lightning-free task modules with the reference's constructor / shared_step contract (models.py)
+# ---------------------------------------------------------------------------------------------------------------
+def _model_cfg(task):
+    if task == "avmnist":
+        c = G.AVMNIST["S"]
+        mods = {"image": dict(c["image"], block_type="MLPMixer"), "audio": dict(c["audio"], block_type="MLPMixer"),
+                "multimodal": dict(c["multimodal"], block_type="FusionMixer", fusion_function="ConcatFusion")}
+        hid = c["multimodal"]["hidden_dim"]
+    elif task == "mimic":
+        c = G.MIMIC_H
+        mods = {"static": dict(c["static"], block_type="MLP"), "time": dict(c["time"], block_type="MLPMixerNoPatching"),
+                "multimodal": dict(c["multimodal"], block_type="FusionMixer", fusion_function="ConcatFusion")}
+        hid = c["multimodal"]["hidden_dim"]
+    else:
+        c = G.MMIMDB
+        mods = {"image": dict(c["image"], block_type="MLPMixer"), "text": dict(c["text"], block_type="MLPMixer"),
+                "multimodal": dict(c["multimodal"], block_type="FusionMixer", fusion_function="ConcatFusion")}
+        hid = c["multimodal"]["hidden_dim"]
+    mods["classification"] = dict(classifier="StandardClassifier", num_classes=c["num_classes"], input_shape=[16, 49, hid])
+    cfg = {"dropout": 0.0, "modalities": mods}
+    if task == "mmimdb":
+        cfg["pos_weight"] = c["pos_weight"]
+    return cfg, c
+
+
+@pytest.mark.parametrize("task", ["avmnist", "mimic", "mmimdb"])
+def test_task_modules_shared_step_vs_reference_golden(task, dev):
+    """AVMnistMixerMultiLoss / MimicMixerMultiLoss / MMIMDBMixerMultiLoss built from cfg dicts like the reference builds
+    them (registry, `.num_patch`, fusion shape algebra), weights loaded through the reference's state-dict keys, fp32
+    mode: shared_step's logits / losses and the autograd gradients against the reference's recorded vectors."""
+    import m2_mixer_amd as M
+    from m2_mixer_amd import models as MD
+    M.set_precision("fp32")
+    model_cfg, c = _model_cfg(task)
+    opt_cfg = {"lr": 1e-2, "betas": (0.9, 0.999), "scheduler_patience": 2}
+    if task == "avmnist":
+        gold, seed, B = load("avmnist_S.npz"), 11, 8
+        net = MD.AVMnistMixerMultiLoss(model_cfg, opt_cfg).to(dev)
+        shapes = G.avmnist_shapes(dict(c, dropout=0.0))
+        image, audio, labels = (t.to(dev) for t in G.avmnist_batch(B, seed + 1, c))
+        batch = {"image": image, "audio": audio, "label": labels}
+        names = {"logits": "step0//logits", "image_logits": "step0//image_logits", "audio_logits": "step0//audio_logits",
+                 "loss": "step0//loss", "loss_image": "step0//loss_image", "loss_audio": "step0//loss_audio",
+                 "loss_fusion": "step0//loss_fusion"}
+    elif task == "mimic":
+        gold, seed, B = load("mimic_H.npz"), 31, 6
+        net = MD.MimicMixerMultiLoss(model_cfg, opt_cfg).to(dev)
+        shapes = G.mimic_shapes(c)
+        batch = tuple(t.to(dev) for t in G.mimic_batch(B, 32, c))
+        names = {k: k for k in ("logits", "logits_static", "logits_time", "loss", "loss_fusion", "loss_static", "loss_time")}
+    else:
+        gold, seed, B = load("mmimdb.npz"), 51, 3
+        net = MD.MMIMDBMixerMultiLoss(model_cfg, opt_cfg).to(dev)
+        shapes = G.mmimdb_shapes(c)
+        image, text, labels = (t.to(dev) for t in G.mmimdb_batch(B, 52, c))
+        batch = {"image": image, "text": text, "label": labels}
+        names = {k: k for k in ("logits", "image_logits", "text_logits", "loss", "loss_image", "loss_text", "loss_fusion")}
+    assert list(net.state_dict().keys()) == list(shapes.keys()), "state-dict keys / creation order must match the reference"
+    net.load_state_dict(G.make_params(shapes, seed))
+    net.train()
+    out = net.shared_step(batch, mode="train")
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    for k, gk in names.items():
+        check(gold, gk, out[k], FP32_ATOL)
+    if task == "avmnist":
+        assert np.array_equal(out["preds"].cpu().numpy(), gold["step0//preds"])
+    if task == "mmimdb":
+        assert np.array_equal(out["preds"].cpu().numpy(), gold["preds"])
+    for k, prm in net.named_parameters():
+        check(gold, f"grad//{k}", prm.grad, 1e-4, 1e-3, what="grad ")
+    opt = net.configure_optimizers()
+    assert isinstance(opt["optimizer"], torch.optim.Adam) and opt["monitor"] == "val_loss"
+    # the fused engine over the same weights gives the same losses
+    eng = net.to_engine(B, precision="fp32")
+    eb = tuple(batch.values()) if isinstance(batch, dict) else batch
+    res = eng.evaluate(*eb)
+    assert abs(float(res["loss"]) - float(out["loss"].detach())) < FP32_ATOL
+    # freezing the unimodal parts (models/avmnist.py:314-324): their parameters stop requiring grad, training loss = fusion loss
+    if task != "mimic":
+        net._freeze_modalities()
+        o2 = net.shared_step(batch, mode="train")
+        assert float((o2["loss"] - o2["loss_fusion"]).detach().abs()) == 0.0
+        assert not any(p.requires_grad for p in net.image_mixer.parameters())
+        assert all(p.requires_grad for p in net.fusion_mixer.parameters())

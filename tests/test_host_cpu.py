@@ -85,12 +85,9 @@ def test_no_patching_and_mlp_keys():
     m.time_mixer, m.static_extractor = t, st
     want = [k for k in G.mimic_shapes(cfg) if k.startswith(("time_mixer.", "static_extractor."))]
     assert list(m.state_dict().keys()) == want
-    # MLP is plain torch: runs on CPU and matches the oracle
-    from oracle import m2mixer_oracle as O
-    x = torch.randn(7, 5)
-    st.eval()
-    p = {"s." + k: v for k, v in st.state_dict().items()}
-    assert torch.allclose(st(x), O.mlp(x, p, "s.", 2, True), atol=1e-6)
+    # like every module here the MLP runs in the HIP library only (csrc/mlp.hip): a CPU tensor is refused
+    with pytest.raises(RuntimeError, match="GPU only"):
+        st(torch.randn(7, 5))
 
 
 def test_cpu_tensors_fail_loudly():
@@ -222,3 +219,46 @@ def test_bench_cli_contract_help():
     assert r.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup"):
         assert flag in r.stdout
+
+
+def test_task_module_surface_and_no_cpu_path():
+    """models.py mirrors the reference's task modules: built from cfg dicts through the registry, state-dict keys in the
+    reference's creation order (checkpoint compatibility), optimizer as configured at models/avmnist.py:413-422 -- and,
+    like every module here, no CPU compute path."""
+    import torch
+    from m2_mixer_amd import models as MD
+    for task, cls, shapes_fn, c in (("avmnist", MD.AVMnistMixerMultiLoss, G.avmnist_shapes, G.AVMNIST["S"]),
+                                    ("mimic", MD.MimicMixerMultiLoss, G.mimic_shapes, G.MIMIC_H),
+                                    ("mmimdb", MD.MMIMDBMixerMultiLoss, G.mmimdb_shapes, G.MMIMDB)):
+        fusion = dict(c["multimodal"], block_type="FusionMixer", fusion_function="ConcatFusion")
+        if task == "mimic":
+            mods = {"static": dict(c["static"], block_type="MLP"), "time": dict(c["time"], block_type="MLPMixerNoPatching")}
+        else:
+            a, b = ("image", "audio") if task == "avmnist" else ("image", "text")
+            mods = {a: dict(c[a], block_type="MLPMixer"), b: dict(c[b], block_type="MLPMixer")}
+        mods["multimodal"] = fusion
+        mods["classification"] = dict(classifier="StandardClassifier", num_classes=c["num_classes"],
+                                      input_shape=[16, 49, c["multimodal"]["hidden_dim"]])
+        cfg = {"dropout": c["dropout"], "modalities": mods}
+        if task == "mmimdb":
+            cfg["pos_weight"] = c["pos_weight"]
+        net = cls(cfg, {"lr": 1e-2, "scheduler_patience": 2})
+        shapes = shapes_fn(c)
+        sd = net.state_dict()
+        assert list(sd.keys()) == list(shapes.keys()), task
+        assert all(tuple(sd[k].shape) == tuple(shapes[k]) for k in shapes), task
+        opt = net.configure_optimizers()
+        assert isinstance(opt["optimizer"], torch.optim.Adam) and opt["optimizer"].defaults["lr"] == 1e-2
+        assert opt["lr_scheduler"].patience == 2 and opt["monitor"] == "val_loss"
+        with pytest.raises(NotImplementedError):
+            cls(dict(cfg, use_softadapt=True), {"lr": 1e-2})
+    net = MD.MimicMixerMultiLoss(cfg if task == "mimic" else
+                                 {"dropout": 0.0, "modalities": {"static": dict(G.MIMIC_H["static"], block_type="MLP"),
+                                                                 "time": dict(G.MIMIC_H["time"], block_type="MLPMixerNoPatching"),
+                                                                 "multimodal": dict(G.MIMIC_H["multimodal"], block_type="FusionMixer",
+                                                                                    fusion_function="ConcatFusion"),
+                                                                 "classification": dict(classifier="StandardClassifier", num_classes=6,
+                                                                                        input_shape=[16, 25, 64])}},
+                                 {"lr": 1e-2})
+    with pytest.raises(RuntimeError, match="GPU only"):
+        net.shared_step(G.mimic_batch(2, 1, G.MIMIC_H))
