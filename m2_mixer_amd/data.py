@@ -1,0 +1,123 @@
+"""Resident-in-HBM input pipeline and the epoch loop around the fused engines.
+
+The reference feeds the model through a torch DataLoader with `num_workers: 2` (datasets/avmnist.py:163-190) and pulls
+`loss.cpu().item()` to the host every step (modules/train_test_module.py:72-84).  At > 600 k samples/s neither survives:
+the whole AV-MNIST training split is 55 000 x 53 KB = 2.9 GB in fp32, a rounding error of one MI355X's 288 GB, so it
+is loaded ONCE into device memory in the reference's on-disk format and batches are views (train / val: `shuffle=False`
+in the reference) or one device-side gather (test: `shuffle=True`); per-step losses and hit counts accumulate in device
+memory and reach the host once per `log_interval_steps`, so the captured graph is never interrupted by a sync.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Iterator, Optional, Tuple
+
+import numpy as np
+import torch
+
+
+class ResidentAVMnist:
+    """`root/{image,audio}/{train,test}_data.npy`, `root/{train,test}_labels.npy` (datasets/avmnist.py:105-114):
+    image (N, 784) or (N, 28, 28) -> (N, 1, 28, 28); audio (N, 112, 112) -> (N, 1, 112, 112); `astype(float32)` only
+    (datasets/avmnist.py:17-21).  Splits as AVMnistDataModule.setup (:175-181): the first 55 000 training samples train,
+    the rest validate; smaller sets (tests, subsets) keep the 11 : 1 proportion."""
+
+    TRAIN_SPLIT = 55000
+
+    def __init__(self, root_dir: str, device="cuda:0", rank: int = 0, world: int = 1):
+        self.device = torch.device(device)
+        self.rank, self.world = rank, world
+        self.splits: Dict[str, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = {}
+        tr = self._load(root_dir, "train")
+        n = tr[2].shape[0]
+        cut = self.TRAIN_SPLIT if n > self.TRAIN_SPLIT else (n * 11) // 12
+        self.splits["train"] = tuple(t[:cut] for t in tr)
+        self.splits["val"] = tuple(t[cut:] for t in tr)
+        if os.path.exists(os.path.join(root_dir, "test_labels.npy")):
+            self.splits["test"] = self._load(root_dir, "test")
+
+    def _load(self, root: str, stage: str):
+        image = np.load(os.path.join(root, "image", f"{stage}_data.npy"))
+        audio = np.load(os.path.join(root, "audio", f"{stage}_data.npy"))
+        labels = np.load(os.path.join(root, f"{stage}_labels.npy"))
+        if image.shape[0] != audio.shape[0] or image.shape[0] != labels.shape[0]:
+            raise ValueError(f"{stage}: image / audio / label counts differ")
+        image = torch.from_numpy(image.astype(np.float32)).reshape(image.shape[0], 1, 28, 28)
+        audio = torch.from_numpy(audio.astype(np.float32))[:, None, :, :]
+        labels = torch.from_numpy(labels.astype(np.int64))
+        return image.to(self.device), audio.to(self.device), labels.to(self.device)
+
+    def num_batches(self, split: str, batch_size: int) -> int:
+        n = self.splits[split][2].shape[0]
+        per_rank = (n + self.world - 1) // self.world
+        return per_rank // batch_size                     # full batches only: the captured graph has a static batch size
+
+    def batches(self, split: str, batch_size: int, shuffle: bool = False,
+                generator: Optional[torch.Generator] = None) -> Iterator[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
+        """Rank r takes samples r, r + world, ... (what Lightning's DistributedSampler(shuffle=False) hands a DDP rank)."""
+        image, audio, labels = self.splits[split]
+        n = labels.shape[0]
+        if shuffle:
+            order = torch.randperm(n, device=self.device, generator=generator)
+        elif self.world > 1:
+            order = torch.arange(n, device=self.device)
+        else:
+            order = None
+        if order is not None and self.world > 1:
+            order = order[self.rank::self.world]
+        for b in range(self.num_batches(split, batch_size)):
+            lo, hi = b * batch_size, (b + 1) * batch_size
+            if order is None:
+                yield image[lo:hi], audio[lo:hi], labels[lo:hi]          # views: zero copies
+            else:
+                idx = order[lo:hi]
+                yield image.index_select(0, idx), audio.index_select(0, idx), labels.index_select(0, idx)
+
+
+class PlateauLR:
+    """torch.optim.lr_scheduler.ReduceLROnPlateau(mode='min', factor=0.1, threshold=1e-4 rel) on the engine's device-side
+    learning rate (models/avmnist.py:416-422: monitor `val_loss`, patience from `scheduler_patience`)."""
+
+    def __init__(self, engine, lr: float, patience: int = 5, factor: float = 0.1, threshold: float = 1e-4, min_lr: float = 0.0):
+        self.engine, self.lr, self.patience, self.factor, self.threshold, self.min_lr = engine, lr, patience, factor, threshold, min_lr
+        self.best, self.bad = float("inf"), 0
+
+    def step(self, metric: float) -> float:
+        if metric < self.best * (1 - self.threshold):
+            self.best, self.bad = metric, 0
+        else:
+            self.bad += 1
+        if self.bad > self.patience:
+            self.lr = max(self.lr * self.factor, self.min_lr)
+            self.engine.set_lr(self.lr)
+            self.bad = 0
+        return self.lr
+
+
+def run_epoch(engine, data: ResidentAVMnist, split: str, batch_size: int, train: bool, log_interval_steps: int = 50,
+              replay=None, log=None) -> Dict[str, float]:
+    """One pass over `split`.  train=True drives the captured step (`replay`, from engine.capture) or engine.train_step;
+    losses (per head + total) and the fusion head's hit count are summed on the device and read back every
+    `log_interval_steps` steps and at the end (cfg `log_interval_steps`, cfg/avmnist/*.yml:3)."""
+    dev = engine.device
+    acc = torch.zeros(5, device=dev, dtype=torch.float64)        # [loss_a, loss_b, loss_fusion, loss, hits]
+    seen, host = 0, np.zeros(5)
+    nb = data.num_batches(split, batch_size)
+    for i, (image, audio, labels) in enumerate(data.batches(split, batch_size, shuffle=(split == "test"))):
+        if train:
+            if replay is not None:
+                replay(image, audio, labels)
+            else:
+                engine.train_step(image, audio, labels)
+        else:
+            engine.evaluate(image, audio, labels)
+        acc[:4] += engine.losses                                   # device-side: no host round trip
+        acc[4] += (engine.preds[2] == labels).sum()
+        seen += batch_size
+        if (i + 1) % log_interval_steps == 0 or i + 1 == nb:
+            host = acc.cpu().numpy()                               # the only sync of the interval
+            if log is not None:
+                log({"split": split, "step": i + 1, "loss": host[3] / (i + 1), "acc": host[4] / seen})
+    steps = max(nb, 1)
+    return {"loss": float(host[3]) / steps, "loss_fusion": float(host[2]) / steps, "acc": float(host[4]) / max(seen, 1),
+            "steps": nb, "samples": seen}

@@ -576,3 +576,33 @@ def test_task_modules_shared_step_vs_reference_golden(task, dev):
         assert float((o2["loss"] - o2["loss_fusion"]).detach().abs()) == 0.0
         assert not any(p.requires_grad for p in net.image_mixer.parameters())
         assert all(p.requires_grad for p in net.fusion_mixer.parameters())
+
+
+def test_resident_pipeline_trains_end_to_end(dev, tmp_path):
+    """SURVEY section 8f rows f1-f3 together: dataset in the reference's .npy layout resident in HBM, batches as views,
+    the captured training step, device-side loss / accuracy accumulators, ReduceLROnPlateau on the device-side lr: two
+    epochs on a small learnable set must classify the held-out split."""
+    from test_host_cpu import _write_avmnist
+    from m2_mixer_amd.data import PlateauLR, ResidentAVMnist, run_epoch
+    from m2_mixer_amd.engine import AVMnistEngine
+    root = str(tmp_path / "avmnist")
+    _write_avmnist(root, 1440, 100, seed=3, learnable=True)
+    data = ResidentAVMnist(root, device=dev)
+    cfg, B = dict(G.AVMNIST["S"]), 120
+    eng = AVMnistEngine(cfg, B, device=dev, precision="bf16", lr=3e-3, seed=0)
+    image, audio, labels = next(iter(data.batches("train", B)))
+    replay = eng.capture(image, audio, labels)
+    sched = PlateauLR(eng, 3e-3, patience=2)
+    logs = []
+    first = run_epoch(eng, data, "val", B, train=False)
+    for _ in range(4):
+        tr = run_epoch(eng, data, "train", B, train=True, log_interval_steps=4, replay=replay, log=logs.append)
+        va = run_epoch(eng, data, "val", B, train=False)
+        sched.step(va["loss"])
+    assert tr["steps"] == 11 and tr["samples"] == 1320 and len(logs) >= 4 * 3
+    assert va["loss"] < 0.5 * first["loss"] and va["acc"] > 0.8, (first, va)
+    # the test split (shuffled on the device) through a second engine sized for its batch, same weights
+    small = AVMnistEngine(cfg, 100, device=dev, precision="bf16", lr=3e-3, seed=0)
+    small.load_state_dict(eng.state_dict())
+    te = run_epoch(small, data, "test", 100, train=False)
+    assert te["acc"] > 0.8, te

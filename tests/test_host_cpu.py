@@ -262,3 +262,58 @@ def test_task_module_surface_and_no_cpu_path():
                                  {"lr": 1e-2})
     with pytest.raises(RuntimeError, match="GPU only"):
         net.shared_step(G.mimic_batch(2, 1, G.MIMIC_H))
+
+
+def _write_avmnist(root, n_train, n_test, seed=0, learnable=False):
+    """A tiny dataset in the reference's on-disk format (datasets/avmnist.py:105-114)."""
+    rng = np.random.default_rng(seed)
+    os.makedirs(os.path.join(root, "image"), exist_ok=True)
+    os.makedirs(os.path.join(root, "audio"), exist_ok=True)
+    for stage, n in (("train", n_train), ("test", n_test)):
+        labels = rng.integers(0, 10, size=n)
+        image = rng.random((n, 784), dtype=np.float32)
+        audio = rng.random((n, 112, 112), dtype=np.float32)
+        if learnable:                         # class k brightens image rows / audio rows of band k
+            for i, k in enumerate(labels):
+                image[i].reshape(28, 28)[2 * k:2 * k + 3, :] += 2.0
+                audio[i, 11 * k:11 * k + 11, :] += 1.0
+        np.save(os.path.join(root, "image", f"{stage}_data.npy"), image)
+        np.save(os.path.join(root, "audio", f"{stage}_data.npy"), audio)
+        np.save(os.path.join(root, f"{stage}_labels.npy"), labels)
+
+
+def test_resident_dataset_format_splits_and_sharding(tmp_path):
+    from m2_mixer_amd.data import PlateauLR, ResidentAVMnist
+    root = str(tmp_path / "avmnist")
+    _write_avmnist(root, 240, 30)
+    ds = ResidentAVMnist(root, device="cpu")
+    image, audio, labels = ds.splits["train"]
+    assert tuple(image.shape) == (220, 1, 28, 28) and tuple(audio.shape) == (220, 1, 112, 112) and labels.dtype == torch.int64
+    assert ds.splits["val"][2].shape[0] == 20 and ds.splits["test"][2].shape[0] == 30        # 11 : 1 as 55 000 : 5 000
+    raw = np.load(os.path.join(root, "image", "train_data.npy"))
+    assert np.array_equal(image[:, 0].reshape(220, 784).numpy(), raw[:220])
+    got = list(ds.batches("train", 50))
+    assert len(got) == 4 == ds.num_batches("train", 50)
+    assert got[1][0].data_ptr() == image[50:100].data_ptr(), "unshuffled single-rank batches must be views"
+    # two ranks: disjoint strided shards, as DistributedSampler(shuffle=False) hands them out
+    r0 = torch.cat([b[2] for b in ResidentAVMnist(root, "cpu", 0, 2).batches("train", 55)])
+    r1 = torch.cat([b[2] for b in ResidentAVMnist(root, "cpu", 1, 2).batches("train", 55)])
+    assert torch.equal(r0, labels[0::2]) and torch.equal(r1, labels[1::2])
+    # shuffled test split: a permutation
+    t = torch.cat([b[2] for b in ds.batches("test", 10, shuffle=True, generator=torch.Generator().manual_seed(1))])
+    assert sorted(t.tolist()) == sorted(ds.splits["test"][2].tolist())
+
+    class FakeEngine:
+        lr = None
+
+        def set_lr(self, lr):
+            self.lr = lr
+
+    eng = FakeEngine()
+    sch = PlateauLR(eng, 1e-2, patience=2)
+    ref_opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1e-2)
+    ref = torch.optim.lr_scheduler.ReduceLROnPlateau(ref_opt, patience=2)
+    for v in (1.0, 0.9, 0.95, 0.93, 0.92, 0.91, 0.5, 0.6, 0.6, 0.6, 0.6):
+        ref.step(v)
+        assert abs(sch.step(v) - ref_opt.param_groups[0]["lr"]) < 1e-12, v
+    assert eng.lr is not None and eng.lr < 1e-2
