@@ -129,6 +129,9 @@ def main():
     ap.add_argument("--model", default="B", choices=["B", "S"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--steps-per-graph", type=int, default=5,
+                    help="N = 1: training steps captured per hipGraph (each with its own input slot); the replay gap between "
+                         "graphs is ~17 us.  Remainder steps run through a single-step graph")
     ap.add_argument("--grad-compress", default="bf16", choices=["none", "bf16"],
                     help="N > 1: dtype of the gradient all-reduce.  bf16 (default: the step computes in bf16 anyway; the "
                          "equivalent of DDP's bf16_compress_hook) halves the bytes on xGMI; none = fp32, exact DDP semantics")
@@ -156,14 +159,26 @@ def main():
     compress = None if args.grad_compress == "none" or args.precision == "fp32" else args.grad_compress
     sync = parallel.GradSync(compress=compress) if world > 1 else None
 
+    spg = 1 if (args.no_graph or world > 1) else max(1, args.steps_per_graph)
     if args.no_graph:
         def step():
             eng.train_step(image, audio, labels, grad_sync=sync)
+        multi = None
     else:
         replay = eng.capture(image, audio, labels, grad_sync=sync)
 
         def step():
             replay()
+        multi = eng.capture(image, audio, labels, steps=spg) if spg > 1 else None
+
+    def run_steps(n):
+        """n training steps: as many multi-step graphs as fit, the remainder one step at a time."""
+        if multi is not None:
+            for _ in range(n // spg):
+                multi()
+            n = n % spg
+        for _ in range(n):
+            step()
 
     def barrier():
         if world > 1:
@@ -171,13 +186,11 @@ def main():
         torch.cuda.synchronize()
 
     log("warm-up")
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     barrier()
     log(f"timing {args.steps} steps")
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     barrier()
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
     loss_end = float(eng.losses[3])
@@ -203,7 +216,7 @@ def main():
         "dtype": args.precision, "data": "synthetic",
         "config": {"workload": f"AV-MNIST M2-Mixer-{args.model}: fwd + bwd + Adam, dropout {cfg['dropout']}, per-GPU batch {B}, "
                                f"global batch {B * world}, {eng.n_params} params",
-                   "parallelism": f"dp{world}", "launch": "eager" if args.no_graph else "hipGraph",
+                   "parallelism": f"dp{world}", "launch": "eager" if args.no_graph else ("hipGraph" if spg == 1 else f"hipGraph, {spg} steps per graph"),
                    "grad_allreduce": (compress or "fp32") if world > 1 else None},
         "roofline": roof,
         "step_mfma_frac": round(world * B * args.steps / elapsed / world * flops_step / B / (peak * 1e12), 4),

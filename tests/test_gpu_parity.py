@@ -606,3 +606,30 @@ def test_resident_pipeline_trains_end_to_end(dev, tmp_path):
     small.load_state_dict(eng.state_dict())
     te = run_epoch(small, data, "test", 100, train=False)
     assert te["acc"] > 0.8, te
+
+
+def test_multi_step_graph_equals_single_steps(dev):
+    """capture(steps=3): three consecutive training steps (own input slots, own dropout draws, own Adam steps) in one
+    hipGraph give the per-step losses of three single-step replays."""
+    from m2_mixer_amd.engine import AVMnistEngine
+    cfg, B = dict(G.AVMNIST["S"]), 32
+    batches = [tuple(t.to(dev) for t in G.avmnist_batch(B, 40 + i, cfg)) for i in range(3)]
+    a = AVMnistEngine(cfg, B, device=dev, precision="bf16", lr=1e-3, seed=5)
+    b = AVMnistEngine(cfg, B, device=dev, precision="bf16", lr=1e-3, seed=5)
+    ra = a.capture(*batches[0])
+    rb = b.capture(*batches[0], steps=3)
+    for e in (a, b):                        # rewind what the capture warm-ups changed
+        e.load_state_dict(AVMnistEngine(cfg, B, device=dev, precision="bf16", lr=1e-3, seed=5).state_dict())
+        e.flat_m.zero_(); e.flat_v.zero_(); e.flat_g.zero_(); e.adam_state[0] = 0.0; e.drop_step.zero_()
+    singles = []
+    for bt in batches:
+        ra(*bt)
+        singles.append(a.losses.clone())
+    multi = rb(*[t for bt in batches for t in bt]).clone()
+    torch.cuda.synchronize()
+    assert multi.shape == (3, 4)
+    for i in range(3):
+        assert torch.allclose(multi[i], singles[i], rtol=0, atol=2e-3), (i, multi[i], singles[i])
+    assert float(b.adam_state[0]) == 3.0 and int(b.drop_step[0]) == 3
+    with pytest.raises(ValueError):
+        rb(*batches[0])                     # a 3-step graph wants 3 batches (or none: reuse the slots)
