@@ -27,6 +27,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense peaks, MI355X_MICROARCH.md "Chip-level parameters"
+# HBM bytes per launch (read + written) from the rocprofv3 PMC passes of this round -- FETCH_SIZE (doubled: the gfx950
+# correction) + WRITE_SIZE, M2-Mixer-B, batch 512, bf16: profiles/r01_pmc_summary.md.  PMC counters cannot be collected from
+# inside the benchmark process; refresh the table when a kernel changes.
+PMC_TRAFFIC_BYTES_B512_BF16 = {
+    "tower_bwd[image]": 207.0e6, "tower_bwd[audio]": 207.0e6, "tower_bwd[fusion]": 171.2e6,
+    "tower_fwd[image]": 62.8e6, "tower_fwd[audio]": 62.8e6, "tower_fwd[fusion]": 40.8e6,
+    "towers_wgrad[all]": 505.8e6,
+}
 
 # AV-MNIST M2-Mixer-B  (reference cfg/avmnist/avmnist_m2-mixer_B.yml:24-56)
 CFG_B = dict(dropout=0.5, num_classes=10,
@@ -207,7 +215,8 @@ def main():
     peak = MFMA_PEAK_TFLOPS[args.precision]
     dom = max(kern.items(), key=lambda kv: kv[1]["us_per_step"])
     roof = {"bound": "mfma", "kernel": dom[0], "achieved": round(dom[1]["flops_per_launch"] / (dom[1]["us_per_launch"] * 1e-6) / 1e12, 2),
-            "peak": peak, "unit": "TFLOP/s", "traffic": None}
+            "peak": peak, "unit": "TFLOP/s",
+            "traffic": PMC_TRAFFIC_BYTES_B512_BF16.get(dom[0]) if (args.model == "B" and B == 512 and args.precision == "bf16") else None}
     roof["frac"] = round(roof["achieved"] / peak, 4)
     out = {
         "metric": "training samples/sec AV-MNIST M2-Mixer-%s %s" % (args.model, args.precision),

@@ -34,7 +34,7 @@ def main(root):
           "| VALU insts / MFMA inst | issue-stall / wave cycles |")
     print("|---|---|---|---|---|---|---|---|---|")
     for (k, grid), c in sorted(agg.items()):
-        mean = {n: sum(v) / len(v) for n, v in c.items()}
+        mean = {n: sorted(v)[len(v) // 2] for n, v in c.items()}       # median: the first launch of a kernel is an outlier
         n = len(next(iter(c.values())))
         rd = 2 * mean.get("FETCH_SIZE", 0) * 1024 / 1e6
         wr = mean.get("WRITE_SIZE", 0) * 1024 / 1e6
