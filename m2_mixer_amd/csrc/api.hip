@@ -91,11 +91,6 @@ extern "C" int m2m_pack(int prec, int mode, int order_k_major, const float* src,
     return pack_impl(prec, mode, order_k_major, src, stride_i, stride_k, I, K, I, K, dst, stream);
 }
 
-__global__ void pad_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int np) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < np) dst[i] = i < n ? src[i] : 0.f;
-}
-
 // All packed copies of every block of a tower in ONE launch: blockIdx.y = 5 * block + which,
 // which: 0 w1n, 1 w1tc, 2 w2c, 3 w2tn (same layouts as pack_impl), 4 ch_b1p.
 template <int P>

@@ -87,26 +87,6 @@ static __device__ __forceinline__ float bf2f(unsigned short b) {
     return __builtin_bit_cast(float, (unsigned int)b << 16);
 }
 
-// Store ONE element into a packed image in LDS/global: logical (i, k) of the matrix the image holds.
-// nkb_stride / nib_stride: block index = ib * s_i + kb * s_k.
-template <int P>
-static __device__ __forceinline__ void st_packed_elem(char* base, int mode, int i, int k, int s_i, int s_k, float v) {
-    typedef Prec<P> Pr;
-    const int ib = i >> 4, il = i & 15;
-    const int kb = k / Pr::KB, kl = k % Pr::KB;
-    int g, e;
-    if (P == PREC_BF16) {
-        if (mode == PACK_NAT) { g = kl >> 3; e = kl & 7; }
-        else { g = (kl >> 2) & 3; e = ((kl >> 4) << 2) | (kl & 3); }
-    } else {
-        if (mode == PACK_NAT) { g = kl & 3; e = kl >> 2; }
-        else { g = kl >> 2; e = kl & 3; }
-    }
-    char* p = base + (long)(ib * s_i + kb * s_k) * 1024 + (g * 16 + il) * 16 + e * Pr::ESZ;
-    if (P == PREC_BF16) *reinterpret_cast<unsigned short*>(p) = f2bf(v);
-    else *reinterpret_cast<float*>(p) = v;
-}
-
 // ---- math -----------------------------------------------------------------------------------------
 // erf(x) as an odd rational polynomial on [-4, 4] (|err| < 5e-7, checked against scipy in
 // tests/test_host_math.py); no exp, one reciprocal.  Coefficients: the float erf rational used by Eigen.
@@ -210,16 +190,6 @@ static __device__ __forceinline__ bool drop_keep(const Drop& d, unsigned int idx
     const unsigned int r = (idx & 1) ? (w >> 16) : (w & 0xFFFFu);
     return r < d.thr;
 }
-// four consecutive elements idx0..idx0+3, idx0 % 4 == 0  -> two hashes
-static __device__ __forceinline__ void drop_keep4(const Drop& d, unsigned int idx0, bool keep[4]) {
-    const unsigned int w0 = mix32(d.key ^ (idx0 >> 1));
-    const unsigned int w1 = mix32(d.key ^ ((idx0 >> 1) + 1));
-    keep[0] = (w0 & 0xFFFFu) < d.thr;
-    keep[1] = (w0 >> 16) < d.thr;
-    keep[2] = (w1 & 0xFFFFu) < d.thr;
-    keep[3] = (w1 >> 16) < d.thr;
-}
-
 // ---- wave helpers -----------------------------------------------------------------------------------
 // Sum over groups of `width` adjacent lanes (width in {4, 8, 16}: DPP, stays in the VALU; 32, 64: the last
 // steps go through ds_bpermute).  Every lane of a group ends up with the group's sum.

@@ -246,12 +246,6 @@ static __device__ __forceinline__ void pack_tile_chn_t(const float* tile, char* 
     }
 }
 
-// copy a packed tile image (bytes, multiple of 16) between LDS and global, 16 bytes per thread step
-static __device__ __forceinline__ void copy16(char* dst, const char* src, int bytes, int tid) {
-    _Pragma("unroll 1") for (int o = tid * 16; o < bytes; o += NTHREADS * 16)
-        *reinterpret_cast<u32x4_t*>(dst + o) = *reinterpret_cast<const u32x4_t*>(src + o);
-}
-
 // accumulator tiles -> chained operand fragment(s)
 template <int P> struct Chain;
 template <> struct Chain<PREC_BF16> {

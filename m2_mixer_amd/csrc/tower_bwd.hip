@@ -1,6 +1,6 @@
 // Backward of a stack of MixerBlocks (+ final LayerNorm): the data-gradient chain -- one launch per tower.
 //
-// Same tiling as the forward: a workgroup owns 64 token rows (whole samples) and walks the blocks in
+// Same tiling as the forward: a workgroup owns BM = 16 token rows (whole samples) and walks the blocks in
 // reverse with the fp32 gradient stream of those rows resident in LDS.  Per block:
 //   channel mixing:  dYd = dY * mask_out;  A = LN2(x_mid) recomputed from the saved x_mid;
 //                    per 32 hidden columns and wave:  Hpre^T = W1 A^T + b1,  dHact^T = W2^T dYd^T   (MFMA)
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
     constexpr bool TOK = NMAX > 0;                      // false: wide path, channel mixing only (rows independent)
     constexpr int NM = TOK ? NMAX : 1;
     constexpr int TILE_F = BM * XLD;                    // floats in one fp32 tile
-    constexpr int IMG_B = BM * D * Pr::ESZ;             // bytes of one packed 64-row image
+    constexpr int IMG_B = BM * D * Pr::ESZ;             // bytes of one packed BM-row image
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SF = SlabGeom<D>::FLOATS;             // floats in one (transposed) reduction slab, >= TILE_F
@@ -104,7 +104,6 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
     const int ns = TOK ? min(SPW, B - s0) : 0;
     const long row0 = TOK ? (long)s0 * N : (long)blockIdx.x * BM;
     const int R = TOK ? ns * N : (int)min((long)BM, (long)B * N - row0);
-    const long tile_off = (long)blockIdx.x * IMG_B;                       // NAT images: consecutive BM-row tiles
     constexpr int TPP = WPAIR / BM;                                         // chain tiles per 32-row pair
     const long pair_off = (long)(blockIdx.x / TPP) * (WPAIR * D * Pr::ESZ); // CHN images: per 32-row pair
     const int tile_in_pair = blockIdx.x % TPP;

@@ -3,7 +3,7 @@
 // Reference semantics: MixerBlock.forward (modules/mixer.py:42-47) applied num_mixers times, then
 // layer_norm (modules/mixer.py:128-131, :158-161, :182-185).
 //
-// Workgroup = 32 token rows (whole samples), resident in LDS as fp32 for the entire tower; 8 waves:
+// Workgroup = BM = 16 token rows (whole samples), resident in LDS as fp32 for the entire tower; 8 waves:
 //   token mixing   LN1 -> per (sample, channel) MLP over the N tokens on the VALU (N, T are tiny);
 //                  the token weights sit zero-padded in LDS (broadcast reads, no bounds branches)
 //   channel mixing LN2 -> packed operand image in LDS; each wave takes 32 hidden columns at a time:

@@ -436,9 +436,9 @@ static WgradPlan wgrad_plan(const m2m_tower* t, int B) {
     const int nchain = wide ? (int)(((long)B * t->N + BM - 1) / BM) : (B + SPW - 1) / SPW;   // chain tiles (BM rows each)
     const int ntiles = (nchain * BM + WBM - 1) / WBM;           // streamed tiles (WBM rows each)
     const int nsl = (t->Cp + WgradGeom<P, D>::COLS - 1) / WgradGeom<P, D>::COLS;   // column slices (128 or 64 columns)
-    // A workgroup streams its operands at the per-CU HBM rate (~27 GB/s), so the launch time is set by the bytes of its
-    // longest workgroup: rows are split into groups until a workgroup has at most 64 tiles (2048 rows) or the launch
-    // reaches ~128 workgroups.  Two groups add their partial results with float atomics onto the zeroed gradient:
+    // A workgroup's time is linear in its number of 32-row steps (~0.85 us each), so the launch time
+    // is set by its longest workgroup: rows are split into groups until a workgroup has at most 64 steps (2048 rows) or the
+    // launch reaches ~128 workgroups.  Two groups add their partial results with float atomics onto the zeroed gradient:
     // a + b == b + a, so the result stays bit-deterministic; more groups (only tiny launches) are not.
     int groups = 1;
     const int wgs = nsl * t->nblocks;
