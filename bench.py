@@ -154,7 +154,7 @@ def main():
     rank, local_rank, world = parallel.init_from_env()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    dev = torch.device(f"cuda:{local_rank}")
+    dev = torch.device(f"cuda:{int(os.environ.get('M2M_FORCE_DEVICE', local_rank))}")      # override: single-GPU rehearsal of N > 1
     torch.cuda.set_device(dev)
     cfg = CFG_B if args.model == "B" else CFG_S
     B = args.batch

@@ -274,13 +274,15 @@ class _FlatEngine:
                     self.optimizer_step(scale)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        # thread_local capture mode: a data-parallel process has other threads (the RCCL watchdog) that may touch the HIP
+        # runtime while this thread captures; only this thread's calls belong to the graph
         g1 = torch.cuda.CUDAGraph()
         if grad_sync is None:
             if steps > 1:
                 self.losses_steps = torch.zeros(steps, *self.losses.shape, device=self.device)
                 self.logits_steps = torch.zeros(steps, *self.logits.shape, device=self.device)
                 self.preds_steps = torch.zeros(steps, *self.preds.shape, dtype=self.preds.dtype, device=self.device)
-            with torch.cuda.graph(g1):
+            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
                 for i in range(steps):
                     if steps > 1:
                         self.losses, self.logits, self.preds = self.losses_steps[i], self.logits_steps[i], self.preds_steps[i]
@@ -288,9 +290,9 @@ class _FlatEngine:
             graphs = (g1,)
         else:
             g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
+            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
                 self.forward_backward(*st)
-            with torch.cuda.graph(g2):
+            with torch.cuda.graph(g2, capture_error_mode="thread_local"):
                 self.optimizer_step(scale)
             graphs = (g1, g2)
         self._graph = graphs
