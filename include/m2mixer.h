@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define M2M_ABI_VERSION 5
+#define M2M_ABI_VERSION 6
 #define M2M_MAX_BLOCKS 8      /* MixerBlocks per m2m_tower; longer towers are chained by the caller */
 #define M2M_ROWS_PER_WG 16    /* token rows one workgroup keeps on chip */
 
@@ -139,6 +139,18 @@ int m2m_tower_forward(const m2m_tower* t, const float* x0, int64_t x0_sample_str
                       float* out, int64_t out_sample_stride, float* pooled,
                       int training, uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream);
 
+/* Two towers (e.g. the image and the audio tower, which run side by side and need half the chip each) in ONE launch
+ * instead of two launches on two streams: no cross-queue fork / join in a replayed graph.  Both towers must be on the
+ * fused path, share precision, hidden_dim, dropout and token class, and have at most 4 blocks; otherwise -1 (launch them
+ * separately).  Arguments per tower as for m2m_tower_forward. */
+typedef struct m2m_tower_io {
+    const float* x0; int64_t x0_sample_stride;
+    float* out; int64_t out_sample_stride;
+    float* pooled;
+} m2m_tower_io;
+int m2m_towers_forward(const m2m_tower* const* towers, const m2m_tower_io* io, int ntowers, int B, int training,
+                       uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream);
+
 /* ---- backward ----------------------------------------------------------------------------------- */
 /* Reverse pass through final LayerNorm + blocks.
  *   d_out / d_out_sample_stride : gradient wrt the tower output tokens, or NULL
@@ -149,6 +161,14 @@ int m2m_tower_forward(const m2m_tower* t, const float* x0, int64_t x0_sample_str
 int m2m_tower_backward(const m2m_tower* t, int B, const float* d_out, int64_t d_out_sample_stride,
                        const float* d_pooled, float* d_x0, int64_t d_x0_sample_stride,
                        uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream);
+/* The two-tower form, arguments per tower as for m2m_tower_backward (same grouping rules as m2m_towers_forward). */
+typedef struct m2m_tower_gio {
+    const float* d_out; int64_t d_out_sample_stride;
+    const float* d_pooled;
+    float* d_x0; int64_t d_x0_sample_stride;
+} m2m_tower_gio;
+int m2m_towers_backward(const m2m_tower* const* towers, const m2m_tower_gio* io, int ntowers, int B,
+                        uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream);
 /* g_ch_w1, g_ch_b1, g_ch_w2 of every block: two contractions over all token rows, streaming the bf16 (fp32 in parity
  * mode) operands m2m_tower_backward stored.  seed / step are accepted for ABI symmetry (dropout is already applied). */
 int m2m_tower_wgrad(const m2m_tower* t, int B, uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream);

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("M2M_LIB_PATH", os.path.join(_HERE, "libm2mixer.so"))   # override: diagnostic builds
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_BLOCKS = 8
 ROWS_PER_WG = 16
 HCHN_PAD = 4096          # >= the pad between operand streams the library uses (csrc/tile.h M2M_HCHN_PAD)
@@ -44,6 +44,16 @@ class Tower(C.Structure):
                 ("p_drop", C.c_float), ("site_base", C.c_uint32),
                 ("lnf_w", _fp), ("lnf_b", _fp), ("g_lnf_w", _fp), ("g_lnf_b", _fp), ("x_final", _fp),
                 ("ws_a", _fp), ("ws_b", _fp), ("blk", Block * MAX_BLOCKS)]
+
+
+class TowerIO(C.Structure):
+    """m2m_tower_io"""
+    _fields_ = [("x0", _fp), ("x0_ss", C.c_int64), ("out", _fp), ("out_ss", C.c_int64), ("pooled", _fp)]
+
+
+class TowerGIO(C.Structure):
+    """m2m_tower_gio"""
+    _fields_ = [("d_out", _fp), ("d_out_ss", C.c_int64), ("d_pooled", _fp), ("d_x0", _fp), ("d_x0_ss", C.c_int64)]
 
 
 class Embed(C.Structure):
@@ -84,6 +94,10 @@ SIGNATURES = {
     "m2m_tower_backward": (C.c_int, [C.POINTER(Tower), C.c_int, _fp, C.c_int64, _fp, _fp, C.c_int64,
                                      C.c_uint32, C.c_uint32, _fp, _fp]),
     "m2m_tower_wgrad": (C.c_int, [C.POINTER(Tower), C.c_int, C.c_uint32, C.c_uint32, _fp, _fp]),
+    "m2m_towers_forward": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.POINTER(TowerIO), C.c_int, C.c_int, C.c_int, C.c_uint32,
+                                     C.c_uint32, _fp, _fp]),
+    "m2m_towers_backward": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.POINTER(TowerGIO), C.c_int, C.c_int, C.c_uint32, C.c_uint32,
+                                      _fp, _fp]),
     "m2m_towers_wgrad": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.POINTER(_fp), C.c_int, C.c_int, _fp]),
     "m2m_counter_add": (C.c_int, [_fp, C.c_uint32, _fp]),
     "m2m_embed_wgrad": (C.c_int, [C.POINTER(Embed), _fp, _fp, C.c_int, _fp]),

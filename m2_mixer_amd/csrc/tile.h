@@ -8,6 +8,8 @@
 #pragma once
 #include "common.h"
 #include "../../include/m2mixer.h"
+#include <stddef.h>
+#include <string.h>
 
 #ifndef BM
 #define BM 16                      // token rows per workgroup of the chain kernels (16 or 32)
@@ -111,6 +113,21 @@ static __device__ __forceinline__ bool drop_keep_elem(const Drop& d, unsigned in
 #define M2M_HCHN_PAD 2304
 #endif
 static __host__ __device__ __forceinline__ long m2m_hchn_stride(long npair) { return npair * 2048 + M2M_HCHN_PAD; }
+
+// A tower descriptor with room for 4 blocks only: two of them (plus per-tower arguments) fit the 4 KiB kernel-argument
+// limit, so a multi-tower launch can take its descriptors BY VALUE (pointers in kernel arguments are known to be global
+// memory; descriptors read from device memory would turn every load into a FLAT access that also ticks lgkmcnt).
+// Layout-identical prefix of m2m_tower: copy sizeof(m2m_tower4) bytes of a tower with nblocks <= 4.
+#define M2M_GROUP_BLOCKS 4
+struct m2m_tower4 {
+    int32_t prec, D, N, T, C, Cp, nblocks, has_final_ln;
+    float p_drop;
+    uint32_t site_base;
+    const float* lnf_w; const float* lnf_b; float* g_lnf_w; float* g_lnf_b; float* x_final; float* ws_a; float* ws_b;
+    m2m_block blk[M2M_GROUP_BLOCKS];
+};
+static_assert(offsetof(m2m_tower4, blk) == offsetof(m2m_tower, blk), "m2m_tower4 must be a prefix of m2m_tower");
+static inline m2m_tower4 m2m_shrink(const m2m_tower* t) { m2m_tower4 r; memcpy(&r, t, sizeof(r)); return r; }
 
 // Which execution path a tower takes (see include/m2mixer.h): fused = whole samples per workgroup.
 static inline bool m2m_is_wide(const m2m_tower* t) { return t->N > 8 || t->D > 128; }

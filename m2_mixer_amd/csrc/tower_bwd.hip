@@ -67,11 +67,13 @@ static __device__ __forceinline__ void ln_backward_tile(const float* xg, int R, 
     __syncthreads();
 }
 
-template <int P, int D, int NMAX, int TG, int DM>
-__global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw, int B, const float* __restrict__ d_out,
-                                                             long d_out_ss, const float* __restrict__ d_pooled,
-                                                             float* __restrict__ d_x0, long d_x0_ss, unsigned int seed,
-                                                             unsigned int step_host, const unsigned int* __restrict__ step_dev) {
+// One workgroup's share of a tower backward: token tile `wg` of `nwg`.  TW is m2m_tower (single-tower launch) or
+// m2m_tower4 (the by-value descriptors of a two-tower launch).
+template <class TW, int P, int D, int NMAX, int TG, int DM>
+static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const float* __restrict__ d_out, long d_out_ss,
+                                                      const float* __restrict__ d_pooled, float* __restrict__ d_x0, long d_x0_ss,
+                                                      unsigned int seed, unsigned int step_host,
+                                                      const unsigned int* __restrict__ step_dev, int wg, int nwg, char* smem) {
     typedef Prec<P> Pr;
     typedef TileGeom<D> G;
     constexpr int XLD = G::XLD, DT = G::DT, KD = D / Pr::KB, NF = Chain<P>::NF;
@@ -80,7 +82,6 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
     constexpr int TILE_F = BM * XLD;                    // floats in one fp32 tile
     constexpr int IMG_B = BM * D * Pr::ESZ;             // bytes of one packed BM-row image
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SF = SlabGeom<D>::FLOATS;             // floats in one (transposed) reduction slab, >= TILE_F
     static_assert(IMG_B <= SF * 4 && TILE_F <= SF, "packed image / fp32 tile must fit the slab it aliases");
     float* dxs = reinterpret_cast<float*>(smem);        // gradient stream
@@ -100,13 +101,13 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
     const int N = tw.N, T = tw.T, Cp = tw.Cp;
     const int SPW = TOK ? BM / N : 0;
-    const int s0 = blockIdx.x * SPW;
+    const int s0 = wg * SPW;
     const int ns = TOK ? min(SPW, B - s0) : 0;
-    const long row0 = TOK ? (long)s0 * N : (long)blockIdx.x * BM;
+    const long row0 = TOK ? (long)s0 * N : (long)wg * BM;
     const int R = TOK ? ns * N : (int)min((long)BM, (long)B * N - row0);
     constexpr int TPP = WPAIR / BM;                                         // chain tiles per 32-row pair
-    const long pair_off = (long)(blockIdx.x / TPP) * (WPAIR * D * Pr::ESZ); // CHN images: per 32-row pair
-    const int tile_in_pair = blockIdx.x % TPP;
+    const long pair_off = (long)(wg / TPP) * (WPAIR * D * Pr::ESZ); // CHN images: per 32-row pair
+    const int tile_in_pair = wg % TPP;
     const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
 
     TIMER_START();
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int u = BM == 16 ? tile_in_pair : mt;        // 16-row half of the 32-row pair
-                const long npair = (gridDim.x + TPP - 1) / TPP, pair = blockIdx.x / TPP;
+                const long npair = (nwg + TPP - 1) / TPP, pair = wg / TPP;
                 f32x4_t od[2], oa[2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
@@ -528,14 +529,80 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
 }
 
 template <int P, int D, int NMAX, int TG, int DM>
+__global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw, int B, const float* __restrict__ d_out,
+                                                             long d_out_ss, const float* __restrict__ d_pooled,
+                                                             float* __restrict__ d_x0, long d_x0_ss, unsigned int seed,
+                                                             unsigned int step_host, const unsigned int* __restrict__ step_dev) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    tower_bwd_body<m2m_tower, P, D, NMAX, TG, DM>(tw, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step_host, step_dev,
+                                                   blockIdx.x, gridDim.x, smem);
+}
+
+// Two towers side by side in ONE launch (blockIdx.y = tower), see tower_fwd.hip.
+struct BwdGroupArgs {
+    m2m_tower4 tw[2];
+    const float* d_out[2];
+    long d_out_ss[2];
+    const float* d_pooled[2];
+    float* d_x0[2];
+    long d_x0_ss[2];
+    int ntiles[2];
+};
+static_assert(sizeof(BwdGroupArgs) <= 3584, "kernel arguments are limited to 4 KiB");
+template <int P, int D, int NMAX, int TG, int DM>
+__global__ __launch_bounds__(NTHREADS) void tower_bwd_group_kernel(const BwdGroupArgs a, int B, unsigned int seed,
+                                                                   unsigned int step_host, const unsigned int* __restrict__ step_dev) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // XCD-aware mapping: workgroups are dealt to the 8 XCDs round-robin (id % 8), each XCD has its own 4 MB L2.  Tower 0
+    // takes XCDs 0-3, tower 1 XCDs 4-7, so an L2 caches ONE tower's weights (2.25 MB per block in the backward chain; both
+    // towers' 4.5 MB would not fit) and each tower's weights are fetched by four L2s instead of eight.
+    const int id = blockIdx.x, xcd = id & 7, t = xcd >> 2;
+    const int wg = (id >> 3) * 4 + (xcd & 3);
+    if (wg >= a.ntiles[t]) return;
+    tower_bwd_body<m2m_tower4, P, D, NMAX, TG, DM>(a.tw[t], B, a.d_out[t], a.d_out_ss[t], a.d_pooled[t], a.d_x0[t], a.d_x0_ss[t],
+                                                    seed, step_host, step_dev, wg, a.ntiles[t], smem);
+}
+
+template <int P, int D, int NMAX, int TG>
+static size_t bwd_lds_bytes() {
+    constexpr int NM = NMAX > 0 ? NMAX : 1;
+    const size_t tile_b = (size_t)BM * TileGeom<D>::XLD * sizeof(float);
+    return 2 * tile_b + 4 * SlabGeom<D>::FLOATS * sizeof(float) + BM * sizeof(float) + GELU_TAB_N * 16 +
+           (size_t)NWAVES * ((32 / TG) * (1 + 2 * NM) + NM) * TG * sizeof(float) + 32 * (2 * NM + 4) * sizeof(float);
+}
+
+template <int P, int D, int NMAX, int TG, int DM>
+static int launch_bwd_group_dm(const BwdGroupArgs& a, int B, unsigned int seed, unsigned int step, const unsigned int* step_dev,
+                               hipStream_t st) {
+    const size_t lds = bwd_lds_bytes<P, D, NMAX, TG>();
+    auto kern = tower_bwd_group_kernel<P, D, NMAX, TG, DM>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const int mx = a.ntiles[0] > a.ntiles[1] ? a.ntiles[0] : a.ntiles[1];
+    const int grid = 8 * ((mx + 3) / 4);                     // see the XCD-aware mapping in the kernel
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, st, a, B, seed, step, step_dev);
+    M2M_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+template <int P, int D, int NMAX, int TG>
+static int launch_bwd_group(const BwdGroupArgs& a, int B, unsigned int seed, unsigned int step, const unsigned int* step_dev,
+                            hipStream_t st) {
+    switch (m2m_drop_mode(1, a.tw[0].p_drop)) {
+        case DM_NONE: return launch_bwd_group_dm<P, D, NMAX, TG, DM_NONE>(a, B, seed, step, step_dev, st);
+        case DM_HALF: return launch_bwd_group_dm<P, D, NMAX, TG, DM_HALF>(a, B, seed, step, step_dev, st);
+        default:      return launch_bwd_group_dm<P, D, NMAX, TG, DM_GEN>(a, B, seed, step, step_dev, st);
+    }
+}
+
+template <int P, int D, int NMAX, int TG, int DM>
 static int launch_bwd_dm(const m2m_tower* t, int B, const float* d_out, long d_out_ss, const float* d_pooled, float* d_x0,
                       long d_x0_ss, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
-    constexpr int NM = NMAX > 0 ? NMAX : 1;
     const int SPW = NMAX > 0 ? BM / t->N : 1;
     const int grid = NMAX > 0 ? (B + SPW - 1) / SPW : (int)(((long)B * t->N + BM - 1) / BM);
-    const size_t tile_b = (size_t)BM * TileGeom<D>::XLD * sizeof(float);
-    const size_t lds = 2 * tile_b + 4 * SlabGeom<D>::FLOATS * sizeof(float) + BM * sizeof(float) + GELU_TAB_N * 16 +
-                       (size_t)NWAVES * ((32 / TG) * (1 + 2 * NM) + NM) * TG * sizeof(float) + 32 * (2 * NM + 4) * sizeof(float);
+    const size_t lds = bwd_lds_bytes<P, D, NMAX, TG>();
     auto kern = tower_bwd_kernel<P, D, NMAX, TG, DM>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -570,6 +637,41 @@ int m2m_chain_backward_rows(const m2m_tower* t, int B, const float* d_out, long 
     M2M_BWDR_CASE(PREC_F32, 32) M2M_BWDR_CASE(PREC_F32, 64) M2M_BWDR_CASE(PREC_F32, 128) M2M_BWDR_CASE(PREC_F32, 256)
 #undef M2M_BWDR_CASE
     m2m_set_error("tower_backward (wide): unsupported (prec, D)", __FILE__, __LINE__);
+    return -1;
+}
+
+bool m2m_can_group(const m2m_tower* a, const m2m_tower* b);
+
+extern "C" int m2m_towers_backward(const m2m_tower* const* towers, const m2m_tower_gio* io, int ntowers, int B, uint32_t seed,
+                                   uint32_t step, const uint32_t* step_dev, void* stream) {
+    if (!towers || !io || ntowers != 2) { m2m_set_error("towers_backward: exactly two towers per launch", __FILE__, __LINE__); return -1; }
+    for (int i = 0; i < 2; ++i)
+        if (int rc = m2m_check_tower(towers[i], B)) return rc;
+    if (!m2m_can_group(towers[0], towers[1])) {
+        m2m_set_error("towers_backward: the two towers do not share a kernel instantiation: launch them separately", __FILE__, __LINE__);
+        return -1;
+    }
+    BwdGroupArgs a;
+    for (int i = 0; i < 2; ++i) {
+        a.tw[i] = m2m_shrink(towers[i]);
+        a.d_out[i] = io[i].d_out; a.d_out_ss[i] = (long)io[i].d_out_sample_stride;
+        a.d_pooled[i] = io[i].d_pooled;
+        a.d_x0[i] = io[i].d_x0; a.d_x0_ss[i] = (long)io[i].d_x0_sample_stride;
+        const int SPW = BM / towers[i]->N;
+        a.ntiles[i] = (B + SPW - 1) / SPW;
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const m2m_tower* t = towers[0];
+#define M2M_BWDG_CASE(PP, DD) \
+    if (t->prec == PP && t->D == DD) {                                                                          \
+        if (t->N <= 4) return launch_bwd_group<PP, DD, 4, 8>(a, B, seed, step, step_dev, st);                   \
+        if (t->T % 16 == 0) return launch_bwd_group<PP, DD, 8, 16>(a, B, seed, step, step_dev, st);             \
+        return launch_bwd_group<PP, DD, 8, 8>(a, B, seed, step, step_dev, st);                                  \
+    }
+    M2M_BWDG_CASE(PREC_BF16, 32) M2M_BWDG_CASE(PREC_BF16, 64) M2M_BWDG_CASE(PREC_BF16, 128)
+    M2M_BWDG_CASE(PREC_F32, 32) M2M_BWDG_CASE(PREC_F32, 64) M2M_BWDG_CASE(PREC_F32, 128)
+#undef M2M_BWDG_CASE
+    m2m_set_error("towers_backward: unsupported (prec, D)", __FILE__, __LINE__);
     return -1;
 }
 

@@ -17,12 +17,13 @@
 TIMER_DECL(g_tm_fwd);
 TIMER_READER(m2m_debug_timers_fwd, g_tm_fwd)
 
-template <int P, int D, int NMAX, int DM>
-__global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw, const float* __restrict__ x0,
-                                                             long x0_ss, int B, float* __restrict__ out, long out_ss,
-                                                             float* __restrict__ pooled, int training,
-                                                             unsigned int seed, unsigned int step_host,
-                                                             const unsigned int* __restrict__ step_dev) {
+// One workgroup's share of a tower forward: token tile `wg`.  TW is m2m_tower (single-tower launch) or m2m_tower4 (the
+// by-value descriptors of a multi-tower launch).
+template <class TW, int P, int D, int NMAX, int DM>
+static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float* __restrict__ x0, long x0_ss, int B,
+                                                      float* __restrict__ out, long out_ss, float* __restrict__ pooled,
+                                                      int training, unsigned int seed, unsigned int step_host,
+                                                      const unsigned int* __restrict__ step_dev, int wg, char* smem) {
     typedef Prec<P> Pr;
     typedef TileGeom<D> G;
     constexpr int XLD = G::XLD, DT = G::DT, KD = D / Pr::KB, NF = Chain<P>::NF;
@@ -30,7 +31,6 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw,
     constexpr int NM = TOK ? NMAX : 1;
     constexpr int TW_LD = 2 * NM + 4;                            // token-weight row: W1 | W2^T | b1 | pad
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xs = reinterpret_cast<float*>(smem);                  // residual stream  [BM][XLD]
     float* slabs = xs + BM * XLD;                                 // 4 transposed slabs [D][SLD]; slab 0 doubles as scratch `ub`
     float* ub = slabs;
@@ -43,9 +43,9 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
     const int N = tw.N, T = tw.T, Cp = tw.Cp;
     const int SPW = TOK ? BM / N : 0;
-    const int s0 = blockIdx.x * SPW;
+    const int s0 = wg * SPW;
     const int ns = TOK ? min(SPW, B - s0) : 0;
-    const long row0 = TOK ? (long)s0 * N : (long)blockIdx.x * BM;   // first global token row of this tile
+    const long row0 = TOK ? (long)s0 * N : (long)wg * BM;           // first global token row of this tile
     const int R = TOK ? ns * N : (int)min((long)BM, (long)B * N - row0);
     const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
 
@@ -260,6 +260,43 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw,
     TIMER_MARK(g_tm_fwd, 5);       // final LN, output, pooled
 }
 
+template <int P, int D, int NMAX, int DM>
+__global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw, const float* __restrict__ x0,
+                                                             long x0_ss, int B, float* __restrict__ out, long out_ss,
+                                                             float* __restrict__ pooled, int training,
+                                                             unsigned int seed, unsigned int step_host,
+                                                             const unsigned int* __restrict__ step_dev) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    tower_fwd_body<m2m_tower, P, D, NMAX, DM>(tw, x0, x0_ss, B, out, out_ss, pooled, training, seed, step_host, step_dev,
+                                               blockIdx.x, smem);
+}
+
+// Two towers side by side in ONE launch (blockIdx.y = tower): the image and audio towers need half the chip each, and as
+// one launch on one stream they cost no cross-queue fork / join in the replayed graph.
+struct FwdGroupArgs {
+    m2m_tower4 tw[2];
+    const float* x0[2];
+    long x0_ss[2];
+    float* out[2];
+    long out_ss[2];
+    float* pooled[2];
+    int ntiles[2];
+};
+static_assert(sizeof(FwdGroupArgs) <= 3584, "kernel arguments are limited to 4 KiB");
+template <int P, int D, int NMAX, int DM>
+__global__ __launch_bounds__(NTHREADS) void tower_fwd_group_kernel(const FwdGroupArgs a, int B, int training, unsigned int seed,
+                                                                   unsigned int step_host, const unsigned int* __restrict__ step_dev) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // XCD-aware mapping: workgroups are dealt to the 8 XCDs round-robin (id % 8), each XCD has its own 4 MB L2.  Tower 0
+    // takes XCDs 0-3, tower 1 XCDs 4-7, so an L2 caches ONE tower's weights (2.25 MB per block in the backward chain; both
+    // towers' 4.5 MB would not fit) and each tower's weights are fetched by four L2s instead of eight.
+    const int id = blockIdx.x, xcd = id & 7, t = xcd >> 2;
+    const int wg = (id >> 3) * 4 + (xcd & 3);
+    if (wg >= a.ntiles[t]) return;
+    tower_fwd_body<m2m_tower4, P, D, NMAX, DM>(a.tw[t], a.x0[t], a.x0_ss[t], B, a.out[t], a.out_ss[t], a.pooled[t], training, seed,
+                                                step_host, step_dev, wg, smem);
+}
+
 template <int P, int D>
 static size_t fwd_lds_bytes() {
     return (size_t)(BM * TileGeom<D>::XLD + 4 * SlabGeom<D>::FLOATS) * sizeof(float) + (size_t)BM * D * Prec<P>::ESZ + (32 * 20 + 8) * sizeof(float) + GELU_TAB_N * 16;
@@ -306,6 +343,71 @@ int m2m_chain_forward_rows(const m2m_tower* t, const float* x0, long x0_ss, int 
     M2M_FWDR_CASE(PREC_F32, 32) M2M_FWDR_CASE(PREC_F32, 64) M2M_FWDR_CASE(PREC_F32, 128) M2M_FWDR_CASE(PREC_F32, 256)
 #undef M2M_FWDR_CASE
     m2m_set_error("tower_forward (wide): unsupported (prec, D)", __FILE__, __LINE__);
+    return -1;
+}
+
+template <int P, int D, int NMAX, int DM>
+static int launch_fwd_group_dm(const FwdGroupArgs& a, int B, int training, unsigned int seed, unsigned int step,
+                               const unsigned int* step_dev, hipStream_t st) {
+    const size_t lds = fwd_lds_bytes<P, D>();
+    auto kern = tower_fwd_group_kernel<P, D, NMAX, DM>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const int mx = a.ntiles[0] > a.ntiles[1] ? a.ntiles[0] : a.ntiles[1];
+    const int grid = 8 * ((mx + 3) / 4);                     // see the XCD-aware mapping in the kernel
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, st, a, B, training, seed, step, step_dev);
+    M2M_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+template <int P, int D, int NMAX>
+static int launch_fwd_group(const FwdGroupArgs& a, int B, int training, unsigned int seed, unsigned int step,
+                            const unsigned int* step_dev, hipStream_t st) {
+    switch (m2m_drop_mode(training, a.tw[0].p_drop)) {
+        case DM_NONE: return launch_fwd_group_dm<P, D, NMAX, DM_NONE>(a, B, training, seed, step, step_dev, st);
+        case DM_HALF: return launch_fwd_group_dm<P, D, NMAX, DM_HALF>(a, B, training, seed, step, step_dev, st);
+        default:      return launch_fwd_group_dm<P, D, NMAX, DM_GEN>(a, B, training, seed, step, step_dev, st);
+    }
+}
+
+// True when two towers can share one chain launch: both on the fused path, same kernel instantiation, <= 4 blocks each.
+bool m2m_can_group(const m2m_tower* a, const m2m_tower* b) {
+    if (m2m_is_wide(a) || m2m_is_wide(b)) return false;
+    if (a->prec != b->prec || a->D != b->D || a->p_drop != b->p_drop) return false;
+    if ((a->N <= 4) != (b->N <= 4) || (a->T % 16 == 0) != (b->T % 16 == 0)) return false;
+    return a->nblocks <= M2M_GROUP_BLOCKS && b->nblocks <= M2M_GROUP_BLOCKS;
+}
+
+extern "C" int m2m_towers_forward(const m2m_tower* const* towers, const m2m_tower_io* io, int ntowers, int B, int training,
+                                  uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream) {
+    if (!towers || !io || ntowers != 2) { m2m_set_error("towers_forward: exactly two towers per launch", __FILE__, __LINE__); return -1; }
+    for (int i = 0; i < 2; ++i)
+        if (int rc = m2m_check_tower(towers[i], B)) return rc;
+    if (!m2m_can_group(towers[0], towers[1])) {
+        m2m_set_error("towers_forward: the two towers do not share a kernel instantiation (fused path, precision, hidden_dim, "
+                      "dropout, token class, <= 4 blocks): launch them separately", __FILE__, __LINE__);
+        return -1;
+    }
+    FwdGroupArgs a;
+    for (int i = 0; i < 2; ++i) {
+        a.tw[i] = m2m_shrink(towers[i]);
+        a.x0[i] = io[i].x0; a.x0_ss[i] = (long)io[i].x0_sample_stride;
+        a.out[i] = io[i].out; a.out_ss[i] = (long)io[i].out_sample_stride;
+        a.pooled[i] = io[i].pooled;
+        const int SPW = BM / towers[i]->N;
+        a.ntiles[i] = (B + SPW - 1) / SPW;
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const m2m_tower* t = towers[0];
+#define M2M_FWDG_CASE(PP, DD) \
+    if (t->prec == PP && t->D == DD) return t->N <= 4 ? launch_fwd_group<PP, DD, 4>(a, B, training, seed, step, step_dev, st) \
+                                                      : launch_fwd_group<PP, DD, 8>(a, B, training, seed, step, step_dev, st);
+    M2M_FWDG_CASE(PREC_BF16, 32) M2M_FWDG_CASE(PREC_BF16, 64) M2M_FWDG_CASE(PREC_BF16, 128)
+    M2M_FWDG_CASE(PREC_F32, 32) M2M_FWDG_CASE(PREC_F32, 64) M2M_FWDG_CASE(PREC_F32, 128)
+#undef M2M_FWDG_CASE
+    m2m_set_error("towers_forward: unsupported (prec, D)", __FILE__, __LINE__);
     return -1;
 }
 

@@ -25,7 +25,7 @@ import torch
 from . import _lib as L
 from . import config
 from .runtime import (BLOCK_FIELDS, BLOCK_KEYS, EmbedRuntime, MlpRuntime, TowerRuntime, block_param_shapes, heads_bce,
-                      heads_ce, towers_wgrad)
+                      heads_ce, can_group, towers_backward, towers_forward, towers_wgrad)
 
 
 def _num_patch(c: dict) -> int:
@@ -386,13 +386,25 @@ class _TwoTowerEngine(_FlatEngine):
         fs = self.Nf * D
         b_part = self.fused.view(-1)[self.Na * D:]
         main, side, _ = self._streams()
-        side.wait_stream(main)
-        with torch.cuda.stream(side):                       # second tower beside the first
-            self.e_b.forward(xb, B, self.x0_b)
-            self.t_b.forward(self.x0_b, self.Nb * D, B, b_part, fs, self.pool_b, training, self.seed, 0, sd)
-        self.e_a.forward(xa, B, self.x0_a)
-        self.t_a.forward(self.x0_a, self.Na * D, B, self.fused, fs, self.pool_a, training, self.seed, 0, sd)
-        main.wait_stream(side)
+        if self.concurrent and can_group(self.t_a, self.t_b):
+            # one launch for both towers (blockIdx.y = tower) on the main stream: no cross-queue fork / join in the graph;
+            # only the second tower's patch embedding (it gates nothing but that tower) runs beside the first one's
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self.e_b.forward(xb, B, self.x0_b)
+            self.e_a.forward(xa, B, self.x0_a)
+            main.wait_stream(side)
+            towers_forward([self.t_a, self.t_b],
+                           [(self.x0_a, self.Na * D, self.fused, fs, self.pool_a), (self.x0_b, self.Nb * D, b_part, fs, self.pool_b)],
+                           B, training, self.seed, 0, sd)
+        else:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):                   # second tower beside the first
+                self.e_b.forward(xb, B, self.x0_b)
+                self.t_b.forward(self.x0_b, self.Nb * D, B, b_part, fs, self.pool_b, training, self.seed, 0, sd)
+            self.e_a.forward(xa, B, self.x0_a)
+            self.t_a.forward(self.x0_a, self.Na * D, B, self.fused, fs, self.pool_a, training, self.seed, 0, sd)
+            main.wait_stream(side)
         self.t_fus.forward(self.fused, fs, B, self.fus_out, fs, self.pool_fus, training, self.seed, 0, sd)
         a, b = self.MODS
         hw = self.head_weights
@@ -417,11 +429,16 @@ class _TwoTowerEngine(_FlatEngine):
         # three queues of a replayed graph raced and sometimes serialised each other), with the two patch-embedding
         # gradients beside it.  Every side stream forks from and joins into `main` directly (a fork from a forked stream
         # crashed hipGraph capture on ROCm 7.2).
-        s_a.wait_stream(main)
-        with torch.cuda.stream(s_a):
-            self.t_a.backward(B, self.d_fused, fs, self.dpool_a, self.dx0_a, self.Na * D, self.seed, 0, sd)
-        self.t_b.backward(B, d_b_part, fs, self.dpool_b, self.dx0_b, self.Nb * D, self.seed, 0, sd)
-        main.wait_stream(s_a)
+        if self.concurrent and can_group(self.t_a, self.t_b):
+            towers_backward([self.t_a, self.t_b],
+                            [(self.d_fused, fs, self.dpool_a, self.dx0_a, self.Na * D), (d_b_part, fs, self.dpool_b, self.dx0_b, self.Nb * D)],
+                            B, self.seed, 0, sd)
+        else:
+            s_a.wait_stream(main)
+            with torch.cuda.stream(s_a):
+                self.t_a.backward(B, self.d_fused, fs, self.dpool_a, self.dx0_a, self.Na * D, self.seed, 0, sd)
+            self.t_b.backward(B, d_b_part, fs, self.dpool_b, self.dx0_b, self.Nb * D, self.seed, 0, sd)
+            main.wait_stream(s_a)
         s_e.wait_stream(main)
         with torch.cuda.stream(s_e):                        # e_b reads the whole input of that modality (audio: 50 KB / sample)
             self.e_b.wgrad(xb, self.dx0_b, B)

@@ -229,6 +229,40 @@ class TowerRuntime:
         return m
 
 
+def can_group(a: TowerRuntime, b: TowerRuntime) -> bool:
+    """Two towers may share one chain launch (m2m_towers_forward / _backward): fused path, same kernel instantiation."""
+    return (not a.wide and not b.wide and a.prec == b.prec and a.D == b.D and a.desc.p_drop == b.desc.p_drop
+            and (a.N <= 4) == (b.N <= 4) and (a.T % 16 == 0) == (b.T % 16 == 0) and a.nblocks <= 4 and b.nblocks <= 4)
+
+
+def towers_forward(towers: Sequence[TowerRuntime], ios: Sequence[tuple], B: int, training: bool, seed: int, step: int,
+                   step_dev: Optional[torch.Tensor] = None):
+    """ios[i] = (x0, x0_ss, out, out_ss, pooled or None): two towers, one launch."""
+    n = len(towers)
+    for t in towers:
+        if training:
+            t.ensure_buffers(B)
+    host = (C.POINTER(L.Tower) * n)(*[C.pointer(t.desc) for t in towers])
+    io = (L.TowerIO * n)()
+    for i, (x0, x0_ss, out, out_ss, pooled) in enumerate(ios):
+        io[i].x0, io[i].x0_ss, io[i].out, io[i].out_ss, io[i].pooled = x0.data_ptr(), x0_ss, out.data_ptr(), out_ss, L.ptr(pooled)
+    L.check(L.lib().m2m_towers_forward(host, io, n, B, int(training), seed & 0xFFFFFFFF, step & 0xFFFFFFFF, L.ptr(step_dev),
+                                       L.stream_ptr()), "towers_forward")
+
+
+def towers_backward(towers: Sequence[TowerRuntime], ios: Sequence[tuple], B: int, seed: int, step: int,
+                    step_dev: Optional[torch.Tensor] = None):
+    """ios[i] = (d_out or None, d_out_ss, d_pooled or None, d_x0, d_x0_ss): two towers, one launch."""
+    n = len(towers)
+    host = (C.POINTER(L.Tower) * n)(*[C.pointer(t.desc) for t in towers])
+    io = (L.TowerGIO * n)()
+    for i, (d_out, d_out_ss, d_pooled, d_x0, d_x0_ss) in enumerate(ios):
+        io[i].d_out, io[i].d_out_ss, io[i].d_pooled = L.ptr(d_out), d_out_ss, L.ptr(d_pooled)
+        io[i].d_x0, io[i].d_x0_ss = d_x0.data_ptr(), d_x0_ss
+    L.check(L.lib().m2m_towers_backward(host, io, n, B, seed & 0xFFFFFFFF, step & 0xFFFFFFFF, L.ptr(step_dev), L.stream_ptr()),
+            "towers_backward")
+
+
 def towers_wgrad(towers: Sequence[TowerRuntime], B: int):
     """Channel-mixing weight gradients of several towers (same precision / hidden_dim) in one launch."""
     n = len(towers)
