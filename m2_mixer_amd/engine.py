@@ -227,8 +227,7 @@ class _FlatEngine:
         self._backward(*batch[:-1])
 
     def fused_step(self, *batch):
-        """forward + backward + Adam + re-pack with the per-tower updates overlapped with the remaining
-        weight-gradient work (no gradient exchange: single-GPU training)."""
+        """forward + backward + Adam + re-pack in one go (no gradient exchange: single-GPU training)."""
         self._prologue()
         self._forward(*batch, training=True, with_grad=True)
         self._backward(*batch[:-1], fused_update=True)
@@ -362,7 +361,8 @@ class _TwoTowerEngine(_FlatEngine):
 
     def pack(self):
         """Rebuild the packed MFMA-operand copies from the fp32 masters (three independent launches + two tiny ones:
-        spread over the side streams)."""
+        spread over the side streams).  Measured and dropped: leaving the side streams unjoined until the next step's
+        first tower launch (inside a multi-step graph) -- the replayed graph got slower, not faster."""
         main, s_b, s_f = self._streams()
         s_b.wait_stream(main)
         s_f.wait_stream(main)
@@ -414,8 +414,8 @@ class _TwoTowerEngine(_FlatEngine):
         self._loss_heads(heads, labels, not training)      # a training step's _prologue already cleared the losses
 
     def _backward(self, xa, xb, fused_update: bool = False):
-        """Backward of the whole model.  fused_update: also apply Adam + re-pack per tower as soon as that tower's
-        gradients are complete (single-GPU path; with a gradient all-reduce the update is a separate phase)."""
+        """Backward of the whole model.  fused_update: also apply Adam + re-pack (single-GPU path; with a gradient
+        all-reduce the update is a separate phase)."""
         B, D = self.B, self.D
         fs = self.Nf * D
         sd = self.drop_step
