@@ -240,7 +240,7 @@ def main():
 
 
 def profile_launches(eng, image, audio, labels, nsteps):
-    """Mean duration of every launch of the training step, measured with events recorded on the stream the
+    """Median duration of every launch of the training step, measured with events recorded on the stream the
     launches go to (torch's current stream == the stream handed to libm2mixer)."""
     import types
     cfg, B = eng.cfg, eng.B
@@ -270,12 +270,12 @@ def profile_launches(eng, image, audio, labels, nsteps):
         patch(rt, "forward", f"tower_fwd[{tname}]", f["channel"] + f["token"])
         patch(rt, "backward", f"tower_bwd[{tname}]", f["channel"] + f["token"] * 2)   # dgrad of both MLPs + token wgrad
         patch(rt, "wgrad", f"tower_wgrad[{tname}]", f["channel"])
-        patch(rt, "pack", f"pack[{tname}]", 0)
     for tname, e in (("image", eng.e_img), ("audio", eng.e_aud)):
         patch(e, "forward", f"embed_fwd[{tname}]", alg[tname]["embed"])
         patch(e, "wgrad", f"embed_wgrad[{tname}]", alg[tname]["embed"])
     import m2_mixer_amd.engine as E
-    orig_heads, orig_twg = E.heads_ce, E.towers_wgrad
+    orig_heads, orig_twg, orig_pack = E.heads_ce, E.towers_wgrad, E.pack_all
+    E.pack_all = timed("pack_all", orig_pack, 0)
     E.heads_ce = timed("heads_ce", orig_heads, alg["heads"] * 3)
     E.towers_wgrad = timed("towers_wgrad[all]", orig_twg, sum(alg[t]["channel"] for t in ("image", "audio", "fusion")))
     try:
@@ -296,13 +296,13 @@ def profile_launches(eng, image, audio, labels, nsteps):
     finally:
         for obj, attr, orig in saved:
             setattr(obj, attr, orig)
-        E.heads_ce, E.towers_wgrad = orig_heads, orig_twg
+        E.heads_ce, E.towers_wgrad, E.pack_all = orig_heads, orig_twg, orig_pack
         eng.concurrent = was_concurrent
     out = {}
     for name, sp in spans.items():
         times = [a.elapsed_time(b) * 1e3 for a, b in sp["events"]]      # us
         times = times[len(times) // 5:]                                   # drop the first fifth
-        per_launch = float(np.mean(times))
+        per_launch = float(np.median(times))                             # median: robust to a stray slow launch
         launches_per_step = len(sp["events"]) / nsteps
         out[name] = {"us_per_launch": per_launch, "us_per_step": per_launch * launches_per_step, "flops_per_launch": sp["flops"]}
     return out

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define M2M_ABI_VERSION 6
+#define M2M_ABI_VERSION 7
 #define M2M_MAX_BLOCKS 8      /* MixerBlocks per m2m_tower; longer towers are chained by the caller */
 #define M2M_ROWS_PER_WG 16    /* token rows one workgroup keeps on chip */
 
@@ -119,6 +119,10 @@ int m2m_pack(int prec, int mode, int order_k_major, const float* src, int64_t st
              int64_t I, int64_t K, void* dst, void* stream);
 int m2m_pack_tower(const m2m_tower* t, void* stream);     /* w1n, w2c, w2tn, w1tc, ch_b1p of every block */
 int m2m_pack_embed(const m2m_embed* e, void* stream);
+/* Everything above for a whole model in ONE launch: up to 3 towers (<= 4 blocks each) and up to 2 embeddings of one
+ * precision.  What the engines run after the fused Adam (replaces the per-module repack implied by
+ * torch.optim.Adam.step updating the weights the next forward reads, models/avmnist.py:412-414). */
+int m2m_pack_all(const m2m_tower* const* towers, int ntowers, const m2m_embed* const* embeds, int nembeds, void* stream);
 
 /* ---- forward ------------------------------------------------------------------------------------ */
 /* x0 (B*N, D) = patches(input) W^T + b.   Replaces MLPMixer.to_patch_embedding / MLPMixerNoPatching.proj. */

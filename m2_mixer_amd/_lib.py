@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("M2M_LIB_PATH", os.path.join(_HERE, "libm2mixer.so"))   # override: diagnostic builds
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_BLOCKS = 8
 ROWS_PER_WG = 16
 HCHN_PAD = 4096          # >= the pad between operand streams the library uses (csrc/tile.h M2M_HCHN_PAD)
@@ -88,6 +88,7 @@ SIGNATURES = {
     "m2m_pack": (C.c_int, [C.c_int, C.c_int, C.c_int, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _fp, _fp]),
     "m2m_pack_tower": (C.c_int, [C.POINTER(Tower), _fp]),
     "m2m_pack_embed": (C.c_int, [C.POINTER(Embed), _fp]),
+    "m2m_pack_all": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.c_int, C.POINTER(C.POINTER(Embed)), C.c_int, _fp]),
     "m2m_embed_forward": (C.c_int, [C.POINTER(Embed), _fp, C.c_int, _fp, _fp]),
     "m2m_tower_forward": (C.c_int, [C.POINTER(Tower), _fp, C.c_int64, C.c_int, _fp, C.c_int64, _fp, C.c_int,
                                     C.c_uint32, C.c_uint32, _fp, _fp]),

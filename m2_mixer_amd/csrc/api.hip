@@ -2,6 +2,7 @@
 #include "tile.h"
 #include <stdio.h>
 #include <string.h>
+#include <algorithm>
 
 static thread_local char g_err[512] = "";
 
@@ -91,25 +92,12 @@ extern "C" int m2m_pack(int prec, int mode, int order_k_major, const float* src,
     return pack_impl(prec, mode, order_k_major, src, stride_i, stride_k, I, K, I, K, dst, stream);
 }
 
-// All packed copies of every block of a tower in ONE launch: blockIdx.y = 5 * block + which,
-// which: 0 w1n, 1 w1tc, 2 w2c, 3 w2tn (same layouts as pack_impl), 4 ch_b1p.
+// One packed 16-byte slot: logical operand X[i][k] = src[i * si + kk * sk], i < I, kk < K, image padded to (Ip, Kp);
+// same layouts as pack_impl.
 template <int P>
-__global__ void pack_tower_kernel(const m2m_tower tw) {
+__device__ __forceinline__ void pack_slot(const float* src, long si, long sk, long I, long K, long Ip, long Kp, int mode,
+                                          int kmajor, char* dst, long slot) {
     typedef Prec<P> Pr;
-    const m2m_block& k = tw.blk[blockIdx.y / 5];
-    const int which = blockIdx.y % 5;
-    const long D = tw.D, C = tw.C, Cp = tw.Cp;
-    const long slot = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (which == 4) {
-        if (slot < Cp) k.ch_b1p[slot] = slot < C ? k.ch_b1[slot] : 0.f;
-        return;
-    }
-    // logical operand X[i][k] = src[i * si + kk * sk], i < I, kk < K, image padded to (Ip, Kp)
-    const float* src; long si, sk, I, K, Ip, Kp; int mode, kmajor; char* dst;
-    if (which == 0)      { src = k.ch_w1; si = D; sk = 1; I = C; K = D; Ip = Cp; Kp = D;  mode = PACK_NAT; kmajor = 0; dst = (char*)k.w1n; }
-    else if (which == 1) { src = k.ch_w1; si = 1; sk = D; I = D; K = C; Ip = D;  Kp = Cp; mode = PACK_CHN; kmajor = 1; dst = (char*)k.w1tc; }
-    else if (which == 2) { src = k.ch_w2; si = C; sk = 1; I = D; K = C; Ip = D;  Kp = Cp; mode = PACK_CHN; kmajor = 1; dst = (char*)k.w2c; }
-    else                 { src = k.ch_w2; si = 1; sk = C; I = C; K = D; Ip = Cp; Kp = D;  mode = PACK_NAT; kmajor = 0; dst = (char*)k.w2tn; }
     const long nIB = Ip / 16, nKB = Kp / Pr::KB;
     if (slot >= nIB * nKB * 64) return;
     const long blk = slot >> 6;
@@ -134,6 +122,25 @@ __global__ void pack_tower_kernel(const m2m_tower tw) {
     *reinterpret_cast<u32x4_t*>(dst + slot * 16) = f.u;
 }
 
+// Packed copies of one tower block.  which: 0 w1n, 1 w1tc, 2 w2c, 3 w2tn, 4 ch_b1p.
+template <int P, class TW>
+__device__ __forceinline__ void pack_block_job(const TW& tw, int block, int which, long slot) {
+    const m2m_block& k = tw.blk[block];
+    const long D = tw.D, C = tw.C, Cp = tw.Cp;
+    if (which == 4) {
+        if (slot < Cp) k.ch_b1p[slot] = slot < C ? k.ch_b1[slot] : 0.f;
+    } else if (which == 0) pack_slot<P>(k.ch_w1, D, 1, C, D, Cp, D, PACK_NAT, 0, (char*)k.w1n, slot);
+    else if (which == 1)   pack_slot<P>(k.ch_w1, 1, D, D, C, D, Cp, PACK_CHN, 1, (char*)k.w1tc, slot);
+    else if (which == 2)   pack_slot<P>(k.ch_w2, C, 1, D, C, D, Cp, PACK_CHN, 1, (char*)k.w2c, slot);
+    else                   pack_slot<P>(k.ch_w2, 1, C, C, D, Cp, D, PACK_NAT, 0, (char*)k.w2tn, slot);
+}
+
+// All packed copies of every block of a tower in ONE launch: blockIdx.y = 5 * block + which.
+template <int P>
+__global__ void pack_tower_kernel(const m2m_tower tw) {
+    pack_block_job<P>(tw, blockIdx.y / 5, blockIdx.y % 5, (long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
 extern "C" int m2m_pack_tower(const m2m_tower* t, void* stream) {
     if (int rc = m2m_check_tower(t, 1)) return rc;
     if (t->nblocks == 0) return 0;
@@ -144,6 +151,73 @@ extern "C" int m2m_pack_tower(const m2m_tower* t, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (t->prec == PREC_BF16) hipLaunchKernelGGL(pack_tower_kernel<PREC_BF16>, grid, dim3(256), 0, st, *t);
     else hipLaunchKernelGGL(pack_tower_kernel<PREC_F32>, grid, dim3(256), 0, st, *t);
+    M2M_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// Every packed copy a model needs after an optimizer step -- up to three towers of <= 4 blocks and two patch
+// embeddings -- in ONE launch (the whole repack is ~100 MB of HBM traffic: one launch at the memory roofline instead of
+// five launches forked over side streams).  blockIdx.y = 5 * M2M_GROUP_BLOCKS * tower + 5 * block + which, then one
+// job per embedding.
+#define M2M_PACK_TOWERS 3
+#define M2M_PACK_EMBEDS 2
+struct PackAllArgs {
+    m2m_tower4 tw[M2M_PACK_TOWERS];
+    m2m_embed em[M2M_PACK_EMBEDS];
+    int nt, ne;
+};
+static_assert(sizeof(PackAllArgs) <= 4096, "kernel arguments are limited to 4 KiB");
+
+template <int P>
+__global__ void pack_all_kernel(const PackAllArgs a) {
+    const long slot = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = 5 * M2M_GROUP_BLOCKS;
+    const int job = blockIdx.y;
+    if (job < per * a.nt) {
+        const int t = job / per, r = job % per;
+        if (r / 5 < a.tw[t].nblocks) pack_block_job<P>(a.tw[t], r / 5, r % 5, slot);
+    } else {
+        const m2m_embed& e = a.em[job - per * a.nt];
+        pack_slot<P>(e.w, e.K, 1, e.D, e.K, e.D, e.Kp, PACK_NAT, 0, (char*)e.wn, slot);
+    }
+}
+
+extern "C" int m2m_pack_all(const m2m_tower* const* towers, int ntowers, const m2m_embed* const* embeds, int nembeds,
+                            void* stream) {
+    if (ntowers < 0 || ntowers > M2M_PACK_TOWERS || nembeds < 0 || nembeds > M2M_PACK_EMBEDS || (ntowers && !towers) ||
+        (nembeds && !embeds) || ntowers + nembeds == 0) {
+        m2m_set_error("pack_all: up to 3 towers and 2 embeddings", __FILE__, __LINE__);
+        return -1;
+    }
+    PackAllArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nt = ntowers; a.ne = nembeds;
+    int prec = -1;
+    long need = 0;
+    for (int i = 0; i < ntowers; ++i) {
+        if (int rc = m2m_check_tower(towers[i], 1)) return rc;
+        if (towers[i]->nblocks > M2M_GROUP_BLOCKS) { m2m_set_error("pack_all: towers of <= 4 blocks", __FILE__, __LINE__); return -1; }
+        if (prec < 0) prec = towers[i]->prec;
+        if (towers[i]->prec != prec) { m2m_set_error("pack_all: one precision per launch", __FILE__, __LINE__); return -1; }
+        a.tw[i] = m2m_shrink(towers[i]);
+        const long KB = prec == PREC_BF16 ? 32 : 16;
+        const long nslots = (long)(towers[i]->Cp / 16) * (towers[i]->D / KB) * 64;
+        need = std::max(need, std::max(nslots, (long)towers[i]->Cp));
+    }
+    for (int i = 0; i < nembeds; ++i) {
+        const m2m_embed* e = embeds[i];
+        if (!e || !e->w || !e->wn) { m2m_set_error("pack_all: null embed", __FILE__, __LINE__); return -1; }
+        if (prec < 0) prec = e->prec;
+        if (e->prec != prec) { m2m_set_error("pack_all: one precision per launch", __FILE__, __LINE__); return -1; }
+        const long KB = prec == PREC_BF16 ? 32 : 16;
+        if (e->D % 16 || e->Kp % KB || e->Kp < e->K) { m2m_set_error("pack_all: bad embed geometry", __FILE__, __LINE__); return -1; }
+        a.em[i] = *e;
+        need = std::max(need, (long)(e->D / 16) * (e->Kp / KB) * 64);
+    }
+    const dim3 grid((unsigned)ceil_div(need, 256), (unsigned)(5 * M2M_GROUP_BLOCKS * ntowers + nembeds));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (prec == PREC_BF16) hipLaunchKernelGGL(pack_all_kernel<PREC_BF16>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(pack_all_kernel<PREC_F32>, grid, dim3(256), 0, st, a);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
 }

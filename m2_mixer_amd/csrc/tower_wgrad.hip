@@ -320,6 +320,16 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, i
             }
         }
     } else {
+        // Shared owners: no-return float atomics onto the zeroed gradient.  dW1's accumulators already put 16 consecutive
+        // d (64 bytes) of one row in 16 lanes.  dW2[d][c] has c in REGISTERS and d across lanes -- 64 different cache
+        // lines per instruction if issued as is -- so each wave transposes its (d x 16 CPW) slice through its part of the
+        // (now free) LDS stage, CHT d-tiles at a time, and issues every atomic over 16 CPW consecutive columns of a row.
+        constexpr int W = 16 * CPW, TLD2 = W + 1, RPI = 64 / W;     // columns per wave, padded LDS row, rows per instruction
+        constexpr int CAP = 16 * (D + 4) / (16 * TLD2);             // d-tiles the wave's LDS part holds
+        constexpr int CHT = CAP >= 4 ? 4 : (CAP >= 2 ? 2 : 1);
+        static_assert(DT % CHT == 0 && CAP >= 1, "dW2 transpose chunks");
+        __syncthreads();                                     // every wave is done reading the stage
+        float* tr = reinterpret_cast<float*>(smem) + wave * 16 * (D + 4);
 #pragma unroll
         for (int j = 0; j < CPW; ++j) {
             if (ct0 + j >= nct) continue;
@@ -328,17 +338,30 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, i
             for (int dt = 0; dt < DT; ++dt) {
                 const int d = 16 * dt + il;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (c0 + r < C) {
-                        atomicAdd(bk.g_ch_w1 + (long)(c0 + r) * D + d, dw1[j][dt][r]);
-                        atomicAdd(bk.g_ch_w2 + (long)d * C + c0 + r, dw2[j][dt][r]);
-                    }
-                }
+                for (int r = 0; r < 4; ++r)
+                    if (c0 + r < C) atomicAdd(bk.g_ch_w1 + (long)(c0 + r) * D + d, dw1[j][dt][r]);
             }
             if (il == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (c0 + r < C) atomicAdd(bk.g_ch_b1 + c0 + r, db1[j][r]);
+            }
+        }
+        const int cw = 16 * ct0 + (lane % W);                // this lane's column in the transposed read
+#pragma unroll
+        for (int ch = 0; ch < DT / CHT; ++ch) {
+#pragma unroll
+            for (int dtl = 0; dtl < CHT; ++dtl)
+#pragma unroll
+                for (int j = 0; j < CPW; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tr[(16 * dtl + il) * TLD2 + 16 * j + 4 * g + r] = dw2[j][CHT * ch + dtl][r];
+            // (one wave: its LDS accesses complete in order, no barrier needed)
+#pragma unroll
+            for (int i = 0; i < 16 * CHT / RPI; ++i) {
+                const int row = RPI * i + lane / W;
+                const float v = tr[row * TLD2 + lane % W];
+                if (cw < C) atomicAdd(bk.g_ch_w2 + (long)(16 * CHT * ch + row) * C + cw, v);
             }
         }
     }
@@ -361,6 +384,7 @@ struct WgradGroupArgs {
     const m2m_tower* tw[WG_MAX_TOWERS];
     int ntiles[WG_MAX_TOWERS], tpg[WG_MAX_TOWERS], groups[WG_MAX_TOWERS], nsl[WG_MAX_TOWERS];
     unsigned char job_tower[WG_MAX_JOBS], job_block[WG_MAX_JOBS];
+    int force_atomic;
 };
 template <int P, int D>
 __global__ __launch_bounds__(WG_THREADS, (WgradGeom<P, D>::MINWAVES)) void tower_wgrad_group_kernel(const WgradGroupArgs a) {
@@ -368,8 +392,8 @@ __global__ __launch_bounds__(WG_THREADS, (WgradGeom<P, D>::MINWAVES)) void tower
     const int t = a.job_tower[blockIdx.y];
     if ((int)blockIdx.x >= a.nsl[t] || (int)blockIdx.z >= a.groups[t]) return;
     const m2m_tower& tw = *a.tw[t];
-    wgrad_body<P, D>(tw.blk[a.job_block[blockIdx.y]], tw.Cp, tw.C, blockIdx.x, blockIdx.z, a.groups[t] == 1, a.ntiles[t],
-                     a.tpg[t], smem);
+    wgrad_body<P, D>(tw.blk[a.job_block[blockIdx.y]], tw.Cp, tw.C, blockIdx.x, blockIdx.z, a.groups[t] == 1 && !a.force_atomic,
+                     a.ntiles[t], a.tpg[t], smem);
 }
 
 struct WgradPlan { int ntiles, nsl, groups, tpg; };
@@ -417,6 +441,7 @@ static int launch_wgrad_group(const m2m_tower* const* host, const m2m_tower* con
         }
     }
     if (njobs == 0) return 0;
+    if (const char* e = getenv("M2M_WGRAD_ATOMIC")) a.force_atomic = atoi(e);
     const size_t lds = (size_t)WgradGeom<P, D>::LDS_B;
     auto kern = tower_wgrad_group_kernel<P, D>;
     static bool attr_done = false;

@@ -25,7 +25,7 @@ import torch
 from . import _lib as L
 from . import config
 from .runtime import (BLOCK_FIELDS, BLOCK_KEYS, EmbedRuntime, MlpRuntime, TowerRuntime, block_param_shapes, heads_bce,
-                      heads_ce, can_group, towers_backward, towers_forward, towers_wgrad)
+                      heads_ce, can_group, can_pack_all, pack_all, towers_backward, towers_forward, towers_wgrad)
 
 
 def _num_patch(c: dict) -> int:
@@ -360,21 +360,15 @@ class _TwoTowerEngine(_FlatEngine):
         return (3, self.B)
 
     def pack(self):
-        """Rebuild the packed MFMA-operand copies from the fp32 masters (three independent launches + two tiny ones:
-        spread over the side streams).  Measured and dropped: leaving the side streams unjoined until the next step's
-        first tower launch (inside a multi-step graph) -- the replayed graph got slower, not faster."""
-        main, s_b, s_f = self._streams()
-        s_b.wait_stream(main)
-        s_f.wait_stream(main)
-        with torch.cuda.stream(s_b):
-            self.t_b.pack(force=True)
-            self.e_b.pack(force=True)
-        with torch.cuda.stream(s_f):
-            self.t_fus.pack(force=True)
-        self.t_a.pack(force=True)
-        self.e_a.pack(force=True)
-        main.wait_stream(s_b)
-        main.wait_stream(s_f)
+        """Rebuild the packed MFMA-operand copies from the fp32 masters: every tower and both embeddings in ONE launch
+        on the main stream (~100 MB of traffic at the HBM roofline).  Replaced five launches forked over the side
+        streams, whose fork and join edges cost more inside the replayed graph than the concurrency returned."""
+        towers, embeds = [self.t_a, self.t_b, self.t_fus], [self.e_a, self.e_b]
+        if can_pack_all(towers, embeds):
+            pack_all(towers, embeds)
+            return
+        for m in towers + embeds:
+            m.pack(force=True)
 
     def _loss_heads(self, heads, labels, zero_losses):
         raise NotImplementedError
@@ -560,13 +554,12 @@ class MimicEngine(_FlatEngine):
         self.preds = torch.zeros(3, B, dtype=torch.int32, device=dev)
 
     def pack(self):
-        main, s_b, s_f = self._streams()
-        s_f.wait_stream(main)
-        with torch.cuda.stream(s_f):
-            self.t_fus.pack(force=True)
-        self.t_time.pack(force=True)
-        self.e_time.pack(force=True)
-        main.wait_stream(s_f)
+        towers, embeds = [self.t_time, self.t_fus], [self.e_time]
+        if can_pack_all(towers, embeds):
+            pack_all(towers, embeds)
+            return
+        for m in towers + embeds:
+            m.pack(force=True)
 
     def _forward(self, static, time, labels, training: bool, with_grad: bool):
         B, D = self.B, self.D

@@ -105,15 +105,21 @@ class TowerRuntime:
                 setattr(self.desc.blk[i], k, v.data_ptr())
             self._keep[f"packed{i}"] = bufs
 
-    def pack(self, force: bool = False):
-        """Refresh the packed MFMA-operand copies when the master weights changed."""
+    def _pack_versions(self):
         cur = []
         for i in range(self.nblocks):
             bp = self._keep[f"params{i}"]
             cur += [bp["ch_w1"]._version, bp["ch_w2"]._version, bp["ch_b1"]._version]
-        if force or cur != self._packed_for:
+        return cur
+
+    def mark_packed(self):
+        self._packed_for = self._pack_versions()
+
+    def pack(self, force: bool = False):
+        """Refresh the packed MFMA-operand copies when the master weights changed."""
+        if force or self._pack_versions() != self._packed_for:
             L.check(L.lib().m2m_pack_tower(C.byref(self.desc), L.stream_ptr()), "pack_tower")
-            self._packed_for = cur
+            self.mark_packed()
 
     # ---- activations saved for backward ---------------------------------------------------------------
     def ensure_buffers(self, B: int):
@@ -271,6 +277,23 @@ def towers_wgrad(towers: Sequence[TowerRuntime], B: int):
     L.check(L.lib().m2m_towers_wgrad(host, dev, n, B, L.stream_ptr()), "towers_wgrad")
 
 
+def can_pack_all(towers: Sequence[TowerRuntime], embeds: Sequence["EmbedRuntime"]) -> bool:
+    precs = {t.prec for t in towers} | {e.prec for e in embeds}
+    return len(towers) <= 3 and len(embeds) <= 2 and len(precs) == 1 and all(t.nblocks <= 4 for t in towers)
+
+
+def pack_all(towers: Sequence[TowerRuntime], embeds: Sequence["EmbedRuntime"]):
+    """Every packed operand copy of a model in one launch (after the optimizer step)."""
+    nt, ne = len(towers), len(embeds)
+    tp = (C.POINTER(L.Tower) * max(nt, 1))(*[C.pointer(t.desc) for t in towers])
+    ep = (C.POINTER(L.Embed) * max(ne, 1))(*[C.pointer(e.desc) for e in embeds])
+    L.check(L.lib().m2m_pack_all(tp, nt, ep, ne, L.stream_ptr()), "pack_all")
+    for t in towers:
+        t.mark_packed()
+    for e in embeds:
+        e.mark_packed()
+
+
 class EmbedRuntime:
     """m2m_embed: Conv2d(Cin, D, (ph, pw), stride=(ph, pw)) + rearrange, or Linear(K, D) on (B, N, K) rows."""
 
@@ -301,11 +324,13 @@ class EmbedRuntime:
     def params_changed(self, w, b) -> bool:
         return w.data_ptr() != self.desc.w or b.data_ptr() != self.desc.b
 
+    def mark_packed(self):
+        self._packed_for = self._keep["w"]._version
+
     def pack(self, force: bool = False):
-        v = self._keep["w"]._version
-        if force or v != self._packed_for:
+        if force or self._keep["w"]._version != self._packed_for:
             L.check(L.lib().m2m_pack_embed(C.byref(self.desc), L.stream_ptr()), "pack_embed")
-            self._packed_for = v
+            self.mark_packed()
 
     def bind_grads(self, g_w: torch.Tensor, g_b: torch.Tensor):
         self.desc.g_w, self.desc.g_b = g_w.data_ptr(), g_b.data_ptr()

@@ -38,6 +38,7 @@ def main():
     print(f"B {B} lib {os.path.basename(os.environ.get('M2M_LIB_PATH', 'libm2mixer.so'))}: "
           f"image alone {timeit(lambda: eng.t_img.wgrad(B, 1, 0, sd)):.1f} us, "
           f"fusion alone {timeit(lambda: eng.t_fus.wgrad(B, 1, 0, sd)):.1f} us, "
+          f"image+audio {timeit(lambda: towers_wgrad([eng.t_a, eng.t_b], B)):.1f} us, "
           f"merged {timeit(lambda: towers_wgrad([eng.t_fus, eng.t_a, eng.t_b], B)):.1f} us")
 
 
