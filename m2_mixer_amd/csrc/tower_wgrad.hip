@@ -36,6 +36,8 @@
 #define WG_MINWAVES 2
 #endif
 #define WG_THREADS (WG_WAVES * 64)
+#define WG_OUT_ATOMIC 0   // how a workgroup hands over its results (wgrad_body)
+#define WG_OUT_ADD 1
 
 TIMER_DECL(g_tm_wg);
 TIMER_READER(m2m_debug_timers_wgrad, g_tm_wg)
@@ -69,7 +71,7 @@ template <int P, int D> struct WgradGeom {
 
 // One workgroup's share: column slice `slice` of block `bk`, token tiles [group * tiles_per_group, ...).
 template <int P, int D>
-static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, int C, int slice, int group, bool single,
+static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, int C, int slice, int group, int mode,
                                                   int ntiles, int tiles_per_group, char* smem) {
     typedef Prec<P> Pr;
     typedef WgradGeom<P, D> G;
@@ -241,16 +243,24 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, i
     }
 
     // ---- results: dw1[j][dt][r] = dW1[c = 16 ct + 4g + r][d = 16dt + il]; dw2 likewise = dW2[d][c] ----
-    // "+=" onto the caller's gradient.  Single owner (one row group): ALL loads of the old values first (they overlap
-    // each other; one dependent load-add-store at a time cost 40 % of the kernel), then the stores.  Two row groups:
-    // no-return float atomics (a + b == b + a: still bit-deterministic); measured 2x slower per byte than the batched
-    // read-modify-write, so only launches that need the split use them.
-    if (single) {
-        // dW1 rows are contiguous in memory (row c = D floats) but the accumulators hold d across lanes and c in registers:
-        // 4-byte accesses in four 64-byte segments per instruction cost 17 us per workgroup.  Transpose each 16 x D tile
-        // through the (now free) LDS stage so that the read-modify-write runs on whole rows, 16 bytes per lane.
+    // WG_OUT_ADD    "+=" onto the caller's gradient by its single owner (one row group): ALL loads of the old values
+    //               first (they overlap each other; one dependent load-add-store at a time cost 40 % of the kernel),
+    //               then the stores.
+    // WG_OUT_ATOMIC "+=" by several row groups: no-return float atomics onto the zeroed gradient (two groups: a + b ==
+    //               b + a, still bit-deterministic).  Device-scope float atomics sustain only ~0.7 TB/s on this part:
+    //               fine for small launches, ruinous for a whole model's gradients.
+    // (Measured and dropped: "=" stores into per-group partial-gradient slots summed by the optimizer -- the loop of a
+    // 2-4 group split is 20-35 us shorter, its 2-4x write-out traffic gives all of it back.)
+    // The accumulators hold one matrix index across lanes and the other in registers, the wrong way round for both
+    // results' row-major layouts (4-byte accesses in 4 to 64 segments per instruction cost 17 us per workgroup), so the
+    // tiles are transposed through the (now free) LDS stage, each wave in its own part (one wave's LDS accesses complete in
+    // order: no barrier beyond the first).
+    __syncthreads();                                         // every wave is done reading the stage
+    float* const o_w1 = bk.g_ch_w1;
+    float* const o_w2 = bk.g_ch_w2;
+    float* const o_b1 = bk.g_ch_b1;
+    if (mode != WG_OUT_ATOMIC) {
         constexpr int TLD = D + 4;                           // padded row (floats): the four g-groups land in different banks
-        __syncthreads();                                     // every wave is done reading the stage
         float* tr = reinterpret_cast<float*>(smem) + wave * 16 * TLD;
 #pragma unroll
         for (int j = 0; j < CPW; ++j) {
@@ -259,7 +269,6 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, i
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) tr[(4 * g + r) * TLD + 16 * dt + il] = dw1[j][dt][r];
-            // (one wave: LDS accesses of a wave complete in order, no barrier needed)
             if (ct < nct) {
                 constexpr int PER = 16 * D / (64 * 4);       // float4 pieces per lane
                 f32x4_t v[PER];
@@ -268,16 +277,31 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, i
                     const int idx = i * 64 + lane, row = idx / (D / 4), c4 = idx % (D / 4);
                     v[i] = *reinterpret_cast<const f32x4_t*>(tr + row * TLD + 4 * c4);
                     const int c = 16 * ct + row;
-                    if (c < C) v[i] = v[i] + *reinterpret_cast<const f32x4_t*>(bk.g_ch_w1 + (long)c * D + 4 * c4);
+                    if (mode == WG_OUT_ADD && c < C) v[i] = v[i] + *reinterpret_cast<const f32x4_t*>(o_w1 + (long)c * D + 4 * c4);
                 }
 #pragma unroll
                 for (int i = 0; i < PER; ++i) {
                     const int idx = i * 64 + lane, row = idx / (D / 4), c4 = idx % (D / 4);
                     const int c = 16 * ct + row;
-                    if (c < C) *reinterpret_cast<f32x4_t*>(bk.g_ch_w1 + (long)c * D + 4 * c4) = v[i];
+                    if (c < C) *reinterpret_cast<f32x4_t*>(o_w1 + (long)c * D + 4 * c4) = v[i];
                 }
             }
         }
+    } else {
+#pragma unroll
+        for (int j = 0; j < CPW; ++j) {
+            if (ct0 + j >= nct) continue;
+            const int c0 = 16 * (ct0 + j) + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = 16 * dt + il;                  // 16 consecutive d of one row in 16 lanes
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c0 + r < C) atomicAdd(o_w1 + (long)(c0 + r) * D + d, dw1[j][dt][r]);
+            }
+        }
+    }
+    if (mode == WG_OUT_ADD) {
 #pragma unroll
         for (int j = 0; j < CPW; ++j) {
             if (ct0 + j >= nct) continue;
@@ -286,7 +310,7 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, i
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 const int d = 16 * dt + il;
-                const float* p2 = bk.g_ch_w2 + (long)d * C + c0;    // four consecutive c of row d
+                const float* p2 = o_w2 + (long)d * C + c0;    // four consecutive c of row d
                 if (vec) {
                     dw2[j][dt] = dw2[j][dt] + *reinterpret_cast<const f32x4_t*>(p2);
                 } else {
@@ -304,7 +328,7 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, i
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 const int d = 16 * dt + il;
-                float* p2 = bk.g_ch_w2 + (long)d * C + c0;
+                float* p2 = o_w2 + (long)d * C + c0;
                 if (vec) {
                     *reinterpret_cast<f32x4_t*>(p2) = dw2[j][dt];
                 } else {
@@ -316,35 +340,25 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, i
             if (il == 0) {                                  // db1[r] is identical in all 16 columns: column 0 writes
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (c0 + r < C) bk.g_ch_b1[c0 + r] += db1[j][r];
+                    if (c0 + r < C) o_b1[c0 + r] += db1[j][r];
             }
         }
     } else {
-        // Shared owners: no-return float atomics onto the zeroed gradient.  dW1's accumulators already put 16 consecutive
-        // d (64 bytes) of one row in 16 lanes.  dW2[d][c] has c in REGISTERS and d across lanes -- 64 different cache
-        // lines per instruction if issued as is -- so each wave transposes its (d x 16 CPW) slice through its part of the
-        // (now free) LDS stage, CHT d-tiles at a time, and issues every atomic over 16 CPW consecutive columns of a row.
+        // dW2[d][c]: each wave transposes its (d x 16 CPW) slice, CHT d-tiles at a time, and writes 16 CPW consecutive
+        // columns of a row per 16 CPW lanes.
         constexpr int W = 16 * CPW, TLD2 = W + 1, RPI = 64 / W;     // columns per wave, padded LDS row, rows per instruction
         constexpr int CAP = 16 * (D + 4) / (16 * TLD2);             // d-tiles the wave's LDS part holds
         constexpr int CHT = CAP >= 4 ? 4 : (CAP >= 2 ? 2 : 1);
         static_assert(DT % CHT == 0 && CAP >= 1, "dW2 transpose chunks");
-        __syncthreads();                                     // every wave is done reading the stage
         float* tr = reinterpret_cast<float*>(smem) + wave * 16 * (D + 4);
 #pragma unroll
         for (int j = 0; j < CPW; ++j) {
-            if (ct0 + j >= nct) continue;
+            if (ct0 + j >= nct || il != 0) continue;
             const int c0 = 16 * (ct0 + j) + 4 * g;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const int d = 16 * dt + il;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (c0 + r < C) atomicAdd(bk.g_ch_w1 + (long)(c0 + r) * D + d, dw1[j][dt][r]);
-            }
-            if (il == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (c0 + r < C) atomicAdd(bk.g_ch_b1 + c0 + r, db1[j][r]);
+            for (int r = 0; r < 4; ++r) {
+                if (c0 + r >= C) continue;
+                atomicAdd(o_b1 + c0 + r, db1[j][r]);
             }
         }
         const int cw = 16 * ct0 + (lane % W);                // this lane's column in the transposed read
@@ -356,12 +370,14 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, i
                 for (int j = 0; j < CPW; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) tr[(16 * dtl + il) * TLD2 + 16 * j + 4 * g + r] = dw2[j][CHT * ch + dtl][r];
-            // (one wave: its LDS accesses complete in order, no barrier needed)
 #pragma unroll
             for (int i = 0; i < 16 * CHT / RPI; ++i) {
                 const int row = RPI * i + lane / W;
                 const float v = tr[row * TLD2 + lane % W];
-                if (cw < C) atomicAdd(bk.g_ch_w2 + (long)(16 * CHT * ch + row) * C + cw, v);
+                if (cw < C) {
+                    float* q = o_w2 + (long)(16 * CHT * ch + row) * C + cw;
+                    atomicAdd(q, v);
+                }
             }
         }
     }
@@ -371,7 +387,8 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, i
 template <int P, int D>
 __global__ __launch_bounds__(WG_THREADS, (WgradGeom<P, D>::MINWAVES)) void tower_wgrad_kernel(const m2m_tower tw, int ntiles, int tiles_per_group) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    wgrad_body<P, D>(tw.blk[blockIdx.y], tw.Cp, tw.C, blockIdx.x, blockIdx.z, gridDim.z == 1, ntiles, tiles_per_group, smem);
+    wgrad_body<P, D>(tw.blk[blockIdx.y], tw.Cp, tw.C, blockIdx.x, blockIdx.z, gridDim.z == 1 ? WG_OUT_ADD : WG_OUT_ATOMIC, ntiles,
+                     tiles_per_group, smem);
 }
 
 // Several towers in ONE launch (blockIdx.y = job = (tower, block)): the three towers of a model finish their backward
@@ -384,7 +401,6 @@ struct WgradGroupArgs {
     const m2m_tower* tw[WG_MAX_TOWERS];
     int ntiles[WG_MAX_TOWERS], tpg[WG_MAX_TOWERS], groups[WG_MAX_TOWERS], nsl[WG_MAX_TOWERS];
     unsigned char job_tower[WG_MAX_JOBS], job_block[WG_MAX_JOBS];
-    int force_atomic;
 };
 template <int P, int D>
 __global__ __launch_bounds__(WG_THREADS, (WgradGeom<P, D>::MINWAVES)) void tower_wgrad_group_kernel(const WgradGroupArgs a) {
@@ -392,7 +408,7 @@ __global__ __launch_bounds__(WG_THREADS, (WgradGeom<P, D>::MINWAVES)) void tower
     const int t = a.job_tower[blockIdx.y];
     if ((int)blockIdx.x >= a.nsl[t] || (int)blockIdx.z >= a.groups[t]) return;
     const m2m_tower& tw = *a.tw[t];
-    wgrad_body<P, D>(tw.blk[a.job_block[blockIdx.y]], tw.Cp, tw.C, blockIdx.x, blockIdx.z, a.groups[t] == 1 && !a.force_atomic,
+    wgrad_body<P, D>(tw.blk[a.job_block[blockIdx.y]], tw.Cp, tw.C, blockIdx.x, blockIdx.z, a.groups[t] == 1 ? WG_OUT_ADD : WG_OUT_ATOMIC,
                      a.ntiles[t], a.tpg[t], smem);
 }
 
@@ -441,7 +457,6 @@ static int launch_wgrad_group(const m2m_tower* const* host, const m2m_tower* con
         }
     }
     if (njobs == 0) return 0;
-    if (const char* e = getenv("M2M_WGRAD_ATOMIC")) a.force_atomic = atoi(e);
     const size_t lds = (size_t)WgradGeom<P, D>::LDS_B;
     auto kern = tower_wgrad_group_kernel<P, D>;
     static bool attr_done = false;
