@@ -277,7 +277,8 @@ def profile_launches(eng, image, audio, labels, nsteps):
     orig_heads, orig_twg, orig_pack = E.heads_ce, E.towers_wgrad, E.pack_all
     E.pack_all = timed("pack_all", orig_pack, 0)
     E.heads_ce = timed("heads_ce", orig_heads, alg["heads"] * 3)
-    E.towers_wgrad = timed("towers_wgrad[all]", orig_twg, sum(alg[t]["channel"] for t in ("image", "audio", "fusion")))
+    E.towers_wgrad = timed("towers_wgrad[all]", orig_twg, sum(alg[t]["channel"] for t in ("image", "audio", "fusion")) +
+                           alg["image"]["embed"] + alg["audio"]["embed"])     # the launch includes both patch-embedding gradients
     try:
         for _ in range(nsteps):
             eng._prologue()

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define M2M_ABI_VERSION 7
+#define M2M_ABI_VERSION 9
 #define M2M_MAX_BLOCKS 8      /* MixerBlocks per m2m_tower; longer towers are chained by the caller */
 #define M2M_ROWS_PER_WG 16    /* token rows one workgroup keeps on chip */
 
@@ -127,6 +127,9 @@ int m2m_pack_all(const m2m_tower* const* towers, int ntowers, const m2m_embed* c
 /* ---- forward ------------------------------------------------------------------------------------ */
 /* x0 (B*N, D) = patches(input) W^T + b.   Replaces MLPMixer.to_patch_embedding / MLPMixerNoPatching.proj. */
 int m2m_embed_forward(const m2m_embed* e, const float* input, int B, float* x0, void* stream);
+/* The two patch embeddings of a two-tower model (same precision and D) in ONE launch. */
+int m2m_embeds_forward(const m2m_embed* const* embeds, const float* const* inputs, float* const* x0s, int nembeds, int B,
+                       void* stream);
 
 /* Blocks + final LayerNorm over a (B, N, D) input.  Replaces the `for mixer_block in self.mixer_blocks`
  * loop + self.layer_norm of MLPMixer/FusionMixer/MLPMixerNoPatching.forward (modules/mixer.py:125-132).
@@ -179,10 +182,16 @@ int m2m_tower_wgrad(const m2m_tower* t, int B, uint32_t seed, uint32_t step, con
 /* The same for up to 4 towers (same precision and hidden_dim) in ONE launch: the towers of a model finish their backward
  * chains together, and one launch lets the hardware balance all their workgroups over the chip.  `dev_towers[i]` is a
  * device-resident byte copy of *towers[i] (kernel arguments are limited to 4 KiB; the caller refreshes the copy whenever
- * a pointer in the descriptor changes, outside any graph capture). */
-int m2m_towers_wgrad(const m2m_tower* const* towers, const m2m_tower* const* dev_towers, int ntowers, int B, void* stream);
+ * a pointer in the descriptor changes, outside any graph capture).
+ * nembeds = 2: the same launch also computes m2m_embed_wgrad for the model's two patch embeddings (inputs[i], d_x0s[i]
+ * as there) in extra workgroups that back-fill the CUs the tower workgroups leave idle; nembeds = 0: towers only. */
+int m2m_towers_wgrad(const m2m_tower* const* towers, const m2m_tower* const* dev_towers, int ntowers,
+                     const m2m_embed* const* embeds, const float* const* inputs, const float* const* d_x0s, int nembeds,
+                     int B, void* stream);
 /* g_w += d_x0^T patches(input), g_b += column sums of d_x0. */
 int m2m_embed_wgrad(const m2m_embed* e, const float* input, const float* d_x0, int B, void* stream);
+int m2m_embeds_wgrad(const m2m_embed* const* embeds, const float* const* inputs, const float* const* d_x0s, int nembeds, int B,
+                     void* stream);                       /* both embeddings of a two-tower model in one launch */
 
 /* ---- heads + multi-head loss (models/avmnist.py:271-298, models/mimic.py:106-121) ------------------ */
 /* For each of nheads heads h: logits_h = pooled_h W_h^T + b_h (K classes), CrossEntropyLoss (mean),

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("M2M_LIB_PATH", os.path.join(_HERE, "libm2mixer.so"))   # override: diagnostic builds
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 7
+ABI_VERSION = 9
 MAX_BLOCKS = 8
 ROWS_PER_WG = 16
 HCHN_PAD = 4096          # >= the pad between operand streams the library uses (csrc/tile.h M2M_HCHN_PAD)
@@ -99,9 +99,12 @@ SIGNATURES = {
                                      C.c_uint32, _fp, _fp]),
     "m2m_towers_backward": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.POINTER(TowerGIO), C.c_int, C.c_int, C.c_uint32, C.c_uint32,
                                       _fp, _fp]),
-    "m2m_towers_wgrad": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.POINTER(_fp), C.c_int, C.c_int, _fp]),
+    "m2m_towers_wgrad": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.POINTER(_fp), C.c_int, C.POINTER(C.POINTER(Embed)), C.POINTER(_fp),
+                                   C.POINTER(_fp), C.c_int, C.c_int, _fp]),
     "m2m_counter_add": (C.c_int, [_fp, C.c_uint32, _fp]),
     "m2m_embed_wgrad": (C.c_int, [C.POINTER(Embed), _fp, _fp, C.c_int, _fp]),
+    "m2m_embeds_wgrad": (C.c_int, [C.POINTER(C.POINTER(Embed)), C.POINTER(_fp), C.POINTER(_fp), C.c_int, C.c_int, _fp]),
+    "m2m_embeds_forward": (C.c_int, [C.POINTER(C.POINTER(Embed)), C.POINTER(_fp), C.POINTER(_fp), C.c_int, C.c_int, _fp]),
     "m2m_heads_ce": (C.c_int, [C.POINTER(Head), C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, C.c_int, _fp]),
     "m2m_step_prologue": (C.c_int, [_fp, _fp, _fp, C.c_int, _fp]),
     "m2m_heads_bce": (C.c_int, [C.POINTER(Head), C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, C.c_int, _fp]),

@@ -1,0 +1,196 @@
+// Patch-embedding weight gradient: the workgroup body, shared by embed.hip (its own launches, 512 threads) and
+// tower_wgrad.hip (as extra workgroups of the merged weight-gradient launch, 256 threads).
+#pragma once
+#include "tile.h"
+
+#define EBM 32             // token rows per tile
+
+int m2m_check_embed(const m2m_embed* e, int B);    // embed.hip
+
+struct PatchGeom {
+    int Cin, H, W, ph, pw, GW, N, K;
+};
+// offset of element k of a patch relative to the patch origin; -1 beyond K
+static __device__ __forceinline__ int patch_koff(const PatchGeom& pg, int k) {
+    if (k >= pg.K) return -1;
+    const int c = k / (pg.ph * pg.pw), rem = k % (pg.ph * pg.pw);
+    const int py = rem / pg.pw, px = rem % pg.pw;
+    return (c * pg.H + py) * pg.W + px;
+}
+// offset of the origin of token row m's patch; -1 beyond M
+static __device__ __forceinline__ long patch_rowbase(const PatchGeom& pg, long m, long M) {
+    if (m >= M) return -1;
+    const long b = m / pg.N;
+    const int n = (int)(m % pg.N);
+    const int gy = n / pg.GW, gx = n % pg.GW;
+    return (b * pg.Cin * pg.H + gy * pg.ph) * (long)pg.W + gx * pg.pw;
+}
+
+// g_w[d][k] += sum_m dx0[m][d] patch[m][k];  workgroup = 64 k columns (chunk) x one group of 32-row tiles.
+// Software-pipelined: the next tile's dx0 rows and patch elements are loaded into registers (12 per thread) while the
+// current tile is packed and multiplied, so the loop runs at the LDS/MFMA rate instead of one exposed memory latency per
+// tile (2.8 -> ~1 us per tile).
+template <int P, int D, int NT>
+static __device__ __forceinline__ void embed_wgrad_body(const m2m_embed& em, const float* __restrict__ in,
+                                                        const float* __restrict__ dx0, long M, int N, int tiles_per_group,
+                                                        int chunk, int group, bool single, char* smem) {
+    typedef Prec<P> Pr;
+    constexpr int DT = D / 16, NKM = EBM / Pr::KB, XLD = TileGeom<D>::XLD;
+    constexpr int KC = 64, KCT = KC / 16, PLD = KC + 4;
+    constexpr int DPW = (DT + (NT / 64) - 1) / (NT / 64);
+    constexpr int NDX = (EBM * (D / 4) + NT - 1) / NT;    // float4 pieces of the dx0 tile per thread
+    constexpr int NPT = EBM * KC / NT;                          // patch elements per thread (rows wave + 8 i, column tid % 64)
+    static_assert(NT % KC == 0 && EBM % (NT / KC) == 0, "patch tile mapping");
+    float* dxt = reinterpret_cast<float*>(smem);                  // [EBM][XLD]   dx0 tile
+    float* pt = dxt + EBM * XLD;                                    // [EBM][PLD]   patch tile
+    char* aimg = reinterpret_cast<char*>(pt + EBM * PLD);           // NAT X[i=d][k=m]  blocks [dt][kbm]
+    char* bimg = aimg + EBM * D * Pr::ESZ;                          // NAT X[i=kk][k=m] blocks [kt][kbm]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
+    PatchGeom pg{em.Cin, em.H, em.W, em.ph, em.pw, em.W / em.pw, N, em.K};
+    const int k0 = chunk * KC;
+    const int ko = patch_koff(pg, k0 + (tid % KC));                 // this thread's patch column, fixed for the whole loop
+
+    f32x4_t acc[DPW][KCT];
+#pragma unroll
+    for (int j = 0; j < DPW; ++j)
+#pragma unroll
+        for (int kt = 0; kt < KCT; ++kt) acc[j][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;                                               // bias gradient (k-chunk 0 only), thread d
+
+    const long ntiles = (M + EBM - 1) / EBM;
+    const long t_begin = (long)group * tiles_per_group;
+    const long t_end = min(ntiles, t_begin + tiles_per_group);
+    float4 dxr[NDX];
+    float ptr_[NPT];
+    auto load_tile = [&](long tl) {
+        const long m0 = tl * EBM;
+#pragma unroll
+        for (int i = 0; i < NDX; ++i) {
+            const int idx = i * NT + tid;
+            const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
+            dxr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < EBM * (D / 4) && m0 + r < M) dxr[i] = *reinterpret_cast<const float4*>(dx0 + (m0 + r) * D + c);
+        }
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const long rb = patch_rowbase(pg, m0 + tid / KC + (NT / KC) * i, M);
+            ptr_[i] = (rb >= 0 && ko >= 0) ? in[rb + ko] : 0.f;
+        }
+    };
+    if (t_begin < t_end) load_tile(t_begin);
+    for (long tl = t_begin; tl < t_end; ++tl) {
+        __syncthreads();                                            // the previous tile's MFMAs are done with the LDS images
+#pragma unroll
+        for (int i = 0; i < NDX; ++i) {
+            const int idx = i * NT + tid;
+            if (idx < EBM * (D / 4)) *reinterpret_cast<float4*>(dxt + (idx / (D / 4)) * XLD + (idx % (D / 4)) * 4) = dxr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) pt[(tid / KC + (NT / KC) * i) * PLD + tid % KC] = ptr_[i];
+        if (tl + 1 < t_end) load_tile(tl + 1);                      // in flight behind the packing and the MFMAs below
+        __syncthreads();
+        if (chunk == 0 && tid < D) {
+            float s = 0.f;
+            for (int r = 0; r < EBM; ++r) s += dxt[r * XLD + tid];
+            bsum += s;
+        }
+        for (int slot = tid; slot < DT * NKM * 64; slot += NT) {
+            const int blk = slot >> 6;
+            *reinterpret_cast<u32x4_t*>(aimg + slot * 16) =
+                gather_slot<P>(dxt, XLD, PACK_NAT, true, blk / NKM, blk % NKM, slot & 63);
+        }
+        for (int slot = tid; slot < KCT * NKM * 64; slot += NT) {
+            const int blk = slot >> 6;
+            *reinterpret_cast<u32x4_t*>(bimg + slot * 16) =
+                gather_slot<P>(pt, PLD, PACK_NAT, true, blk / NKM, blk % NKM, slot & 63);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) {
+            const int dt = wave + (NT / 64) * j;
+            if (dt < DT) {
+#pragma unroll
+                for (int kbm = 0; kbm < NKM; ++kbm) {
+                    const Frag a = ld_frag_lds(aimg, dt * NKM + kbm, lane);
+#pragma unroll
+                    for (int kt = 0; kt < KCT; ++kt) {
+                        const Frag b = ld_frag_lds(bimg, kt * NKM + kbm, lane);
+                        Pr::mma(acc[j][kt], a, b);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) {
+        const int dt = wave + (NT / 64) * j;
+        if (dt < DT) {
+#pragma unroll
+            for (int kt = 0; kt < KCT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int d = 16 * dt + 4 * g + r, k = k0 + 16 * kt + il;
+                    if (k < em.K) {
+                        float* p = em.g_w + (long)d * em.K + k;
+                        if (single) *p += acc[j][kt][r]; else atomicAdd(p, acc[j][kt][r]);
+                    }
+                }
+        }
+    }
+    if (chunk == 0 && tid < D) { if (single) em.g_b[tid] += bsum; else atomicAdd(em.g_b + tid, bsum); }
+}
+
+// Both patch embeddings of a two-tower model behind one launch: workgroups [0, nwg(0)) serve embedding 0, the rest 1.
+#define EMB_GROUP 2
+struct EmbedWgradGroupArgs {
+    m2m_embed em[EMB_GROUP];
+    const float* in[EMB_GROUP];
+    const float* dx0[EMB_GROUP];
+    long M[EMB_GROUP];
+    int N[EMB_GROUP], tpg[EMB_GROUP], nchunks[EMB_GROUP], groups[EMB_GROUP];
+};
+template <int P, int D, int NT>
+static __device__ __forceinline__ void embed_wgrad_group_body(const EmbedWgradGroupArgs& a, int id, char* smem) {
+    const int n0 = a.nchunks[0] * a.groups[0];
+    const int e = id < n0 ? 0 : 1;
+    if (e) id -= n0;
+    embed_wgrad_body<P, D, NT>(a.em[e], a.in[e], a.dx0[e], a.M[e], a.N[e], a.tpg[e], id % a.nchunks[e], id / a.nchunks[e],
+                               a.groups[e] == 1, smem);
+}
+
+struct EmbedWgradPlan { long M; int N, nchunks, groups, tpg; };
+static EmbedWgradPlan embed_wgrad_plan(const m2m_embed* e, int B, int target_wgs) {
+    EmbedWgradPlan pl;
+    pl.N = (e->H / e->ph) * (e->W / e->pw);
+    pl.M = (long)B * pl.N;
+    pl.nchunks = (e->K + 63) / 64;
+    const long ntiles = (pl.M + EBM - 1) / EBM;
+    long groups = (target_wgs + pl.nchunks - 1) / pl.nchunks;  // row groups add with atomics
+    if (groups > ntiles / 4) groups = ntiles / 4;
+    if (groups < 1) groups = 1;
+    pl.tpg = (int)((ntiles + groups - 1) / groups);
+    pl.groups = (int)((ntiles + pl.tpg - 1) / pl.tpg);
+    return pl;
+}
+template <int D, int P> static constexpr size_t embed_wgrad_lds() {   // independent of the thread count
+    return (size_t)EBM * TileGeom<D>::XLD * 4 + (size_t)EBM * 68 * 4 + (size_t)EBM * D * Prec<P>::ESZ + (size_t)EBM * 64 * Prec<P>::ESZ;
+}
+
+
+// Fills the group arguments (embedding with more row tiles per workgroup first); returns the number of workgroups.
+static inline int embed_wgrad_group_args(EmbedWgradGroupArgs& a, const m2m_embed* const* es, const float* const* ins,
+                                         const float* const* dx0s, int B, int target_wgs) {
+    memset(&a, 0, sizeof(a));
+    EmbedWgradPlan pl[EMB_GROUP];
+    for (int i = 0; i < EMB_GROUP; ++i) pl[i] = embed_wgrad_plan(es[i], B, target_wgs);
+    const int first = pl[1].tpg > pl[0].tpg ? 1 : 0;
+    int total = 0;
+    for (int k = 0; k < EMB_GROUP; ++k) {
+        const int i = k == 0 ? first : 1 - first;
+        a.em[k] = *es[i]; a.in[k] = ins[i]; a.dx0[k] = dx0s[i];
+        a.M[k] = pl[i].M; a.N[k] = pl[i].N; a.tpg[k] = pl[i].tpg; a.nchunks[k] = pl[i].nchunks; a.groups[k] = pl[i].groups;
+        total += pl[i].nchunks * pl[i].groups;
+    }
+    return total;
+}

@@ -14,6 +14,7 @@
 // With one row group every result element has a single owner and is written without atomics; two groups add onto the
 // zeroed gradient with float atomics (a + b == b + a: still bit-deterministic).
 #include "tile.h"
+#include "embed_wgrad.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -401,14 +402,26 @@ struct WgradGroupArgs {
     const m2m_tower* tw[WG_MAX_TOWERS];
     int ntiles[WG_MAX_TOWERS], tpg[WG_MAX_TOWERS], groups[WG_MAX_TOWERS], nsl[WG_MAX_TOWERS];
     unsigned char job_tower[WG_MAX_JOBS], job_block[WG_MAX_JOBS];
+    int max_nsl, njobs, n_tower_wgs;
 };
+// The grid is one-dimensional: id -> (slice, job, group) in that order (slice fastest), then -- so that they are dispatched
+// last and back-fill the CUs whose tower workgroup has finished -- the workgroups of the model's two patch-embedding
+// weight gradients (embed_wgrad.h).  A second launch beside this one costs a fork and a join in the replayed graph
+// (~10 us each) and slows this kernel by contending for the same CUs.
 template <int P, int D>
-__global__ __launch_bounds__(WG_THREADS, (WgradGeom<P, D>::MINWAVES)) void tower_wgrad_group_kernel(const WgradGroupArgs a) {
+__global__ __launch_bounds__(WG_THREADS, (WgradGeom<P, D>::MINWAVES)) void tower_wgrad_group_kernel(const WgradGroupArgs a,
+                                                                                                    const EmbedWgradGroupArgs ea) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int t = a.job_tower[blockIdx.y];
-    if ((int)blockIdx.x >= a.nsl[t] || (int)blockIdx.z >= a.groups[t]) return;
+    const int id = blockIdx.x;
+    if (id >= a.n_tower_wgs) {
+        embed_wgrad_group_body<P, D, WG_THREADS>(ea, id - a.n_tower_wgs, smem);
+        return;
+    }
+    const int slice = id % a.max_nsl, job = (id / a.max_nsl) % a.njobs, group = id / (a.max_nsl * a.njobs);
+    const int t = a.job_tower[job];
+    if (slice >= a.nsl[t] || group >= a.groups[t]) return;
     const m2m_tower& tw = *a.tw[t];
-    wgrad_body<P, D>(tw.blk[a.job_block[blockIdx.y]], tw.Cp, tw.C, blockIdx.x, blockIdx.z, a.groups[t] == 1 ? WG_OUT_ADD : WG_OUT_ATOMIC,
+    wgrad_body<P, D>(tw.blk[a.job_block[job]], tw.Cp, tw.C, slice, group, a.groups[t] == 1 ? WG_OUT_ADD : WG_OUT_ATOMIC,
                      a.ntiles[t], a.tpg[t], smem);
 }
 
@@ -432,7 +445,8 @@ static int launch_wgrad(const m2m_tower* t, int B, hipStream_t st) {
 }
 
 template <int P, int D>
-static int launch_wgrad_group(const m2m_tower* const* host, const m2m_tower* const* dev, int n, int B, hipStream_t st) {
+static int launch_wgrad_group(const m2m_tower* const* host, const m2m_tower* const* dev, int n, const m2m_embed* const* embeds,
+                              const float* const* inputs, const float* const* d_x0s, int nembeds, int B, hipStream_t st) {
     WgradGroupArgs a;
     memset(&a, 0, sizeof(a));
     int njobs = 0, max_nsl = 1, max_groups = 1;
@@ -456,15 +470,21 @@ static int launch_wgrad_group(const m2m_tower* const* host, const m2m_tower* con
             ++njobs;
         }
     }
-    if (njobs == 0) return 0;
-    const size_t lds = (size_t)WgradGeom<P, D>::LDS_B;
+    if (njobs == 0 && nembeds == 0) return 0;
+    a.max_nsl = max_nsl; a.njobs = njobs; a.n_tower_wgs = max_nsl * njobs * max_groups;
+    EmbedWgradGroupArgs ea;
+    memset(&ea, 0, sizeof(ea));
+    // ~2 embedding workgroups per CU: they are short and only fill what the tower workgroups leave idle
+    const int n_embed_wgs = nembeds ? embed_wgrad_group_args(ea, embeds, inputs, d_x0s, B, 512) : 0;
+    const size_t lds_t = (size_t)WgradGeom<P, D>::LDS_B, lds_e = nembeds ? embed_wgrad_lds<D, P>() : 0;
+    const size_t lds = lds_t > lds_e ? lds_t : lds_e;
     auto kern = tower_wgrad_group_kernel<P, D>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
         M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        attr_lds = lds;
     }
-    hipLaunchKernelGGL(kern, dim3(max_nsl, njobs, max_groups), dim3(WG_THREADS), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.n_tower_wgs + n_embed_wgs)), dim3(WG_THREADS), lds, st, a, ea);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -509,9 +529,14 @@ extern "C" int m2m_tower_wgrad(const m2m_tower* t, int B, uint32_t seed, uint32_
     return -1;
 }
 
-extern "C" int m2m_towers_wgrad(const m2m_tower* const* towers, const m2m_tower* const* dev_towers, int ntowers, int B,
-                                void* stream) {
+extern "C" int m2m_towers_wgrad(const m2m_tower* const* towers, const m2m_tower* const* dev_towers, int ntowers,
+                                const m2m_embed* const* embeds, const float* const* inputs, const float* const* d_x0s, int nembeds,
+                                int B, void* stream) {
     if (!towers || !dev_towers || ntowers < 1 || ntowers > WG_MAX_TOWERS) { m2m_set_error("towers_wgrad: 1..4 towers", __FILE__, __LINE__); return -1; }
+    if (nembeds != 0 && (nembeds != EMB_GROUP || !embeds || !inputs || !d_x0s)) {
+        m2m_set_error("towers_wgrad: no patch embeddings or exactly two", __FILE__, __LINE__);
+        return -1;
+    }
     for (int i = 0; i < ntowers; ++i) {
         if (int rc = m2m_check_tower(towers[i], B)) return rc;
         if (!dev_towers[i]) { m2m_set_error("towers_wgrad: missing device-resident descriptor", __FILE__, __LINE__); return -1; }
@@ -520,9 +545,17 @@ extern "C" int m2m_towers_wgrad(const m2m_tower* const* towers, const m2m_tower*
             return -1;
         }
     }
+    for (int i = 0; i < nembeds; ++i) {
+        if (int rc = m2m_check_embed(embeds[i], B)) return rc;
+        if (!inputs[i] || !d_x0s[i]) { m2m_set_error("towers_wgrad: null embedding input", __FILE__, __LINE__); return -1; }
+        if (embeds[i]->prec != towers[0]->prec || embeds[i]->D != towers[0]->D) {
+            m2m_set_error("towers_wgrad: embeddings must share the towers' precision and hidden_dim", __FILE__, __LINE__);
+            return -1;
+        }
+    }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const m2m_tower* t = towers[0];
-#define M2M_WGG_CASE(PP, DD) if (t->prec == PP && t->D == DD) return launch_wgrad_group<PP, DD>(towers, dev_towers, ntowers, B, st);
+#define M2M_WGG_CASE(PP, DD) if (t->prec == PP && t->D == DD) return launch_wgrad_group<PP, DD>(towers, dev_towers, ntowers, embeds, inputs, d_x0s, nembeds, B, st);
     M2M_WGG_CASE(PREC_BF16, 32) M2M_WGG_CASE(PREC_BF16, 64) M2M_WGG_CASE(PREC_BF16, 128) M2M_WGG_CASE(PREC_BF16, 256)
     M2M_WGG_CASE(PREC_F32, 32) M2M_WGG_CASE(PREC_F32, 64) M2M_WGG_CASE(PREC_F32, 128) M2M_WGG_CASE(PREC_F32, 256)
 #undef M2M_WGG_CASE

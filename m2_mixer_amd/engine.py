@@ -25,7 +25,8 @@ import torch
 from . import _lib as L
 from . import config
 from .runtime import (BLOCK_FIELDS, BLOCK_KEYS, EmbedRuntime, MlpRuntime, TowerRuntime, block_param_shapes, heads_bce,
-                      heads_ce, can_group, can_pack_all, pack_all, towers_backward, towers_forward, towers_wgrad)
+                      heads_ce, can_group, can_group_embeds, can_pack_all, embeds_forward, pack_all,
+                      towers_backward, towers_forward, towers_wgrad)
 
 
 def _num_patch(c: dict) -> int:
@@ -381,13 +382,13 @@ class _TwoTowerEngine(_FlatEngine):
         b_part = self.fused.view(-1)[self.Na * D:]
         main, side, _ = self._streams()
         if self.concurrent and can_group(self.t_a, self.t_b):
-            # one launch for both towers (blockIdx.y = tower) on the main stream: no cross-queue fork / join in the graph;
-            # only the second tower's patch embedding (it gates nothing but that tower) runs beside the first one's
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
+            # one launch for both patch embeddings, one for both towers (blockIdx.y = tower), all on the main stream: no
+            # cross-queue fork / join in the graph (a join costs ~6 us even when its event fired long ago)
+            if can_group_embeds(self.e_a, self.e_b):
+                embeds_forward([self.e_a, self.e_b], [xa, xb], [self.x0_a, self.x0_b], B)
+            else:
+                self.e_a.forward(xa, B, self.x0_a)
                 self.e_b.forward(xb, B, self.x0_b)
-            self.e_a.forward(xa, B, self.x0_a)
-            main.wait_stream(side)
             towers_forward([self.t_a, self.t_b],
                            [(self.x0_a, self.Na * D, self.fused, fs, self.pool_a), (self.x0_b, self.Nb * D, b_part, fs, self.pool_b)],
                            B, training, self.seed, 0, sd)
@@ -419,10 +420,11 @@ class _TwoTowerEngine(_FlatEngine):
         main, s_a, _ = self._streams()
         s_e = self.s_emb if self.concurrent else main
         # The two tower chains fill the chip (128 + 128 workgroups) side by side; then ONE launch computes the channel-mixing
-        # weight gradients of all three towers (the hardware dispatcher balances their ~480 workgroups; three launches on
-        # three queues of a replayed graph raced and sometimes serialised each other), with the two patch-embedding
-        # gradients beside it.  Every side stream forks from and joins into `main` directly (a fork from a forked stream
-        # crashed hipGraph capture on ROCm 7.2).
+        # weight gradients of all three towers (the hardware dispatcher balances their ~300 workgroups; three launches on
+        # three queues of a replayed graph raced and sometimes serialised each other) AND the two patch-embedding
+        # gradients, whose workgroups back-fill the CUs the tower workgroups leave idle: the whole step is one queue.
+        # (Any side stream forks from and joins into `main` directly: a fork from a forked stream crashed hipGraph
+        # capture on ROCm 7.2.)
         if self.concurrent and can_group(self.t_a, self.t_b):
             towers_backward([self.t_a, self.t_b],
                             [(self.d_fused, fs, self.dpool_a, self.dx0_a, self.Na * D), (d_b_part, fs, self.dpool_b, self.dx0_b, self.Nb * D)],
@@ -433,12 +435,15 @@ class _TwoTowerEngine(_FlatEngine):
                 self.t_a.backward(B, self.d_fused, fs, self.dpool_a, self.dx0_a, self.Na * D, self.seed, 0, sd)
             self.t_b.backward(B, d_b_part, fs, self.dpool_b, self.dx0_b, self.Nb * D, self.seed, 0, sd)
             main.wait_stream(s_a)
-        s_e.wait_stream(main)
-        with torch.cuda.stream(s_e):                        # e_b reads the whole input of that modality (audio: 50 KB / sample)
-            self.e_b.wgrad(xb, self.dx0_b, B)
-            self.e_a.wgrad(xa, self.dx0_a, B)
-        towers_wgrad([self.t_fus, self.t_a, self.t_b], B)
-        main.wait_stream(s_e)
+        if can_group_embeds(self.e_a, self.e_b) and self.e_a.prec == self.t_a.prec and self.e_a.D == self.t_a.D:
+            towers_wgrad([self.t_fus, self.t_a, self.t_b], B, [self.e_a, self.e_b], [xa, xb], [self.dx0_a, self.dx0_b])
+        else:
+            s_e.wait_stream(main)
+            with torch.cuda.stream(s_e):
+                self.e_b.wgrad(xb, self.dx0_b, B)
+                self.e_a.wgrad(xa, self.dx0_a, B)
+            towers_wgrad([self.t_fus, self.t_a, self.t_b], B)
+            main.wait_stream(s_e)
         if fused_update:
             self._adam(0, self.n_params, 1.0, False)
             self.pack()

@@ -269,12 +269,17 @@ def towers_backward(towers: Sequence[TowerRuntime], ios: Sequence[tuple], B: int
             "towers_backward")
 
 
-def towers_wgrad(towers: Sequence[TowerRuntime], B: int):
-    """Channel-mixing weight gradients of several towers (same precision / hidden_dim) in one launch."""
-    n = len(towers)
+def towers_wgrad(towers: Sequence[TowerRuntime], B: int, embeds: Sequence["EmbedRuntime"] = (),
+                 inputs: Sequence[torch.Tensor] = (), d_x0s: Sequence[torch.Tensor] = ()):
+    """Channel-mixing weight gradients of several towers (same precision / hidden_dim) in one launch; with `embeds`
+    (the model's two patch embeddings, their inputs and d_x0) also the embedding gradients, in the same launch."""
+    n, ne = len(towers), len(embeds)
     host = (C.POINTER(L.Tower) * n)(*[C.pointer(t.desc) for t in towers])
     dev = (C.c_void_p * n)(*[t.device_desc() for t in towers])
-    L.check(L.lib().m2m_towers_wgrad(host, dev, n, B, L.stream_ptr()), "towers_wgrad")
+    ep = (C.POINTER(L.Embed) * max(ne, 1))(*[C.pointer(e.desc) for e in embeds])
+    ip = (C.c_void_p * max(ne, 1))(*[t.data_ptr() for t in inputs])
+    dp = (C.c_void_p * max(ne, 1))(*[t.data_ptr() for t in d_x0s])
+    L.check(L.lib().m2m_towers_wgrad(host, dev, n, ep, ip, dp, ne, B, L.stream_ptr()), "towers_wgrad")
 
 
 def can_pack_all(towers: Sequence[TowerRuntime], embeds: Sequence["EmbedRuntime"]) -> bool:
@@ -343,6 +348,28 @@ class EmbedRuntime:
     def wgrad(self, inp: torch.Tensor, d_x0: torch.Tensor, B: int):
         L.check(L.lib().m2m_embed_wgrad(C.byref(self.desc), inp.data_ptr(), d_x0.data_ptr(), B, L.stream_ptr()),
                 "embed_wgrad")
+
+
+def can_group_embeds(a: EmbedRuntime, b: EmbedRuntime) -> bool:
+    return a.prec == b.prec and a.D == b.D
+
+
+def embeds_forward(embeds: Sequence[EmbedRuntime], inputs: Sequence[torch.Tensor], x0s: Sequence[torch.Tensor], B: int):
+    """Both patch embeddings of a two-tower model in one launch."""
+    n = len(embeds)
+    ep = (C.POINTER(L.Embed) * n)(*[C.pointer(e.desc) for e in embeds])
+    ip = (C.c_void_p * n)(*[t.data_ptr() for t in inputs])
+    xp = (C.c_void_p * n)(*[t.data_ptr() for t in x0s])
+    L.check(L.lib().m2m_embeds_forward(ep, ip, xp, n, B, L.stream_ptr()), "embeds_forward")
+
+
+def embeds_wgrad(embeds: Sequence[EmbedRuntime], inputs: Sequence[torch.Tensor], d_x0s: Sequence[torch.Tensor], B: int):
+    """Weight / bias gradients of both patch embeddings in one launch."""
+    n = len(embeds)
+    ep = (C.POINTER(L.Embed) * n)(*[C.pointer(e.desc) for e in embeds])
+    ip = (C.c_void_p * n)(*[t.data_ptr() for t in inputs])
+    dp = (C.c_void_p * n)(*[t.data_ptr() for t in d_x0s])
+    L.check(L.lib().m2m_embeds_wgrad(ep, ip, dp, n, B, L.stream_ptr()), "embeds_wgrad")
 
 
 class MlpRuntime:

@@ -39,7 +39,8 @@ def main():
           f"image alone {timeit(lambda: eng.t_img.wgrad(B, 1, 0, sd)):.1f} us, "
           f"fusion alone {timeit(lambda: eng.t_fus.wgrad(B, 1, 0, sd)):.1f} us, "
           f"image+audio {timeit(lambda: towers_wgrad([eng.t_a, eng.t_b], B)):.1f} us, "
-          f"merged {timeit(lambda: towers_wgrad([eng.t_fus, eng.t_a, eng.t_b], B)):.1f} us")
+          f"merged {timeit(lambda: towers_wgrad([eng.t_fus, eng.t_a, eng.t_b], B)):.1f} us, "
+          f"merged + embeds {timeit(lambda: towers_wgrad([eng.t_fus, eng.t_a, eng.t_b], B, [eng.e_a, eng.e_b], list(batch[:2]), [eng.dx0_a, eng.dx0_b])):.1f} us")
 
 
 if __name__ == "__main__":
