@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define M2M_ABI_VERSION 9
+#define M2M_ABI_VERSION 10
 #define M2M_MAX_BLOCKS 8      /* MixerBlocks per m2m_tower; longer towers are chained by the caller */
 #define M2M_ROWS_PER_WG 16    /* token rows one workgroup keeps on chip */
 
@@ -127,9 +127,13 @@ int m2m_pack_all(const m2m_tower* const* towers, int ntowers, const m2m_embed* c
 /* ---- forward ------------------------------------------------------------------------------------ */
 /* x0 (B*N, D) = patches(input) W^T + b.   Replaces MLPMixer.to_patch_embedding / MLPMixerNoPatching.proj. */
 int m2m_embed_forward(const m2m_embed* e, const float* input, int B, float* x0, void* stream);
-/* The two patch embeddings of a two-tower model (same precision and D) in ONE launch. */
-int m2m_embeds_forward(const m2m_embed* const* embeds, const float* const* inputs, float* const* x0s, int nembeds, int B,
-                       void* stream);
+/* The two patch embeddings of a two-tower model (same precision and D) in ONE launch.  nsplits[i] (NULL: all 1) > 1
+ * splits embedding i's contraction over K across that many workgroups per row tile; split s writes its partial sum
+ * (split 0 includes the bias) to x0s[i] + s * part_strides[i] floats, and the consumer adds the parts
+ * (m2m_tower_io.x0_parts).  m2m_embed_fwd_splits says how many splits pay off for an embedding (1 or 2). */
+int m2m_embeds_forward(const m2m_embed* const* embeds, const float* const* inputs, float* const* x0s, const int* nsplits,
+                       const int64_t* part_strides, int nembeds, int B, void* stream);
+int m2m_embed_fwd_splits(const m2m_embed* e);
 
 /* Blocks + final LayerNorm over a (B, N, D) input.  Replaces the `for mixer_block in self.mixer_blocks`
  * loop + self.layer_norm of MLPMixer/FusionMixer/MLPMixerNoPatching.forward (modules/mixer.py:125-132).
@@ -154,6 +158,8 @@ typedef struct m2m_tower_io {
     const float* x0; int64_t x0_sample_stride;
     float* out; int64_t out_sample_stride;
     float* pooled;
+    int32_t x0_parts;            /* 0 / 1: x0 is the input.  2..4: the input is the sum of x0_parts buffers, part p at */
+    int64_t x0_part_stride;      /*        x0 + p * x0_part_stride floats (k-split partial sums of m2m_embeds_forward) */
 } m2m_tower_io;
 int m2m_towers_forward(const m2m_tower* const* towers, const m2m_tower_io* io, int ntowers, int B, int training,
                        uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream);

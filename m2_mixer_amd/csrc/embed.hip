@@ -125,12 +125,14 @@ static __device__ __forceinline__ void embed_fwd_body(const m2m_embed& em, const
 // consecutive pixels of one patch row, so every thread loads its slot's 32 bytes straight from the image, converts and
 // writes the 16-byte slot: no fp32 staging tile, no offset tables, one barrier per 256-wide stage (the packed stage is
 // double-buffered), and a register ring keeps EMB_FDEPTH stages of loads in flight (the generic path has one 128-wide stage
-// in flight and spends its time on per-element LDS table lookups: 25 -> ~10 us for the audio embedding at batch 512).
+// in flight and spends its time on per-element LDS table lookups).  Audio embedding at batch 512: 25 -> 19 us, of which
+// ~7 us are fixed (launch, first loads, epilogue), ~5 us the 25.7 MB of input at the HBM roofline and ~6 us the packed weight
+// streamed from L2 by every workgroup (measured by removing either stream).
 #define EMB_FKS 256
 #define EMB_FDEPTH 3
 template <int D>
 static __device__ __forceinline__ void embed_fwd_fast_body(const m2m_embed& em, const float* __restrict__ in, long M, int N,
-                                                           float* __restrict__ x0, int wg, char* smem) {
+                                                           float* __restrict__ x0, int wg, int split, int nsplit, char* smem) {
     typedef Prec<PREC_BF16> Pr;
     constexpr int KSB = EMB_FKS / 32, DT = D / 16, DPW = (DT + NWAVES - 1) / NWAVES, IMG_B = 16 * EMB_FKS * 2;
     static_assert(KSB == NWAVES, "one k-block of the stage per wave");
@@ -140,7 +142,13 @@ static __device__ __forceinline__ void embed_fwd_fast_body(const m2m_embed& em, 
     const long m0 = (long)wg * 16;
     const long rb = patch_rowbase(pg, m0 + il, M);          // this thread's token row (slot row il), -1 beyond M
     const int nKB = em.Kp / 32;
-    const int nst = (em.Kp + EMB_FKS - 1) / EMB_FKS;
+    // k-split: `nsplit` workgroups share a row tile, each contracting a contiguous range of stages into its own partial
+    // output (x0 points at this split's part; the tower forward adds the parts).  The loop is bound by streaming the
+    // packed weight (D x Kp bf16 per workgroup, ~32 B/clk per CU): splitting K halves that stream per workgroup and fills
+    // the chip (batch 512: 128 row tiles on 256 CUs).
+    const int nst_all = (em.Kp + EMB_FKS - 1) / EMB_FKS;
+    const int per = (nst_all + nsplit - 1) / nsplit;
+    const int st_begin = split * per, nst = min(nst_all, st_begin + per);
 
     f32x4_t acc[DPW];
 #pragma unroll
@@ -164,12 +172,12 @@ static __device__ __forceinline__ void embed_fwd_fast_body(const m2m_embed& em, 
         }
     };
     auto step = [&](Pre& p, int st) {
-        const bool valid = rb >= 0 && st * EMB_FKS + wave * 32 + 8 * g < em.K;
+        const bool valid = rb >= 0 && st < nst && st * EMB_FKS + wave * 32 + 8 * g < em.K;
         Frag f;
         f.u[0] = pack_bf2(p.p0[0], p.p0[1]); f.u[1] = pack_bf2(p.p0[2], p.p0[3]);
         f.u[2] = pack_bf2(p.p1[0], p.p1[1]); f.u[3] = pack_bf2(p.p1[2], p.p1[3]);
         if (!valid) f.u = u32x4_t{0u, 0u, 0u, 0u};
-        char* cur = img + (st & 1) * IMG_B;
+        char* cur = img + ((st - st_begin) & 1) * IMG_B;
         *reinterpret_cast<u32x4_t*>(cur + tid * 16) = f.u;    // block kb = wave, lane
         __syncthreads();                                        // (also: everyone is done with the stage before last)
 #pragma unroll
@@ -183,8 +191,8 @@ static __device__ __forceinline__ void embed_fwd_fast_body(const m2m_embed& em, 
     };
     Pre ring[EMB_FDEPTH];
 #pragma unroll
-    for (int d = 0; d < EMB_FDEPTH; ++d) load(ring[d], d);
-    for (int st = 0; st < nst; st += EMB_FDEPTH) {
+    for (int d = 0; d < EMB_FDEPTH; ++d) load(ring[d], st_begin + d);
+    for (int st = st_begin; st < nst; st += EMB_FDEPTH) {
 #pragma unroll
         for (int d = 0; d < EMB_FDEPTH; ++d) step(ring[d], st + d);
     }
@@ -193,7 +201,7 @@ static __device__ __forceinline__ void embed_fwd_fast_body(const m2m_embed& em, 
         const int dt = wave + NWAVES * j;
         if (dt < DT) {
             const int d = 16 * dt + il;
-            const float bv = em.b[d];
+            const float bv = split == 0 ? em.b[d] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const long m = m0 + 4 * g + r;
@@ -211,7 +219,7 @@ template <int P, int D, int RB>
 __global__ __launch_bounds__(NTHREADS) void embed_fwd_kernel(const m2m_embed em, const float* __restrict__ in, long M, int N,
                                                              float* __restrict__ x0, int fast) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (P == PREC_BF16 && fast) embed_fwd_fast_body<D>(em, in, M, N, x0, blockIdx.x, smem);
+    if (P == PREC_BF16 && fast) embed_fwd_fast_body<D>(em, in, M, N, x0, blockIdx.x, 0, 1, smem);
     else embed_fwd_body<P, D, RB>(em, in, M, N, x0, blockIdx.x, smem);
 }
 
@@ -222,14 +230,18 @@ struct EmbedFwdGroupArgs {
     const float* in[2];
     float* x0[2];
     long M[2];
-    int N[2], nwg0, fast[2];
+    int N[2], nwg0, fast[2], nsplit[2];
+    long part_stride[2];       // floats between the k-split partial outputs
 };
 template <int P, int D, int RB>
 __global__ __launch_bounds__(NTHREADS) void embed_fwd_group_kernel(const EmbedFwdGroupArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int e = (int)blockIdx.x < a.nwg0 ? 0 : 1;
     const int wg = e ? blockIdx.x - a.nwg0 : blockIdx.x;
-    if (P == PREC_BF16 && a.fast[e]) embed_fwd_fast_body<D>(a.em[e], a.in[e], a.M[e], a.N[e], a.x0[e], wg, smem);
+    if (P == PREC_BF16 && a.fast[e]) {
+        const int ns = a.nsplit[e], split = wg % ns;
+        embed_fwd_fast_body<D>(a.em[e], a.in[e], a.M[e], a.N[e], a.x0[e] + split * a.part_stride[e], wg / ns, split, ns, smem);
+    }
     else embed_fwd_body<P, D, RB>(a.em[e], a.in[e], a.M[e], a.N[e], a.x0[e], wg, smem);
 }
 
@@ -272,7 +284,8 @@ static int launch_embed_fwd(const m2m_embed* e, const float* in, int B, float* x
     return 0;
 }
 template <int P, int D>
-static int launch_embed_fwd_group(const m2m_embed* const* es, const float* const* ins, float* const* x0s, int B, hipStream_t st) {
+static int launch_embed_fwd_group(const m2m_embed* const* es, const float* const* ins, float* const* x0s, const int* nsplits,
+                                  const int64_t* part_strides, int B, hipStream_t st) {
     constexpr int RB = 16;
     EmbedFwdGroupArgs a;
     memset(&a, 0, sizeof(a));
@@ -283,7 +296,13 @@ static int launch_embed_fwd_group(const m2m_embed* const* es, const float* const
         const int N = (es[i]->H / es[i]->ph) * (es[i]->W / es[i]->pw);
         a.em[k] = *es[i]; a.in[k] = ins[i]; a.x0[k] = x0s[i]; a.N[k] = N; a.M[k] = (long)B * N;
         a.fast[k] = embed_fwd_fast_ok(es[i], ins[i]);
-        const int nwg = (int)((a.M[k] + RB - 1) / RB);
+        a.nsplit[k] = nsplits ? nsplits[i] : 1;
+        a.part_stride[k] = part_strides ? (long)part_strides[i] : 0;
+        if (a.nsplit[k] < 1 || a.nsplit[k] > 4 || (a.nsplit[k] > 1 && (!a.fast[k] || a.part_stride[k] < a.M[k] * (long)D))) {
+            m2m_set_error("embeds_forward: k-splits need the fast path (m2m_embed_fwd_splits) and a part stride >= B*N*D", __FILE__, __LINE__);
+            return -1;
+        }
+        const int nwg = (int)((a.M[k] + RB - 1) / RB) * a.nsplit[k];
         if (k == 0) a.nwg0 = nwg;
         total += nwg;
     }
@@ -362,8 +381,15 @@ extern "C" int m2m_embeds_wgrad(const m2m_embed* const* embeds, const float* con
     return -1;
 }
 
-extern "C" int m2m_embeds_forward(const m2m_embed* const* embeds, const float* const* inputs, float* const* x0s, int nembeds, int B,
-                                  void* stream) {
+// How many k-splits m2m_embeds_forward should be given for this embedding: 2 when the fast path applies and K is long
+// enough for the weight stream to dominate (the audio spectrogram patches), else 1.
+extern "C" int m2m_embed_fwd_splits(const m2m_embed* e) {
+    if (!e) return 1;
+    return (embed_fwd_fast_ok(e, nullptr) && e->Kp >= 4 * EMB_FKS) ? 2 : 1;
+}
+
+extern "C" int m2m_embeds_forward(const m2m_embed* const* embeds, const float* const* inputs, float* const* x0s, const int* nsplits,
+                                  const int64_t* part_strides, int nembeds, int B, void* stream) {
     if (!embeds || !inputs || !x0s || nembeds != 2) { m2m_set_error("embeds_forward: exactly two embeddings", __FILE__, __LINE__); return -1; }
     for (int i = 0; i < nembeds; ++i) {
         if (int rc = m2m_check_embed(embeds[i], B)) return rc;
@@ -374,7 +400,7 @@ extern "C" int m2m_embeds_forward(const m2m_embed* const* embeds, const float* c
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const m2m_embed* e = embeds[0];
-#define M2M_EFG_CASE(PP, DD) if (e->prec == PP && e->D == DD) return launch_embed_fwd_group<PP, DD>(embeds, inputs, x0s, B, st);
+#define M2M_EFG_CASE(PP, DD) if (e->prec == PP && e->D == DD) return launch_embed_fwd_group<PP, DD>(embeds, inputs, x0s, nsplits, part_strides, B, st);
     M2M_EFG_CASE(PREC_BF16, 32) M2M_EFG_CASE(PREC_BF16, 64) M2M_EFG_CASE(PREC_BF16, 128) M2M_EFG_CASE(PREC_BF16, 256)
     M2M_EFG_CASE(PREC_F32, 32) M2M_EFG_CASE(PREC_F32, 64) M2M_EFG_CASE(PREC_F32, 128) M2M_EFG_CASE(PREC_F32, 256)
 #undef M2M_EFG_CASE

@@ -20,7 +20,8 @@ TIMER_READER(m2m_debug_timers_fwd, g_tm_fwd)
 // One workgroup's share of a tower forward: token tile `wg`.  TW is m2m_tower (single-tower launch) or m2m_tower4 (the
 // by-value descriptors of a multi-tower launch).
 template <class TW, int P, int D, int NMAX, int DM>
-static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float* __restrict__ x0, long x0_ss, int B,
+static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float* __restrict__ x0, long x0_ss, int x0_parts,
+                                                      long x0_pstride, int B,
                                                       float* __restrict__ out, long out_ss, float* __restrict__ pooled,
                                                       int training, unsigned int seed, unsigned int step_host,
                                                       const unsigned int* __restrict__ step_dev, int wg, char* smem) {
@@ -55,7 +56,15 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
     _Pragma("unroll 1") for (int idx = tid; idx < BM * (D / 4); idx += NTHREADS) {
         const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < R) { const long gr = row0 + r; v = *reinterpret_cast<const float4*>(x0 + (gr / N) * x0_ss + (gr % N) * D + c); }
+        if (r < R) {
+            const long gr = row0 + r;
+            const float* src = x0 + (gr / N) * x0_ss + (gr % N) * D + c;
+            v = *reinterpret_cast<const float4*>(src);
+            for (int p = 1; p < x0_parts; ++p) {             // k-split partial sums of the patch embedding (m2m_embeds_forward)
+                const float4 u = *reinterpret_cast<const float4*>(src + p * x0_pstride);
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+        }
         *reinterpret_cast<float4*>(xs + r * XLD + c) = v;
     }
     __syncthreads();
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_kernel(const m2m_tower tw,
                                                              unsigned int seed, unsigned int step_host,
                                                              const unsigned int* __restrict__ step_dev) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    tower_fwd_body<m2m_tower, P, D, NMAX, DM>(tw, x0, x0_ss, B, out, out_ss, pooled, training, seed, step_host, step_dev,
+    tower_fwd_body<m2m_tower, P, D, NMAX, DM>(tw, x0, x0_ss, 1, 0, B, out, out_ss, pooled, training, seed, step_host, step_dev,
                                                blockIdx.x, smem);
 }
 
@@ -277,6 +286,8 @@ struct FwdGroupArgs {
     m2m_tower4 tw[2];
     const float* x0[2];
     long x0_ss[2];
+    int x0_parts[2];
+    long x0_pstride[2];
     float* out[2];
     long out_ss[2];
     float* pooled[2];
@@ -293,7 +304,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_group_kernel(const FwdGrou
     const int id = blockIdx.x, xcd = id & 7, t = xcd >> 2;
     const int wg = (id >> 3) * 4 + (xcd & 3);
     if (wg >= a.ntiles[t]) return;
-    tower_fwd_body<m2m_tower4, P, D, NMAX, DM>(a.tw[t], a.x0[t], a.x0_ss[t], B, a.out[t], a.out_ss[t], a.pooled[t], training, seed,
+    tower_fwd_body<m2m_tower4, P, D, NMAX, DM>(a.tw[t], a.x0[t], a.x0_ss[t], a.x0_parts[t], a.x0_pstride[t], B, a.out[t], a.out_ss[t], a.pooled[t], training, seed,
                                                 step_host, step_dev, wg, smem);
 }
 
@@ -394,6 +405,9 @@ extern "C" int m2m_towers_forward(const m2m_tower* const* towers, const m2m_towe
     for (int i = 0; i < 2; ++i) {
         a.tw[i] = m2m_shrink(towers[i]);
         a.x0[i] = io[i].x0; a.x0_ss[i] = (long)io[i].x0_sample_stride;
+        a.x0_parts[i] = io[i].x0_parts > 1 ? io[i].x0_parts : 1;
+        a.x0_pstride[i] = (long)io[i].x0_part_stride;
+        if (a.x0_parts[i] > 4) { m2m_set_error("towers_forward: at most 4 input parts", __FILE__, __LINE__); return -1; }
         a.out[i] = io[i].out; a.out_ss[i] = (long)io[i].out_sample_stride;
         a.pooled[i] = io[i].pooled;
         const int SPW = BM / towers[i]->N;

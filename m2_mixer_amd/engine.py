@@ -349,7 +349,11 @@ class _TwoTowerEngine(_FlatEngine):
         self.e_b = make_embed(f"{b}_mixer.", cb)
         B, D, dev = self.B, self.D, self.device
         f = lambda *s: torch.zeros(*s, device=dev)
-        self.x0_a, self.x0_b = f(B * self.Na, D), f(B * self.Nb, D)
+        # embedding outputs; a long-K embedding (audio) is computed as k-split partial sums that the tower launch adds
+        grouped = can_group_embeds(self.e_a, self.e_b) and can_group(self.t_a, self.t_b)
+        self.x0_splits = (self.e_a.fwd_splits(), self.e_b.fwd_splits()) if grouped else (1, 1)
+        self._x0_a, self._x0_b = f(self.x0_splits[0], B * self.Na, D), f(self.x0_splits[1], B * self.Nb, D)
+        self.x0_a, self.x0_b = self._x0_a[0], self._x0_b[0]
         self.fused, self.fus_out = f(B, self.Nf, D), f(B, self.Nf, D)
         self.pool_a, self.pool_b, self.pool_fus = f(B, D), f(B, D), f(B, D)
         self.dpool_a, self.dpool_b, self.dpool_fus = f(B, D), f(B, D), f(B, D)
@@ -384,13 +388,16 @@ class _TwoTowerEngine(_FlatEngine):
         if self.concurrent and can_group(self.t_a, self.t_b):
             # one launch for both patch embeddings, one for both towers (blockIdx.y = tower), all on the main stream: no
             # cross-queue fork / join in the graph (a join costs ~6 us even when its event fired long ago)
+            sa, sb = self.x0_splits
             if can_group_embeds(self.e_a, self.e_b):
-                embeds_forward([self.e_a, self.e_b], [xa, xb], [self.x0_a, self.x0_b], B)
+                embeds_forward([self.e_a, self.e_b], [xa, xb], [self._x0_a, self._x0_b], B, [sa, sb])
             else:
+                sa = sb = 1
                 self.e_a.forward(xa, B, self.x0_a)
                 self.e_b.forward(xb, B, self.x0_b)
             towers_forward([self.t_a, self.t_b],
-                           [(self.x0_a, self.Na * D, self.fused, fs, self.pool_a), (self.x0_b, self.Nb * D, b_part, fs, self.pool_b)],
+                           [(self.x0_a, self.Na * D, self.fused, fs, self.pool_a, sa, B * self.Na * D),
+                            (self.x0_b, self.Nb * D, b_part, fs, self.pool_b, sb, B * self.Nb * D)],
                            B, training, self.seed, 0, sd)
         else:
             side.wait_stream(main)

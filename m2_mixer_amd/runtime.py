@@ -243,15 +243,17 @@ def can_group(a: TowerRuntime, b: TowerRuntime) -> bool:
 
 def towers_forward(towers: Sequence[TowerRuntime], ios: Sequence[tuple], B: int, training: bool, seed: int, step: int,
                    step_dev: Optional[torch.Tensor] = None):
-    """ios[i] = (x0, x0_ss, out, out_ss, pooled or None): two towers, one launch."""
+    """ios[i] = (x0, x0_ss, out, out_ss, pooled or None[, x0_parts, x0_part_stride]): two towers, one launch.  With
+    x0_parts > 1 the input is the sum of that many buffers (the k-split partial sums of embeds_forward)."""
     n = len(towers)
     for t in towers:
         if training:
             t.ensure_buffers(B)
     host = (C.POINTER(L.Tower) * n)(*[C.pointer(t.desc) for t in towers])
     io = (L.TowerIO * n)()
-    for i, (x0, x0_ss, out, out_ss, pooled) in enumerate(ios):
+    for i, (x0, x0_ss, out, out_ss, pooled, *parts) in enumerate(ios):
         io[i].x0, io[i].x0_ss, io[i].out, io[i].out_ss, io[i].pooled = x0.data_ptr(), x0_ss, out.data_ptr(), out_ss, L.ptr(pooled)
+        io[i].x0_parts, io[i].x0_part_stride = parts if parts else (1, 0)
     L.check(L.lib().m2m_towers_forward(host, io, n, B, int(training), seed & 0xFFFFFFFF, step & 0xFFFFFFFF, L.ptr(step_dev),
                                        L.stream_ptr()), "towers_forward")
 
@@ -341,6 +343,10 @@ class EmbedRuntime:
         self.desc.g_w, self.desc.g_b = g_w.data_ptr(), g_b.data_ptr()
         self._keep["g"] = (g_w, g_b)
 
+    def fwd_splits(self) -> int:
+        """k-splits embeds_forward should use for this embedding (1: none)."""
+        return int(L.lib().m2m_embed_fwd_splits(C.byref(self.desc)))
+
     def forward(self, inp: torch.Tensor, B: int, x0: torch.Tensor):
         L.check(L.lib().m2m_embed_forward(C.byref(self.desc), inp.data_ptr(), B, x0.data_ptr(), L.stream_ptr()),
                 "embed_forward")
@@ -354,13 +360,17 @@ def can_group_embeds(a: EmbedRuntime, b: EmbedRuntime) -> bool:
     return a.prec == b.prec and a.D == b.D
 
 
-def embeds_forward(embeds: Sequence[EmbedRuntime], inputs: Sequence[torch.Tensor], x0s: Sequence[torch.Tensor], B: int):
-    """Both patch embeddings of a two-tower model in one launch."""
+def embeds_forward(embeds: Sequence[EmbedRuntime], inputs: Sequence[torch.Tensor], x0s: Sequence[torch.Tensor], B: int,
+                   nsplits: Optional[Sequence[int]] = None):
+    """Both patch embeddings of a two-tower model in one launch.  nsplits[i] > 1: x0s[i] is (nsplits[i], B*N, D) and
+    receives k-split partial sums (EmbedRuntime.fwd_splits says when that pays off); the consumer adds them."""
     n = len(embeds)
     ep = (C.POINTER(L.Embed) * n)(*[C.pointer(e.desc) for e in embeds])
     ip = (C.c_void_p * n)(*[t.data_ptr() for t in inputs])
     xp = (C.c_void_p * n)(*[t.data_ptr() for t in x0s])
-    L.check(L.lib().m2m_embeds_forward(ep, ip, xp, n, B, L.stream_ptr()), "embeds_forward")
+    ns = (C.c_int * n)(*(nsplits if nsplits is not None else [1] * n))
+    ps = (C.c_int64 * n)(*[B * e.N * e.D for e in embeds])
+    L.check(L.lib().m2m_embeds_forward(ep, ip, xp, ns, ps, n, B, L.stream_ptr()), "embeds_forward")
 
 
 def embeds_wgrad(embeds: Sequence[EmbedRuntime], inputs: Sequence[torch.Tensor], d_x0s: Sequence[torch.Tensor], B: int):

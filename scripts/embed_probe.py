@@ -13,5 +13,5 @@ x0 = eng.x0_b.clone()
 print(os.path.basename(os.environ.get("M2M_LIB_PATH", "default")),
       "audio %.1f us" % timeit(lambda: eng.e_b.forward(batch[1], B, eng.x0_b)),
       "image %.1f us" % timeit(lambda: eng.e_a.forward(batch[0], B, eng.x0_a)),
-      "both %.1f us" % timeit(lambda: embeds_forward([eng.e_a, eng.e_b], list(batch[:2]), [eng.x0_a, eng.x0_b], B)),
+      "both %.1f us" % timeit(lambda: embeds_forward([eng.e_a, eng.e_b], list(batch[:2]), [eng._x0_a, eng._x0_b], B, list(eng.x0_splits))),
       "maxdiff vs step %.2e" % (eng.x0_b - x0).abs().max().item())
