@@ -137,7 +137,7 @@ def main():
     ap.add_argument("--model", default="B", choices=["B", "S"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--steps-per-graph", type=int, default=5,
+    ap.add_argument("--steps-per-graph", type=int, default=10,
                     help="N = 1: training steps captured per hipGraph (each with its own input slot); the replay gap between "
                          "graphs is ~17 us.  Remainder steps run through a single-step graph")
     ap.add_argument("--grad-compress", default="bf16", choices=["none", "bf16"],

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define M2M_ABI_VERSION 10
+#define M2M_ABI_VERSION 11
 #define M2M_MAX_BLOCKS 8      /* MixerBlocks per m2m_tower; longer towers are chained by the caller */
 #define M2M_ROWS_PER_WG 16    /* token rows one workgroup keeps on chip */
 
@@ -131,8 +131,13 @@ int m2m_embed_forward(const m2m_embed* e, const float* input, int B, float* x0, 
  * splits embedding i's contraction over K across that many workgroups per row tile; split s writes its partial sum
  * (split 0 includes the bias) to x0s[i] + s * part_strides[i] floats, and the consumer adds the parts
  * (m2m_tower_io.x0_parts).  m2m_embed_fwd_splits says how many splits pay off for an embedding (1 or 2). */
+/* head != NULL: the launch also performs m2m_step_prologue(head->...) -- the embeddings are the first launch of a training
+ * step and read none of those values, so the step needs no separate prologue launch. */
+typedef struct m2m_step_head {
+    float* adam_state; uint32_t* drop_counter; float* losses; int32_t nlosses;
+} m2m_step_head;
 int m2m_embeds_forward(const m2m_embed* const* embeds, const float* const* inputs, float* const* x0s, const int* nsplits,
-                       const int64_t* part_strides, int nembeds, int B, void* stream);
+                       const int64_t* part_strides, int nembeds, int B, const m2m_step_head* head, void* stream);
 int m2m_embed_fwd_splits(const m2m_embed* e);
 
 /* Blocks + final LayerNorm over a (B, N, D) input.  Replaces the `for mixer_block in self.mixer_blocks`

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("M2M_LIB_PATH", os.path.join(_HERE, "libm2mixer.so"))   # override: diagnostic builds
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 MAX_BLOCKS = 8
 ROWS_PER_WG = 16
 HCHN_PAD = 4096          # >= the pad between operand streams the library uses (csrc/tile.h M2M_HCHN_PAD)
@@ -50,6 +50,11 @@ class TowerIO(C.Structure):
     """m2m_tower_io"""
     _fields_ = [("x0", _fp), ("x0_ss", C.c_int64), ("out", _fp), ("out_ss", C.c_int64), ("pooled", _fp),
                 ("x0_parts", C.c_int32), ("x0_part_stride", C.c_int64)]
+
+
+class StepHead(C.Structure):
+    """m2m_step_head"""
+    _fields_ = [("adam_state", _fp), ("drop_counter", _fp), ("losses", _fp), ("nlosses", C.c_int32)]
 
 
 class TowerGIO(C.Structure):
@@ -106,7 +111,7 @@ SIGNATURES = {
     "m2m_embed_wgrad": (C.c_int, [C.POINTER(Embed), _fp, _fp, C.c_int, _fp]),
     "m2m_embeds_wgrad": (C.c_int, [C.POINTER(C.POINTER(Embed)), C.POINTER(_fp), C.POINTER(_fp), C.c_int, C.c_int, _fp]),
     "m2m_embeds_forward": (C.c_int, [C.POINTER(C.POINTER(Embed)), C.POINTER(_fp), C.POINTER(_fp), C.POINTER(C.c_int), C.POINTER(C.c_int64),
-                                     C.c_int, C.c_int, _fp]),
+                                     C.c_int, C.c_int, C.POINTER(StepHead), _fp]),
     "m2m_embed_fwd_splits": (C.c_int, [C.POINTER(Embed)]),
     "m2m_heads_ce": (C.c_int, [C.POINTER(Head), C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, C.c_int, _fp]),
     "m2m_step_prologue": (C.c_int, [_fp, _fp, _fp, C.c_int, _fp]),

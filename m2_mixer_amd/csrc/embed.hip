@@ -232,10 +232,22 @@ struct EmbedFwdGroupArgs {
     long M[2];
     int N[2], nwg0, fast[2], nsplit[2];
     long part_stride[2];       // floats between the k-split partial outputs
+    // head of a training step folded into this launch (the first one of the step; nothing in it reads these):
+    // adam_state[0] += 1, *drop_counter += 1, losses[0..nlosses) = 0 -- what m2m_step_prologue does in a launch of its own
+    float* adam_state;
+    unsigned int* drop_counter;
+    float* losses;
+    int nlosses, prologue;
 };
 template <int P, int D, int RB>
 __global__ __launch_bounds__(NTHREADS) void embed_fwd_group_kernel(const EmbedFwdGroupArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (a.prologue && blockIdx.x == 0) {
+        const int t = threadIdx.x;
+        if (t == 0 && a.adam_state) a.adam_state[0] += 1.0f;
+        if (t == 1 && a.drop_counter) *a.drop_counter += 1u;
+        if (a.losses && t < a.nlosses) a.losses[t] = 0.f;
+    }
     const int e = (int)blockIdx.x < a.nwg0 ? 0 : 1;
     const int wg = e ? blockIdx.x - a.nwg0 : blockIdx.x;
     if (P == PREC_BF16 && a.fast[e]) {
@@ -285,10 +297,14 @@ static int launch_embed_fwd(const m2m_embed* e, const float* in, int B, float* x
 }
 template <int P, int D>
 static int launch_embed_fwd_group(const m2m_embed* const* es, const float* const* ins, float* const* x0s, const int* nsplits,
-                                  const int64_t* part_strides, int B, hipStream_t st) {
+                                  const int64_t* part_strides, const m2m_step_head* head, int B, hipStream_t st) {
     constexpr int RB = 16;
     EmbedFwdGroupArgs a;
     memset(&a, 0, sizeof(a));
+    if (head) {
+        if (head->nlosses < 0 || head->nlosses > 64) { m2m_set_error("embeds_forward: step head nlosses must be in [0, 64]", __FILE__, __LINE__); return -1; }
+        a.prologue = 1; a.adam_state = head->adam_state; a.drop_counter = head->drop_counter; a.losses = head->losses; a.nlosses = head->nlosses;
+    }
     const int first = es[1]->Kp > es[0]->Kp ? 1 : 0;
     int total = 0;
     for (int k = 0; k < 2; ++k) {
@@ -389,7 +405,7 @@ extern "C" int m2m_embed_fwd_splits(const m2m_embed* e) {
 }
 
 extern "C" int m2m_embeds_forward(const m2m_embed* const* embeds, const float* const* inputs, float* const* x0s, const int* nsplits,
-                                  const int64_t* part_strides, int nembeds, int B, void* stream) {
+                                  const int64_t* part_strides, int nembeds, int B, const m2m_step_head* head, void* stream) {
     if (!embeds || !inputs || !x0s || nembeds != 2) { m2m_set_error("embeds_forward: exactly two embeddings", __FILE__, __LINE__); return -1; }
     for (int i = 0; i < nembeds; ++i) {
         if (int rc = m2m_check_embed(embeds[i], B)) return rc;
@@ -400,7 +416,7 @@ extern "C" int m2m_embeds_forward(const m2m_embed* const* embeds, const float* c
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const m2m_embed* e = embeds[0];
-#define M2M_EFG_CASE(PP, DD) if (e->prec == PP && e->D == DD) return launch_embed_fwd_group<PP, DD>(embeds, inputs, x0s, nsplits, part_strides, B, st);
+#define M2M_EFG_CASE(PP, DD) if (e->prec == PP && e->D == DD) return launch_embed_fwd_group<PP, DD>(embeds, inputs, x0s, nsplits, part_strides, head, B, st);
     M2M_EFG_CASE(PREC_BF16, 32) M2M_EFG_CASE(PREC_BF16, 64) M2M_EFG_CASE(PREC_BF16, 128) M2M_EFG_CASE(PREC_BF16, 256)
     M2M_EFG_CASE(PREC_F32, 32) M2M_EFG_CASE(PREC_F32, 64) M2M_EFG_CASE(PREC_F32, 128) M2M_EFG_CASE(PREC_F32, 256)
 #undef M2M_EFG_CASE

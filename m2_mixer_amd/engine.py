@@ -223,14 +223,12 @@ class _FlatEngine:
         """forward (dropout on) -> multi-head loss -> backward; gradients are ADDED into flat_g, which must be
         zero on entry: it is cleared at construction and again by every optimizer_step (the Adam kernel clears
         each element it consumes), so no separate fill pass is needed."""
-        self._prologue()
-        self._forward(*batch, training=True, with_grad=True)
+        self._forward(*batch, training=True, with_grad=True, prologue=True)
         self._backward(*batch[:-1])
 
     def fused_step(self, *batch):
         """forward + backward + Adam + re-pack in one go (no gradient exchange: single-GPU training)."""
-        self._prologue()
-        self._forward(*batch, training=True, with_grad=True)
+        self._forward(*batch, training=True, with_grad=True, prologue=True)
         self._backward(*batch[:-1], fused_update=True)
         return self.losses
 
@@ -379,7 +377,7 @@ class _TwoTowerEngine(_FlatEngine):
         raise NotImplementedError
 
     # ---- one training step (enqueue only; no host synchronisation) ----------------------------------------
-    def _forward(self, xa, xb, labels, training: bool, with_grad: bool):
+    def _forward(self, xa, xb, labels, training: bool, with_grad: bool, prologue: bool = False):
         B, D = self.B, self.D
         sd = self.drop_step if training else None
         fs = self.Nf * D
@@ -390,8 +388,12 @@ class _TwoTowerEngine(_FlatEngine):
             # cross-queue fork / join in the graph (a join costs ~6 us even when its event fired long ago)
             sa, sb = self.x0_splits
             if can_group_embeds(self.e_a, self.e_b):
-                embeds_forward([self.e_a, self.e_b], [xa, xb], [self._x0_a, self._x0_b], B, [sa, sb])
+                # the step prologue (counters, losses = 0) rides in this launch, the first one of the step
+                head = (self.adam_state, self.drop_step, self.losses) if prologue else None
+                embeds_forward([self.e_a, self.e_b], [xa, xb], [self._x0_a, self._x0_b], B, [sa, sb], head)
             else:
+                if prologue:
+                    self._prologue()
                 sa = sb = 1
                 self.e_a.forward(xa, B, self.x0_a)
                 self.e_b.forward(xb, B, self.x0_b)
@@ -400,6 +402,8 @@ class _TwoTowerEngine(_FlatEngine):
                             (self.x0_b, self.Nb * D, b_part, fs, self.pool_b, sb, B * self.Nb * D)],
                            B, training, self.seed, 0, sd)
         else:
+            if prologue:
+                self._prologue()
             side.wait_stream(main)
             with torch.cuda.stream(side):                   # second tower beside the first
                 self.e_b.forward(xb, B, self.x0_b)
@@ -573,7 +577,9 @@ class MimicEngine(_FlatEngine):
         for m in towers + embeds:
             m.pack(force=True)
 
-    def _forward(self, static, time, labels, training: bool, with_grad: bool):
+    def _forward(self, static, time, labels, training: bool, with_grad: bool, prologue: bool = False):
+        if prologue:
+            self._prologue()
         B, D = self.B, self.D
         sd = self.drop_step if training else None
         fs = self.Nf * D

@@ -361,16 +361,21 @@ def can_group_embeds(a: EmbedRuntime, b: EmbedRuntime) -> bool:
 
 
 def embeds_forward(embeds: Sequence[EmbedRuntime], inputs: Sequence[torch.Tensor], x0s: Sequence[torch.Tensor], B: int,
-                   nsplits: Optional[Sequence[int]] = None):
+                   nsplits: Optional[Sequence[int]] = None, step_head: Optional[tuple] = None):
     """Both patch embeddings of a two-tower model in one launch.  nsplits[i] > 1: x0s[i] is (nsplits[i], B*N, D) and
-    receives k-split partial sums (EmbedRuntime.fwd_splits says when that pays off); the consumer adds them."""
+    receives k-split partial sums (EmbedRuntime.fwd_splits says when that pays off); the consumer adds them.
+    step_head = (adam_state, drop_counter, losses): the launch also does the step prologue (m2m_step_prologue)."""
     n = len(embeds)
     ep = (C.POINTER(L.Embed) * n)(*[C.pointer(e.desc) for e in embeds])
     ip = (C.c_void_p * n)(*[t.data_ptr() for t in inputs])
     xp = (C.c_void_p * n)(*[t.data_ptr() for t in x0s])
     ns = (C.c_int * n)(*(nsplits if nsplits is not None else [1] * n))
     ps = (C.c_int64 * n)(*[B * e.N * e.D for e in embeds])
-    L.check(L.lib().m2m_embeds_forward(ep, ip, xp, ns, ps, n, B, L.stream_ptr()), "embeds_forward")
+    head = None
+    if step_head is not None:
+        adam_state, drop_counter, losses = step_head
+        head = C.byref(L.StepHead(adam_state.data_ptr(), drop_counter.data_ptr(), losses.data_ptr(), losses.numel()))
+    L.check(L.lib().m2m_embeds_forward(ep, ip, xp, ns, ps, n, B, head, L.stream_ptr()), "embeds_forward")
 
 
 def embeds_wgrad(embeds: Sequence[EmbedRuntime], inputs: Sequence[torch.Tensor], d_x0s: Sequence[torch.Tensor], B: int):
