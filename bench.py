@@ -31,9 +31,9 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense peaks, MI355X_MICRO
 # correction) + WRITE_SIZE, M2-Mixer-B, batch 512, bf16: profiles/r01_pmc_summary.md.  PMC counters cannot be collected from
 # inside the benchmark process; refresh the table when a kernel changes.
 PMC_TRAFFIC_BYTES_B512_BF16 = {
-    "tower_bwd[image]": 207.0e6, "tower_bwd[audio]": 207.0e6, "tower_bwd[fusion]": 171.2e6,
-    "tower_fwd[image]": 62.8e6, "tower_fwd[audio]": 62.8e6, "tower_fwd[fusion]": 40.8e6,
-    "towers_wgrad[all]": 505.8e6,
+    "towers_bwd[image+audio]": 347.3e6, "tower_bwd[fusion]": 172.0e6,
+    "towers_fwd[image+audio]": 75.7e6, "tower_fwd[fusion]": 40.8e6,
+    "towers_wgrad[all+embeds]": 559.0e6,
 }
 
 # AV-MNIST M2-Mixer-B  (reference cfg/avmnist/avmnist_m2-mixer_B.yml:24-56)
@@ -143,6 +143,9 @@ def main():
     ap.add_argument("--grad-compress", default="bf16", choices=["none", "bf16"],
                     help="N > 1: dtype of the gradient all-reduce.  bf16 (default: the step computes in bf16 anyway; the "
                          "equivalent of DDP's bf16_compress_hook) halves the bytes on xGMI; none = fp32, exact DDP semantics")
+    ap.add_argument("--preheat-ms", type=float, default=300.0,
+                    help="~this many ms of untimed steps (preheat_ms / 0.75 of them) before the W warm-up steps, so a fresh box's "
+                         "clocks have ramped up when the warm-up starts (reported in config.preheat_ms; 0 disables)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--profile-steps", type=int, default=10, help="eager steps with HIP events around every launch")
@@ -193,6 +196,11 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    if args.preheat_ms > 0:
+        n_pre = int(args.preheat_ms / 0.75)                 # a fixed step count: every rank must issue the same collectives
+        log(f"preheat: {n_pre} untimed steps (~{args.preheat_ms:.0f} ms)")
+        run_steps(n_pre)
+    barrier()
     log("warm-up")
     run_steps(args.warmup)
     barrier()
@@ -226,7 +234,7 @@ def main():
         "config": {"workload": f"AV-MNIST M2-Mixer-{args.model}: fwd + bwd + Adam, dropout {cfg['dropout']}, per-GPU batch {B}, "
                                f"global batch {B * world}, {eng.n_params} params",
                    "parallelism": f"dp{world}", "launch": "eager" if args.no_graph else ("hipGraph" if spg == 1 else f"hipGraph, {spg} steps per graph"),
-                   "grad_allreduce": (compress or "fp32") if world > 1 else None},
+                   "grad_allreduce": (compress or "fp32") if world > 1 else None, "preheat_ms": args.preheat_ms},
         "roofline": roof,
         "step_mfma_frac": round(world * B * args.steps / elapsed / world * flops_step / B / (peak * 1e12), 4),
         "algorithmic_gflop_per_step": round(flops_step / 1e9, 2),
@@ -240,9 +248,9 @@ def main():
 
 
 def profile_launches(eng, image, audio, labels, nsteps):
-    """Median duration of every launch of the training step, measured with events recorded on the stream the
+    """Median duration of every launch of the training step -- the very launches the replayed graph holds (the step
+    runs on ONE stream, so an eager pass is already serialized) -- measured with events recorded on the stream the
     launches go to (torch's current stream == the stream handed to libm2mixer)."""
-    import types
     cfg, B = eng.cfg, eng.B
     alg = algorithmic_flops(cfg, B)
     spans = {}
@@ -257,36 +265,31 @@ def profile_launches(eng, image, audio, labels, nsteps):
             return r
         return wrapper
 
-    saved = []
-    was_concurrent, eng.concurrent = eng.concurrent, False     # serialise: one launch in flight at a time
-
-    def patch(obj, attr, name, flops):
-        orig = getattr(obj, attr)
-        saved.append((obj, attr, orig))
-        setattr(obj, attr, timed(name, orig, flops))
-
-    for tname, rt in (("image", eng.t_img), ("audio", eng.t_aud), ("fusion", eng.t_fus)):
-        f = alg[tname]
-        patch(rt, "forward", f"tower_fwd[{tname}]", f["channel"] + f["token"])
-        patch(rt, "backward", f"tower_bwd[{tname}]", f["channel"] + f["token"] * 2)   # dgrad of both MLPs + token wgrad
-        patch(rt, "wgrad", f"tower_wgrad[{tname}]", f["channel"])
-    for tname, e in (("image", eng.e_img), ("audio", eng.e_aud)):
-        patch(e, "forward", f"embed_fwd[{tname}]", alg[tname]["embed"])
-        patch(e, "wgrad", f"embed_wgrad[{tname}]", alg[tname]["embed"])
     import m2_mixer_amd.engine as E
-    orig_heads, orig_twg, orig_pack = E.heads_ce, E.towers_wgrad, E.pack_all
-    E.pack_all = timed("pack_all", orig_pack, 0)
-    E.heads_ce = timed("heads_ce", orig_heads, alg["heads"] * 3)
-    E.towers_wgrad = timed("towers_wgrad[all]", orig_twg, sum(alg[t]["channel"] for t in ("image", "audio", "fusion")) +
-                           alg["image"]["embed"] + alg["audio"]["embed"])     # the launch includes both patch-embedding gradients
+    from m2_mixer_amd import _lib as L
+    two = ("image", "audio")
+    f_tow = lambda t: alg[t]["channel"] + alg[t]["token"]
+    b_tow = lambda t: alg[t]["channel"] + alg[t]["token"] * 2          # dgrad of both MLPs + token-mixing wgrad
+    emb = sum(alg[t]["embed"] for t in two)
+    patches = [                                                       # (object, attribute, name, algorithmic FLOPs per launch)
+        (E, "embeds_forward", "embeds_fwd[image+audio]", emb),
+        (E, "towers_forward", "towers_fwd[image+audio]", sum(f_tow(t) for t in two)),
+        (eng.t_fus, "forward", "tower_fwd[fusion]", f_tow("fusion")),
+        (E, "heads_ce", "heads_ce", alg["heads"] * 3),
+        (eng.t_fus, "backward", "tower_bwd[fusion]", b_tow("fusion")),
+        (E, "towers_backward", "towers_bwd[image+audio]", sum(b_tow(t) for t in two)),
+        (E, "towers_wgrad", "towers_wgrad[all+embeds]", sum(alg[t]["channel"] for t in ("image", "audio", "fusion")) + emb),
+        (E, "pack_all", "pack_all", 0),
+    ]
+    saved = [(o, a, getattr(o, a)) for o, a, _, _ in patches]
+    for o, a, name, flops in patches:
+        setattr(o, a, timed(name, getattr(o, a), flops))
     try:
         for _ in range(nsteps):
-            eng._prologue()
-            eng._forward(image, audio, labels, True, True)
+            eng._forward(image, audio, labels, True, True, prologue=True)
             eng._backward(image, audio)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            from m2_mixer_amd import _lib as L
             L.check(L.lib().m2m_adam_step(eng.flat_p.data_ptr(), eng.flat_g.data_ptr(), eng.flat_m.data_ptr(),
                                           eng.flat_v.data_ptr(), eng.n_params, eng.adam_state.data_ptr(), eng.betas[0],
                                           eng.betas[1], eng.eps, eng.weight_decay, -1.0, 0, L.stream_ptr()))
@@ -295,10 +298,8 @@ def profile_launches(eng, image, audio, labels, nsteps):
             eng.pack()
         torch.cuda.synchronize()
     finally:
-        for obj, attr, orig in saved:
-            setattr(obj, attr, orig)
-        E.heads_ce, E.towers_wgrad, E.pack_all = orig_heads, orig_twg, orig_pack
-        eng.concurrent = was_concurrent
+        for o, a, orig in saved:
+            setattr(o, a, orig)
     out = {}
     for name, sp in spans.items():
         times = [a.elapsed_time(b) * 1e3 for a, b in sp["events"]]      # us

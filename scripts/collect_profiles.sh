@@ -1,0 +1,30 @@
+#!/bin/bash
+# Everything profiles/ holds for a round, in one go.  Run on the GPU box from the repo root:
+#   gpurun --timeout 1200 -- 'bash scripts/collect_profiles.sh'      ->  gpurun_out/final/
+# (PMC counters are collected in their own passes, with --kernel-trace only.)
+set -e
+R=${GRAFT_REPO_ROOT:-$PWD}
+O=$R/gpurun_out/final
+rm -rf $O
+mkdir -p $O/pmc
+cd $R
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+echo "bench done"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline \
+    > $O/bench_under_rocprof.json 2> $O/rocprof.err
+echo "stats done"
+for pass in "mfma:SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "fetch:FETCH_SIZE" "write:WRITE_SIZE" \
+            "valu:SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY"; do
+    tag=${pass%%:*}
+    ctr=${pass#*:}
+    mkdir -p $O/pmc/$tag
+    rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc/$tag -o p -- python3 $R/bench.py --steps 3 --warmup 1 --preheat-ms 0 \
+        --no-cpu-baseline --no-graph --profile-steps 1 > $O/pmc/$tag.json 2> $O/pmc/$tag.err
+    echo "pmc $tag done"
+done
+cd $R
+python scripts/timeline.py $O/stats/s_kernel_trace.csv 25 > $O/step_timeline.txt
+python scripts/pmc_summary.py $O/pmc > $O/pmc_summary_table.md
+python scripts/bench_configs.py > $O/secondary_configs.jsonl 2> $O/secondary.err
+echo "all done"

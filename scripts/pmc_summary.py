@@ -13,7 +13,7 @@ import glob
 import os
 import sys
 
-KEEP = ("tower_", "embed_", "adam_kernel", "heads_ce", "pack_tower")
+KEEP = ("tower_", "embed_", "adam_kernel", "heads_kernel", "pack_all", "pack_tower")
 
 
 def short(name):
