@@ -271,6 +271,70 @@ def test_full_size_properties(dev):
     assert all(abs(float(v) - np.log(10)) < 0.5 for v in la[:3])
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_grouped_launches_match_single_launches(prec, dev):
+    """The one-launch entry points the replayed step uses (m2m_embeds_forward with its k-split partial sums,
+    m2m_towers_wgrad carrying the two patch embeddings, m2m_pack_all) against the single-object entry points on the same
+    inputs, at the benchmark's batch: same arithmetic, only the order of a few fp32 sums differs."""
+    from m2_mixer_amd.engine import AVMnistEngine
+    from m2_mixer_amd.runtime import embeds_forward, pack_all, towers_wgrad
+    cfg = dict(G.AVMNIST["B"])
+    B = 512 if prec == "bf16" else 64
+    eng = AVMnistEngine(cfg, B, device=dev, precision=prec, lr=1e-3, seed=3)
+    image, audio, labels = (t.to(dev) for t in G.avmnist_batch(B, 5, cfg))
+    if prec == "bf16":
+        assert eng.x0_splits[1] == 2 and eng.x0_splits[0] == 1       # audio: fast path with a k-split; image: generic path
+    else:
+        assert eng.x0_splits == (1, 1)
+    # ---- patch embeddings: grouped (+ partial sums) vs one launch each
+    embeds_forward([eng.e_a, eng.e_b], [image, audio], [eng._x0_a, eng._x0_b], B, list(eng.x0_splits))
+    got_a, got_b = eng._x0_a.sum(0), eng._x0_b.sum(0)
+    ref_a, ref_b = torch.empty_like(got_a), torch.empty_like(got_b)
+    eng.e_a.forward(image, B, ref_a)
+    eng.e_b.forward(audio, B, ref_b)
+    torch.cuda.synchronize()
+    assert relerr(got_a, ref_a) < 1e-5 and relerr(got_b, ref_b) < 1e-5
+    # ---- weight gradients: towers + embeddings in one launch vs separate launches (after a real forward / backward)
+    eng.forward_backward(image, audio, labels)
+    torch.cuda.synchronize()
+    g_merged = eng.flat_g.clone()
+    keys = [k for k in eng.grads if "to_patch_embedding" in k or                  # what the weight-gradient launch computes
+            k.endswith(("channel_mix.1.net.0.weight", "channel_mix.1.net.0.bias", "channel_mix.1.net.3.weight"))]
+    assert len(keys) == 3 * 10 + 4
+    for k in keys:
+        eng.grads[k].zero_()
+    for t in (eng.t_fus, eng.t_a, eng.t_b):
+        t.wgrad(B, eng.seed, 0, eng.drop_step)
+    eng.e_a.wgrad(image, eng.dx0_a, B)
+    eng.e_b.wgrad(audio, eng.dx0_b, B)
+    torch.cuda.synchronize()
+    for k in keys:
+        g = eng.grads[k]
+        o = (g.data_ptr() - eng.flat_g.data_ptr()) // 4
+        assert relerr(g_merged[o:o + g.numel()].view_as(g), g) < 1e-4, k
+    # ---- operand packing: the whole model in one launch vs per tower / per embedding, bit for bit
+    towers, embeds = [eng.t_a, eng.t_b, eng.t_fus], [eng.e_a, eng.e_b]
+    pack_all(towers, embeds)
+    torch.cuda.synchronize()
+    packed = [[{k: v.clone() for k, v in t._keep[f"packed{i}"].items()} for i in range(t.nblocks)] for t in towers]
+    wn = [e._keep["wn"].clone() for e in embeds]
+    for t in towers:
+        for i in range(t.nblocks):
+            for v in t._keep[f"packed{i}"].values():
+                v.zero_()
+        t.pack(force=True)
+    for e in embeds:
+        e._keep["wn"].zero_()
+        e.pack(force=True)
+    torch.cuda.synchronize()
+    for t, pt in zip(towers, packed):
+        for i in range(t.nblocks):
+            for k, v in t._keep[f"packed{i}"].items():
+                assert torch.equal(v, pt[i][k]), k
+    for e, w in zip(embeds, wn):
+        assert torch.equal(e._keep["wn"], w)
+
+
 def test_training_reduces_loss_bf16(dev):
     """A few dozen Adam steps on one fixed synthetic batch must overfit it (end-to-end sanity of fwd, bwd,
     wgrad, Adam and re-packing of the weights in bf16 mode with dropout on)."""
