@@ -165,21 +165,100 @@ struct PackAllArgs {
     m2m_tower4 tw[M2M_PACK_TOWERS];
     m2m_embed em[M2M_PACK_EMBEDS];
     int nt, ne;
+    int tile_end[M2M_PACK_TOWERS];     // running count of (block, 32-column group) tiles up to and including tower t
+    int embed_wgs0;                    // workgroups (256 slots each) of embedding 0
 };
 static_assert(sizeof(PackAllArgs) <= 4096, "kernel arguments are limited to 4 KiB");
 
-template <int P>
-__global__ void pack_all_kernel(const PackAllArgs a) {
-    const long slot = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int per = 5 * M2M_GROUP_BLOCKS;
-    const int job = blockIdx.y;
-    if (job < per * a.nt) {
-        const int t = job / per, r = job % per;
-        if (r / 5 < a.tw[t].nblocks) pack_block_job<P>(a.tw[t], r / 5, r % 5, slot);
-    } else {
-        const m2m_embed& e = a.em[job - per * a.nt];
-        pack_slot<P>(e.w, e.K, 1, e.D, e.K, e.D, e.Kp, PACK_NAT, 0, (char*)e.wn, slot);
+// One workgroup = one 32-column group q of one block: W1 rows [32q, 32q + 32) (one contiguous 32 x D chunk) and W2 columns
+// [32q, 32q + 32) are read ONCE, coalesced, into LDS and all four packed copies (w1n, w1tc, w2c, w2tn) plus ch_b1p are
+// written from there.  (The slot-per-thread kernels above gather every master element twice, the transposed copies with
+// 4-byte loads in 64-byte segments: 28 us for the whole model against ~100 MB of unavoidable traffic.)
+template <int P, class TW>
+static __device__ __forceinline__ void pack_block_tile(const TW& tw, int block, int q, char* smem) {
+    typedef Prec<P> Pr;
+    const m2m_block& k = tw.blk[block];
+    const int D = tw.D, C = tw.C, L1 = D + 1, L2 = 33;
+    float* t1 = reinterpret_cast<float*>(smem);            // [32][D + 1]   W1[32q + r][d]
+    float* t2 = t1 + 32 * L1;                               // [D][33]       W2[d][32q + j]
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int c0 = 32 * q;
+    for (int idx = tid; idx < 32 * (D / 4); idx += nthr) {
+        const int r = idx / (D / 4), d4 = (idx % (D / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c0 + r < C) v = *reinterpret_cast<const float4*>(k.ch_w1 + (long)(c0 + r) * D + d4);
+        float* o = t1 + r * L1 + d4;
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
     }
+    for (int idx = tid; idx < D * 32; idx += nthr) {
+        const int d = idx >> 5, j = idx & 31;
+        t2[d * L2 + j] = c0 + j < C ? k.ch_w2[(long)d * C + c0 + j] : 0.f;
+    }
+    if (tid < 32) k.ch_b1p[c0 + tid] = c0 + tid < C ? k.ch_b1[c0 + tid] : 0.f;
+    __syncthreads();
+    const int nKB = D / Pr::KB, nIB = D / 16, CB = 32 / Pr::KB;      // k-blocks along d; 16-row blocks along d; c k-blocks per tile
+    auto emit = [&](char* dst, long blk, int lane, const float (&v)[8]) {
+        Frag f;
+        if (P == PREC_BF16) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f.u[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f.f[e] = v[e];
+        }
+        *reinterpret_cast<u32x4_t*>(dst + (blk * 64 + lane) * 16) = f.u;
+    };
+    // NAT copies, X[i = c][k = d]: blocks (ib = 2q + h, kb); w1n from t1[c][d], w2tn from t2[d][c]
+    for (int s = tid; s < 2 * nKB * 64; s += nthr) {
+        const int lane = s & 63, bl = s >> 6, h = bl / nKB, kb = bl % nKB, g = lane >> 4, il = lane & 15;
+        const int r = 16 * h + il;
+        float v1[8], v2[8];
+#pragma unroll
+        for (int e = 0; e < Pr::EPL; ++e) {
+            const int d = kb * Pr::KB + Pr::kmap(PACK_NAT, g, e);
+            v1[e] = t1[r * L1 + d];
+            v2[e] = t2[d * L2 + r];
+        }
+        const long blk = (long)(2 * q + h) * nKB + kb;
+        emit((char*)k.w1n, blk, lane, v1);
+        emit((char*)k.w2tn, blk, lane, v2);
+    }
+    // CHN copies, k-major, X[i = d][k = c]: blocks (kb = CB q + h, ib); w1tc from t1[c][d], w2c from t2[d][c]
+    for (int s = tid; s < CB * nIB * 64; s += nthr) {
+        const int lane = s & 63, bl = s >> 6, h = bl / nIB, ib = bl % nIB, g = lane >> 4, il = lane & 15;
+        const int d = 16 * ib + il;
+        float v1[8], v2[8];
+#pragma unroll
+        for (int e = 0; e < Pr::EPL; ++e) {
+            const int j = h * Pr::KB + Pr::kmap(PACK_CHN, g, e);
+            v1[e] = t1[j * L1 + d];
+            v2[e] = t2[d * L2 + j];
+        }
+        const long blk = (long)(CB * q + h) * nIB + ib;
+        emit((char*)k.w1tc, blk, lane, v1);
+        emit((char*)k.w2c, blk, lane, v2);
+    }
+}
+
+// blockIdx.x: the towers' (block, column group) tiles first -- tower t owns tile_end[t - 1] .. tile_end[t] -- then the
+// embeddings' slots, 256 per workgroup.
+template <int P>
+__global__ __launch_bounds__(256) void pack_all_kernel(const PackAllArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int id = blockIdx.x;
+    if (id < a.tile_end[M2M_PACK_TOWERS - 1]) {
+        int t = 0;
+        while (id >= a.tile_end[t]) ++t;
+        if (t) id -= a.tile_end[t - 1];
+        const int nq = a.tw[t].Cp >> 5;
+        pack_block_tile<P>(a.tw[t], id / nq, id % nq, smem);
+        return;
+    }
+    id -= a.tile_end[M2M_PACK_TOWERS - 1];
+    const int e = id < a.embed_wgs0 ? 0 : 1;
+    if (e) id -= a.embed_wgs0;
+    const m2m_embed& em = a.em[e];
+    pack_slot<P>(em.w, em.K, 1, em.D, em.K, em.D, em.Kp, PACK_NAT, 0, (char*)em.wn, (long)id * 256 + threadIdx.x);
 }
 
 extern "C" int m2m_pack_all(const m2m_tower* const* towers, int ntowers, const m2m_embed* const* embeds, int nembeds,
@@ -192,18 +271,20 @@ extern "C" int m2m_pack_all(const m2m_tower* const* towers, int ntowers, const m
     PackAllArgs a;
     memset(&a, 0, sizeof(a));
     a.nt = ntowers; a.ne = nembeds;
-    int prec = -1;
-    long need = 0;
-    for (int i = 0; i < ntowers; ++i) {
-        if (int rc = m2m_check_tower(towers[i], 1)) return rc;
-        if (towers[i]->nblocks > M2M_GROUP_BLOCKS) { m2m_set_error("pack_all: towers of <= 4 blocks", __FILE__, __LINE__); return -1; }
-        if (prec < 0) prec = towers[i]->prec;
-        if (towers[i]->prec != prec) { m2m_set_error("pack_all: one precision per launch", __FILE__, __LINE__); return -1; }
-        a.tw[i] = m2m_shrink(towers[i]);
-        const long KB = prec == PREC_BF16 ? 32 : 16;
-        const long nslots = (long)(towers[i]->Cp / 16) * (towers[i]->D / KB) * 64;
-        need = std::max(need, std::max(nslots, (long)towers[i]->Cp));
+    int prec = -1, tiles = 0, maxD = 0;
+    for (int i = 0; i < M2M_PACK_TOWERS; ++i) {
+        if (i < ntowers) {
+            if (int rc = m2m_check_tower(towers[i], 1)) return rc;
+            if (towers[i]->nblocks > M2M_GROUP_BLOCKS) { m2m_set_error("pack_all: towers of <= 4 blocks", __FILE__, __LINE__); return -1; }
+            if (prec < 0) prec = towers[i]->prec;
+            if (towers[i]->prec != prec) { m2m_set_error("pack_all: one precision per launch", __FILE__, __LINE__); return -1; }
+            a.tw[i] = m2m_shrink(towers[i]);
+            tiles += towers[i]->nblocks * (towers[i]->Cp / 32);
+            maxD = std::max(maxD, (int)towers[i]->D);
+        }
+        a.tile_end[i] = tiles;
     }
+    int embed_wgs = 0;
     for (int i = 0; i < nembeds; ++i) {
         const m2m_embed* e = embeds[i];
         if (!e || !e->w || !e->wn) { m2m_set_error("pack_all: null embed", __FILE__, __LINE__); return -1; }
@@ -212,12 +293,22 @@ extern "C" int m2m_pack_all(const m2m_tower* const* towers, int ntowers, const m
         const long KB = prec == PREC_BF16 ? 32 : 16;
         if (e->D % 16 || e->Kp % KB || e->Kp < e->K) { m2m_set_error("pack_all: bad embed geometry", __FILE__, __LINE__); return -1; }
         a.em[i] = *e;
-        need = std::max(need, (long)(e->D / 16) * (e->Kp / KB) * 64);
+        const int wgs = (int)ceil_div((long)(e->D / 16) * (e->Kp / KB) * 64, 256);
+        if (i == 0) a.embed_wgs0 = wgs;
+        embed_wgs += wgs;
     }
-    const dim3 grid((unsigned)ceil_div(need, 256), (unsigned)(5 * M2M_GROUP_BLOCKS * ntowers + nembeds));
+    const size_t lds = (size_t)(32 * (maxD + 1) + maxD * 33) * sizeof(float);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (prec == PREC_BF16) hipLaunchKernelGGL(pack_all_kernel<PREC_BF16>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(pack_all_kernel<PREC_F32>, grid, dim3(256), 0, st, a);
+    static size_t attr_lds[2] = {0, 0};
+    const int pi = prec == PREC_BF16 ? 0 : 1;
+    if (lds > attr_lds[pi]) {
+        const void* fn = prec == PREC_BF16 ? reinterpret_cast<const void*>(pack_all_kernel<PREC_BF16>) : reinterpret_cast<const void*>(pack_all_kernel<PREC_F32>);
+        M2M_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds[pi] = lds;
+    }
+    const dim3 grid((unsigned)(tiles + embed_wgs));
+    if (prec == PREC_BF16) hipLaunchKernelGGL(pack_all_kernel<PREC_BF16>, grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(pack_all_kernel<PREC_F32>, grid, dim3(256), lds, st, a);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
 }
