@@ -168,7 +168,7 @@ def main():
     eng.pack()
     image, audio, labels = make_batch(cfg, B, parallel.shard_batch_seed(1234, rank), dev)
     compress = None if args.grad_compress == "none" or args.precision == "fp32" else args.grad_compress
-    sync = parallel.GradSync(compress=compress) if world > 1 else None
+    sync = parallel.GradSync(compress=compress, widen=False) if world > 1 else None      # Adam reads the bf16 sum directly
 
     spg = 1 if (args.no_graph or world > 1) else max(1, args.steps_per_graph)
     if args.no_graph:

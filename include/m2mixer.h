@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define M2M_ABI_VERSION 11
+#define M2M_ABI_VERSION 12
 #define M2M_MAX_BLOCKS 8      /* MixerBlocks per m2m_tower; longer towers are chained by the caller */
 #define M2M_ROWS_PER_WG 16    /* token rows one workgroup keeps on chip */
 
@@ -261,6 +261,11 @@ int m2m_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
                   float* state, float beta1, float beta2, float eps, float weight_decay,
                   float grad_scale, int bump_step, void* stream);
                   /* grad_scale < 0: scale by |grad_scale| and clear grad afterwards */
+/* The same with the gradient VALUE read from a bf16 copy of `grad` (same indexing) -- the compressed, all-reduced gradient
+ * of the data-parallel step (DDP's bf16_compress_hook), consumed without a pass to widen it; `grad` is only cleared. */
+int m2m_adam_step_bf16(float* param, float* grad, const void* grad_bf16, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       float* state, float beta1, float beta2, float eps, float weight_decay,
+                       float grad_scale, int bump_step, void* stream);
 
 /* Head of a training step, ONE launch: adam_state[0] += 1 (the step count m2m_adam_step reads), *drop_counter += 1
  * (the step_dev of the tower calls), losses[0 .. nlosses) = 0.  Any pointer may be NULL. */

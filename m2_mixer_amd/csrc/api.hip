@@ -325,9 +325,12 @@ __global__ void adam_bump_kernel(float* state) { state[0] += 1.0f; }
 
 // gscale < 0 requests "consume": after the update the gradient element is cleared, so the next step starts from
 // zeroed gradients without a separate fill pass (|gscale| is the scale).
-__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ gr, float* __restrict__ m,
-                            float* __restrict__ v, long n, const float* __restrict__ state, float b1, float b2,
-                            float eps, float wd, float gscale_in) {
+// LOWP: the gradient VALUE comes from a bf16 copy (the all-reduced, compressed gradient of the data-parallel step: no pass
+// to widen it back); the fp32 gradient buffer is only cleared.
+template <bool LOWP>
+__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ gr, const unsigned short* __restrict__ gb,
+                            float* __restrict__ m, float* __restrict__ v, long n, const float* __restrict__ state, float b1,
+                            float b2, float eps, float wd, float gscale_in) {
     const bool consume = gscale_in < 0.f;
     const float gscale = consume ? -gscale_in : gscale_in;
     const float stepf = state[0], lr = state[1];
@@ -337,7 +340,7 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ gr, float
     const float inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        float g = gr[i] * gscale;
+        float g = (LOWP ? __uint_as_float((unsigned int)gb[i] << 16) : gr[i]) * gscale;
         if (consume) gr[i] = 0.f;
         const float pv = p[i];
         if (wd != 0.f) g = __builtin_fmaf(wd, pv, g);
@@ -350,19 +353,32 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ gr, float
     }
 }
 
-extern "C" int m2m_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
-                             float beta1, float beta2, float eps, float weight_decay, float grad_scale, int bump_step,
-                             void* stream) {
+static int adam_launch(float* param, float* grad, const void* grad_bf16, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
+                       float beta1, float beta2, float eps, float weight_decay, float grad_scale, int bump_step, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (bump_step) hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, st, state);
     if (n <= 0) return 0;
     const int threads = 256;
     long grid = ceil_div(n, threads);
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)grid), dim3(threads), 0, st, param, grad, exp_avg, exp_avg_sq, (long)n,
-                       state, beta1, beta2, eps, weight_decay, grad_scale);
+    const unsigned short* gb = reinterpret_cast<const unsigned short*>(grad_bf16);
+    if (gb) hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)grid), dim3(threads), 0, st, param, grad, gb, exp_avg, exp_avg_sq,
+                               (long)n, state, beta1, beta2, eps, weight_decay, grad_scale);
+    else hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)grid), dim3(threads), 0, st, param, grad, gb, exp_avg, exp_avg_sq,
+                            (long)n, state, beta1, beta2, eps, weight_decay, grad_scale);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
+}
+extern "C" int m2m_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
+                             float beta1, float beta2, float eps, float weight_decay, float grad_scale, int bump_step,
+                             void* stream) {
+    return adam_launch(param, grad, nullptr, exp_avg, exp_avg_sq, n, state, beta1, beta2, eps, weight_decay, grad_scale, bump_step, stream);
+}
+extern "C" int m2m_adam_step_bf16(float* param, float* grad, const void* grad_bf16, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                  float* state, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                                  int bump_step, void* stream) {
+    if (!grad_bf16) { m2m_set_error("adam_step_bf16: null bf16 gradient", __FILE__, __LINE__); return -1; }
+    return adam_launch(param, grad, grad_bf16, exp_avg, exp_avg_sq, n, state, beta1, beta2, eps, weight_decay, grad_scale, bump_step, stream);
 }
 
 // One tiny launch at the head of a training step instead of three scattered through it (each tiny kernel costs

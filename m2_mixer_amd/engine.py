@@ -207,12 +207,22 @@ class _FlatEngine:
         self.adam_state[1] = lr
 
     # ---- optimizer -------------------------------------------------------------------------------------------
-    def _adam(self, lo: int, hi: int, grad_scale: float, bump: bool):
+    def _adam(self, lo: int, hi: int, grad_scale: float, bump: bool, grad_bf16: Optional[torch.Tensor] = None):
+        """Adam over flat elements [lo, hi); clears the gradients it consumes.  grad_bf16: a bf16 copy of the whole flat
+        gradient (the compressed all-reduce result) to take the values from instead of flat_g."""
         n = hi - lo
         off = lo * 4
-        L.check(L.lib().m2m_adam_step(self.flat_p.data_ptr() + off, self.flat_g.data_ptr() + off, self.flat_m.data_ptr() + off,
-                                      self.flat_v.data_ptr() + off, n, self.adam_state.data_ptr(), self.betas[0], self.betas[1],
-                                      self.eps, self.weight_decay, -abs(grad_scale), int(bump), L.stream_ptr()), "adam_step")
+        tail = (self.adam_state.data_ptr(), self.betas[0], self.betas[1], self.eps, self.weight_decay, -abs(grad_scale), int(bump),
+                L.stream_ptr())
+        if grad_bf16 is None:
+            L.check(L.lib().m2m_adam_step(self.flat_p.data_ptr() + off, self.flat_g.data_ptr() + off, self.flat_m.data_ptr() + off,
+                                          self.flat_v.data_ptr() + off, n, *tail), "adam_step")
+        else:
+            if grad_bf16.dtype != torch.bfloat16 or grad_bf16.numel() != self.n_params or not grad_bf16.is_cuda:
+                raise RuntimeError("grad_bf16 must be a bf16 device copy of the whole flat gradient")
+            L.check(L.lib().m2m_adam_step_bf16(self.flat_p.data_ptr() + off, self.flat_g.data_ptr() + off,
+                                               grad_bf16.data_ptr() + lo * 2, self.flat_m.data_ptr() + off,
+                                               self.flat_v.data_ptr() + off, n, *tail), "adam_step_bf16")
 
     def _prologue(self):
         """Head of a training step: Adam step count += 1, dropout counter += 1, losses = 0 -- one tiny launch."""
@@ -232,8 +242,8 @@ class _FlatEngine:
         self._backward(*batch[:-1], fused_update=True)
         return self.losses
 
-    def optimizer_step(self, grad_scale: float = 1.0):
-        self._adam(0, self.n_params, grad_scale, False)                       # negative scale inside: clears the gradients
+    def optimizer_step(self, grad_scale: float = 1.0, grad_bf16: Optional[torch.Tensor] = None):
+        self._adam(0, self.n_params, grad_scale, False, grad_bf16)            # negative scale inside: clears the gradients
         self.pack()                                                            # (the step counters were advanced by _prologue)
 
     def train_step(self, *batch, grad_sync=None):
@@ -242,7 +252,7 @@ class _FlatEngine:
         if grad_sync is None:
             return self.fused_step(*batch)
         self.forward_backward(*batch)
-        self.optimizer_step(grad_sync(self.flat_g))
+        self.optimizer_step(grad_sync(self.flat_g), getattr(grad_sync, "reduced_bf16", None))
         return self.losses
 
     # ---- hipGraph capture -----------------------------------------------------------------------------------
@@ -269,7 +279,7 @@ class _FlatEngine:
                 else:
                     self.forward_backward(*st)
                     scale = grad_sync(self.flat_g)
-                    self.optimizer_step(scale)
+                    self.optimizer_step(scale, getattr(grad_sync, "reduced_bf16", None))
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         # thread_local capture mode: a data-parallel process has other threads (the RCCL watchdog) that may touch the HIP
@@ -291,7 +301,7 @@ class _FlatEngine:
             with torch.cuda.graph(g1, capture_error_mode="thread_local"):
                 self.forward_backward(*st)
             with torch.cuda.graph(g2, capture_error_mode="thread_local"):
-                self.optimizer_step(scale)
+                self.optimizer_step(scale, getattr(grad_sync, "reduced_bf16", None))   # (the buffer exists since the warm-up)
             graphs = (g1, g2)
         self._graph = graphs
 

@@ -554,6 +554,27 @@ def test_data_parallel_step_path_matches_fused_step(dev):
     assert float((da.sign() == db.sign()).float().mean()) > 0.995
 
 
+def test_adam_from_bf16_gradient_equals_adam_from_widened_gradient(dev):
+    """The data-parallel step hands Adam the all-reduced gradient as bf16 (GradSync(widen=False)); the update must be
+    bit-identical to widening that bf16 gradient into the fp32 buffer first, and the fp32 buffer must come out cleared."""
+    from m2_mixer_amd.engine import AVMnistEngine
+    cfg = dict(G.AVMNIST["S"])
+    a = AVMnistEngine(cfg, 8, device=dev, precision="bf16", lr=1e-2, seed=1)
+    b = AVMnistEngine(cfg, 8, device=dev, precision="bf16", lr=1e-2, seed=1)
+    b.load_state_dict(a.state_dict())
+    g = torch.randn(a.n_params, device=dev) * 1e-2
+    gb = g.to(torch.bfloat16)
+    for e in (a, b):
+        e._prologue()
+    a.flat_g.copy_(gb)                      # reference: widen, then the fp32 Adam
+    a.optimizer_step(0.5)
+    b.flat_g.copy_(g)                       # the local fp32 gradient stays in place and is only cleared
+    b.optimizer_step(0.5, gb)
+    torch.cuda.synchronize()
+    assert torch.equal(a.flat_p, b.flat_p) and torch.equal(a.flat_m, b.flat_m) and torch.equal(a.flat_v, b.flat_v)
+    assert float(b.flat_g.abs().max()) == 0.0
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # the callers: Lightning-free task modules with the reference's constructor / shared_step contract (models.py)
 # ---------------------------------------------------------------------------------------------------------------

@@ -188,6 +188,12 @@ def _gloo_worker(rank, world, port, q):
     parallel.broadcast_parameters(p)
     scale = parallel.GradSync()(flat)
     scale16 = parallel.GradSync(compress="bf16")(flat16 := (torch.ones(64) * (rank + 1)))
+    keep = parallel.GradSync(compress="bf16", widen=False)        # the sum stays in bf16 for an optimizer that reads it there
+    local = torch.ones(64) * (rank + 1)
+    keep(local)
+    assert torch.equal(local, torch.ones(64) * (rank + 1)), "widen=False must leave the local gradient alone"
+    assert torch.equal(keep.reduced_bf16.float(), torch.full((64,), 3.0))
+    assert parallel.GradSync(compress="bf16").reduced_bf16 is None and parallel.GradSync().reduced_bf16 is None
     tmax = parallel.max_over_ranks(1.0 + rank, device="cpu")
     q.put((rank, flat.clone(), scale, p.clone(), flat16.clone(), scale16, tmax, parallel.shard_batch_seed(1234, rank)))
     torch.distributed.destroy_process_group()
