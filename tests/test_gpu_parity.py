@@ -175,7 +175,7 @@ def test_avmnist_step_fp32_vs_reference_golden(size, B, seed, dev):
         check(gold, f"after2//{k}", eng.params[k], 2.5e-2, 0.0, what="param ")
 
 
-@pytest.mark.parametrize("size,B", [("S", 8), ("B", 40)])
+@pytest.mark.parametrize("size,B", [("S", 8), ("B", 40), ("B", 13)])      # 13: ragged row tiles in every launch
 def test_avmnist_step_bf16_vs_oracle(size, B, dev):
     eng, cfg = _engine(size, B, "bf16", dev, dropout=0.0)
     shapes = G.avmnist_shapes(cfg)
