@@ -130,7 +130,8 @@ int m2m_embed_forward(const m2m_embed* e, const float* input, int B, float* x0, 
 /* The two patch embeddings of a two-tower model (same precision and D) in ONE launch.  nsplits[i] (NULL: all 1) > 1
  * splits embedding i's contraction over K across that many workgroups per row tile; split s writes its partial sum
  * (split 0 includes the bias) to x0s[i] + s * part_strides[i] floats, and the consumer adds the parts
- * (m2m_tower_io.x0_parts).  m2m_embed_fwd_splits says how many splits pay off for an embedding (1 or 2). */
+ * (m2m_tower_io.x0_parts).  m2m_embed_fwd_splits says how many splits pay off for an embedding (1 or 2); an embedding or
+ * input the split kernel cannot take (fp32 mode, unaligned input) still fills all requested parts (sum in part 0, zeros after). */
 /* head != NULL: the launch also performs m2m_step_prologue(head->...) -- the embeddings are the first launch of a training
  * step and read none of those values, so the step needs no separate prologue launch. */
 typedef struct m2m_step_head {

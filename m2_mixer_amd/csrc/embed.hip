@@ -254,7 +254,20 @@ __global__ __launch_bounds__(NTHREADS) void embed_fwd_group_kernel(const EmbedFw
         const int ns = a.nsplit[e], split = wg % ns;
         embed_fwd_fast_body<D>(a.em[e], a.in[e], a.M[e], a.N[e], a.x0[e] + split * a.part_stride[e], wg / ns, split, ns, smem);
     }
-    else embed_fwd_body<P, D, RB>(a.em[e], a.in[e], a.M[e], a.N[e], a.x0[e], wg, smem);
+    else {
+        // generic path asked for partial sums (an input the fast path cannot take, e.g. not 16-byte aligned): split 0 computes
+        // the whole sum into part 0, the other splits' workgroups clear their rows of their part
+        const int ns = a.nsplit[e], split = wg % ns, tile = wg / ns;
+        if (split == 0) embed_fwd_body<P, D, RB>(a.em[e], a.in[e], a.M[e], a.N[e], a.x0[e], tile, smem);
+        else {
+            float* part = a.x0[e] + split * a.part_stride[e];
+            const long m0 = (long)tile * RB;
+            for (int idx = threadIdx.x; idx < RB * D; idx += NTHREADS) {
+                const long m = m0 + idx / D;
+                if (m < a.M[e]) part[m * D + idx % D] = 0.f;
+            }
+        }
+    }
 }
 
 template <int P, int D>
@@ -314,8 +327,8 @@ static int launch_embed_fwd_group(const m2m_embed* const* es, const float* const
         a.fast[k] = embed_fwd_fast_ok(es[i], ins[i]);
         a.nsplit[k] = nsplits ? nsplits[i] : 1;
         a.part_stride[k] = part_strides ? (long)part_strides[i] : 0;
-        if (a.nsplit[k] < 1 || a.nsplit[k] > 4 || (a.nsplit[k] > 1 && (!a.fast[k] || a.part_stride[k] < a.M[k] * (long)D))) {
-            m2m_set_error("embeds_forward: k-splits need the fast path (m2m_embed_fwd_splits) and a part stride >= B*N*D", __FILE__, __LINE__);
+        if (a.nsplit[k] < 1 || a.nsplit[k] > 4 || (a.nsplit[k] > 1 && a.part_stride[k] < a.M[k] * (long)D)) {
+            m2m_set_error("embeds_forward: 1..4 k-splits, part stride >= B*N*D", __FILE__, __LINE__);
             return -1;
         }
         const int nwg = (int)((a.M[k] + RB - 1) / RB) * a.nsplit[k];

@@ -294,6 +294,13 @@ def test_grouped_launches_match_single_launches(prec, dev):
     eng.e_b.forward(audio, B, ref_b)
     torch.cuda.synchronize()
     assert relerr(got_a, ref_a) < 1e-5 and relerr(got_b, ref_b) < 1e-5
+    # an input the fast path cannot take (not 16-byte aligned) still honours the requested partial sums
+    odd = torch.empty(audio.numel() + 1, device=dev)[1:].view_as(audio).copy_(audio)
+    assert odd.data_ptr() % 16 != 0
+    eng._x0_b.fill_(7.0)
+    embeds_forward([eng.e_a, eng.e_b], [image, odd], [eng._x0_a, eng._x0_b], B, list(eng.x0_splits))
+    torch.cuda.synchronize()
+    assert relerr(eng._x0_b.sum(0), ref_b) < 1e-5
     # ---- weight gradients: towers + embeddings in one launch vs separate launches (after a real forward / backward)
     eng.forward_backward(image, audio, labels)
     torch.cuda.synchronize()
