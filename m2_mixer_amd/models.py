@@ -14,13 +14,44 @@ reference uses.  SoftAdapt / GradBlend weighting are outside the scope of this b
 """
 from __future__ import annotations
 
-from typing import Any, Dict, Optional, Tuple
+import os
+import pickle
+from typing import Any, Dict, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
 from torch import nn
 
 from . import modules
+
+
+class _LenientPickle:
+    """`pickle_module` for torch.load that survives a Lightning `.ckpt` written by the reference's environment: its
+    `hyper_parameters` / callback states pickle classes of packages this build does not need (omegaconf, pytorch_lightning).
+    Unknown classes become inert placeholders; the tensors under `state_dict` load normally."""
+    __name__ = "m2_mixer_amd.models._LenientPickle"
+
+    class _Placeholder:
+        def __init__(self, *a, **k):
+            pass
+
+        def __setstate__(self, state):
+            pass
+
+        def __call__(self, *a, **k):
+            return self
+
+    class Unpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            try:
+                return super().find_class(module, name)
+            except (ImportError, AttributeError):
+                return type(name, (_LenientPickle._Placeholder,), {"__module__": module})
+
+    load = staticmethod(pickle.load)
+    dumps = staticmethod(pickle.dumps)
+    dump = staticmethod(pickle.dump)
+    Pickler = pickle.Pickler
 
 
 class _Cfg(dict):
@@ -93,6 +124,51 @@ class _MultiLossModule(nn.Module):
                     p.requires_grad = False
         self.modalities_freezed = True
 
+    # ---- checkpoint I/O ------------------------------------------------------------
+    checkpoint_path: Optional[str] = None
+    #: the per-step outputs the reference's test_epoch_end concatenates and dumps (models/avmnist.py:382-398)
+    TEST_PRED_KEYS: Tuple[str, ...] = ()
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, map_location=None, hparams_file=None, strict: bool = True, **kwargs):
+        """Build the module from `model_cfg` / `optimizer_cfg` (passed as the reference's run.py:48-50 does) and load the
+        weights of a Lightning `.ckpt` -- a torch.save'd dict whose `state_dict` uses exactly the sub-module names of this
+        class (models/avmnist.py:400-411 remembers the path for the test_preds.pt dump; so does this)."""
+        if "model_cfg" not in kwargs or "optimizer_cfg" not in kwargs:
+            raise TypeError("load_from_checkpoint needs model_cfg= and optimizer_cfg= (the reference passes both, run.py:48-50)")
+        ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=False, pickle_module=_LenientPickle)
+        state = ckpt["state_dict"] if isinstance(ckpt, dict) and "state_dict" in ckpt else ckpt
+        model = cls(kwargs.pop("model_cfg"), kwargs.pop("optimizer_cfg"), **kwargs)
+        model.load_state_dict(state, strict=strict)
+        model.checkpoint_path = str(checkpoint_path)
+        model.current_epoch = int(ckpt.get("epoch", 0)) if isinstance(ckpt, dict) else 0
+        return model
+
+    def save_checkpoint(self, path, epoch: Optional[int] = None, global_step: int = 0) -> str:
+        """A `.ckpt` in Lightning's top-level layout (`state_dict`, `epoch`, `global_step`): what load_from_checkpoint --
+        this one or a LightningModule's -- reads the weights from."""
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        torch.save({"state_dict": {k: v.detach().cpu() for k, v in self.state_dict().items()},
+                    "epoch": self.current_epoch if epoch is None else int(epoch), "global_step": int(global_step),
+                    "pytorch-lightning_version": "m2_mixer_amd"}, path)
+        self.checkpoint_path = str(path)
+        return str(path)
+
+    def save_test_preds(self, outputs: Sequence[Dict[str, torch.Tensor]], save_dir: Optional[str] = None) -> str:
+        """test_epoch_end's dump (models/avmnist.py:382-398): the listed shared_step outputs of every test batch,
+        concatenated, as `test_preds.pt` next to the checkpoint."""
+        if save_dir is None:
+            if self.checkpoint_path is None:
+                raise RuntimeError("save_test_preds: no checkpoint path to save next to; pass save_dir")
+            save_dir = os.path.dirname(self.checkpoint_path)
+        os.makedirs(save_dir or ".", exist_ok=True)
+        if not self.TEST_PRED_KEYS:
+            raise NotImplementedError(f"{type(self).__name__}: the reference dumps no test predictions for this task")
+        out = {k: torch.cat([o[k].detach().cpu() for o in outputs]) for k in self.TEST_PRED_KEYS}
+        path = os.path.join(save_dir, "test_preds.pt")
+        torch.save(out, path)
+        return path
+
     def configure_optimizers(self) -> Dict[str, Any]:
         """models/avmnist.py:413-422."""
         from torch.optim.lr_scheduler import ReduceLROnPlateau
@@ -123,6 +199,8 @@ class AVMnistMixerMultiLoss(_MultiLossModule):
     """batch = {'image': (B,1,28,28), 'audio': (B,1,112,112), 'label': (B,)}"""
 
     MODS = ("image", "audio")
+
+    TEST_PRED_KEYS = ("preds", "preds_image", "preds_audio", "labels", "image_logits", "audio_logits", "logits")
 
     def __init__(self, model_cfg, optimizer_cfg, **kwargs):
         super().__init__(model_cfg, optimizer_cfg, **kwargs)
@@ -168,6 +246,8 @@ class MMIMDBMixerMultiLoss(_MultiLossModule):
     """batch = {'image': (B,3,160,256), 'text': (B,1,160,256), 'label': (B,23) multi-hot}"""
 
     MODS = ("image", "text")
+
+    TEST_PRED_KEYS = ("preds", "preds_image", "preds_text", "labels", "image_logits", "text_logits", "logits")   # models/mmimdb.py:194-209
 
     def __init__(self, model_cfg, optimizer_cfg, **kwargs):
         super().__init__(model_cfg, optimizer_cfg, **kwargs)

@@ -270,6 +270,54 @@ def test_task_module_surface_and_no_cpu_path():
         net.shared_step(G.mimic_batch(2, 1, G.MIMIC_H))
 
 
+def test_checkpoint_io_lightning_layout(tmp_path):
+    """a Lightning-style `.ckpt` (top-level `state_dict` with the reference's key names, plus
+    `hyper_parameters` pickling a class of a package that is not installed here) loads through load_from_checkpoint, which
+    remembers the path; test_preds.pt gets the reference's keys (models/avmnist.py:382-398)."""
+    import importlib
+    import types
+    import torch
+    from m2_mixer_amd import models as MD
+    c = G.AVMNIST["S"]
+    mods = {"image": dict(c["image"], block_type="MLPMixer"), "audio": dict(c["audio"], block_type="MLPMixer"),
+            "multimodal": dict(c["multimodal"], block_type="FusionMixer", fusion_function="ConcatFusion"),
+            "classification": dict(classifier="StandardClassifier", num_classes=10, input_shape=[16, 49, c["multimodal"]["hidden_dim"]])}
+    cfg, ocfg = {"dropout": 0.1, "modalities": mods}, {"lr": 1e-2, "scheduler_patience": 2}
+    src = MD.AVMnistMixerMultiLoss(cfg, dict(ocfg))
+    with torch.no_grad():
+        for i, p in enumerate(src.parameters()):
+            p.copy_(torch.randn_like(p) * 0.1 + i * 1e-3)
+    # a foreign object inside the checkpoint whose class cannot be imported at load time
+    fake = types.ModuleType("omegaconf_not_installed_here")
+    fake.DictConfig = type("DictConfig", (), {"__module__": "omegaconf_not_installed_here", "__init__": lambda self, d=None: setattr(self, "d", d)})
+    sys.modules["omegaconf_not_installed_here"] = fake
+    ck = tmp_path / "version_0" / "checkpoints" / "epoch=3-step=400.ckpt"
+    ck.parent.mkdir(parents=True)
+    torch.save({"epoch": 3, "global_step": 400, "pytorch-lightning_version": "1.8.6", "state_dict": src.state_dict(),
+                "hyper_parameters": {"model_cfg": fake.DictConfig({"x": 1})}, "optimizer_states": [{}], "lr_schedulers": [{}]}, ck)
+    del sys.modules["omegaconf_not_installed_here"]
+    with pytest.raises(Exception):
+        torch.load(ck, weights_only=False)                       # the plain unpickler cannot resolve the foreign class
+    net = MD.AVMnistMixerMultiLoss.load_from_checkpoint(ck, optimizer_cfg=dict(ocfg), model_cfg=cfg)
+    assert net.checkpoint_path == str(ck) and net.current_epoch == 3
+    for (k, a), (k2, b) in zip(src.state_dict().items(), net.state_dict().items()):
+        assert k == k2 and torch.equal(a, b), k
+    with pytest.raises(TypeError):
+        MD.AVMnistMixerMultiLoss.load_from_checkpoint(ck)
+    # our own checkpoints go through the same door
+    out = net.save_checkpoint(tmp_path / "own" / "last.ckpt", epoch=7, global_step=9)
+    again = MD.AVMnistMixerMultiLoss.load_from_checkpoint(out, optimizer_cfg=dict(ocfg), model_cfg=cfg)
+    assert again.current_epoch == 7 and all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), again.state_dict().values()))
+    # test_preds.pt next to the checkpoint, the reference's keys, batches concatenated
+    outs = [{k: torch.full((4, 10) if "logits" in k else (4,), float(i)) for k in net.TEST_PRED_KEYS} for i in range(3)]
+    path = net.save_test_preds(outs)
+    assert os.path.dirname(path) == os.path.dirname(out) and os.path.basename(path) == "test_preds.pt"     # next to the last checkpoint
+    dump = torch.load(path)
+    assert sorted(dump) == sorted(["preds", "preds_image", "preds_audio", "labels", "image_logits", "audio_logits", "logits"])
+    assert dump["logits"].shape == (12, 10) and dump["preds"].shape == (12,) and float(dump["labels"][-1]) == 2.0
+    assert "preds_text" in MD.MMIMDBMixerMultiLoss.TEST_PRED_KEYS and MD.MimicMixerMultiLoss.TEST_PRED_KEYS == ()
+
+
 def _write_avmnist(root, n_train, n_test, seed=0, learnable=False):
     """A tiny dataset in the reference's on-disk format (datasets/avmnist.py:105-114)."""
     rng = np.random.default_rng(seed)
