@@ -157,8 +157,7 @@ extern "C" int m2m_pack_tower(const m2m_tower* t, void* stream) {
 
 // Every packed copy a model needs after an optimizer step -- up to three towers of <= 4 blocks and two patch
 // embeddings -- in ONE launch (the whole repack is ~100 MB of HBM traffic: one launch at the memory roofline instead of
-// five launches forked over side streams).  blockIdx.y = 5 * M2M_GROUP_BLOCKS * tower + 5 * block + which, then one
-// job per embedding.
+// five launches forked over side streams).  Grid layout: see pack_all_kernel.
 #define M2M_PACK_TOWERS 3
 #define M2M_PACK_EMBEDS 2
 struct PackAllArgs {

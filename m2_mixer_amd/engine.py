@@ -144,7 +144,8 @@ class _FlatEngine:
         self.losses = torch.zeros(4, device=dev)
         self._graph = None
         self._static = None
-        # the second modality / the fusion weight gradients run beside the first modality on side streams
+        # side streams for the paths whose towers cannot share a launch (wide towers, mixed shapes, the MIMIC static MLP): the
+        # second modality runs beside the first.  The AV-MNIST step needs none of them: nine launches on the main stream.
         self.s_b = torch.cuda.Stream(device=dev)
         self.s_fus = torch.cuda.Stream(device=dev)
         self.s_emb = torch.cuda.Stream(device=dev)
