@@ -215,7 +215,15 @@ def main():
     # ---- per-launch timing (HIP events on the launch stream), eager pass of the very same step ----
     kern = profile_launches(eng, image, audio, labels, args.profile_steps) if rank == 0 else None
 
+    def finish():
+        """All ranks leave together: a peer that exits while rank 0 is still profiling would tear the communicator down
+        under it."""
+        if world > 1:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+
     if rank != 0:
+        finish()
         return
     ms = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
@@ -245,6 +253,7 @@ def main():
         log("cpu baseline (oracle) ...")
         out["cpu_baseline"] = cpu_baseline(cfg, B, args.cpu_budget)
     print(json.dumps(out), flush=True)
+    finish()
 
 
 def profile_launches(eng, image, audio, labels, nsteps):
