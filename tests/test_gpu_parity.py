@@ -196,6 +196,26 @@ def test_avmnist_step_bf16_vs_oracle(size, B, dev):
         assert relerr(eng.grads[k], g) < 6e-2, k
 
 
+@pytest.mark.parametrize("prec,B", [("fp32", 1), ("fp32", 3), ("bf16", 1), ("bf16", 5)])
+def test_avmnist_eval_tiny_and_odd_batches_vs_oracle(prec, B, dev):
+    """validation / test step (dropout off) on batches smaller than any tile of the kernels: a single sample, odd counts --
+    every launch of the step runs with ragged row tiles, partial sample groups and mostly-empty workgroups."""
+    eng, cfg = _engine("B", B, prec, dev)                   # cfg dropout 0.5: evaluate() must ignore it
+    shapes = G.avmnist_shapes(cfg)
+    params = dict(G.make_params(shapes, 31))
+    eng.load_state_dict(params)
+    image, audio, labels = G.avmnist_batch(B, 32, cfg)
+    out = eng.evaluate(image.to(dev), audio.to(dev), labels.to(dev))
+    torch.cuda.synchronize()
+    ref = O.avmnist_forward(image, audio, labels, params, cfg)
+    tol = FP32_ATOL if prec == "fp32" else BF16_REL
+    for k in ("logits", "image_logits", "audio_logits"):
+        assert abserr(out[k], ref[k]) < tol, k
+    assert abs(float(out["loss"]) - float(ref["loss"])) < (1e-3 if prec == "fp32" else 2e-2)
+    if prec == "fp32":
+        assert torch.equal(out["preds"].cpu().long(), ref["preds"])
+
+
 def test_module_path_towers_and_no_patching(dev):
     """The reference-shaped nn.Modules (registry -> MLPMixer / FusionMixer / MLPMixerNoPatching) under torch
     autograd, fp32 mode, against the oracle."""
