@@ -13,7 +13,8 @@
 #include "tile.h"
 
 #define TW_COLS 64                 // columns (lanes) per workgroup
-#define TW_TMAX 32                 // token_dim upper bound (h[] registers)
+#define TW_TMAX 32                 // token_dim upper bound; the kernels are instantiated for TM = 16 and 32 hidden units (h[] registers,
+                                   // LDS weight rows): token_dim <= 16 (MIMIC, MM-IMDb) does half the work in half the LDS
 #define TW_LDW (TW_COLS + 1)       // padded row stride of the per-column LDS tiles
 
 int m2m_chain_forward_rows(const m2m_tower* t, const float* x0, long x0_ss, int B, float* out, long out_ss, int training,
@@ -34,16 +35,16 @@ static __host__ __device__ __forceinline__ TokGeom tok_geom(int D) {
     g.spw = D >= TW_COLS ? 1 : TW_COLS / D;
     return g;
 }
-static __host__ __device__ __forceinline__ size_t tok_lds_floats(int N, int spw) { return (size_t)2 * N * TW_TMAX + TW_TMAX + N + 2 * spw * N; }
+static __host__ __device__ __forceinline__ size_t tok_lds_floats(int N, int spw, int TM) { return (size_t)2 * N * TM + TM + N + 2 * spw * N; }
 
-static __device__ __forceinline__ void tok_stage_weights(const m2m_block& bk, int N, int T, float* w1s, float* w2s, float* b1s,
+static __device__ __forceinline__ void tok_stage_weights(const m2m_block& bk, int N, int T, int TM, float* w1s, float* w2s, float* b1s,
                                                          float* b2s, int lane) {
-    for (int i = lane; i < N * TW_TMAX; i += TW_COLS) {
-        const int n = i / TW_TMAX, t = i % TW_TMAX;
+    for (int i = lane; i < N * TM; i += TW_COLS) {
+        const int n = i / TM, t = i % TM;
         w1s[i] = t < T ? bk.tok_w1[t * N + n] : 0.f;
         w2s[i] = t < T ? bk.tok_w2[n * T + t] : 0.f;
     }
-    if (lane < TW_TMAX) b1s[lane] = lane < T ? bk.tok_b1[lane] : 0.f;
+    if (lane < TM) b1s[lane] = lane < T ? bk.tok_b1[lane] : 0.f;
     for (int n = lane; n < N; n += TW_COLS) b2s[n] = bk.tok_b2[n];
 }
 // one wave: statistics of `rows` rows; row r lives at src + (r / N) * ss + (r % N) * D  (r counted from sample s_first)
@@ -76,7 +77,7 @@ static __device__ __forceinline__ void tok_row_stats(const float* __restrict__ s
 }
 
 // ---- forward: x_mid = x + Dropout(W2 Dropout(GELU(W1 LN1(x)^T + b1)) + b2)^T  (modules/mixer.py:30-35, :43) ------
-template <int P, int DM>
+template <int P, int DM, int TM>
 __global__ __launch_bounds__(TW_COLS) void token_fwd_kernel(const m2m_tower tw, int b, const float* __restrict__ src, long src_ss,
                                                             int B, float* __restrict__ x_mid, float* __restrict__ save_x_in,
                                                             int training, unsigned int seed, unsigned int step_host,
@@ -85,11 +86,11 @@ __global__ __launch_bounds__(TW_COLS) void token_fwd_kernel(const m2m_tower tw, 
     const int N = tw.N, T = tw.T, D = tw.D;
     const TokGeom tg = tok_geom(D);
     float* w1s = smf;
-    float* w2s = w1s + N * TW_TMAX;
-    float* b1s = w2s + N * TW_TMAX;
-    float* b2s = b1s + TW_TMAX;
+    float* w2s = w1s + N * TM;
+    float* b1s = w2s + N * TM;
+    float* b2s = b1s + TM;
     float* stats = b2s + N;
-    gtab_t* gtab = reinterpret_cast<gtab_t*>(smf + ((tok_lds_floats(N, tg.spw) + 3) & ~(size_t)3));
+    gtab_t* gtab = reinterpret_cast<gtab_t*>(smf + ((tok_lds_floats(N, tg.spw, TM) + 3) & ~(size_t)3));
 
     const int lane = threadIdx.x;
     const m2m_block& bk = tw.blk[b];
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(TW_COLS) void token_fwd_kernel(const m2m_tower tw, 
     const int chunk = blockIdx.x % tg.chunks;
     const int ns = min(tg.spw, B - s_first);
     if (Act<P>::USES_TABLE) gelu_tab_fill(gtab, lane, TW_COLS);
-    tok_stage_weights(bk, N, T, w1s, w2s, b1s, b2s, lane);
+    tok_stage_weights(bk, N, T, TM, w1s, w2s, b1s, b2s, lane);
     tok_row_stats(src, src_ss, s_first, ns * N, N, D, stats, lane);
     __syncthreads();
 
@@ -115,14 +116,14 @@ __global__ __launch_bounds__(TW_COLS) void token_fwd_kernel(const m2m_tower tw, 
     const float* col = src + (long)s * src_ss + d;
     const float* st = stats + 2 * sl * N;
 
-    float h[TW_TMAX];
+    float h[TM];
 #pragma unroll
-    for (int t = 0; t < TW_TMAX; ++t) h[t] = b1s[t];
+    for (int t = 0; t < TM; ++t) h[t] = b1s[t];
     for (int n = 0; n < N; ++n) {
         const float u = (col[(long)n * D] - st[2 * n]) * st[2 * n + 1] * gam + bet;
-        const float4* wr = reinterpret_cast<const float4*>(w1s + n * TW_TMAX);
+        const float4* wr = reinterpret_cast<const float4*>(w1s + n * TM);
 #pragma unroll
-        for (int t4 = 0; t4 < TW_TMAX / 4; ++t4) {
+        for (int t4 = 0; t4 < TM / 4; ++t4) {
             const float4 w = wr[t4];
             h[4 * t4 + 0] = __builtin_fmaf(w.x, u, h[4 * t4 + 0]);
             h[4 * t4 + 1] = __builtin_fmaf(w.y, u, h[4 * t4 + 1]);
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(TW_COLS) void token_fwd_kernel(const m2m_tower tw, 
         }
     }
 #pragma unroll
-    for (int t = 0; t < TW_TMAX; ++t) {
+    for (int t = 0; t < TM; ++t) {
         if (t < T) {
             const float v = Act<P>::gelu(gtab, h[t]) * dr_th.scale;
             h[t] = drop_row_keep<DM>(dr_th, bd, T, t) ? v : 0.f;
@@ -140,10 +141,10 @@ __global__ __launch_bounds__(TW_COLS) void token_fwd_kernel(const m2m_tower tw, 
         }
     }
     for (int n = 0; n < N; ++n) {
-        const float4* wr = reinterpret_cast<const float4*>(w2s + n * TW_TMAX);
+        const float4* wr = reinterpret_cast<const float4*>(w2s + n * TM);
         float o0 = b2s[n], o1 = 0.f, o2 = 0.f, o3 = 0.f;
 #pragma unroll
-        for (int t4 = 0; t4 < TW_TMAX / 4; ++t4) {
+        for (int t4 = 0; t4 < TM / 4; ++t4) {
             const float4 w = wr[t4];
             o0 = __builtin_fmaf(w.x, h[4 * t4 + 0], o0);
             o1 = __builtin_fmaf(w.y, h[4 * t4 + 1], o1);
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(TW_COLS) void token_fwd_kernel(const m2m_tower tw, 
 
 // ---- backward, column part: dU (gradient wrt LN1 output) + token-MLP parameter gradients --------------------------
 //   g_mid : gradient wrt x_mid (dense rows);  x_in : saved block input (dense rows);  du_out : receives dU (dense rows)
-template <int P, int DM>
+template <int P, int DM, int TM>
 __global__ __launch_bounds__(TW_COLS) void token_bwd_cols_kernel(const m2m_tower tw, int b, const float* __restrict__ g_mid, int B,
                                                                  float* __restrict__ du_out, unsigned int seed,
                                                                  unsigned int step_host, const unsigned int* __restrict__ step_dev) {
@@ -168,15 +169,15 @@ __global__ __launch_bounds__(TW_COLS) void token_bwd_cols_kernel(const m2m_tower
     const int N = tw.N, T = tw.T, D = tw.D;
     const TokGeom tg = tok_geom(D);
     float* w1s = smf;
-    float* w2s = w1s + N * TW_TMAX;
-    float* b1s = w2s + N * TW_TMAX;
-    float* b2s = b1s + TW_TMAX;
+    float* w2s = w1s + N * TM;
+    float* b1s = w2s + N * TM;
+    float* b2s = b1s + TM;
     float* stats = b2s + N;
-    gtab_t* gtab = reinterpret_cast<gtab_t*>(smf + ((tok_lds_floats(N, tg.spw) + 3) & ~(size_t)3));
+    gtab_t* gtab = reinterpret_cast<gtab_t*>(smf + ((tok_lds_floats(N, tg.spw, TM) + 3) & ~(size_t)3));
     float* us = reinterpret_cast<float*>(gtab + GELU_TAB_N);   // [N][TW_LDW]  LN1 output of each column
     float* dvs = us + N * TW_LDW;                               // [N][TW_LDW]  masked upstream gradient
     float* hs = dvs + N * TW_LDW;                               // [32][TW_LDW] hidden activation (after dropout)
-    float* dhs = hs + TW_TMAX * TW_LDW;                         // [32][TW_LDW] gradient wrt the hidden pre-activation
+    float* dhs = hs + TM * TW_LDW;                         // [32][TW_LDW] gradient wrt the hidden pre-activation
 
     const int lane = threadIdx.x;
     const m2m_block& bk = tw.blk[b];
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(TW_COLS) void token_bwd_cols_kernel(const m2m_tower
     const int chunk = blockIdx.x % tg.chunks;
     const int ns = min(tg.spw, B - s_first);
     if (Act<P>::USES_TABLE) gelu_tab_fill(gtab, lane, TW_COLS);
-    tok_stage_weights(bk, N, T, w1s, w2s, b1s, b2s, lane);
+    tok_stage_weights(bk, N, T, TM, w1s, w2s, b1s, b2s, lane);
     tok_row_stats(bk.x_in, (long)N * D, s_first, ns * N, N, D, stats, lane);
     __syncthreads();
 
@@ -202,9 +203,9 @@ __global__ __launch_bounds__(TW_COLS) void token_bwd_cols_kernel(const m2m_tower
     const long col0 = (long)s * N * D + d;
     const float* st = stats + 2 * (pv ? sl : 0) * N;
 
-    float h[TW_TMAX], dh[TW_TMAX];
+    float h[TM], dh[TM];
 #pragma unroll
-    for (int t = 0; t < TW_TMAX; ++t) { h[t] = b1s[t]; dh[t] = 0.f; }
+    for (int t = 0; t < TM; ++t) { h[t] = b1s[t]; dh[t] = 0.f; }
     for (int n = 0; n < N; ++n) {
         float u = 0.f, dv = 0.f;
         if (pv) {
@@ -214,10 +215,10 @@ __global__ __launch_bounds__(TW_COLS) void token_bwd_cols_kernel(const m2m_tower
         }
         us[n * TW_LDW + lane] = u;
         dvs[n * TW_LDW + lane] = dv;
-        const float4* wr1 = reinterpret_cast<const float4*>(w1s + n * TW_TMAX);
-        const float4* wr2 = reinterpret_cast<const float4*>(w2s + n * TW_TMAX);
+        const float4* wr1 = reinterpret_cast<const float4*>(w1s + n * TM);
+        const float4* wr2 = reinterpret_cast<const float4*>(w2s + n * TM);
 #pragma unroll
-        for (int t4 = 0; t4 < TW_TMAX / 4; ++t4) {
+        for (int t4 = 0; t4 < TM / 4; ++t4) {
             const float4 a = wr1[t4], c = wr2[t4];
             h[4 * t4 + 0] = __builtin_fmaf(a.x, u, h[4 * t4 + 0]);
             h[4 * t4 + 1] = __builtin_fmaf(a.y, u, h[4 * t4 + 1]);
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(TW_COLS) void token_bwd_cols_kernel(const m2m_tower
     }
     // hidden activation and gradient wrt the pre-activation; dh[] is reused for the latter
 #pragma unroll
-    for (int t = 0; t < TW_TMAX; ++t) {
+    for (int t = 0; t < TM; ++t) {
         float hact = 0.f, dhp = 0.f;
         if (t < T) {
             float gl, dgl;
@@ -247,10 +248,10 @@ __global__ __launch_bounds__(TW_COLS) void token_bwd_cols_kernel(const m2m_tower
     // dU[n] = sum_t W1[t][n] dHpre[t]
     if (pv) {
         for (int n = 0; n < N; ++n) {
-            const float4* wr = reinterpret_cast<const float4*>(w1s + n * TW_TMAX);
+            const float4* wr = reinterpret_cast<const float4*>(w1s + n * TM);
             float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
 #pragma unroll
-            for (int t4 = 0; t4 < TW_TMAX / 4; ++t4) {
+            for (int t4 = 0; t4 < TM / 4; ++t4) {
                 const float4 w = wr[t4];
                 o0 = __builtin_fmaf(w.x, dh[4 * t4 + 0], o0);
                 o1 = __builtin_fmaf(w.y, dh[4 * t4 + 1], o1);
@@ -379,25 +380,25 @@ static m2m_tower block_view(const m2m_tower* t, int b) {
     return v;
 }
 
-template <int P, int DM>
+template <int P, int DM, int TM>
 static int launch_token_fwd(const m2m_tower* t, int b, const float* src, long src_ss, int B, float* x_mid, float* save_x_in,
                             int training, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
     const TokGeom g = tok_geom(t->D);
     const int grid = ((B + g.spw - 1) / g.spw) * g.chunks;
-    const size_t lds = ((tok_lds_floats(t->N, g.spw) + 3) & ~(size_t)3) * sizeof(float) + GELU_TAB_N * 16;
-    hipLaunchKernelGGL((token_fwd_kernel<P, DM>), dim3(grid), dim3(TW_COLS), lds, st, *t, b, src, src_ss, B, x_mid, save_x_in,
+    const size_t lds = ((tok_lds_floats(t->N, g.spw, TM) + 3) & ~(size_t)3) * sizeof(float) + GELU_TAB_N * 16;
+    hipLaunchKernelGGL((token_fwd_kernel<P, DM, TM>), dim3(grid), dim3(TW_COLS), lds, st, *t, b, src, src_ss, B, x_mid, save_x_in,
                        training, seed, step, step_dev);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
 }
-template <int P, int DM>
+template <int P, int DM, int TM>
 static int launch_token_bwd(const m2m_tower* t, int b, const float* g_mid, int B, float* du, unsigned int seed, unsigned int step,
                             const unsigned int* step_dev, hipStream_t st) {
     const TokGeom g = tok_geom(t->D);
     const int grid = ((B + g.spw - 1) / g.spw) * g.chunks;
-    const size_t lds = ((tok_lds_floats(t->N, g.spw) + 3) & ~(size_t)3) * sizeof(float) + GELU_TAB_N * 16 +
-                       (size_t)(2 * t->N + 2 * TW_TMAX) * TW_LDW * sizeof(float);
-    auto kern = token_bwd_cols_kernel<P, DM>;
+    const size_t lds = ((tok_lds_floats(t->N, g.spw, TM) + 3) & ~(size_t)3) * sizeof(float) + GELU_TAB_N * 16 +
+                       (size_t)(2 * t->N + 2 * TM) * TW_LDW * sizeof(float);
+    auto kern = token_bwd_cols_kernel<P, DM, TM>;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
         M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -407,17 +408,22 @@ static int launch_token_bwd(const m2m_tower* t, int b, const float* g_mid, int B
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
 }
-#define M2M_TOK_DISPATCH(FN, training_, ...)                                                        \
+#define M2M_TOK_DISPATCH_TM(FN, TM_, training_, ...)                                                \
     do {                                                                                            \
         const int dm_ = m2m_drop_mode(training_, t->p_drop);                                       \
         if (t->prec == PREC_BF16) {                                                                 \
-            if (dm_ == DM_NONE) return FN<PREC_BF16, DM_NONE>(__VA_ARGS__);                        \
-            if (dm_ == DM_HALF) return FN<PREC_BF16, DM_HALF>(__VA_ARGS__);                        \
-            return FN<PREC_BF16, DM_GEN>(__VA_ARGS__);                                             \
+            if (dm_ == DM_NONE) return FN<PREC_BF16, DM_NONE, TM_>(__VA_ARGS__);                   \
+            if (dm_ == DM_HALF) return FN<PREC_BF16, DM_HALF, TM_>(__VA_ARGS__);                   \
+            return FN<PREC_BF16, DM_GEN, TM_>(__VA_ARGS__);                                        \
         }                                                                                           \
-        if (dm_ == DM_NONE) return FN<PREC_F32, DM_NONE>(__VA_ARGS__);                             \
-        if (dm_ == DM_HALF) return FN<PREC_F32, DM_HALF>(__VA_ARGS__);                             \
-        return FN<PREC_F32, DM_GEN>(__VA_ARGS__);                                                  \
+        if (dm_ == DM_NONE) return FN<PREC_F32, DM_NONE, TM_>(__VA_ARGS__);                        \
+        if (dm_ == DM_HALF) return FN<PREC_F32, DM_HALF, TM_>(__VA_ARGS__);                        \
+        return FN<PREC_F32, DM_GEN, TM_>(__VA_ARGS__);                                             \
+    } while (0)
+#define M2M_TOK_DISPATCH(FN, training_, ...)                                                        \
+    do {                                                                                            \
+        if (t->T <= 16) M2M_TOK_DISPATCH_TM(FN, 16, training_, __VA_ARGS__);                       \
+        M2M_TOK_DISPATCH_TM(FN, 32, training_, __VA_ARGS__);                                       \
     } while (0)
 
 static int token_fwd(const m2m_tower* t, int b, const float* src, long src_ss, int B, float* x_mid, float* save_x_in, int training,
