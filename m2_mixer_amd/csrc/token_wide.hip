@@ -16,6 +16,7 @@
 #define TW_TMAX 32                 // token_dim upper bound; the kernels are instantiated for TM = 16 and 32 hidden units (h[] registers,
                                    // LDS weight rows): token_dim <= 16 (MIMIC, MM-IMDb) does half the work in half the LDS
 #define TW_LDW (TW_COLS + 1)       // padded row stride of the per-column LDS tiles
+#define TW_NC 16                   // tokens per chunk of the parameter-gradient reduction (backward)
 
 int m2m_chain_forward_rows(const m2m_tower* t, const float* x0, long x0_ss, int B, float* out, long out_ss, int training,
                            unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st);
@@ -174,9 +175,9 @@ __global__ __launch_bounds__(TW_COLS) void token_bwd_cols_kernel(const m2m_tower
     float* b2s = b1s + TM;
     float* stats = b2s + N;
     gtab_t* gtab = reinterpret_cast<gtab_t*>(smf + ((tok_lds_floats(N, tg.spw, TM) + 3) & ~(size_t)3));
-    float* us = reinterpret_cast<float*>(gtab + GELU_TAB_N);   // [N][TW_LDW]  LN1 output of each column
-    float* dvs = us + N * TW_LDW;                               // [N][TW_LDW]  masked upstream gradient
-    float* hs = dvs + N * TW_LDW;                               // [32][TW_LDW] hidden activation (after dropout)
+    float* us = reinterpret_cast<float*>(gtab + GELU_TAB_N);   // [TW_NC][TW_LDW]  LN1 output of each column, one chunk of tokens
+    float* dvs = us + TW_NC * TW_LDW;                           // [TW_NC][TW_LDW]  masked upstream gradient, same chunk
+    float* hs = dvs + TW_NC * TW_LDW;                           // [TM][TW_LDW] hidden activation (after dropout)
     float* dhs = hs + TM * TW_LDW;                         // [32][TW_LDW] gradient wrt the hidden pre-activation
 
     const int lane = threadIdx.x;
@@ -206,15 +207,18 @@ __global__ __launch_bounds__(TW_COLS) void token_bwd_cols_kernel(const m2m_tower
     float h[TM], dh[TM];
 #pragma unroll
     for (int t = 0; t < TM; ++t) { h[t] = b1s[t]; dh[t] = 0.f; }
-    for (int n = 0; n < N; ++n) {
-        float u = 0.f, dv = 0.f;
+    // LN1 output and masked upstream gradient of token n of this lane's column (zero for padding lanes)
+    auto u_dv = [&](int n, float& u, float& dv) {
+        u = 0.f; dv = 0.f;
         if (pv) {
             u = (bk.x_in[col0 + (long)n * D] - st[2 * n]) * st[2 * n + 1] * gam + bet;
             const float gv = g_mid[col0 + (long)n * D] * dr_to.scale;
             dv = drop_row_keep<DM>(dr_to, bd, N, n) ? gv : 0.f;
         }
-        us[n * TW_LDW + lane] = u;
-        dvs[n * TW_LDW + lane] = dv;
+    };
+    for (int n = 0; n < N; ++n) {
+        float u, dv;
+        u_dv(n, u, dv);
         const float4* wr1 = reinterpret_cast<const float4*>(w1s + n * TM);
         const float4* wr2 = reinterpret_cast<const float4*>(w2s + n * TM);
 #pragma unroll
@@ -262,34 +266,47 @@ __global__ __launch_bounds__(TW_COLS) void token_bwd_cols_kernel(const m2m_tower
         }
     }
     __syncthreads();
-    // parameter gradients: each lane owns (n, t) pairs and sums over the workgroup's 64 columns (fixed order),
-    // then one float atomic per value per workgroup
-    for (int p = lane; p < N * T; p += TW_COLS) {
-        const int n = p / T, t = p % T;
-        const float* ur = us + n * TW_LDW;
-        const float* vr = dvs + n * TW_LDW;
-        const float* hr = hs + t * TW_LDW;
-        const float* gr = dhs + t * TW_LDW;
-        float a = 0.f, c = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < TW_COLS; ++k) {
-            a = __builtin_fmaf(gr[k], ur[k], a);         // dW1[t][n] += dHpre[t] U[n]
-            c = __builtin_fmaf(vr[k], hr[k], c);         // dW2[n][t] += dV[n] Hact[t]
-        }
-        atomicAdd(bk.g_tok_w1 + t * N + n, a);
-        atomicAdd(bk.g_tok_w2 + n * T + t, c);
-    }
+    // parameter gradients: sums over the workgroup's 64 columns (fixed order), then one float atomic per value per
+    // workgroup.  U and dV go through LDS one chunk of TW_NC tokens at a time (recomputed from x_in / g_mid, which are
+    // L2-resident by now): a full [N][64] tile of each was the bulk of the kernel's LDS and held MM-IMDb's fusion tower
+    // (N = 80) to two single-wave workgroups per CU.
     if (lane < T) {
         const float* gr = dhs + lane * TW_LDW;
         float a = 0.f;
         for (int k = 0; k < TW_COLS; ++k) a += gr[k];
         atomicAdd(bk.g_tok_b1 + lane, a);
     }
-    for (int n = lane; n < N; n += TW_COLS) {
-        const float* vr = dvs + n * TW_LDW;
-        float a = 0.f;
-        for (int k = 0; k < TW_COLS; ++k) a += vr[k];
-        atomicAdd(bk.g_tok_b2 + n, a);
+    for (int n0 = 0; n0 < N; n0 += TW_NC) {
+        const int nc = min(TW_NC, N - n0);
+        for (int j = 0; j < nc; ++j) {
+            float u, dv;
+            u_dv(n0 + j, u, dv);
+            us[j * TW_LDW + lane] = u;
+            dvs[j * TW_LDW + lane] = dv;
+        }
+        __syncthreads();
+        for (int p = lane; p < nc * T; p += TW_COLS) {
+            const int j = p / T, t = p % T, n = n0 + j;
+            const float* ur = us + j * TW_LDW;
+            const float* vr = dvs + j * TW_LDW;
+            const float* hr = hs + t * TW_LDW;
+            const float* gr = dhs + t * TW_LDW;
+            float a = 0.f, c = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < TW_COLS; ++k) {
+                a = __builtin_fmaf(gr[k], ur[k], a);         // dW1[t][n] += dHpre[t] U[n]
+                c = __builtin_fmaf(vr[k], hr[k], c);         // dW2[n][t] += dV[n] Hact[t]
+            }
+            atomicAdd(bk.g_tok_w1 + t * N + n, a);
+            atomicAdd(bk.g_tok_w2 + n * T + t, c);
+        }
+        if (lane < nc) {
+            const float* vr = dvs + lane * TW_LDW;
+            float a = 0.f;
+            for (int k = 0; k < TW_COLS; ++k) a += vr[k];
+            atomicAdd(bk.g_tok_b2 + n0 + lane, a);
+        }
+        __syncthreads();
     }
 }
 
@@ -397,7 +414,7 @@ static int launch_token_bwd(const m2m_tower* t, int b, const float* g_mid, int B
     const TokGeom g = tok_geom(t->D);
     const int grid = ((B + g.spw - 1) / g.spw) * g.chunks;
     const size_t lds = ((tok_lds_floats(t->N, g.spw, TM) + 3) & ~(size_t)3) * sizeof(float) + GELU_TAB_N * 16 +
-                       (size_t)(2 * t->N + 2 * TM) * TW_LDW * sizeof(float);
+                       (size_t)(2 * TW_NC + 2 * TM) * TW_LDW * sizeof(float);
     auto kern = token_bwd_cols_kernel<P, DM, TM>;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
