@@ -91,7 +91,6 @@ __global__ __launch_bounds__(TW_COLS) void token_fwd_kernel(const m2m_tower tw, 
     float* b1s = w2s + N * TM;
     float* b2s = b1s + TM;
     float* stats = b2s + N;
-    gtab_t* gtab = reinterpret_cast<gtab_t*>(smf + ((tok_lds_floats(N, tg.spw, TM) + 3) & ~(size_t)3));
 
     const int lane = threadIdx.x;
     const m2m_block& bk = tw.blk[b];
@@ -103,7 +102,6 @@ __global__ __launch_bounds__(TW_COLS) void token_fwd_kernel(const m2m_tower tw, 
     const int s_first = (blockIdx.x / tg.chunks) * tg.spw;
     const int chunk = blockIdx.x % tg.chunks;
     const int ns = min(tg.spw, B - s_first);
-    if (Act<P>::USES_TABLE) gelu_tab_fill(gtab, lane, TW_COLS);
     tok_stage_weights(bk, N, T, TM, w1s, w2s, b1s, b2s, lane);
     tok_row_stats(src, src_ss, s_first, ns * N, N, D, stats, lane);
     __syncthreads();
@@ -135,7 +133,7 @@ __global__ __launch_bounds__(TW_COLS) void token_fwd_kernel(const m2m_tower tw, 
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
         if (t < T) {
-            const float v = Act<P>::gelu(gtab, h[t]) * dr_th.scale;
+            const float v = gelu_f(h[t]) * dr_th.scale;      // a lane has token_dim (<= 32) of these: cheaper than filling a table
             h[t] = drop_row_keep<DM>(dr_th, bd, T, t) ? v : 0.f;
         } else {
             h[t] = 0.f;
@@ -174,8 +172,7 @@ __global__ __launch_bounds__(TW_COLS) void token_bwd_cols_kernel(const m2m_tower
     float* b1s = w2s + N * TM;
     float* b2s = b1s + TM;
     float* stats = b2s + N;
-    gtab_t* gtab = reinterpret_cast<gtab_t*>(smf + ((tok_lds_floats(N, tg.spw, TM) + 3) & ~(size_t)3));
-    float* us = reinterpret_cast<float*>(gtab + GELU_TAB_N);   // [TW_NC][TW_LDW]  LN1 output of each column, one chunk of tokens
+    float* us = smf + ((tok_lds_floats(N, tg.spw, TM) + 3) & ~(size_t)3);   // [TW_NC][TW_LDW]  LN1 output of each column, one chunk of tokens
     float* dvs = us + TW_NC * TW_LDW;                           // [TW_NC][TW_LDW]  masked upstream gradient, same chunk
     float* hs = dvs + TW_NC * TW_LDW;                           // [TM][TW_LDW] hidden activation (after dropout)
     float* dhs = hs + TM * TW_LDW;                         // [32][TW_LDW] gradient wrt the hidden pre-activation
@@ -190,7 +187,6 @@ __global__ __launch_bounds__(TW_COLS) void token_bwd_cols_kernel(const m2m_tower
     const int s_first = (blockIdx.x / tg.chunks) * tg.spw;
     const int chunk = blockIdx.x % tg.chunks;
     const int ns = min(tg.spw, B - s_first);
-    if (Act<P>::USES_TABLE) gelu_tab_fill(gtab, lane, TW_COLS);
     tok_stage_weights(bk, N, T, TM, w1s, w2s, b1s, b2s, lane);
     tok_row_stats(bk.x_in, (long)N * D, s_first, ns * N, N, D, stats, lane);
     __syncthreads();
@@ -240,7 +236,7 @@ __global__ __launch_bounds__(TW_COLS) void token_bwd_cols_kernel(const m2m_tower
         float hact = 0.f, dhp = 0.f;
         if (t < T) {
             float gl, dgl;
-            Act<P>::gelu_grad(gtab, h[t], gl, dgl);
+            gelu_grad_f(h[t], gl, dgl);
             const bool keep = pv && drop_row_keep<DM>(dr_th, bd, T, t);
             hact = keep ? gl * dr_th.scale : 0.f;
             dhp = keep ? dh[t] * dr_th.scale * dgl : 0.f;
@@ -403,7 +399,7 @@ static int launch_token_fwd(const m2m_tower* t, int b, const float* src, long sr
                             int training, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
     const TokGeom g = tok_geom(t->D);
     const int grid = ((B + g.spw - 1) / g.spw) * g.chunks;
-    const size_t lds = ((tok_lds_floats(t->N, g.spw, TM) + 3) & ~(size_t)3) * sizeof(float) + GELU_TAB_N * 16;
+    const size_t lds = ((tok_lds_floats(t->N, g.spw, TM) + 3) & ~(size_t)3) * sizeof(float);
     hipLaunchKernelGGL((token_fwd_kernel<P, DM, TM>), dim3(grid), dim3(TW_COLS), lds, st, *t, b, src, src_ss, B, x_mid, save_x_in,
                        training, seed, step, step_dev);
     M2M_CHECK_HIP(hipGetLastError());
@@ -414,7 +410,7 @@ static int launch_token_bwd(const m2m_tower* t, int b, const float* g_mid, int B
                             const unsigned int* step_dev, hipStream_t st) {
     const TokGeom g = tok_geom(t->D);
     const int grid = ((B + g.spw - 1) / g.spw) * g.chunks;
-    const size_t lds = ((tok_lds_floats(t->N, g.spw, TM) + 3) & ~(size_t)3) * sizeof(float) + GELU_TAB_N * 16 +
+    const size_t lds = ((tok_lds_floats(t->N, g.spw, TM) + 3) & ~(size_t)3) * sizeof(float) +
                        (size_t)(2 * TW_NC + 2 * TM) * TW_LDW * sizeof(float);
     auto kern = token_bwd_cols_kernel<P, DM, TM>;
     static size_t attr_lds = 0;
