@@ -504,7 +504,7 @@ static WgradPlan wgrad_plan(const m2m_tower* t, int B) {
     const int wgs = nsl * t->nblocks;
     while (wgs * groups < 128 && (ntiles + groups - 1) / groups > 64) ++groups;
     if (groups < (32 + wgs - 1) / wgs) groups = (32 + wgs - 1) / wgs;
-    if (const char* e = getenv("M2M_WGRAD_GROUPS")) groups = atoi(e);
+    if (const char* e = getenv("M2M_WGRAD_GROUPS")) groups = atoi(e);   // diagnostic override (scripts/wgrad_probe.py sweeps it); unset in production
     if (groups < 1) groups = 1;
     int tpg = (ntiles + groups - 1) / groups;
     if (tpg < 4) tpg = 4;
