@@ -17,6 +17,7 @@
                                    // LDS weight rows): token_dim <= 16 (MIMIC, MM-IMDb) does half the work in half the LDS
 #define TW_LDW (TW_COLS + 1)       // padded row stride of the per-column LDS tiles
 #define TW_NC 16                   // tokens per chunk of the parameter-gradient reduction (backward)
+#define TW_UB 8                    // tokens whose global loads are issued together
 
 int m2m_chain_forward_rows(const m2m_tower* t, const float* x0, long x0_ss, int B, float* out, long out_ss, int training,
                            unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st);
@@ -51,29 +52,39 @@ static __device__ __forceinline__ void tok_stage_weights(const m2m_block& bk, in
 // one wave: statistics of `rows` rows; row r lives at src + (r / N) * ss + (r % N) * D  (r counted from sample s_first)
 static __device__ __forceinline__ void tok_row_stats(const float* __restrict__ src, long ss, int s_first, int rows, int N, int D,
                                                      float* stats, int lane) {
-    for (int r = 0; r < rows; ++r) {
-        const float* row = src + (long)(s_first + r / N) * ss + (long)(r % N) * D;
-        float v[4], s = 0.f;
+    // four rows per batch: all their loads are requested before the first reduction (one memory round trip per batch, not
+    // per row -- this single wave has nothing else to hide it behind)
+    constexpr int RB = 4;
+    for (int r0 = 0; r0 < rows; r0 += RB) {
+        float v[RB][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = lane + 64 * i;
-            v[i] = c < D ? row[c] : 0.f;
-            s += v[i];
-        }
-        s = wave_sum_xor(s, 64);
-        const float mean = s / (float)D;
-        float s2 = 0.f;
+        for (int j = 0; j < RB; ++j) {
+            const int r = min(r0 + j, rows - 1);
+            const float* row = src + (long)(s_first + r / N) * ss + (long)(r % N) * D;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = lane + 64 * i;
-            const float dlt = c < D ? v[i] - mean : 0.f;
-            s2 = __builtin_fmaf(dlt, dlt, s2);
+            for (int i = 0; i < 4; ++i) {
+                const int c = lane + 64 * i;
+                v[j][i] = c < D ? row[c] : 0.f;
+            }
         }
-        s2 = wave_sum_xor(s2, 64);
-        const float vv = s2 / (float)D + 1e-5f;
-        float rstd = __builtin_amdgcn_rsqf(vv);
-        rstd = rstd * (1.5f - 0.5f * vv * rstd * rstd);
-        if (lane == 0) { stats[2 * r] = mean; stats[2 * r + 1] = rstd; }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            float s = (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+            s = wave_sum_xor(s, 64);
+            const float mean = s / (float)D;
+            float s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = lane + 64 * i;
+                const float dlt = c < D ? v[j][i] - mean : 0.f;
+                s2 = __builtin_fmaf(dlt, dlt, s2);
+            }
+            s2 = wave_sum_xor(s2, 64);
+            const float vv = s2 / (float)D + 1e-5f;
+            float rstd = __builtin_amdgcn_rsqf(vv);
+            rstd = rstd * (1.5f - 0.5f * vv * rstd * rstd);
+            if (lane == 0 && r0 + j < rows) { stats[2 * (r0 + j)] = mean; stats[2 * (r0 + j) + 1] = rstd; }
+        }
     }
 }
 
@@ -118,16 +129,27 @@ __global__ __launch_bounds__(TW_COLS) void token_fwd_kernel(const m2m_tower tw, 
     float h[TM];
 #pragma unroll
     for (int t = 0; t < TM; ++t) h[t] = b1s[t];
-    for (int n = 0; n < N; ++n) {
-        const float u = (col[(long)n * D] - st[2 * n]) * st[2 * n + 1] * gam + bet;
-        const float4* wr = reinterpret_cast<const float4*>(w1s + n * TM);
+    // The column's N values are TW_UB rows apart in memory: requested TW_UB at a time, so that the wave (the only one of its
+    // workgroup) waits for one memory round trip per TW_UB tokens instead of one per token.
+    for (int n0 = 0; n0 < N; n0 += TW_UB) {
+        float xv[TW_UB];
 #pragma unroll
-        for (int t4 = 0; t4 < TM / 4; ++t4) {
-            const float4 w = wr[t4];
-            h[4 * t4 + 0] = __builtin_fmaf(w.x, u, h[4 * t4 + 0]);
-            h[4 * t4 + 1] = __builtin_fmaf(w.y, u, h[4 * t4 + 1]);
-            h[4 * t4 + 2] = __builtin_fmaf(w.z, u, h[4 * t4 + 2]);
-            h[4 * t4 + 3] = __builtin_fmaf(w.w, u, h[4 * t4 + 3]);
+        for (int j = 0; j < TW_UB; ++j) xv[j] = col[(long)min(n0 + j, N - 1) * D];
+#pragma unroll
+        for (int j = 0; j < TW_UB; ++j) {
+            const int n = n0 + j;
+            if (n < N) {
+                const float u = (xv[j] - st[2 * n]) * st[2 * n + 1] * gam + bet;
+                const float4* wr = reinterpret_cast<const float4*>(w1s + n * TM);
+#pragma unroll
+                for (int t4 = 0; t4 < TM / 4; ++t4) {
+                    const float4 w = wr[t4];
+                    h[4 * t4 + 0] = __builtin_fmaf(w.x, u, h[4 * t4 + 0]);
+                    h[4 * t4 + 1] = __builtin_fmaf(w.y, u, h[4 * t4 + 1]);
+                    h[4 * t4 + 2] = __builtin_fmaf(w.z, u, h[4 * t4 + 2]);
+                    h[4 * t4 + 3] = __builtin_fmaf(w.w, u, h[4 * t4 + 3]);
+                }
+            }
         }
     }
 #pragma unroll
@@ -139,22 +161,30 @@ __global__ __launch_bounds__(TW_COLS) void token_fwd_kernel(const m2m_tower tw, 
             h[t] = 0.f;
         }
     }
-    for (int n = 0; n < N; ++n) {
-        const float4* wr = reinterpret_cast<const float4*>(w2s + n * TM);
-        float o0 = b2s[n], o1 = 0.f, o2 = 0.f, o3 = 0.f;
+    for (int n0 = 0; n0 < N; n0 += TW_UB) {
+        float xv[TW_UB];
 #pragma unroll
-        for (int t4 = 0; t4 < TM / 4; ++t4) {
-            const float4 w = wr[t4];
-            o0 = __builtin_fmaf(w.x, h[4 * t4 + 0], o0);
-            o1 = __builtin_fmaf(w.y, h[4 * t4 + 1], o1);
-            o2 = __builtin_fmaf(w.z, h[4 * t4 + 2], o2);
-            o3 = __builtin_fmaf(w.w, h[4 * t4 + 3], o3);
+        for (int j = 0; j < TW_UB; ++j) xv[j] = col[(long)min(n0 + j, N - 1) * D];
+#pragma unroll
+        for (int j = 0; j < TW_UB; ++j) {
+            const int n = n0 + j;
+            if (n < N) {
+                const float4* wr = reinterpret_cast<const float4*>(w2s + n * TM);
+                float o0 = b2s[n], o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#pragma unroll
+                for (int t4 = 0; t4 < TM / 4; ++t4) {
+                    const float4 w = wr[t4];
+                    o0 = __builtin_fmaf(w.x, h[4 * t4 + 0], o0);
+                    o1 = __builtin_fmaf(w.y, h[4 * t4 + 1], o1);
+                    o2 = __builtin_fmaf(w.z, h[4 * t4 + 2], o2);
+                    o3 = __builtin_fmaf(w.w, h[4 * t4 + 3], o3);
+                }
+                const float o = (o0 + o1) + (o2 + o3);
+                const long off = ((long)s * N + n) * D + d;
+                if (save_x_in) save_x_in[off] = xv[j];
+                x_mid[off] = xv[j] + (drop_row_keep<DM>(dr_to, bd, N, n) ? o * dr_to.scale : 0.f);
+            }
         }
-        const float o = (o0 + o1) + (o2 + o3);
-        const float xv = col[(long)n * D];
-        const long off = ((long)s * N + n) * D + d;
-        if (save_x_in) save_x_in[off] = xv;
-        x_mid[off] = xv + (drop_row_keep<DM>(dr_to, bd, N, n) ? o * dr_to.scale : 0.f);
     }
 }
 
@@ -204,17 +234,30 @@ __global__ __launch_bounds__(TW_COLS) void token_bwd_cols_kernel(const m2m_tower
 #pragma unroll
     for (int t = 0; t < TM; ++t) { h[t] = b1s[t]; dh[t] = 0.f; }
     // LN1 output and masked upstream gradient of token n of this lane's column (zero for padding lanes)
-    auto u_dv = [&](int n, float& u, float& dv) {
-        u = 0.f; dv = 0.f;
-        if (pv) {
-            u = (bk.x_in[col0 + (long)n * D] - st[2 * n]) * st[2 * n + 1] * gam + bet;
-            const float gv = g_mid[col0 + (long)n * D] * dr_to.scale;
-            dv = drop_row_keep<DM>(dr_to, bd, N, n) ? gv : 0.f;
+    // TW_UB tokens at a time: all their loads are requested before the first is used (see the forward kernel)
+    auto u_dv8 = [&](int n0, float (&u)[TW_UB], float (&dv)[TW_UB]) {
+        float xv[TW_UB], gv[TW_UB];
+#pragma unroll
+        for (int j = 0; j < TW_UB; ++j) {
+            const long o = col0 + (long)min(n0 + j, N - 1) * D;
+            xv[j] = pv ? bk.x_in[o] : 0.f;
+            gv[j] = pv ? g_mid[o] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < TW_UB; ++j) {
+            const int n = min(n0 + j, N - 1);
+            u[j] = pv ? (xv[j] - st[2 * n]) * st[2 * n + 1] * gam + bet : 0.f;
+            dv[j] = (pv && drop_row_keep<DM>(dr_to, bd, N, n)) ? gv[j] * dr_to.scale : 0.f;
         }
     };
-    for (int n = 0; n < N; ++n) {
-        float u, dv;
-        u_dv(n, u, dv);
+    for (int n0 = 0; n0 < N; n0 += TW_UB) {
+      float u8[TW_UB], dv8[TW_UB];
+      u_dv8(n0, u8, dv8);
+#pragma unroll
+      for (int j = 0; j < TW_UB; ++j) {
+        const int n = n0 + j;
+        if (n >= N) break;
+        const float u = u8[j], dv = dv8[j];
         const float4* wr1 = reinterpret_cast<const float4*>(w1s + n * TM);
         const float4* wr2 = reinterpret_cast<const float4*>(w2s + n * TM);
 #pragma unroll
@@ -229,6 +272,7 @@ __global__ __launch_bounds__(TW_COLS) void token_bwd_cols_kernel(const m2m_tower
             dh[4 * t4 + 2] = __builtin_fmaf(c.z, dv, dh[4 * t4 + 2]);
             dh[4 * t4 + 3] = __builtin_fmaf(c.w, dv, dh[4 * t4 + 3]);
         }
+      }
     }
     // hidden activation and gradient wrt the pre-activation; dh[] is reused for the latter
 #pragma unroll
@@ -275,11 +319,17 @@ __global__ __launch_bounds__(TW_COLS) void token_bwd_cols_kernel(const m2m_tower
     }
     for (int n0 = 0; n0 < N; n0 += TW_NC) {
         const int nc = min(TW_NC, N - n0);
-        for (int j = 0; j < nc; ++j) {
-            float u, dv;
-            u_dv(n0 + j, u, dv);
-            us[j * TW_LDW + lane] = u;
-            dvs[j * TW_LDW + lane] = dv;
+        static_assert(TW_NC % TW_UB == 0, "a chunk is a whole number of load batches");
+        for (int j0 = 0; j0 < nc; j0 += TW_UB) {
+            float u8[TW_UB], dv8[TW_UB];
+            u_dv8(n0 + j0, u8, dv8);
+#pragma unroll
+            for (int j = 0; j < TW_UB; ++j) {
+                if (j0 + j < nc) {
+                    us[(j0 + j) * TW_LDW + lane] = u8[j];
+                    dvs[(j0 + j) * TW_LDW + lane] = dv8[j];
+                }
+            }
         }
         __syncthreads();
         for (int p = lane; p < nc * T; p += TW_COLS) {
