@@ -18,6 +18,8 @@
 #define TW_LDW (TW_COLS + 1)       // padded row stride of the per-column LDS tiles
 #define TW_NC 16                   // tokens per chunk of the parameter-gradient reduction (backward)
 #define TW_UB 8                    // tokens whose global loads are issued together
+#define TW_WAVES 4                 // waves per workgroup: all own the same 64 columns, each a quarter of the tokens
+#define TW_THREADS (TW_WAVES * 64)
 
 int m2m_chain_forward_rows(const m2m_tower* t, const float* x0, long x0_ss, int B, float* out, long out_ss, int training,
                            unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st);
@@ -40,26 +42,27 @@ static __host__ __device__ __forceinline__ TokGeom tok_geom(int D) {
 static __host__ __device__ __forceinline__ size_t tok_lds_floats(int N, int spw, int TM) { return (size_t)2 * N * TM + TM + N + 2 * spw * N; }
 
 static __device__ __forceinline__ void tok_stage_weights(const m2m_block& bk, int N, int T, int TM, float* w1s, float* w2s, float* b1s,
-                                                         float* b2s, int lane) {
-    for (int i = lane; i < N * TM; i += TW_COLS) {
+                                                         float* b2s, int lane, int nthreads = TW_COLS) {
+    for (int i = lane; i < N * TM; i += nthreads) {
         const int n = i / TM, t = i % TM;
         w1s[i] = t < T ? bk.tok_w1[t * N + n] : 0.f;
         w2s[i] = t < T ? bk.tok_w2[n * T + t] : 0.f;
     }
     if (lane < TM) b1s[lane] = lane < T ? bk.tok_b1[lane] : 0.f;
-    for (int n = lane; n < N; n += TW_COLS) b2s[n] = bk.tok_b2[n];
+    for (int n = lane; n < N; n += nthreads) b2s[n] = bk.tok_b2[n];
 }
 // one wave: statistics of `rows` rows; row r lives at src + (r / N) * ss + (r % N) * D  (r counted from sample s_first)
+// (rows r_begin, r_begin + r_step, ...: the waves of a workgroup share the rows)
 static __device__ __forceinline__ void tok_row_stats(const float* __restrict__ src, long ss, int s_first, int rows, int N, int D,
-                                                     float* stats, int lane) {
+                                                     float* stats, int lane, int r_begin = 0, int r_step = 1) {
     // four rows per batch: all their loads are requested before the first reduction (one memory round trip per batch, not
     // per row -- this single wave has nothing else to hide it behind)
     constexpr int RB = 4;
-    for (int r0 = 0; r0 < rows; r0 += RB) {
+    for (int r0 = r_begin; r0 < rows; r0 += RB * r_step) {
         float v[RB][4];
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
-            const int r = min(r0 + j, rows - 1);
+            const int r = min(r0 + j * r_step, rows - 1);
             const float* row = src + (long)(s_first + r / N) * ss + (long)(r % N) * D;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -83,17 +86,17 @@ static __device__ __forceinline__ void tok_row_stats(const float* __restrict__ s
             const float vv = s2 / (float)D + 1e-5f;
             float rstd = __builtin_amdgcn_rsqf(vv);
             rstd = rstd * (1.5f - 0.5f * vv * rstd * rstd);
-            if (lane == 0 && r0 + j < rows) { stats[2 * (r0 + j)] = mean; stats[2 * (r0 + j) + 1] = rstd; }
+            if (lane == 0 && r0 + j * r_step < rows) { stats[2 * (r0 + j * r_step)] = mean; stats[2 * (r0 + j * r_step) + 1] = rstd; }
         }
     }
 }
 
 // ---- forward: x_mid = x + Dropout(W2 Dropout(GELU(W1 LN1(x)^T + b1)) + b2)^T  (modules/mixer.py:30-35, :43) ------
 template <int P, int DM, int TM>
-__global__ __launch_bounds__(TW_COLS) void token_fwd_kernel(const m2m_tower tw, int b, const float* __restrict__ src, long src_ss,
-                                                            int B, float* __restrict__ x_mid, float* __restrict__ save_x_in,
-                                                            int training, unsigned int seed, unsigned int step_host,
-                                                            const unsigned int* __restrict__ step_dev) {
+__global__ __launch_bounds__(TW_THREADS) void token_fwd_kernel(const m2m_tower tw, int b, const float* __restrict__ src, long src_ss,
+                                                               int B, float* __restrict__ x_mid, float* __restrict__ save_x_in,
+                                                               int training, unsigned int seed, unsigned int step_host,
+                                                               const unsigned int* __restrict__ step_dev) {
     extern __shared__ __attribute__((aligned(16))) float smf[];
     const int N = tw.N, T = tw.T, D = tw.D;
     const TokGeom tg = tok_geom(D);
@@ -102,8 +105,10 @@ __global__ __launch_bounds__(TW_COLS) void token_fwd_kernel(const m2m_tower tw, 
     float* b1s = w2s + N * TM;
     float* b2s = b1s + TM;
     float* stats = b2s + N;
+    float* hp = smf + ((tok_lds_floats(N, tg.spw, TM) + 3) & ~(size_t)3);   // [TW_WAVES][TM][64] partial hidden pre-activations
+    float* ha = hp + TW_WAVES * TM * TW_COLS;                               // [TM][64]           hidden activations
 
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const m2m_block& bk = tw.blk[b];
     const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
     const unsigned int site = tw.site_base + 4u * b;
@@ -113,32 +118,35 @@ __global__ __launch_bounds__(TW_COLS) void token_fwd_kernel(const m2m_tower tw, 
     const int s_first = (blockIdx.x / tg.chunks) * tg.spw;
     const int chunk = blockIdx.x % tg.chunks;
     const int ns = min(tg.spw, B - s_first);
-    tok_stage_weights(bk, N, T, TM, w1s, w2s, b1s, b2s, lane);
-    tok_row_stats(src, src_ss, s_first, ns * N, N, D, stats, lane);
+    tok_stage_weights(bk, N, T, TM, w1s, w2s, b1s, b2s, tid, TW_THREADS);
+    tok_row_stats(src, src_ss, s_first, ns * N, N, D, stats, lane, wave, TW_WAVES);
     __syncthreads();
 
     const int sl = D >= TW_COLS ? 0 : lane / D;
     const int d = D >= TW_COLS ? chunk * TW_COLS + lane : lane % D;
-    if (sl >= ns) return;
-    const int s = s_first + sl;
+    const bool pv = sl < ns;                                 // (no early exit: every thread reaches the barriers below)
+    const int s = s_first + (pv ? sl : 0);
     const unsigned int bd = (unsigned int)s * D + d;
     const float gam = bk.ln1_w[d], bet = bk.ln1_b[d];
     const float* col = src + (long)s * src_ss + d;
-    const float* st = stats + 2 * sl * N;
+    const float* st = stats + 2 * (pv ? sl : 0) * N;
+    // this wave's tokens: a quarter of the N tokens of the column (the four waves work on the same 64 columns)
+    const int NQ = (N + TW_WAVES - 1) / TW_WAVES;
+    const int nb = wave * NQ, ne = min(N, nb + NQ);
 
     float h[TM];
 #pragma unroll
-    for (int t = 0; t < TM; ++t) h[t] = b1s[t];
-    // The column's N values are TW_UB rows apart in memory: requested TW_UB at a time, so that the wave (the only one of its
-    // workgroup) waits for one memory round trip per TW_UB tokens instead of one per token.
-    for (int n0 = 0; n0 < N; n0 += TW_UB) {
+    for (int t = 0; t < TM; ++t) h[t] = wave == 0 ? b1s[t] : 0.f;
+    // The column's values are whole rows apart in memory: requested TW_UB at a time, so that the wave waits for one memory
+    // round trip per TW_UB tokens instead of one per token.
+    for (int n0 = nb; n0 < ne; n0 += TW_UB) {
         float xv[TW_UB];
 #pragma unroll
-        for (int j = 0; j < TW_UB; ++j) xv[j] = col[(long)min(n0 + j, N - 1) * D];
+        for (int j = 0; j < TW_UB; ++j) xv[j] = pv ? col[(long)min(n0 + j, ne - 1) * D] : 0.f;
 #pragma unroll
         for (int j = 0; j < TW_UB; ++j) {
             const int n = n0 + j;
-            if (n < N) {
+            if (n < ne) {
                 const float u = (xv[j] - st[2 * n]) * st[2 * n + 1] * gam + bet;
                 const float4* wr = reinterpret_cast<const float4*>(w1s + n * TM);
 #pragma unroll
@@ -152,23 +160,34 @@ __global__ __launch_bounds__(TW_COLS) void token_fwd_kernel(const m2m_tower tw, 
             }
         }
     }
+    // the waves' partial sums meet in LDS; each wave finishes a quarter of the hidden units (GELU, dropout) for all
 #pragma unroll
-    for (int t = 0; t < TM; ++t) {
+    for (int t = 0; t < TM; ++t) hp[(wave * TM + t) * TW_COLS + lane] = h[t];
+    __syncthreads();
+#pragma unroll
+    for (int tq = 0; tq < TM / TW_WAVES; ++tq) {
+        const int t = wave * (TM / TW_WAVES) + tq;
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < TW_WAVES; ++w) a += hp[(w * TM + t) * TW_COLS + lane];
+        float v = 0.f;
         if (t < T) {
-            const float v = gelu_f(h[t]) * dr_th.scale;      // a lane has token_dim (<= 32) of these: cheaper than filling a table
-            h[t] = drop_row_keep<DM>(dr_th, bd, T, t) ? v : 0.f;
-        } else {
-            h[t] = 0.f;
+            v = gelu_f(a) * dr_th.scale;
+            v = drop_row_keep<DM>(dr_th, bd, T, t) ? v : 0.f;
         }
+        ha[t * TW_COLS + lane] = v;
     }
-    for (int n0 = 0; n0 < N; n0 += TW_UB) {
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TM; ++t) h[t] = ha[t * TW_COLS + lane];
+    for (int n0 = nb; n0 < ne; n0 += TW_UB) {
         float xv[TW_UB];
 #pragma unroll
-        for (int j = 0; j < TW_UB; ++j) xv[j] = col[(long)min(n0 + j, N - 1) * D];
+        for (int j = 0; j < TW_UB; ++j) xv[j] = pv ? col[(long)min(n0 + j, ne - 1) * D] : 0.f;
 #pragma unroll
         for (int j = 0; j < TW_UB; ++j) {
             const int n = n0 + j;
-            if (n < N) {
+            if (n < ne && pv) {
                 const float4* wr = reinterpret_cast<const float4*>(w2s + n * TM);
                 float o0 = b2s[n], o1 = 0.f, o2 = 0.f, o3 = 0.f;
 #pragma unroll
@@ -449,8 +468,9 @@ static int launch_token_fwd(const m2m_tower* t, int b, const float* src, long sr
                             int training, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
     const TokGeom g = tok_geom(t->D);
     const int grid = ((B + g.spw - 1) / g.spw) * g.chunks;
-    const size_t lds = ((tok_lds_floats(t->N, g.spw, TM) + 3) & ~(size_t)3) * sizeof(float);
-    hipLaunchKernelGGL((token_fwd_kernel<P, DM, TM>), dim3(grid), dim3(TW_COLS), lds, st, *t, b, src, src_ss, B, x_mid, save_x_in,
+    const size_t lds = ((tok_lds_floats(t->N, g.spw, TM) + 3) & ~(size_t)3) * sizeof(float) +
+                       (size_t)(TW_WAVES + 1) * TM * TW_COLS * sizeof(float);
+    hipLaunchKernelGGL((token_fwd_kernel<P, DM, TM>), dim3(grid), dim3(TW_THREADS), lds, st, *t, b, src, src_ss, B, x_mid, save_x_in,
                        training, seed, step, step_dev);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
