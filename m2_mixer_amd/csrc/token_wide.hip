@@ -210,9 +210,9 @@ __global__ __launch_bounds__(TW_THREADS) void token_fwd_kernel(const m2m_tower t
 // ---- backward, column part: dU (gradient wrt LN1 output) + token-MLP parameter gradients --------------------------
 //   g_mid : gradient wrt x_mid (dense rows);  x_in : saved block input (dense rows);  du_out : receives dU (dense rows)
 template <int P, int DM, int TM>
-__global__ __launch_bounds__(TW_COLS) void token_bwd_cols_kernel(const m2m_tower tw, int b, const float* __restrict__ g_mid, int B,
-                                                                 float* __restrict__ du_out, unsigned int seed,
-                                                                 unsigned int step_host, const unsigned int* __restrict__ step_dev) {
+__global__ __launch_bounds__(TW_THREADS) void token_bwd_cols_kernel(const m2m_tower tw, int b, const float* __restrict__ g_mid, int B,
+                                                                    float* __restrict__ du_out, unsigned int seed,
+                                                                    unsigned int step_host, const unsigned int* __restrict__ step_dev) {
     extern __shared__ __attribute__((aligned(16))) float smf[];
     const int N = tw.N, T = tw.T, D = tw.D;
     const TokGeom tg = tok_geom(D);
@@ -221,12 +221,13 @@ __global__ __launch_bounds__(TW_COLS) void token_bwd_cols_kernel(const m2m_tower
     float* b1s = w2s + N * TM;
     float* b2s = b1s + TM;
     float* stats = b2s + N;
-    float* us = smf + ((tok_lds_floats(N, tg.spw, TM) + 3) & ~(size_t)3);   // [TW_NC][TW_LDW]  LN1 output of each column, one chunk of tokens
-    float* dvs = us + TW_NC * TW_LDW;                           // [TW_NC][TW_LDW]  masked upstream gradient, same chunk
-    float* hs = dvs + TW_NC * TW_LDW;                           // [TM][TW_LDW] hidden activation (after dropout)
-    float* dhs = hs + TM * TW_LDW;                         // [32][TW_LDW] gradient wrt the hidden pre-activation
+    float* hs = smf + ((tok_lds_floats(N, tg.spw, TM) + 3) & ~(size_t)3);   // [TM][TW_LDW] hidden activation (after dropout)
+    float* dhs = hs + TM * TW_LDW;                              // [TM][TW_LDW] gradient wrt the hidden pre-activation
+    float* part = dhs + TM * TW_LDW;                            // per wave: [2][TM][64] partial h | dh, later its
+                                                                //           [2][TW_NC][TW_LDW] chunk of U | dV  (whichever is larger)
+    constexpr int PART_F = 2 * TM * TW_COLS > 2 * TW_NC * TW_LDW ? 2 * TM * TW_COLS : 2 * TW_NC * TW_LDW;
 
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const m2m_block& bk = tw.blk[b];
     const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
     const unsigned int site = tw.site_base + 4u * b;
@@ -236,8 +237,8 @@ __global__ __launch_bounds__(TW_COLS) void token_bwd_cols_kernel(const m2m_tower
     const int s_first = (blockIdx.x / tg.chunks) * tg.spw;
     const int chunk = blockIdx.x % tg.chunks;
     const int ns = min(tg.spw, B - s_first);
-    tok_stage_weights(bk, N, T, TM, w1s, w2s, b1s, b2s, lane);
-    tok_row_stats(bk.x_in, (long)N * D, s_first, ns * N, N, D, stats, lane);
+    tok_stage_weights(bk, N, T, TM, w1s, w2s, b1s, b2s, tid, TW_THREADS);
+    tok_row_stats(bk.x_in, (long)N * D, s_first, ns * N, N, D, stats, lane, wave, TW_WAVES);
     __syncthreads();
 
     const int sl = D >= TW_COLS ? 0 : lane / D;
@@ -248,69 +249,92 @@ __global__ __launch_bounds__(TW_COLS) void token_bwd_cols_kernel(const m2m_tower
     const float gam = bk.ln1_w[d], bet = bk.ln1_b[d];
     const long col0 = (long)s * N * D + d;
     const float* st = stats + 2 * (pv ? sl : 0) * N;
+    // this wave's tokens: a quarter of the N tokens of the column (the four waves work on the same 64 columns)
+    const int NQ = (N + TW_WAVES - 1) / TW_WAVES;
+    const int nb = wave * NQ, ne = min(N, nb + NQ);
 
-    float h[TM], dh[TM];
-#pragma unroll
-    for (int t = 0; t < TM; ++t) { h[t] = b1s[t]; dh[t] = 0.f; }
-    // LN1 output and masked upstream gradient of token n of this lane's column (zero for padding lanes)
-    // TW_UB tokens at a time: all their loads are requested before the first is used (see the forward kernel)
-    auto u_dv8 = [&](int n0, float (&u)[TW_UB], float (&dv)[TW_UB]) {
+    // LN1 output and masked upstream gradient of tokens n0 .. n0 + TW_UB - 1 (clamped to < nmax) of this lane's column:
+    // all their loads are requested before the first is used
+    auto u_dv8 = [&](int n0, int nmax, float (&u)[TW_UB], float (&dv)[TW_UB]) {
         float xv[TW_UB], gv[TW_UB];
 #pragma unroll
         for (int j = 0; j < TW_UB; ++j) {
-            const long o = col0 + (long)min(n0 + j, N - 1) * D;
+            const long o = col0 + (long)min(n0 + j, nmax - 1) * D;
             xv[j] = pv ? bk.x_in[o] : 0.f;
             gv[j] = pv ? g_mid[o] : 0.f;
         }
 #pragma unroll
         for (int j = 0; j < TW_UB; ++j) {
-            const int n = min(n0 + j, N - 1);
+            const int n = min(n0 + j, nmax - 1);
             u[j] = pv ? (xv[j] - st[2 * n]) * st[2 * n + 1] * gam + bet : 0.f;
             dv[j] = (pv && drop_row_keep<DM>(dr_to, bd, N, n)) ? gv[j] * dr_to.scale : 0.f;
         }
     };
-    for (int n0 = 0; n0 < N; n0 += TW_UB) {
-      float u8[TW_UB], dv8[TW_UB];
-      u_dv8(n0, u8, dv8);
+
+    float h[TM], dh[TM];
 #pragma unroll
-      for (int j = 0; j < TW_UB; ++j) {
-        const int n = n0 + j;
-        if (n >= N) break;
-        const float u = u8[j], dv = dv8[j];
-        const float4* wr1 = reinterpret_cast<const float4*>(w1s + n * TM);
-        const float4* wr2 = reinterpret_cast<const float4*>(w2s + n * TM);
+    for (int t = 0; t < TM; ++t) { h[t] = wave == 0 ? b1s[t] : 0.f; dh[t] = 0.f; }
+    for (int n0 = nb; n0 < ne; n0 += TW_UB) {
+        float u8[TW_UB], dv8[TW_UB];
+        u_dv8(n0, ne, u8, dv8);
 #pragma unroll
-        for (int t4 = 0; t4 < TM / 4; ++t4) {
-            const float4 a = wr1[t4], c = wr2[t4];
-            h[4 * t4 + 0] = __builtin_fmaf(a.x, u, h[4 * t4 + 0]);
-            h[4 * t4 + 1] = __builtin_fmaf(a.y, u, h[4 * t4 + 1]);
-            h[4 * t4 + 2] = __builtin_fmaf(a.z, u, h[4 * t4 + 2]);
-            h[4 * t4 + 3] = __builtin_fmaf(a.w, u, h[4 * t4 + 3]);
-            dh[4 * t4 + 0] = __builtin_fmaf(c.x, dv, dh[4 * t4 + 0]);
-            dh[4 * t4 + 1] = __builtin_fmaf(c.y, dv, dh[4 * t4 + 1]);
-            dh[4 * t4 + 2] = __builtin_fmaf(c.z, dv, dh[4 * t4 + 2]);
-            dh[4 * t4 + 3] = __builtin_fmaf(c.w, dv, dh[4 * t4 + 3]);
+        for (int j = 0; j < TW_UB; ++j) {
+            const int n = n0 + j;
+            if (n >= ne) break;
+            const float u = u8[j], dv = dv8[j];
+            const float4* wr1 = reinterpret_cast<const float4*>(w1s + n * TM);
+            const float4* wr2 = reinterpret_cast<const float4*>(w2s + n * TM);
+#pragma unroll
+            for (int t4 = 0; t4 < TM / 4; ++t4) {
+                const float4 a = wr1[t4], c = wr2[t4];
+                h[4 * t4 + 0] = __builtin_fmaf(a.x, u, h[4 * t4 + 0]);
+                h[4 * t4 + 1] = __builtin_fmaf(a.y, u, h[4 * t4 + 1]);
+                h[4 * t4 + 2] = __builtin_fmaf(a.z, u, h[4 * t4 + 2]);
+                h[4 * t4 + 3] = __builtin_fmaf(a.w, u, h[4 * t4 + 3]);
+                dh[4 * t4 + 0] = __builtin_fmaf(c.x, dv, dh[4 * t4 + 0]);
+                dh[4 * t4 + 1] = __builtin_fmaf(c.y, dv, dh[4 * t4 + 1]);
+                dh[4 * t4 + 2] = __builtin_fmaf(c.z, dv, dh[4 * t4 + 2]);
+                dh[4 * t4 + 3] = __builtin_fmaf(c.w, dv, dh[4 * t4 + 3]);
+            }
         }
-      }
     }
-    // hidden activation and gradient wrt the pre-activation; dh[] is reused for the latter
+    // the waves' partial sums meet in LDS; each wave finishes a quarter of the hidden units: activation and gradient wrt the
+    // pre-activation -> hs / dhs tiles (kept for the parameter gradients); then every wave reads all of dHpre back
+    {
+        float* mine = part + wave * PART_F;
 #pragma unroll
-    for (int t = 0; t < TM; ++t) {
+        for (int t = 0; t < TM; ++t) {
+            mine[t * TW_COLS + lane] = h[t];
+            mine[(TM + t) * TW_COLS + lane] = dh[t];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tq = 0; tq < TM / TW_WAVES; ++tq) {
+        const int t = wave * (TM / TW_WAVES) + tq;
+        float hsum = 0.f, dsum = 0.f;
+#pragma unroll
+        for (int w = 0; w < TW_WAVES; ++w) {
+            hsum += part[w * PART_F + t * TW_COLS + lane];
+            dsum += part[w * PART_F + (TM + t) * TW_COLS + lane];
+        }
         float hact = 0.f, dhp = 0.f;
         if (t < T) {
             float gl, dgl;
-            gelu_grad_f(h[t], gl, dgl);
+            gelu_grad_f(hsum, gl, dgl);
             const bool keep = pv && drop_row_keep<DM>(dr_th, bd, T, t);
             hact = keep ? gl * dr_th.scale : 0.f;
-            dhp = keep ? dh[t] * dr_th.scale * dgl : 0.f;
+            dhp = keep ? dsum * dr_th.scale * dgl : 0.f;
         }
-        dh[t] = dhp;
         hs[t * TW_LDW + lane] = hact;
         dhs[t * TW_LDW + lane] = dhp;
     }
-    // dU[n] = sum_t W1[t][n] dHpre[t]
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TM; ++t) dh[t] = dhs[t * TW_LDW + lane];
+    // dU[n] = sum_t W1[t][n] dHpre[t], this wave's tokens
     if (pv) {
-        for (int n = 0; n < N; ++n) {
+        for (int n = nb; n < ne; ++n) {
             const float4* wr = reinterpret_cast<const float4*>(w1s + n * TM);
             float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
 #pragma unroll
@@ -324,24 +348,26 @@ __global__ __launch_bounds__(TW_COLS) void token_bwd_cols_kernel(const m2m_tower
             du_out[col0 + (long)n * D] = (o0 + o1) + (o2 + o3);
         }
     }
-    __syncthreads();
     // parameter gradients: sums over the workgroup's 64 columns (fixed order), then one float atomic per value per
-    // workgroup.  (Measured and dropped: the two column sums as fp32 16x16x4 MFMAs fed from the LDS tiles -- 30 %
-    // slower at MIMIC's batch 8192, where 8192 workgroups then reach their atomics on the same ~800 addresses together.)  U and dV go through LDS one chunk of TW_NC tokens at a time (recomputed from x_in / g_mid, which are
-    // L2-resident by now): a full [N][64] tile of each was the bulk of the kernel's LDS and held MM-IMDb's fusion tower
-    // (N = 80) to two single-wave workgroups per CU.
-    if (lane < T) {
+    // workgroup.  U and dV go through LDS one chunk of TW_NC tokens at a time (recomputed from x_in / g_mid, which are
+    // L2-resident by now), chunk c by wave c % TW_WAVES in its own part of LDS -- the partial sums above are dead: every wave
+    // passed the second barrier only after all had read them -- so the loop needs no further workgroup barrier.
+    // (Measured and dropped: the two column sums as fp32 16x16x4 MFMAs fed from the LDS tiles -- 30 % slower at MIMIC's batch
+    // 8192, where 8192 workgroups then reach their atomics on the same ~800 addresses together.)
+    if (wave == 0 && lane < T) {
         const float* gr = dhs + lane * TW_LDW;
         float a = 0.f;
         for (int k = 0; k < TW_COLS; ++k) a += gr[k];
         atomicAdd(bk.g_tok_b1 + lane, a);
     }
-    for (int n0 = 0; n0 < N; n0 += TW_NC) {
+    float* us = part + wave * PART_F;                           // [TW_NC][TW_LDW]  LN1 output of each column, one chunk of tokens
+    float* dvs = us + TW_NC * TW_LDW;                           // [TW_NC][TW_LDW]  masked upstream gradient, same chunk
+    static_assert(TW_NC % TW_UB == 0, "a chunk is a whole number of load batches");
+    for (int n0 = wave * TW_NC; n0 < N; n0 += TW_WAVES * TW_NC) {
         const int nc = min(TW_NC, N - n0);
-        static_assert(TW_NC % TW_UB == 0, "a chunk is a whole number of load batches");
         for (int j0 = 0; j0 < nc; j0 += TW_UB) {
             float u8[TW_UB], dv8[TW_UB];
-            u_dv8(n0 + j0, u8, dv8);
+            u_dv8(n0 + j0, N, u8, dv8);
 #pragma unroll
             for (int j = 0; j < TW_UB; ++j) {
                 if (j0 + j < nc) {
@@ -350,7 +376,8 @@ __global__ __launch_bounds__(TW_COLS) void token_bwd_cols_kernel(const m2m_tower
                 }
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): this wave's LDS writes are done (wave-private tile)
+        __builtin_amdgcn_wave_barrier();
         for (int p = lane; p < nc * T; p += TW_COLS) {
             const int j = p / T, t = p % T, n = n0 + j;
             const float* ur = us + j * TW_LDW;
@@ -372,7 +399,8 @@ __global__ __launch_bounds__(TW_COLS) void token_bwd_cols_kernel(const m2m_tower
             for (int k = 0; k < TW_COLS; ++k) a += vr[k];
             atomicAdd(bk.g_tok_b2 + n0 + lane, a);
         }
-        __syncthreads();
+        __builtin_amdgcn_s_waitcnt(0xc07f);                     // reads done before the next chunk overwrites the tile
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -480,15 +508,16 @@ static int launch_token_bwd(const m2m_tower* t, int b, const float* g_mid, int B
                             const unsigned int* step_dev, hipStream_t st) {
     const TokGeom g = tok_geom(t->D);
     const int grid = ((B + g.spw - 1) / g.spw) * g.chunks;
+    const size_t part_f = 2 * TM * TW_COLS > 2 * TW_NC * TW_LDW ? 2 * TM * TW_COLS : 2 * TW_NC * TW_LDW;
     const size_t lds = ((tok_lds_floats(t->N, g.spw, TM) + 3) & ~(size_t)3) * sizeof(float) +
-                       (size_t)(2 * TW_NC + 2 * TM) * TW_LDW * sizeof(float);
+                       ((size_t)2 * TM * TW_LDW + TW_WAVES * part_f) * sizeof(float);
     auto kern = token_bwd_cols_kernel<P, DM, TM>;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
         M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(TW_COLS), lds, st, *t, b, g_mid, B, du, seed, step, step_dev);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(TW_THREADS), lds, st, *t, b, g_mid, B, du, seed, step, step_dev);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
 }
