@@ -476,8 +476,16 @@ __global__ void token_mean_kernel(const float* __restrict__ out, long out_ss, in
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)B * D) return;
     const long s = i / D, d = i % D;
+    const float* col = out + s * out_ss + d;
     float a = 0.f;
-    for (int n = 0; n < N; ++n) a += out[s * out_ss + (long)n * D + d];
+    for (int n0 = 0; n0 < N; n0 += TW_UB) {                 // TW_UB loads in flight per round trip (same summation order)
+        float v[TW_UB];
+#pragma unroll
+        for (int j = 0; j < TW_UB; ++j) v[j] = col[(long)min(n0 + j, N - 1) * D];
+#pragma unroll
+        for (int j = 0; j < TW_UB; ++j)
+            if (n0 + j < N) a += v[j];
+    }
     pooled[i] = a * (1.0f / (float)N);
 }
 
