@@ -411,23 +411,24 @@ __global__ __launch_bounds__(TW_THREADS) void token_bwd_cols_kernel(const m2m_to
 __global__ __launch_bounds__(256) void ln1_bwd_rows_kernel(const float* __restrict__ x_in, const float* __restrict__ g_mid,
                                                            const float* du, const float* __restrict__ gamma,
                                                            long rows, int N, int D, float* dst, long dst_ss,
-                                                           float* __restrict__ g_w, float* __restrict__ g_b) {
+                                                           float* __restrict__ g_w, float* __restrict__ g_b, int rows_per_wg) {
     __shared__ float acc_w[4][256], acc_b[4][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float gw[4] = {0.f, 0.f, 0.f, 0.f}, gb[4] = {0.f, 0.f, 0.f, 0.f}, gm[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) gm[i] = (lane + 64 * i) < D ? gamma[lane + 64 * i] : 0.f;
-    const long r0 = (long)blockIdx.x * LN_ROWS;
-    for (int rr = wave; rr < LN_ROWS; rr += 4) {
+    const long r0 = (long)blockIdx.x * rows_per_wg;
+    for (int rr = wave; rr < rows_per_wg; rr += 4) {
         const long r = r0 + rr;
         if (r >= rows) break;
         const float* xr = x_in + r * D;
-        float v[4], u[4], s = 0.f;
+        float v[4], u[4], gmid[4], s = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i) {                        // all three streams of the row requested together
             const int c = lane + 64 * i;
             v[i] = c < D ? xr[c] : 0.f;
             u[i] = c < D ? du[r * D + c] : 0.f;
+            gmid[i] = c < D ? g_mid[r * D + c] : 0.f;
             s += v[i];
         }
         s = wave_sum_xor(s, 64);
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(256) void ln1_bwd_rows_kernel(const float* __restri
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = lane + 64 * i;
-            if (c < D) orow[c] = g_mid[r * D + c] + rstd * (gg[i] - gsum - v[i] * gxsum);
+            if (c < D) orow[c] = gmid[i] + rstd * (gg[i] - gsum - v[i] * gxsum);
         }
     }
 #pragma unroll
@@ -610,8 +611,10 @@ int m2m_backward_wide(const m2m_tower* t, int B, const float* d_out, long d_out_
         // gradient wrt the block input -> ws_a in place (row-local), or the caller's buffer for the first block
         float* dst = b > 0 ? t->ws_a : d_x0;
         const long dst_ss = b > 0 ? dense : d_x0_ss;
-        hipLaunchKernelGGL(ln1_bwd_rows_kernel, dim3((unsigned)((rows + LN_ROWS - 1) / LN_ROWS)), dim3(256), 0, st, bk.x_in, t->ws_b,
-                           t->ws_a, bk.ln1_w, rows, t->N, t->D, dst, dst_ss, bk.g_ln1_w, bk.g_ln1_b);
+        // rows per workgroup: 32 (8 per wave) when there are plenty, 8 at small batch so that the chip is not left to 80 workgroups
+        const int rpw = rows >= 16384 ? LN_ROWS : 8;
+        hipLaunchKernelGGL(ln1_bwd_rows_kernel, dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(256), 0, st, bk.x_in, t->ws_b,
+                           t->ws_a, bk.ln1_w, rows, t->N, t->D, dst, dst_ss, bk.g_ln1_w, bk.g_ln1_b, rpw);
         M2M_CHECK_HIP(hipGetLastError());
         up = t->ws_a;
         up_ss = dense;
