@@ -212,7 +212,7 @@ __global__ __launch_bounds__(TW_THREADS) void token_fwd_kernel(const m2m_tower t
 template <int P, int DM, int TM>
 __global__ __launch_bounds__(TW_THREADS) void token_bwd_cols_kernel(const m2m_tower tw, int b, const float* __restrict__ g_mid, int B,
                                                                     float* __restrict__ du_out, unsigned int seed,
-                                                                    unsigned int step_host, const unsigned int* __restrict__ step_dev) {
+                                                                    unsigned int step_host, const unsigned int* __restrict__ step_dev, int iters) {
     extern __shared__ __attribute__((aligned(16))) float smf[];
     const int N = tw.N, T = tw.T, D = tw.D;
     const TokGeom tg = tok_geom(D);
@@ -226,6 +226,13 @@ __global__ __launch_bounds__(TW_THREADS) void token_bwd_cols_kernel(const m2m_to
     float* part = dhs + TM * TW_LDW;                            // per wave: [2][TM][64] partial h | dh, later its
                                                                 //           [2][TW_NC][TW_LDW] chunk of U | dV  (whichever is larger)
     constexpr int PART_F = 2 * TM * TW_COLS > 2 * TW_NC * TW_LDW ? 2 * TM * TW_COLS : 2 * TW_NC * TW_LDW;
+    // parameter-gradient accumulators over the `iters` column blocks this workgroup walks: every value has one owner (a lane
+    // of a wave), so they are plain LDS read-modify-writes; the float atomics -- the same few hundred addresses for every
+    // workgroup of the launch -- happen once per workgroup at the end
+    float* gw1s = part + TW_WAVES * PART_F;                      // [T][N]
+    float* gw2s = gw1s + N * TM;                                // [N][T]
+    float* gb1s = gw2s + N * TM;                                // [TM]
+    float* gb2s = gb1s + TM;                                    // [N]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const m2m_block& bk = tw.blk[b];
@@ -234,10 +241,15 @@ __global__ __launch_bounds__(TW_THREADS) void token_bwd_cols_kernel(const m2m_to
     const Drop dr_th = make_drop(true, tw.p_drop, seed, step, site + 0);
     const Drop dr_to = make_drop(true, tw.p_drop, seed, step, site + 1);
 
-    const int s_first = (blockIdx.x / tg.chunks) * tg.spw;
-    const int chunk = blockIdx.x % tg.chunks;
-    const int ns = min(tg.spw, B - s_first);
     tok_stage_weights(bk, N, T, TM, w1s, w2s, b1s, b2s, tid, TW_THREADS);
+    for (int i = tid; i < 2 * N * TM + TM + N; i += TW_THREADS) gw1s[i] = 0.f;
+    const int nblk = ((B + tg.spw - 1) / tg.spw) * tg.chunks;   // column blocks of the launch
+    for (int it = 0; it < iters; ++it) {
+    const int blk = blockIdx.x * iters + it;
+    if (blk >= nblk) break;                                      // (uniform)
+    const int s_first = (blk / tg.chunks) * tg.spw;
+    const int chunk = blk % tg.chunks;
+    const int ns = min(tg.spw, B - s_first);
     tok_row_stats(bk.x_in, (long)N * D, s_first, ns * N, N, D, stats, lane, wave, TW_WAVES);
     __syncthreads();
 
@@ -358,7 +370,7 @@ __global__ __launch_bounds__(TW_THREADS) void token_bwd_cols_kernel(const m2m_to
         const float* gr = dhs + lane * TW_LDW;
         float a = 0.f;
         for (int k = 0; k < TW_COLS; ++k) a += gr[k];
-        atomicAdd(bk.g_tok_b1 + lane, a);
+        gb1s[lane] += a;
     }
     float* us = part + wave * PART_F;                           // [TW_NC][TW_LDW]  LN1 output of each column, one chunk of tokens
     float* dvs = us + TW_NC * TW_LDW;                           // [TW_NC][TW_LDW]  masked upstream gradient, same chunk
@@ -390,18 +402,27 @@ __global__ __launch_bounds__(TW_THREADS) void token_bwd_cols_kernel(const m2m_to
                 a = __builtin_fmaf(gr[k], ur[k], a);         // dW1[t][n] += dHpre[t] U[n]
                 c = __builtin_fmaf(vr[k], hr[k], c);         // dW2[n][t] += dV[n] Hact[t]
             }
-            atomicAdd(bk.g_tok_w1 + t * N + n, a);
-            atomicAdd(bk.g_tok_w2 + n * T + t, c);
+            gw1s[t * N + n] += a;
+            gw2s[n * T + t] += c;
         }
         if (lane < nc) {
             const float* vr = dvs + lane * TW_LDW;
             float a = 0.f;
             for (int k = 0; k < TW_COLS; ++k) a += vr[k];
-            atomicAdd(bk.g_tok_b2 + n0 + lane, a);
+            gb2s[n0 + lane] += a;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);                     // reads done before the next chunk overwrites the tile
         __builtin_amdgcn_wave_barrier();
     }
+    __syncthreads();                                             // the next column block overwrites stats / hs / dhs
+    }
+    __syncthreads();
+    for (int i = tid; i < T * N; i += TW_THREADS) {
+        atomicAdd(bk.g_tok_w1 + i, gw1s[i]);
+        atomicAdd(bk.g_tok_w2 + i, gw2s[i]);
+    }
+    if (tid < T) atomicAdd(bk.g_tok_b1 + tid, gb1s[tid]);
+    for (int n = tid; n < N; n += TW_THREADS) atomicAdd(bk.g_tok_b2 + n, gb2s[n]);
 }
 
 // ---- backward, row part: dx_in = g_mid + LN1'(dU); gamma / beta gradients ------------------------------------------
@@ -516,17 +537,21 @@ template <int P, int DM, int TM>
 static int launch_token_bwd(const m2m_tower* t, int b, const float* g_mid, int B, float* du, unsigned int seed, unsigned int step,
                             const unsigned int* step_dev, hipStream_t st) {
     const TokGeom g = tok_geom(t->D);
-    const int grid = ((B + g.spw - 1) / g.spw) * g.chunks;
+    const int nblk = ((B + g.spw - 1) / g.spw) * g.chunks;
+    // column blocks per workgroup: one until the launch has more than ~1024 workgroups (4 per CU), then enough to stay there
+    // -- the token-weight gradients end in float atomics on the same few hundred addresses from every workgroup
+    const int iters = nblk > 1024 ? (nblk + 1023) / 1024 : 1;
+    const int grid = (nblk + iters - 1) / iters;
     const size_t part_f = 2 * TM * TW_COLS > 2 * TW_NC * TW_LDW ? 2 * TM * TW_COLS : 2 * TW_NC * TW_LDW;
     const size_t lds = ((tok_lds_floats(t->N, g.spw, TM) + 3) & ~(size_t)3) * sizeof(float) +
-                       ((size_t)2 * TM * TW_LDW + TW_WAVES * part_f) * sizeof(float);
+                       ((size_t)2 * TM * TW_LDW + TW_WAVES * part_f + 2 * t->N * TM + TM + t->N) * sizeof(float);
     auto kern = token_bwd_cols_kernel<P, DM, TM>;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
         M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(TW_THREADS), lds, st, *t, b, g_mid, B, du, seed, step, step_dev);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(TW_THREADS), lds, st, *t, b, g_mid, B, du, seed, step, step_dev, iters);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
 }
