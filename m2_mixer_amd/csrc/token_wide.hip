@@ -636,8 +636,9 @@ int m2m_backward_wide(const m2m_tower* t, int B, const float* d_out, long d_out_
         // gradient wrt the block input -> ws_a in place (row-local), or the caller's buffer for the first block
         float* dst = b > 0 ? t->ws_a : d_x0;
         const long dst_ss = b > 0 ? dense : d_x0_ss;
-        // rows per workgroup: 32 (8 per wave) when there are plenty, 8 at small batch so that the chip is not left to 80 workgroups
-        const int rpw = rows >= 16384 ? LN_ROWS : 8;
+        // rows per workgroup: 32 (8 per wave) when there are plenty, 8 at small batch so that the chip is not left to 80
+        // workgroups, 128 when there are so many that the gamma / beta atomics of thousands of workgroups queue up
+        const int rpw = rows >= 131072 ? 4 * LN_ROWS : (rows >= 16384 ? LN_ROWS : 8);   // (large: fewer workgroups on the same 2 D atomics)
         hipLaunchKernelGGL(ln1_bwd_rows_kernel, dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(256), 0, st, bk.x_in, t->ws_b,
                            t->ws_a, bk.ln1_w, rows, t->N, t->D, dst, dst_ss, bk.g_ln1_w, bk.g_ln1_b, rpw);
         M2M_CHECK_HIP(hipGetLastError());
