@@ -501,6 +501,33 @@ def test_wide_models_bf16_vs_oracle_and_training(task, dev):
     assert np.isfinite(last) and last < 0.85 * first, (first, last)
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_mimic_large_batch_token_gradients_vs_oracle(prec, dev):
+    """Batch 2500 on the wide path: the token-mixing backward walks several column blocks per workgroup (more than 1024
+    blocks in the launch, a ragged last workgroup) and accumulates the token-weight gradients in LDS, the LayerNorm-1 backward
+    takes its larger row groups.  Every gradient against autograd through the oracle."""
+    from m2_mixer_amd.engine import MimicEngine
+    cfg, B = dict(G.MIMIC_H), 2500
+    cfg["dropout"] = 0.0
+    shapes = G.mimic_shapes(cfg)
+    params = dict(G.make_params(shapes, 19))
+    batch = G.mimic_batch(B, 23, cfg)
+    eng = MimicEngine(cfg, B, device=dev, precision=prec, lr=1e-3, init=False)
+    eng.load_state_dict(params)
+    eng.forward_backward(*(t.to(dev) for t in batch))
+    torch.cuda.synchronize()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = O.mimic_forward(*batch, leaves, cfg)
+    ref["loss"].backward()
+    tol_l, tol_g = (FP32_ATOL, 2e-3) if prec == "fp32" else (BF16_REL, 6e-2)
+    assert abserr(eng.logits[2], ref["logits"]) < tol_l * max(1.0, float(ref["logits"].detach().abs().max()))
+    assert abs(float(eng.losses[3]) - float(ref["loss"].detach())) < (1e-3 if prec == "fp32" else 2e-2)
+    for k, leaf in leaves.items():
+        if k.endswith("token_mix.2.net.3.bias"):      # exactly-zero true gradient
+            continue
+        assert relerr(eng.grads[k], leaf.grad) < tol_g, k
+
+
 def test_static_mlp_dropout_consistency(dev):
     """The MIMIC static MLP (Linear-ReLU-Dropout x2 + Linear) with dropout on: forward equals the oracle under the
     masks the kernel drew (read back from the saved activations), backward equals autograd through those masks."""
