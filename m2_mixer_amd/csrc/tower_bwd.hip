@@ -188,8 +188,13 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
         // identity block of the transposing MFMA (bf16): lane (g, il) is non-zero iff g == il >> 2, at element il & 3
         const unsigned int id_sel = (g == (il >> 2)) ? ((il & 1) ? 0x3F800000u : 0x00003F80u) : 0u;
         const unsigned int id_a = (il & 2) ? 0u : id_sel, id_b = (il & 2) ? id_sel : 0u;
-        Frag w1f[2][KD], w2f[2][KD];
-        if (wave < npairs) {
+        // hidden_dim <= 128: the W1 / W2^T fragments of a whole step (2 x 2 x KD) live in registers and the next step's are
+        // requested during this one's epilogue.  hidden_dim 256: that is 128 registers next to 64 accumulators and the 64 of
+        // the third product -- the kernel spilled ~200 -- and such towers have few steps per wave (C = 512: two), so there the
+        // first two products stream their fragments two k-blocks at a time, nothing held across steps.
+        constexpr bool HOLD = D <= 128;
+        Frag w1f[2][HOLD ? KD : 1], w2f[2][HOLD ? KD : 1];
+        if (HOLD && wave < npairs) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -210,6 +215,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                 gacc[mt][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
                 gacc[mt][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             }
+            if constexpr (HOLD) {
 #pragma unroll
             for (int kb = 0; kb < KD; ++kb) {
 #pragma unroll
@@ -222,6 +228,32 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                     Pr::mma(gacc[mt][1], w2f[1][kb], dy);
                 }
             }
+            } else {
+                constexpr int KG = 2;
+#pragma unroll
+                for (int k0 = 0; k0 < KD; k0 += KG) {
+                    Frag u1[2][KG], u2[2][KG];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int kk = 0; kk < KG; ++kk) {
+                            u1[t][kk] = ld_frag_global(bk.w1n, (long)(2 * q + t) * KD + k0 + kk, lane);
+                            u2[t][kk] = ld_frag_global(bk.w2tn, (long)(2 * q + t) * KD + k0 + kk, lane);
+                        }
+#pragma unroll
+                    for (int kk = 0; kk < KG; ++kk) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            const Frag a = ld_frag_lds(at, mt * KD + k0 + kk, lane);
+                            const Frag dy = ld_frag_lds(dyp, mt * KD + k0 + kk, lane);
+                            Pr::mma(hacc[mt][0], u1[0][kk], a);
+                            Pr::mma(hacc[mt][1], u1[1][kk], a);
+                            Pr::mma(gacc[mt][0], u2[0][kk], dy);
+                            Pr::mma(gacc[mt][1], u2[1][kk], dy);
+                        }
+                    }
+                }
+            }
             // this step's W1^T fragments (third product) and the next step's W1 / W2^T fragments: in flight
             // during the epilogue.  The scheduling barrier keeps the compiler from hoisting these loads above
             // the MFMAs that still read the current fragments (which would double the live registers).
@@ -231,7 +263,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
             for (int f = 0; f < NF; ++f)
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) w3f[f][dt] = ld_frag_global(bk.w1tc, (long)(q * NF + f) * DT + dt, lane);
-            if (q + NWAVES < npairs) {
+            if (HOLD && q + NWAVES < npairs) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
