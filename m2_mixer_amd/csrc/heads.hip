@@ -29,6 +29,7 @@ __global__ __launch_bounds__(NTHREADS) void heads_kernel(const HeadArgs ha, cons
     float* wl = pl + HEAD_S * DL;                         // weights     [K][DL]
     float* lg = wl + HEAD_MAXK * DL;                      // logits / dlogits [HEAD_S][HEAD_MAXK]
     float* red = lg + HEAD_S * HEAD_MAXK;                 // [HEAD_S] loss terms
+    float* tm = red + HEAD_S;                             // [HEAD_S][HEAD_MAXK] per-element loss terms (BCE)
 
     const int tid = threadIdx.x;
     const int hI = blockIdx.y;
@@ -54,23 +55,35 @@ __global__ __launch_bounds__(NTHREADS) void heads_kernel(const HeadArgs ha, cons
         }
     }
     __syncthreads();
-    // softmax / loss / prediction / dlogits, one thread per sample
-    if (tid < HEAD_S) {
-        float term = 0.f;
-        if (BCE && tid < ns) {
-            const int s = tid;
-            const float scale = hd.weight / ((float)B * (float)K);
-            for (int k = 0; k < K; ++k) {
+    // loss / prediction / dlogits.  BCE: every (sample, label) element is independent -- one thread each (the transcendental
+    // functions of K = 23 labels in one thread's loop made this the longest phase of the MM-IMDb heads); CE: softmax needs
+    // the row, one thread per sample.
+    if (BCE) {
+        const float scale = hd.weight / ((float)B * (float)K);
+        for (int idx = tid; idx < HEAD_S * K; idx += NTHREADS) {
+            const int s = idx / K, k = idx % K;
+            float term = 0.f, dl = 0.f;
+            if (s < ns) {
                 const float x = lg[s * HEAD_MAXK + k], y = targets[(long)(s0 + s) * K + k], pw = pos_weight[k];
                 // log sigmoid(x) = min(x, 0) - log1p(exp(-|x|));  log(1 - sigmoid(x)) = log sigmoid(x) - x
                 const float ls = __builtin_fminf(x, 0.f) - log1pf(__expf(-__builtin_fabsf(x)));
-                term -= pw * y * ls + (1.f - y) * (ls - x);
+                term = -(pw * y * ls + (1.f - y) * (ls - x));
                 const float sg = 1.0f / (1.0f + __expf(-x));
-                lg[s * HEAD_MAXK + k] = scale * ((1.f - y) * sg - pw * y * (1.f - sg));
+                dl = scale * ((1.f - y) * sg - pw * y * (1.f - sg));
                 preds[((long)hI * B + s0 + s) * K + k] = x > 0.f ? 1 : 0;
             }
-            term /= (float)K;
-        } else if (tid < ns) {
+            lg[s * HEAD_MAXK + k] = dl;
+            tm[s * HEAD_MAXK + k] = term;
+        }
+        __syncthreads();
+        if (tid < HEAD_S) {
+            float term = 0.f;
+            for (int k = 0; k < K; ++k) term += tm[tid * HEAD_MAXK + k];      // label order, as the single-thread loop summed
+            red[tid] = term / (float)K;
+        }
+    } else if (tid < HEAD_S) {
+        float term = 0.f;
+        if (tid < ns) {
             const int s = tid;
             const int y = (int)labels[s0 + s];
             float mx = lg[s * HEAD_MAXK];
@@ -139,7 +152,7 @@ static int launch_heads(const m2m_head* heads, int nheads, const void* labels, c
     for (int i = nheads; i < HEAD_MAXH; ++i) ha.h[i] = heads[0];
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (zero_losses) hipLaunchKernelGGL(zero_floats_kernel, dim3(1), dim3(64), 0, st, losses, nheads + 1);
-    const size_t lds = sizeof(float) * ((size_t)HEAD_S * (D + 1) + (size_t)HEAD_MAXK * (D + 1) + HEAD_S * HEAD_MAXK + HEAD_S);
+    const size_t lds = sizeof(float) * ((size_t)HEAD_S * (D + 1) + (size_t)HEAD_MAXK * (D + 1) + 2 * HEAD_S * HEAD_MAXK + HEAD_S);
     static bool done = false;
     if (!done) { M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(heads_kernel<BCE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); done = true; }
     hipLaunchKernelGGL(heads_kernel<BCE>, dim3((B + HEAD_S - 1) / HEAD_S, nheads), dim3(NTHREADS), lds, st, ha, labels, pos_weight, B, D, K, logits, losses, preds, nheads);
