@@ -89,7 +89,7 @@ static __device__ __forceinline__ float bf2f(unsigned short b) {
 
 // ---- math -----------------------------------------------------------------------------------------
 // erf(x) as an odd rational polynomial on [-4, 4] (|err| < 5e-7, checked against scipy in
-// tests/test_host_math.py); no exp, one reciprocal.  Coefficients: the float erf rational used by Eigen.
+// tests/test_host_cpu.py::test_erf_rational_coefficients); no exp, one reciprocal.  Coefficients: the float erf rational used by Eigen.
 static __device__ __forceinline__ float erf_fast(float x) {
     x = __builtin_fminf(__builtin_fmaxf(x, -4.0f), 4.0f);
     const float x2 = x * x;

@@ -47,14 +47,21 @@ class ResidentAVMnist:
         labels = torch.from_numpy(labels.astype(np.int64))
         return image.to(self.device), audio.to(self.device), labels.to(self.device)
 
-    def num_batches(self, split: str, batch_size: int) -> int:
+    def num_samples(self, split: str) -> int:
+        """Samples of `split` this rank sees: r, r + world, ... (Lightning's DistributedSampler(shuffle=False) pads the last
+        ranks with repeats; here a rank simply gets one sample fewer)."""
         n = self.splits[split][2].shape[0]
-        per_rank = (n + self.world - 1) // self.world
-        return per_rank // batch_size                     # full batches only: the captured graph has a static batch size
+        return (n - self.rank + self.world - 1) // self.world
 
-    def batches(self, split: str, batch_size: int, shuffle: bool = False,
-                generator: Optional[torch.Generator] = None) -> Iterator[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
-        """Rank r takes samples r, r + world, ... (what Lightning's DistributedSampler(shuffle=False) hands a DDP rank)."""
+    def num_batches(self, split: str, batch_size: int, drop_last: bool = False) -> int:
+        """The reference's DataLoaders keep the ragged last batch (`drop_last` is left False, datasets/avmnist.py:180-190)."""
+        n = self.num_samples(split)
+        return n // batch_size if drop_last else (n + batch_size - 1) // batch_size
+
+    def batches(self, split: str, batch_size: int, shuffle: bool = False, generator: Optional[torch.Generator] = None,
+                drop_last: bool = False) -> Iterator[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
+        """Rank r takes samples r, r + world, ... (what Lightning's DistributedSampler(shuffle=False) hands a DDP rank).
+        The last batch may be smaller than batch_size (drop_last=False, as the reference)."""
         image, audio, labels = self.splits[split]
         n = labels.shape[0]
         if shuffle:
@@ -65,8 +72,9 @@ class ResidentAVMnist:
             order = None
         if order is not None and self.world > 1:
             order = order[self.rank::self.world]
-        for b in range(self.num_batches(split, batch_size)):
-            lo, hi = b * batch_size, (b + 1) * batch_size
+        mine = self.num_samples(split)
+        for b in range(self.num_batches(split, batch_size, drop_last)):
+            lo, hi = b * batch_size, min((b + 1) * batch_size, mine)
             if order is None:
                 yield image[lo:hi], audio[lo:hi], labels[lo:hi]          # views: zero copies
             else:
@@ -95,29 +103,60 @@ class PlateauLR:
 
 
 def run_epoch(engine, data: ResidentAVMnist, split: str, batch_size: int, train: bool, log_interval_steps: int = 50,
-              replay=None, log=None) -> Dict[str, float]:
-    """One pass over `split`.  train=True drives the captured step (`replay`, from engine.capture) or engine.train_step;
-    losses (per head + total) and the fusion head's hit count are summed on the device and read back every
-    `log_interval_steps` steps and at the end (cfg `log_interval_steps`, cfg/avmnist/*.yml:3)."""
+              replay=None, log=None, tail_engine=None) -> Dict[str, float]:
+    """One pass over EVERY sample of `split` (the reference's loaders keep the ragged last batch,
+    datasets/avmnist.py:180-190).  train=True drives the captured step (`replay`, from engine.capture) or
+    engine.train_step.  A last batch smaller than batch_size -- the captured graph and the engine's buffers have a static
+    batch size -- goes through `tail_engine` (default: engine.sibling(remainder), same parameters / Adam state, built on
+    first use and kept on the engine), eagerly; packed operand copies are re-synchronised around it.
+
+    Per-step values are summed on the device and read back every `log_interval_steps` steps and at the end (cfg
+    `log_interval_steps`, cfg/avmnist/*.yml:3): the four losses (modules/train_test_module.py:72-92: step losses), the three
+    heads' hit counts (torchmetrics Accuracy on `preds`, :79-82, :105-110).  Returned:
+      loss              sample-weighted mean of the step losses = what `self.log('val_loss', ..., on_epoch=True)` reduces to,
+                        the quantity ReduceLROnPlateau / EarlyStopping monitor (run.py:61-67, models/avmnist.py:416-422)
+      loss_step_mean    plain mean over steps = the wandb `val_loss` / `train_loss` number (train_test_module.py:92, :113)
+      loss_image / loss_audio / loss_fusion   step means (models/avmnist.py:326-337)
+      acc, acc_image, acc_audio, hits*, steps, samples"""
     dev = engine.device
-    acc = torch.zeros(5, device=dev, dtype=torch.float64)        # [loss_a, loss_b, loss_fusion, loss, hits]
-    seen, host = 0, np.zeros(5)
+    # [loss_a, loss_b, loss_fusion, loss] step sums | the same weighted by the step's batch size | hits a, b, fusion
+    acc = torch.zeros(11, device=dev, dtype=torch.float64)
+    seen, host = 0, np.zeros(11)
     nb = data.num_batches(split, batch_size)
+    n_tail = data.num_samples(split) % batch_size
     for i, (image, audio, labels) in enumerate(data.batches(split, batch_size, shuffle=(split == "test"))):
+        bs = labels.shape[0]
+        eng = engine
+        if bs != batch_size:                                       # the ragged last batch
+            if tail_engine is None:
+                tail_engine = getattr(engine, "_tail_engines", {}).get(bs)
+            if tail_engine is None:
+                tail_engine = engine.sibling(bs)
+                engine.__dict__.setdefault("_tail_engines", {})[bs] = tail_engine
+            eng = tail_engine
+            eng.pack()                                             # its packed copies missed every step since its last use
+            image, audio, labels = image.contiguous(), audio.contiguous(), labels.contiguous()
         if train:
-            if replay is not None:
+            if replay is not None and eng is engine:
                 replay(image, audio, labels)
             else:
-                engine.train_step(image, audio, labels)
+                eng.train_step(image, audio, labels)
         else:
-            engine.evaluate(image, audio, labels)
-        acc[:4] += engine.losses                                   # device-side: no host round trip
-        acc[4] += (engine.preds[2] == labels).sum()
-        seen += batch_size
+            eng.evaluate(image, audio, labels)
+        if eng is not engine and train:
+            engine.pack()                                          # the tail step changed the weights
+        acc[:4] += eng.losses                                      # device-side: no host round trip
+        acc[4:8] += eng.losses * bs
+        acc[8:11] += (eng.preds == labels.to(eng.preds.dtype)[None, :]).sum(dim=1)
+        seen += bs
         if (i + 1) % log_interval_steps == 0 or i + 1 == nb:
             host = acc.cpu().numpy()                               # the only sync of the interval
             if log is not None:
-                log({"split": split, "step": i + 1, "loss": host[3] / (i + 1), "acc": host[4] / seen})
-    steps = max(nb, 1)
-    return {"loss": float(host[3]) / steps, "loss_fusion": float(host[2]) / steps, "acc": float(host[4]) / max(seen, 1),
+                log({"split": split, "step": i + 1, "loss": host[3] / (i + 1), "acc": host[10] / seen})
+    steps, n = max(nb, 1), max(seen, 1)
+    a, b = getattr(engine, "MODS", ("image", "audio"))
+    return {"loss": float(host[7]) / n, "loss_step_mean": float(host[3]) / steps,
+            f"loss_{a}": float(host[0]) / steps, f"loss_{b}": float(host[1]) / steps, "loss_fusion": float(host[2]) / steps,
+            "acc": float(host[10]) / n, f"acc_{a}": float(host[8]) / n, f"acc_{b}": float(host[9]) / n,
+            "hits": int(round(host[10])), f"hits_{a}": int(round(host[8])), f"hits_{b}": int(round(host[9])),
             "steps": nb, "samples": seen}

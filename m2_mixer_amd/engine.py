@@ -101,7 +101,11 @@ class _FlatEngine:
 
     SEGMENTS: Tuple[str, ...] = ()
 
-    def __init__(self, cfg: dict, batch_size: int, device, precision, lr, betas, eps, weight_decay, seed, init):
+    def __init__(self, cfg: dict, batch_size: int, device, precision, lr, betas, eps, weight_decay, seed, init, share=None):
+        """share: another engine of the same model; this one then works on ITS parameters, gradients, Adam state and
+        step counters (its own activation buffers and packed operand copies, for another batch size) -- the second,
+        smaller step that takes the ragged last batch of an epoch (data.run_epoch).  After a step on one of the two
+        the other one's packed copies are stale: call its pack() before using it."""
         self.cfg, self.B = cfg, int(batch_size)
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -115,18 +119,27 @@ class _FlatEngine:
         n = sum(int(torch.Size(s).numel()) for s in self.shapes.values())
         self.n_params = n
         dev = self.device
-        self.flat_p = torch.zeros(n, device=dev)
-        self.flat_g = torch.zeros(n, device=dev)
-        self.flat_m = torch.zeros(n, device=dev)
-        self.flat_v = torch.zeros(n, device=dev)
+        if share is not None:
+            if share.n_params != n or list(share.shapes.items()) != list(self.shapes.items()) or share.device != dev:
+                raise RuntimeError("share=: the other engine must hold the same model on the same device")
+            self.flat_p, self.flat_g, self.flat_m, self.flat_v = share.flat_p, share.flat_g, share.flat_m, share.flat_v
+        else:
+            self.flat_p = torch.zeros(n, device=dev)
+            self.flat_g = torch.zeros(n, device=dev)
+            self.flat_m = torch.zeros(n, device=dev)
+            self.flat_v = torch.zeros(n, device=dev)
         self.params: Dict[str, torch.Tensor] = OrderedDict()
         self.grads: Dict[str, torch.Tensor] = OrderedDict()
+        self.exp_avg: Dict[str, torch.Tensor] = OrderedDict()        # Adam's first / second moments, same keys
+        self.exp_avg_sq: Dict[str, torch.Tensor] = OrderedDict()
         bounds: Dict[str, Tuple[int, int]] = {}
         off = 0
         for k, shp in self.shapes.items():
             cnt = int(torch.Size(shp).numel())
             self.params[k] = self.flat_p[off:off + cnt].view(shp)
             self.grads[k] = self.flat_g[off:off + cnt].view(shp)
+            self.exp_avg[k] = self.flat_m[off:off + cnt].view(shp)
+            self.exp_avg_sq[k] = self.flat_v[off:off + cnt].view(shp)
             seg = self._segment_of(k)
             lo, hi = bounds.get(seg, (off, off))
             if hi != off:
@@ -135,10 +148,13 @@ class _FlatEngine:
             off += cnt
         # contiguous segments of the flat buffers, one per tower (the last one also holds the heads)
         self.segments = bounds
-        self.adam_state = torch.tensor([0.0, lr, 0.0, 0.0], device=dev)     # [step, lr, -, -]
-        self.drop_step = torch.zeros(1, dtype=torch.int32, device=dev)       # device-side dropout step counter
-        self.seed = seed & 0xFFFFFFFF
-        if init:
+        if share is not None:
+            self.adam_state, self.drop_step = share.adam_state, share.drop_step
+        else:
+            self.adam_state = torch.tensor([0.0, lr, 0.0, 0.0], device=dev)     # [step, lr, -, -]
+            self.drop_step = torch.zeros(1, dtype=torch.int32, device=dev)       # device-side dropout step counter
+        self.seed = (share.seed if share is not None else seed) & 0xFFFFFFFF
+        if init and share is None:
             self.reset_parameters(seed)
         self.logits = torch.zeros(3, self.B, self.K, device=dev)
         self.losses = torch.zeros(4, device=dev)
@@ -192,20 +208,69 @@ class _FlatEngine:
                 v = (torch.rand(shp, generator=gen) * 2 - 1) * bound
             self.params[k].copy_(v)
 
+    #: non-parameter entries a reference state_dict may carry for this model (buffers of its loss modules)
+    EXTRA_STATE_KEYS: Tuple[str, ...] = ()
+
+    def _consume_extra_state(self, key: str, value: torch.Tensor):
+        raise KeyError(key)
+
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
         missing = [k for k in self.shapes if k not in sd]
-        extra = [k for k in sd if k not in self.shapes]
+        extra = [k for k in sd if k not in self.shapes and k not in self.EXTRA_STATE_KEYS]
         if missing or extra:
             raise KeyError(f"state dict mismatch: missing {missing[:4]}, unexpected {extra[:4]}")
         for k in self.shapes:
             self.params[k].copy_(sd[k].to(self.device, torch.float32).reshape(self.shapes[k]))
+        for k in self.EXTRA_STATE_KEYS:
+            if k in sd:
+                self._consume_extra_state(k, sd[k])
         self.pack()
 
+    def _extra_state(self) -> "OrderedDict[str, torch.Tensor]":
+        return OrderedDict()
+
     def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
-        return OrderedDict((k, v.detach().clone()) for k, v in self.params.items())
+        """The reference module's state_dict: parameters under its key names, in its order, then the loss-module buffers."""
+        out = OrderedDict((k, v.detach().clone()) for k, v in self.params.items())
+        out.update(self._extra_state())
+        return out
+
+    def optimizer_state_dict(self) -> dict:
+        """torch.optim.Adam.state_dict() layout (what Lightning stores under `optimizer_states[0]`): per parameter index
+        `step`, `exp_avg`, `exp_avg_sq`; one param group with this engine's hyper-parameters."""
+        step = float(self.adam_state[0])
+        state = {i: {"step": torch.tensor(step), "exp_avg": self.exp_avg[k].detach().cpu().clone(),
+                     "exp_avg_sq": self.exp_avg_sq[k].detach().cpu().clone()} for i, k in enumerate(self.shapes)}
+        group = {"lr": float(self.adam_state[1]), "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                 "amsgrad": False, "maximize": False, "params": list(range(len(self.shapes)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, osd: dict):
+        keys = list(self.shapes)
+        if sorted(osd["state"].keys()) != list(range(len(keys))):
+            raise KeyError("optimizer state: expected one entry per parameter, indexed in parameters() order")
+        steps = {float(st["step"]) for st in osd["state"].values()}
+        if len(steps) != 1:
+            raise RuntimeError("optimizer state: the fused Adam keeps ONE step count for all parameters")
+        for i, k in enumerate(keys):
+            self.exp_avg[k].copy_(osd["state"][i]["exp_avg"].to(self.device, torch.float32).reshape(self.shapes[k]))
+            self.exp_avg_sq[k].copy_(osd["state"][i]["exp_avg_sq"].to(self.device, torch.float32).reshape(self.shapes[k]))
+        self.adam_state[0] = steps.pop()
+        self.set_lr(float(osd["param_groups"][0]["lr"]))
 
     def set_lr(self, lr: float):
         self.adam_state[1] = lr
+
+    def _sibling_kwargs(self) -> dict:
+        return {"fusion_loss_weight": self.fusion_loss_weight} if hasattr(self, "fusion_loss_weight") else {}
+
+    def sibling(self, batch_size: int):
+        """An engine for another batch size over THIS engine's parameters, gradients, Adam state and step counters
+        (constructor argument share=): the step that takes an epoch's ragged last batch, or a validation engine."""
+        prec = {v: k for k, v in L.PREC_BY_NAME.items() if k in ("bf16", "fp32")}[self.prec]
+        return type(self)(self.cfg, batch_size, device=self.device, precision=prec, lr=float(self.adam_state[1]),
+                          betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, seed=self.seed, init=False,
+                          share=self, **self._sibling_kwargs())
 
     # ---- optimizer -------------------------------------------------------------------------------------------
     def _adam(self, lo: int, hi: int, grad_scale: float, bump: bool, grad_bf16: Optional[torch.Tensor] = None):
@@ -263,13 +328,18 @@ class _FlatEngine:
         steps > 1 (single-GPU path only) captures that many consecutive training steps in ONE graph -- every replayed
         graph costs ~17 us of launch gap on this platform, which is 2 % of a step -- with one static input slot per step:
         replay(*batch_0, *batch_1, ...) or replay() to reuse what the slots hold; losses / logits / preds of step i land
-        in self.losses_steps[i] etc. (self.losses / logits / preds alias the LAST step's slot afterwards)."""
+        in self.losses_steps[i] etc. (replay() returns, and replay.losses is, that (steps, 4) buffer; the engine's own
+        losses / logits / preds are left to the single-step paths).
+        capture() does not train: the warm-up steps it needs are undone (parameters, Adam moments, step counters)."""
         if steps < 1 or (steps > 1 and grad_sync is not None):
             raise ValueError("steps > 1 is only supported without a gradient exchange")
         nb = len(batch)
         slots = [tuple(t.clone() for t in batch) for _ in range(steps)]
         self._static = slots[0] if steps == 1 else slots
         st = slots[0]
+        # The warm-up below runs REAL training steps (lazy initialisation of the launches must happen outside the capture).
+        # Everything they change is put back afterwards, so capture() leaves the model exactly as it found it.
+        snap = [t.clone() for t in (self.flat_p, self.flat_m, self.flat_v, self.flat_g, self.adam_state, self.drop_step)]
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -283,19 +353,30 @@ class _FlatEngine:
                     self.optimizer_step(scale, getattr(grad_sync, "reduced_bf16", None))
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        for dst, src in zip((self.flat_p, self.flat_m, self.flat_v, self.flat_g, self.adam_state, self.drop_step), snap):
+            dst.copy_(src)
+        self.pack()
+        torch.cuda.synchronize()
         # thread_local capture mode: a data-parallel process has other threads (the RCCL watchdog) that may touch the HIP
         # runtime while this thread captures; only this thread's calls belong to the graph
         g1 = torch.cuda.CUDAGraph()
+        out_losses = self.losses
         if grad_sync is None:
             if steps > 1:
+                # per-step output slots of THIS graph; the engine's own losses / logits / preds stay what they were (other
+                # captured graphs and evaluate() write those)
+                home = (self.losses, self.logits, self.preds)
                 self.losses_steps = torch.zeros(steps, *self.losses.shape, device=self.device)
                 self.logits_steps = torch.zeros(steps, *self.logits.shape, device=self.device)
                 self.preds_steps = torch.zeros(steps, *self.preds.shape, dtype=self.preds.dtype, device=self.device)
+                out_losses = self.losses_steps
             with torch.cuda.graph(g1, capture_error_mode="thread_local"):
                 for i in range(steps):
                     if steps > 1:
                         self.losses, self.logits, self.preds = self.losses_steps[i], self.logits_steps[i], self.preds_steps[i]
                     self.fused_step(*slots[i])
+            if steps > 1:
+                self.losses, self.logits, self.preds = home
             graphs = (g1,)
         else:
             g2 = torch.cuda.CUDAGraph()
@@ -317,8 +398,9 @@ class _FlatEngine:
             if grad_sync is not None:
                 grad_sync(self.flat_g)
                 graphs[1].replay()
-            return self.losses_steps if steps > 1 else self.losses
+            return out_losses                     # this graph's own buffer: (4,) or, for a multi-step graph, (steps, 4)
 
+        replay.losses = out_losses
         return replay
 
 
@@ -488,12 +570,13 @@ class AVMnistEngine(_TwoTowerEngine):
 
     def __init__(self, cfg: dict, batch_size: int, device="cuda:0", precision: Optional[str] = None,
                  lr: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                 fusion_loss_weight: float = 1.0 / 3, seed: int = 42, init: bool = True):
+                 fusion_loss_weight: float = 1.0 / 3, seed: int = 42, init: bool = True, share=None):
         w = fusion_loss_weight
         ow = (1 - w) / 2
         # loss = (w Lf + ow Li + ow La) * 3      (models/avmnist.py:289-290)
         self.head_weights = {"image": 3 * ow, "audio": 3 * ow, "fusion": 3 * w}
-        super().__init__(cfg, batch_size, device, precision, lr, betas, eps, weight_decay, seed, init)
+        self.fusion_loss_weight = w
+        super().__init__(cfg, batch_size, device, precision, lr, betas, eps, weight_decay, seed, init, share)
 
     def _loss_heads(self, heads, labels, zero_losses):
         heads_ce(heads, labels, self.B, self.D, self.K, out=(self.logits, self.losses, self.preds), zero_losses=zero_losses)
@@ -514,15 +597,29 @@ class MMIMDBEngine(_TwoTowerEngine):
     preds = sigmoid(logits) > 0.5 (:128-133); labels are (B, K) multi-hot floats."""
 
     MODS = ("image", "text")
+    #: buffers of the three BCEWithLogitsLoss modules in the reference's state_dict (models/mmimdb.py:47-50)
+    EXTRA_STATE_KEYS = ("image_criterion.pos_weight", "text_criterion.pos_weight", "fusion_criterion.pos_weight")
 
     def __init__(self, cfg: dict, batch_size: int, device="cuda:0", precision: Optional[str] = None,
                  lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                 seed: int = 42, init: bool = True):
+                 seed: int = 42, init: bool = True, share=None):
         self.head_weights = {"image": 1.0, "text": 1.0, "fusion": 1.0}
-        super().__init__(cfg, batch_size, device, precision, lr, betas, eps, weight_decay, seed, init)
+        super().__init__(cfg, batch_size, device, precision, lr, betas, eps, weight_decay, seed, init, share)
         self.pos_weight = torch.tensor(cfg["pos_weight"], dtype=torch.float32, device=self.device)
         if self.pos_weight.numel() != self.K:
             raise RuntimeError("pos_weight needs one entry per class")
+
+    def _consume_extra_state(self, key, value):
+        v = value.to(self.device, torch.float32).reshape(-1)
+        if v.numel() != self.K:
+            raise RuntimeError(f"{key}: expected {self.K} entries")
+        if key == self.EXTRA_STATE_KEYS[0]:
+            self.pos_weight.copy_(v)                 # one pos_weight serves the three heads (the reference builds them equal)
+        elif not torch.equal(v, self.pos_weight):
+            raise RuntimeError(f"{key} differs from image_criterion.pos_weight: the fused heads kernel takes one pos_weight")
+
+    def _extra_state(self):
+        return OrderedDict((k, self.pos_weight.detach().clone()) for k in self.EXTRA_STATE_KEYS)
 
     def _preds_shape(self):
         return (3, self.B, self.K)
@@ -539,11 +636,12 @@ class MimicEngine(_FlatEngine):
 
     def __init__(self, cfg: dict, batch_size: int, device="cuda:0", precision: Optional[str] = None,
                  lr: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                 fusion_loss_weight: float = 1.0 / 3, seed: int = 42, init: bool = True):
+                 fusion_loss_weight: float = 1.0 / 3, seed: int = 42, init: bool = True, share=None):
         w = fusion_loss_weight
         ow = (1 - w) / 2
         self.head_weights = {"static": ow, "time": ow, "fusion": w}
-        super().__init__(cfg, batch_size, device, precision, lr, betas, eps, weight_decay, seed, init)
+        self.fusion_loss_weight = w
+        super().__init__(cfg, batch_size, device, precision, lr, betas, eps, weight_decay, seed, init, share)
 
     def _param_shapes(self, cfg):
         return mimic_param_shapes(cfg)

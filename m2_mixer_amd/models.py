@@ -54,6 +54,27 @@ class _LenientPickle:
     Pickler = pickle.Pickler
 
 
+#: the Lightning release the reference pins (requirements.txt:8); a PEP 440 string, because Lightning's checkpoint migration
+#: parses this field with packaging.version.Version
+LIGHTNING_VERSION = "1.8.6"
+
+
+def _load_checkpoint_file(path, map_location, trusted: bool):
+    """torch.load of a `.ckpt`.  First with `weights_only=True` (tensors and plain containers only: nothing in the file can
+    run code) -- enough for checkpoints written by save_checkpoint.  A Lightning checkpoint written by the reference's
+    environment pickles omegaconf / pytorch_lightning classes next to the `state_dict`; reading those needs the full
+    unpickler, which executes whatever the file says -- only with `trusted=True`, i.e. for files the caller vouches for."""
+    try:
+        return torch.load(path, map_location=map_location, weights_only=True)
+    except Exception as e:
+        if not trusted:
+            raise RuntimeError(
+                f"{path}: not loadable with weights_only=True ({type(e).__name__}: {str(e)[:200]}).  A checkpoint that "
+                "pickles foreign classes (Lightning hyper-parameters, omegaconf) needs load_from_checkpoint(..., trusted=True); "
+                "unpickling runs code from the file, so pass it only for checkpoints from a source you trust") from e
+    return torch.load(path, map_location=map_location, weights_only=False, pickle_module=_LenientPickle)
+
+
 class _Cfg(dict):
     """dict with attribute access, recursively (stands in for omegaconf.DictConfig)."""
 
@@ -133,10 +154,11 @@ class _MultiLossModule(nn.Module):
     def load_from_checkpoint(cls, checkpoint_path, map_location=None, hparams_file=None, strict: bool = True, **kwargs):
         """Build the module from `model_cfg` / `optimizer_cfg` (passed as the reference's run.py:48-50 does) and load the
         weights of a Lightning `.ckpt` -- a torch.save'd dict whose `state_dict` uses exactly the sub-module names of this
-        class (models/avmnist.py:400-411 remembers the path for the test_preds.pt dump; so does this)."""
+        class (models/avmnist.py:400-411 remembers the path for the test_preds.pt dump; so does this).
+        trusted=True allows the full unpickler for checkpoints that carry foreign pickled classes (see _load_checkpoint_file)."""
         if "model_cfg" not in kwargs or "optimizer_cfg" not in kwargs:
             raise TypeError("load_from_checkpoint needs model_cfg= and optimizer_cfg= (the reference passes both, run.py:48-50)")
-        ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=False, pickle_module=_LenientPickle)
+        ckpt = _load_checkpoint_file(checkpoint_path, map_location or "cpu", kwargs.pop("trusted", False))
         state = ckpt["state_dict"] if isinstance(ckpt, dict) and "state_dict" in ckpt else ckpt
         model = cls(kwargs.pop("model_cfg"), kwargs.pop("optimizer_cfg"), **kwargs)
         model.load_state_dict(state, strict=strict)
@@ -144,13 +166,21 @@ class _MultiLossModule(nn.Module):
         model.current_epoch = int(ckpt.get("epoch", 0)) if isinstance(ckpt, dict) else 0
         return model
 
-    def save_checkpoint(self, path, epoch: Optional[int] = None, global_step: int = 0) -> str:
-        """A `.ckpt` in Lightning's top-level layout (`state_dict`, `epoch`, `global_step`): what load_from_checkpoint --
-        this one or a LightningModule's -- reads the weights from."""
+    def save_checkpoint(self, path, epoch: Optional[int] = None, global_step: int = 0, engine=None) -> str:
+        """A `.ckpt` in Lightning's top-level layout (`state_dict`, `epoch`, `global_step`, `pytorch-lightning_version`,
+        `optimizer_states`, `lr_schedulers`): what load_from_checkpoint -- this one or a LightningModule's -- reads.
+        engine: a fused engine trained over these weights; its parameters are written instead of the module's and its Adam
+        state goes to `optimizer_states[0]` in torch.optim.Adam's state_dict layout (parameter index = position in
+        `parameters()` order), so training can resume (engine.load_optimizer_state_dict)."""
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-        torch.save({"state_dict": {k: v.detach().cpu() for k, v in self.state_dict().items()},
-                    "epoch": self.current_epoch if epoch is None else int(epoch), "global_step": int(global_step),
-                    "pytorch-lightning_version": "m2_mixer_amd"}, path)
+        sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
+        ckpt = {"state_dict": sd, "epoch": self.current_epoch if epoch is None else int(epoch), "global_step": int(global_step),
+                "pytorch-lightning_version": LIGHTNING_VERSION, "optimizer_states": [], "lr_schedulers": []}
+        if engine is not None:
+            for k, v in engine.state_dict().items():
+                sd[k] = v.detach().cpu()
+            ckpt["optimizer_states"] = [engine.optimizer_state_dict()]
+        torch.save(ckpt, path)
         self.checkpoint_path = str(path)
         return str(path)
 
@@ -255,10 +285,12 @@ class MMIMDBMixerMultiLoss(_MultiLossModule):
         self.image_mixer = modules.get_block_by_name(**m.image, dropout=self.dropout)
         self.text_mixer = modules.get_block_by_name(**m.text, dropout=self.dropout)
         self._fusion_and_heads(self.image_mixer.num_patch, self.text_mixer.num_patch, m.image.hidden_dim, m.text.hidden_dim)
-        self.register_buffer("pos_weight", torch.tensor(list(self.model_cfg.pos_weight), dtype=torch.float32), persistent=False)
-
-    def _bce(self, logits, target):
-        return nn.functional.binary_cross_entropy_with_logits(logits, target, pos_weight=self.pos_weight)
+        # three BCEWithLogitsLoss modules under the reference's names (models/mmimdb.py:47-50): their persistent `pos_weight`
+        # buffers are part of every reference state_dict (`image_criterion.pos_weight`, ...), so checkpoints round-trip
+        pos_weight = torch.tensor(list(self.model_cfg.pos_weight), dtype=torch.float32)
+        self.image_criterion = nn.BCEWithLogitsLoss(pos_weight=pos_weight.clone())
+        self.text_criterion = nn.BCEWithLogitsLoss(pos_weight=pos_weight.clone())
+        self.fusion_criterion = nn.BCEWithLogitsLoss(pos_weight=pos_weight.clone())
 
     def shared_step(self, batch, **kwargs):
         image, text, labels = batch["image"], batch["text"], batch["label"]
@@ -275,7 +307,8 @@ class MMIMDBMixerMultiLoss(_MultiLossModule):
         text_logits = self.classifier_text(text_tok.mean(dim=1))
         logits = self.classifier_fusion(fused)
         y = labels.float()
-        loss_image, loss_text, loss_fusion = self._bce(image_logits, y), self._bce(text_logits, y), self._bce(logits, y)
+        loss_image, loss_text = self.image_criterion(image_logits, y), self.text_criterion(text_logits, y)
+        loss_fusion = self.fusion_criterion(logits, y)
         loss = loss_image + loss_text + loss_fusion                                              # models/mmimdb.py:115-123
         if self.modalities_freezed and mode == "train":
             loss = loss_fusion
@@ -285,7 +318,10 @@ class MMIMDBMixerMultiLoss(_MultiLossModule):
 
     def _engine_cfg(self):
         cfg = super()._engine_cfg()
-        cfg["pos_weight"] = list(self.model_cfg.pos_weight)
+        pw = [c.pos_weight for c in (self.image_criterion, self.text_criterion, self.fusion_criterion)]
+        if not (torch.equal(pw[0], pw[1]) and torch.equal(pw[0], pw[2])):
+            raise RuntimeError("the fused engine takes one pos_weight for all three heads (models/mmimdb.py:47-50 builds them equal)")
+        cfg["pos_weight"] = pw[0].detach().cpu().tolist()          # the loaded buffers, not the cfg: a checkpoint may carry its own
         return cfg
 
     def _make_engine(self, cfg, batch_size, device, precision):

@@ -85,6 +85,7 @@ class TowerRuntime:
             self._keep["lnf"] = tuple(lnf)
         self.device = blocks[0]["ln1_w"].device if blocks else lnf[0].device
         self._param_ptrs, self._param_versions = ptrs, vers
+        self._packed_for = None            # new storage: whatever the packed copies hold belongs to the old one
         self._ensure_packed_buffers()
 
     def params_changed(self, blocks, lnf) -> bool:
@@ -115,8 +116,14 @@ class TowerRuntime:
     def mark_packed(self):
         self._packed_for = self._pack_versions()
 
+    def invalidate(self):
+        """Call after editing a weight in a way autograd's version counter does not see (`p.data.copy_()`, `p.data = ...`):
+        the next pack() then rebuilds the packed copies."""
+        self._packed_for = None
+
     def pack(self, force: bool = False):
-        """Refresh the packed MFMA-operand copies when the master weights changed."""
+        """Refresh the packed MFMA-operand copies when the master weights changed (detected through the tensors' version
+        counters and, in bind_params, their storage; `.data` edits need invalidate())."""
         if force or self._pack_versions() != self._packed_for:
             L.check(L.lib().m2m_pack_tower(C.byref(self.desc), L.stream_ptr()), "pack_tower")
             self.mark_packed()
@@ -323,6 +330,7 @@ class EmbedRuntime:
             raise RuntimeError(f"embedding weight: expected contiguous float32 with {self.D * self.K} elements")
         self.desc.w, self.desc.b = w.data_ptr(), b.data_ptr()
         self._keep["w"], self._keep["b"] = w, b
+        self._packed_for = None            # new storage: the packed copy belongs to the old one
         if "wn" not in self._keep:
             wn = torch.zeros(L.packed_bytes(self.prec, self.D, self.desc.Kp), dtype=torch.uint8, device=w.device)
             self.desc.wn = wn.data_ptr()

@@ -1,0 +1,327 @@
+"""GPU parity tests (-m gpu) of the exact configuration bench.py times, and of the callers either side of the path.
+
+  * the benchmark's kernel instantiations -- bf16 operands, M2-Mixer-B, dropout ON (p = 0.5: one-bit masks; p = 0.1:
+    16-bit draws), the two-tower grouped launches, and at batch 512 the column-split launches -- against the CPU oracle
+    fed the very keep-masks the kernels regenerate (m2m_dropout_mask);
+  * Adam's moments and the updated parameters against the oracle's optimizer state;
+  * MM-IMDb / MIMIC-H at the batch sizes of their configs and at a large batch;
+  * the epoch loop (every sample, ragged last batch) and the checkpoint round trip against the oracle.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gen_util as G
+from oracle import m2mixer_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+FP32_ATOL = 1e-3       # BASELINE.json north_star: logits within 1e-3 in fp32
+BF16_LOGITS = 3e-2     # bf16 operands, fp32 accumulate: absolute on O(1) logits
+BF16_GRAD_REL = 6e-2   # relative to the gradient tensor's max
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from m2_mixer_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12)
+
+
+def abserr(a, b):
+    return float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max())
+
+
+def engine_masks(eng, B):
+    """The keep-masks of every dropout site of the three towers at the engine's current step, in the oracle's layout."""
+    step, seed = int(eng.drop_step[0]), eng.seed
+    out = {}
+    for name, rt in ((eng.MODS[0], eng.t_a), (eng.MODS[1], eng.t_b), ("fusion", eng.t_fus)):
+        blocks = []
+        for b in range(rt.nblocks):
+            m = {"tok_h": rt.dropout_mask(b, 0, B, seed, step).view(B, rt.D, rt.T),
+                 "tok_o": rt.dropout_mask(b, 1, B, seed, step).view(B, rt.D, rt.N),
+                 "ch_h": rt.dropout_mask(b, 2, B, seed, step).view(B, rt.N, rt.Cp)[:, :, :rt.C],
+                 "ch_o": rt.dropout_mask(b, 3, B, seed, step).view(B, rt.N, rt.D)}
+            blocks.append({k: v.float().cpu() for k, v in m.items()})
+        out[name] = blocks
+    return out
+
+
+def p_effective(p):
+    """The keep probability is quantised to 16 bits; the kernels scale by 1 / keep_q."""
+    return 1 - round((1 - p) * 65536) / 65536
+
+
+def assert_preds_match(pred, logits_ref, tol):
+    """Class predictions must be identical wherever the oracle's top-2 margin exceeds what the tolerance can flip."""
+    top2 = logits_ref.topk(2, dim=1).values
+    decided = (top2[:, 0] - top2[:, 1]) > 2 * tol
+    assert decided.float().mean() > 0.5
+    assert torch.equal(pred.cpu().long()[decided], logits_ref.argmax(1)[decided])
+
+
+@pytest.mark.parametrize("p_drop,B", [(0.5, 40), (0.5, 13), (0.1, 40), (0.1, 13), (0.5, 512)])
+def test_bench_instantiation_with_dropout_vs_oracle(p_drop, B, dev):
+    """bf16, M2-Mixer-B, dropout on, through the launches the benchmark's graph holds (B = 512: exactly bench.py's
+    configuration; B = 40 / 13: the same templates with ragged tiles).  The oracle gets the masks the kernels draw."""
+    from m2_mixer_amd.engine import AVMnistEngine
+    cfg = dict(G.AVMNIST["B"], dropout=p_drop)
+    eng = AVMnistEngine(cfg, B, device=dev, precision="bf16", lr=1e-2, init=False)
+    shapes = G.avmnist_shapes(cfg)
+    params = dict(G.make_params(shapes, 17))
+    eng.load_state_dict(params)
+    image, audio, labels = G.avmnist_batch(B, 18, cfg)
+    eng.forward_backward(image.to(dev), audio.to(dev), labels.to(dev))
+    torch.cuda.synchronize()
+    masks = engine_masks(eng, B)
+    keep = float(np.mean([m["ch_h"].mean() for m in masks["image"]]))
+    assert abs(keep - (1 - p_drop)) < 0.02, keep
+    ref = O.avmnist_train_step(image, audio, labels, dict(params), cfg, {}, lr=1e-2, drop_p=p_effective(p_drop), masks=masks)
+    for i, k in enumerate(("image_logits", "audio_logits", "logits")):
+        assert abserr(eng.logits[i], ref[k]) < BF16_LOGITS, k
+        assert_preds_match(eng.preds[i], ref[k], BF16_LOGITS)
+    for i, k in enumerate(("loss_image", "loss_audio", "loss_fusion", "loss")):
+        assert abs(float(eng.losses[i]) - float(ref[k])) < 2e-2, k
+    for k, g in ref["grads"].items():
+        if k.endswith("token_mix.2.net.3.bias"):       # exactly-zero true gradient
+            continue
+        assert relerr(eng.grads[k], g) < BF16_GRAD_REL, k
+
+
+@pytest.mark.parametrize("size,B,seed", [("S", 8, 11), ("M", 4, 21), ("B", 8, 12)])
+def test_adam_moments_and_parameters_vs_oracle(size, B, seed, dev):
+    """Two optimisation steps, fp32 mode: Adam's first / second moments (linear / quadratic in the gradient, hence
+    well-conditioned) against the oracle's optimizer state, and the parameters wherever the gradient is not ~0 (Adam's
+    first step moves a parameter by lr * g / (|g| + eps): at |g| ~ eps that is noise).  A no-op or mis-scaled update
+    moves the parameters by up to lr = 1e-2 from the oracle's: the tolerance is 2 % of that."""
+    from m2_mixer_amd.engine import AVMnistEngine
+    cfg = dict(G.AVMNIST[size], dropout=0.0)
+    eng = AVMnistEngine(cfg, B, device=dev, precision="fp32", lr=1e-2, init=False)
+    shapes = G.avmnist_shapes(cfg)
+    params = dict(G.make_params(shapes, seed))
+    eng.load_state_dict(params)
+    image, audio, labels = G.avmnist_batch(B, seed + 1, cfg)
+    gb = (image.to(dev), audio.to(dev), labels.to(dev))
+    state, significant = {}, {k: torch.ones(s, dtype=torch.bool) for k, s in shapes.items()}
+    for step in (1, 2):
+        ref = O.avmnist_train_step(image, audio, labels, params, cfg, state, lr=1e-2)      # updates params / state in place
+        eng.train_step(*gb)
+        torch.cuda.synchronize()
+        assert float(eng.adam_state[0]) == step and float(eng.flat_g.abs().max()) == 0.0
+        for k in shapes:
+            if k.endswith("token_mix.2.net.3.bias"):
+                continue
+            g = ref["grads"][k]
+            gmax = float(g.abs().max())
+            assert abserr(eng.exp_avg[k], state["m"][k]) < 1e-3 * max(gmax, 1e-6), (step, k)
+            assert abserr(eng.exp_avg_sq[k], state["v"][k]) < 2e-3 * max(gmax * gmax, 1e-12), (step, k)
+            significant[k] &= g.abs() > max(1e-6, 1e-3 * gmax)
+            sel = significant[k]
+            if bool(sel.any()):
+                err = (eng.params[k].cpu() - params[k])[sel].abs().max()
+                assert float(err) < 2e-4, (step, k, float(err))
+    assert sum(int(v.sum()) for v in significant.values()) > 0.5 * eng.n_params
+
+
+@pytest.mark.parametrize("task,B", [("mimic", 128), ("mmimdb", 32), ("mmimdb", 256)])
+def test_wide_models_bf16_at_config_batches_vs_oracle(task, B, dev):
+    """MIMIC-H at its cfg batch (128), MM-IMDb at its cfg batch (32 per GPU) and at 256 (the D = 256 token backward
+    walks several column blocks per workgroup there): bf16 against autograd through the oracle."""
+    from m2_mixer_amd.engine import MimicEngine, MMIMDBEngine
+    if task == "mimic":
+        cfg = dict(G.MIMIC_H, dropout=0.0)
+        shapes, batch = G.mimic_shapes(cfg), G.mimic_batch(B, 61, cfg)
+        eng = MimicEngine(cfg, B, device=dev, precision="bf16", lr=1e-3, init=False)
+        fwd = lambda p: O.mimic_forward(*batch, p, cfg)
+        names = ("logits_static", "logits_time", "logits")
+    else:
+        cfg = dict(G.MMIMDB, dropout=0.0)
+        shapes, batch = G.mmimdb_shapes(cfg), G.mmimdb_batch(B, 62, cfg)
+        eng = MMIMDBEngine(cfg, B, device=dev, precision="bf16", lr=1e-3, init=False)
+        fwd = lambda p: O.mmimdb_forward(*batch, p, cfg, torch.tensor(cfg["pos_weight"]))
+        names = ("image_logits", "text_logits", "logits")
+    params = dict(G.make_params(shapes, 63))
+    eng.load_state_dict(params)
+    eng.forward_backward(*(t.to(dev) for t in batch))
+    torch.cuda.synchronize()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = fwd(leaves)
+    ref["loss"].backward()
+    for i, k in enumerate(names):
+        assert abserr(eng.logits[i], ref[k]) < BF16_LOGITS * max(1.0, float(ref[k].detach().abs().max())), k
+    assert abs(float(eng.losses[3]) - float(ref["loss"].detach())) < 2e-2 * max(1.0, abs(float(ref["loss"].detach())))
+    for k, leaf in leaves.items():
+        if k.endswith("token_mix.2.net.3.bias"):
+            continue
+        assert relerr(eng.grads[k], leaf.grad) < BF16_GRAD_REL, k
+
+
+def test_capture_leaves_the_model_untouched_and_graphs_keep_their_own_outputs(dev):
+    """capture() needs warm-up steps; it must put back everything they changed.  A multi-step graph has its own
+    per-step output buffers and must not redirect the single-step graph's."""
+    from m2_mixer_amd.engine import AVMnistEngine
+    cfg, B = dict(G.AVMNIST["S"]), 32
+    batch = tuple(t.to(dev) for t in G.avmnist_batch(B, 70, cfg))
+    eng = AVMnistEngine(cfg, B, device=dev, precision="bf16", lr=1e-3, seed=9)
+    before = [t.clone() for t in (eng.flat_p, eng.flat_m, eng.flat_v, eng.flat_g, eng.adam_state, eng.drop_step)]
+    single = eng.capture(*batch)
+    multi = eng.capture(*batch, steps=3)
+    torch.cuda.synchronize()
+    for a, b in zip(before, (eng.flat_p, eng.flat_m, eng.flat_v, eng.flat_g, eng.adam_state, eng.drop_step)):
+        assert torch.equal(a, b)
+    # same state, same counters: the eager step, the single-step graph and step 0 of the 3-step graph agree
+    ref = AVMnistEngine(cfg, B, device=dev, precision="bf16", lr=1e-3, seed=9)
+    ref.train_step(*batch)
+    out1 = single().clone()
+    torch.cuda.synchronize()
+    assert torch.allclose(out1, ref.losses, rtol=0, atol=2e-3)
+    assert out1.shape == (4,) and single.losses is eng.losses
+    outm = multi()
+    torch.cuda.synchronize()
+    assert outm.shape == (3, 4) and multi.losses is outm
+    assert torch.equal(eng.losses, out1), "the multi-step graph must not write the single-step graph's loss buffer"
+    assert float(eng.adam_state[0]) == 4.0 and int(eng.drop_step[0]) == 4
+
+
+def _oracle_epoch(data, split, batch_size, params, cfg):
+    """What the reference's validation loop accumulates (modules/train_test_module.py:95-113): step losses and hits."""
+    image, audio, labels = (t.cpu() for t in data.splits[split])
+    losses, hits, n = [], np.zeros(3), labels.shape[0]
+    for lo in range(0, n, batch_size):
+        sl = slice(lo, min(lo + batch_size, n))
+        out = O.avmnist_forward(image[sl], audio[sl], labels[sl], params, cfg)
+        losses.append([float(out[k]) for k in ("loss_image", "loss_audio", "loss_fusion", "loss")] + [sl.stop - sl.start])
+        hits += [int((out[k] == labels[sl]).sum()) for k in ("preds_image", "preds_audio", "preds")]
+    return np.array(losses), hits
+
+
+def test_run_epoch_covers_every_sample_and_matches_the_oracle(dev, tmp_path):
+    """f1 / f2: validation over a split whose size is not a multiple of the batch (the reference keeps the last partial
+    batch, datasets/avmnist.py:180-190): accumulated losses and all three heads' hit counts against the oracle evaluated
+    over the same split; then one training epoch with a ragged last batch advances Adam once per batch."""
+    from test_host_cpu import _write_avmnist
+    from m2_mixer_amd.data import ResidentAVMnist, run_epoch
+    from m2_mixer_amd.engine import AVMnistEngine
+    root = str(tmp_path / "avmnist")
+    _write_avmnist(root, 300, 37, seed=5, learnable=True)           # train 275, val 25, test 37
+    data = ResidentAVMnist(root, device=dev)
+    cfg, B = dict(G.AVMNIST["S"], dropout=0.0), 16
+    eng = AVMnistEngine(cfg, B, device=dev, precision="fp32", lr=1e-3, init=False)
+    params = dict(G.make_params(G.avmnist_shapes(cfg), 77))
+    eng.load_state_dict(params)
+    for split in ("val", "train"):
+        got = run_epoch(eng, data, split, B, train=False)
+        ls, hits = _oracle_epoch(data, split, B, params, cfg)
+        n = int(ls[:, 4].sum())
+        assert got["samples"] == n == data.splits[split][2].shape[0] and got["steps"] == len(ls)
+        assert n % B != 0, "the split must end in a partial batch for this test to mean anything"
+        assert abs(got["loss"] - float((ls[:, 3] * ls[:, 4]).sum() / n)) < FP32_ATOL
+        assert abs(got["loss_step_mean"] - float(ls[:, 3].mean())) < FP32_ATOL
+        for j, k in enumerate(("loss_image", "loss_audio", "loss_fusion")):
+            assert abs(got[k] - float(ls[:, j].mean())) < FP32_ATOL, k
+        assert [got["hits_image"], got["hits_audio"], got["hits"]] == [int(h) for h in hits]
+    # training: 275 = 17 x 16 + 3 -> 18 optimizer steps, the last one through the 3-sample sibling engine
+    replay = eng.capture(*next(iter(data.batches("train", B))))
+    tr = run_epoch(eng, data, "train", B, train=True, replay=replay)
+    torch.cuda.synchronize()
+    assert tr["steps"] == 18 and tr["samples"] == 275 and float(eng.adam_state[0]) == 18.0
+    state, p2 = {}, dict(params)
+    image, audio, labels = (t.cpu() for t in data.splits["train"])
+    for lo in range(0, 275, B):
+        sl = slice(lo, min(lo + B, 275))
+        O.avmnist_train_step(image[sl], audio[sl], labels[sl], p2, cfg, state, lr=1e-3)
+    va, (ls, hits) = run_epoch(eng, data, "val", B, train=False), _oracle_epoch(data, "val", B, p2, cfg)
+    assert abs(va["loss"] - float((ls[:, 3] * ls[:, 4]).sum() / ls[:, 4].sum())) < 5e-3
+
+
+def _lightning_ckpt(path, state_dict, epoch=3):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    torch.save({"epoch": epoch, "global_step": 100, "pytorch-lightning_version": "1.8.6",
+                "state_dict": {k: v.clone() for k, v in state_dict.items()}, "optimizer_states": [], "lr_schedulers": []}, path)
+    return path
+
+
+def test_checkpoint_to_predictions_round_trip_vs_oracle(dev, tmp_path):
+    """f4 on the GPU: oracle-seeded weights written in Lightning's `.ckpt` layout under the reference's key names ->
+    load_from_checkpoint -> to_engine -> evaluate: logits within 1e-3 (fp32), class predictions bit-exact against the
+    oracle; test_preds.pt has the reference's keys and shapes (models/avmnist.py:382-398).  Then MM-IMDb, whose reference
+    state_dict carries the loss modules' pos_weight buffers; and an engine's Adam state through optimizer_states."""
+    from m2_mixer_amd import models as MD
+    c = G.AVMNIST["S"]
+    mods = {"image": dict(c["image"], block_type="MLPMixer"), "audio": dict(c["audio"], block_type="MLPMixer"),
+            "multimodal": dict(c["multimodal"], block_type="FusionMixer", fusion_function="ConcatFusion"),
+            "classification": dict(classifier="StandardClassifier", num_classes=10, input_shape=[16, 49, c["multimodal"]["hidden_dim"]])}
+    cfg, ocfg = {"dropout": 0.1, "modalities": mods}, {"lr": 1e-2, "scheduler_patience": 2}
+    params = G.make_params(G.avmnist_shapes(c), 81)
+    ck = _lightning_ckpt(str(tmp_path / "version_0" / "checkpoints" / "epoch=3-step=100.ckpt"), params)
+    net = MD.AVMnistMixerMultiLoss.load_from_checkpoint(ck, model_cfg=cfg, optimizer_cfg=dict(ocfg)).to(dev)
+    B = 24
+    image, audio, labels = G.avmnist_batch(2 * B, 82, c)
+    eng = net.to_engine(B, precision="fp32")
+    outs = []
+    for lo in (0, B):
+        sl = slice(lo, lo + B)
+        res = eng.evaluate(image[sl].to(dev), audio[sl].to(dev), labels[sl].to(dev))
+        torch.cuda.synchronize()
+        ref = O.avmnist_forward(image[sl], audio[sl], labels[sl], params, c)
+        for k in ("logits", "image_logits", "audio_logits"):
+            assert abserr(res[k], ref[k]) < FP32_ATOL, k
+        for k in ("preds", "preds_image", "preds_audio"):
+            assert torch.equal(res[k].cpu().long(), ref[k]), k
+        outs.append({"labels": labels[sl], **{k: res[k].clone() for k in net.TEST_PRED_KEYS if k != "labels"}})
+    dump = torch.load(net.save_test_preds(outs))
+    assert os.path.dirname(net.checkpoint_path) == str(tmp_path / "version_0" / "checkpoints")
+    assert sorted(dump) == sorted(["preds", "preds_image", "preds_audio", "labels", "image_logits", "audio_logits", "logits"])
+    assert dump["logits"].shape == (2 * B, 10) and dump["preds"].shape == (2 * B,)
+    full = O.avmnist_forward(image, audio, labels, params, c)
+    assert torch.equal(dump["preds"].long(), full["preds"]) and abserr(dump["logits"], full["logits"]) < FP32_ATOL
+    # the module path (torch autograd over the HIP towers) agrees with the engine on the loaded weights
+    net.eval()
+    with torch.no_grad():
+        mo = net.shared_step({"image": image[:B].to(dev), "audio": audio[:B].to(dev), "label": labels[:B].to(dev)}, mode="val")
+    assert abserr(mo["logits"], full["logits"][:B]) < BF16_LOGITS        # module default precision is bf16
+    # ---- an engine's training state through save_checkpoint(engine=...) and back
+    eng.train_step(image[:B].to(dev), audio[:B].to(dev), labels[:B].to(dev))
+    torch.cuda.synchronize()
+    out = net.save_checkpoint(str(tmp_path / "resume" / "last.ckpt"), epoch=4, global_step=101, engine=eng)
+    raw = torch.load(out, weights_only=True)
+    assert len(raw["optimizer_states"]) == 1 and len(raw["optimizer_states"][0]["state"]) == len(eng.shapes)
+    again = MD.AVMnistMixerMultiLoss.load_from_checkpoint(out, model_cfg=cfg, optimizer_cfg=dict(ocfg)).to(dev)
+    eng2 = again.to_engine(B, precision="fp32")
+    eng2.load_optimizer_state_dict(raw["optimizer_states"][0])
+    assert torch.equal(eng2.flat_p, eng.flat_p) and torch.equal(eng2.flat_m, eng.flat_m) and torch.equal(eng2.flat_v, eng.flat_v)
+    assert float(eng2.adam_state[0]) == 1.0
+    # torch.optim.Adam accepts the same optimizer state (the layout Lightning stores)
+    opt = again.configure_optimizers()["optimizer"]
+    opt.load_state_dict(raw["optimizer_states"][0])
+    # ---- MM-IMDb: the reference's state_dict ends with the three criteria's pos_weight buffers
+    cm = G.MMIMDB
+    mmods = {"image": dict(cm["image"], block_type="MLPMixer"), "text": dict(cm["text"], block_type="MLPMixer"),
+             "multimodal": dict(cm["multimodal"], block_type="FusionMixer", fusion_function="ConcatFusion"),
+             "classification": dict(classifier="StandardClassifier", num_classes=cm["num_classes"],
+                                    input_shape=[16, 49, cm["multimodal"]["hidden_dim"]])}
+    mcfg = {"dropout": 0.0, "modalities": mmods, "pos_weight": [1.0] * cm["num_classes"]}       # cfg value differs from the checkpoint's
+    mparams = G.make_params(G.mmimdb_shapes(cm), 83)
+    pw = torch.tensor(cm["pos_weight"], dtype=torch.float32)
+    sd = dict(mparams, **{f"{n}_criterion.pos_weight": pw.clone() for n in ("image", "text", "fusion")})
+    mck = _lightning_ckpt(str(tmp_path / "mm" / "last.ckpt"), sd)
+    mnet = MD.MMIMDBMixerMultiLoss.load_from_checkpoint(mck, model_cfg=mcfg, optimizer_cfg={"lr": 1e-3}).to(dev)
+    Bm = 4
+    mi, mt, ml = G.mmimdb_batch(Bm, 84, cm)
+    meng = mnet.to_engine(Bm, precision="fp32")
+    assert torch.equal(meng.pos_weight.cpu(), pw), "the checkpoint's pos_weight, not the cfg's, must reach the heads kernel"
+    mres = meng.evaluate(mi.to(dev), mt.to(dev), ml.to(dev))
+    torch.cuda.synchronize()
+    mref = O.mmimdb_forward(mi, mt, ml, mparams, cm, pw)
+    assert abserr(mres["logits"], mref["logits"]) < FP32_ATOL and abs(float(mres["loss"]) - float(mref["loss"])) < FP32_ATOL
+    assert torch.equal(mres["preds"].cpu().long(), mref["preds"])
+    assert list(meng.state_dict().keys()) == list(sd.keys())

@@ -169,10 +169,8 @@ def test_avmnist_step_fp32_vs_reference_golden(size, B, seed, dev):
     torch.cuda.synchronize()
     check(gold, "step1//logits", eng.logits[2], 5e-3)
     assert np.array_equal(eng.preds[2].cpu().numpy(), gold["step1//preds"])
-    for k in shapes:
-        if k.endswith("token_mix.2.net.3.bias"):      # zero true gradient: Adam amplifies rounding noise (see test_oracle_golden)
-            continue
-        check(gold, f"after2//{k}", eng.params[k], 2.5e-2, 0.0, what="param ")
+    # (the parameters after the two Adam steps, and Adam's moments, are checked against the oracle's optimizer state in
+    #  tests/test_gpu_bench_path.py::test_adam_moments_and_parameters_vs_oracle, at 2 % of lr)
 
 
 @pytest.mark.parametrize("size,B", [("S", 8), ("B", 40), ("B", 13)])      # 13: ragged row tiles in every launch
@@ -687,8 +685,8 @@ def test_task_modules_shared_step_vs_reference_golden(task, dev):
         image, text, labels = (t.to(dev) for t in G.mmimdb_batch(B, 52, c))
         batch = {"image": image, "text": text, "label": labels}
         names = {k: k for k in ("logits", "image_logits", "text_logits", "loss", "loss_image", "loss_text", "loss_fusion")}
-    assert list(net.state_dict().keys()) == list(shapes.keys()), "state-dict keys / creation order must match the reference"
-    net.load_state_dict(G.make_params(shapes, seed))
+    assert [k for k, _ in net.named_parameters()] == list(shapes.keys()), "parameter names / creation order must match the reference"
+    net.load_state_dict(G.make_params(shapes, seed), strict=False)     # (MM-IMDb: the criteria's pos_weight buffers keep the cfg values)
     net.train()
     out = net.shared_step(batch, mode="train")
     out["loss"].backward()

@@ -195,7 +195,9 @@ def _gloo_worker(rank, world, port, q):
     assert torch.equal(keep.reduced_bf16.float(), torch.full((64,), 3.0))
     assert parallel.GradSync(compress="bf16").reduced_bf16 is None and parallel.GradSync().reduced_bf16 is None
     tmax = parallel.max_over_ranks(1.0 + rank, device="cpu")
-    q.put((rank, flat.clone(), scale, p.clone(), flat16.clone(), scale16, tmax, parallel.shard_batch_seed(1234, rank)))
+    # plain lists, not tensors: a tensor crosses a torch.multiprocessing queue as a shared-memory handle that the parent
+    # must open while this process still lives -- a worker that exits first makes q.get() raise EOFError
+    q.put((rank, flat.tolist(), scale, p.tolist(), flat16.tolist(), scale16, tmax, parallel.shard_batch_seed(1234, rank)))
     torch.distributed.destroy_process_group()
 
 
@@ -213,9 +215,9 @@ def test_grad_sync_gloo_world2():
         assert p.exitcode == 0
     for rank, flat, scale, prm, flat16, scale16, tmax, seed in out:
         assert scale == 0.5 and scale16 == 0.5
-        assert torch.equal(flat, torch.arange(1000, dtype=torch.float32) * 3)      # sum over ranks
-        assert torch.equal(prm, torch.zeros(10))                                     # broadcast from rank 0
-        assert torch.equal(flat16, torch.full((64,), 3.0))
+        assert flat == (torch.arange(1000, dtype=torch.float32) * 3).tolist()      # sum over ranks
+        assert prm == [0.0] * 10                                                     # broadcast from rank 0
+        assert flat16 == [3.0] * 64
         assert tmax == 2.0
         assert seed == 1234 + rank
 
@@ -251,7 +253,9 @@ def test_task_module_surface_and_no_cpu_path():
         net = cls(cfg, {"lr": 1e-2, "scheduler_patience": 2})
         shapes = shapes_fn(c)
         sd = net.state_dict()
-        assert list(sd.keys()) == list(shapes.keys()), task
+        extra = ["image_criterion.pos_weight", "text_criterion.pos_weight", "fusion_criterion.pos_weight"] if task == "mmimdb" else []
+        assert list(sd.keys()) == list(shapes.keys()) + extra, task       # parameters, then the loss modules' buffers
+        assert [k for k, _ in net.named_parameters()] == list(shapes.keys()), task
         assert all(tuple(sd[k].shape) == tuple(shapes[k]) for k in shapes), task
         opt = net.configure_optimizers()
         assert isinstance(opt["optimizer"], torch.optim.Adam) and opt["optimizer"].defaults["lr"] == 1e-2
@@ -298,16 +302,23 @@ def test_checkpoint_io_lightning_layout(tmp_path):
     del sys.modules["omegaconf_not_installed_here"]
     with pytest.raises(Exception):
         torch.load(ck, weights_only=False)                       # the plain unpickler cannot resolve the foreign class
-    net = MD.AVMnistMixerMultiLoss.load_from_checkpoint(ck, optimizer_cfg=dict(ocfg), model_cfg=cfg)
+    # a file that needs the full unpickler is refused unless the caller vouches for it (unpickling runs code from the file)
+    with pytest.raises(RuntimeError, match="trusted=True"):
+        MD.AVMnistMixerMultiLoss.load_from_checkpoint(ck, optimizer_cfg=dict(ocfg), model_cfg=cfg)
+    net = MD.AVMnistMixerMultiLoss.load_from_checkpoint(ck, optimizer_cfg=dict(ocfg), model_cfg=cfg, trusted=True)
     assert net.checkpoint_path == str(ck) and net.current_epoch == 3
     for (k, a), (k2, b) in zip(src.state_dict().items(), net.state_dict().items()):
         assert k == k2 and torch.equal(a, b), k
     with pytest.raises(TypeError):
         MD.AVMnistMixerMultiLoss.load_from_checkpoint(ck)
-    # our own checkpoints go through the same door
+    # our own checkpoints go through the same door -- with the safe loader (tensors and plain containers only)
     out = net.save_checkpoint(tmp_path / "own" / "last.ckpt", epoch=7, global_step=9)
     again = MD.AVMnistMixerMultiLoss.load_from_checkpoint(out, optimizer_cfg=dict(ocfg), model_cfg=cfg)
     assert again.current_epoch == 7 and all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), again.state_dict().values()))
+    raw = torch.load(out, weights_only=True)
+    from packaging.version import Version
+    assert Version(raw["pytorch-lightning_version"]) == Version("1.8.6")      # Lightning's migration parses this field
+    assert raw["optimizer_states"] == [] and raw["lr_schedulers"] == []
     # test_preds.pt next to the checkpoint, the reference's keys, batches concatenated
     outs = [{k: torch.full((4, 10) if "logits" in k else (4,), float(i)) for k in net.TEST_PRED_KEYS} for i in range(3)]
     path = net.save_test_preds(outs)
@@ -316,6 +327,36 @@ def test_checkpoint_io_lightning_layout(tmp_path):
     assert sorted(dump) == sorted(["preds", "preds_image", "preds_audio", "labels", "image_logits", "audio_logits", "logits"])
     assert dump["logits"].shape == (12, 10) and dump["preds"].shape == (12,) and float(dump["labels"][-1]) == 2.0
     assert "preds_text" in MD.MMIMDBMixerMultiLoss.TEST_PRED_KEYS and MD.MimicMixerMultiLoss.TEST_PRED_KEYS == ()
+
+
+def test_mmimdb_checkpoint_keys_round_trip_with_the_reference_layout(tmp_path):
+    """The reference's MMIMDBMixerMultiLoss holds three nn.BCEWithLogitsLoss(pos_weight=...) submodules
+    (models/mmimdb.py:47-50), so every reference state_dict ends with `image_criterion.pos_weight`,
+    `text_criterion.pos_weight`, `fusion_criterion.pos_weight`.  Keys built here from the reference's construction order
+    (the class itself needs pytorch_lightning to import): towers, fusion mixer, heads, then the three buffers."""
+    import torch
+    from m2_mixer_amd import models as MD
+    c = G.MMIMDB
+    mods = {"image": dict(c["image"], block_type="MLPMixer"), "text": dict(c["text"], block_type="MLPMixer"),
+            "multimodal": dict(c["multimodal"], block_type="FusionMixer", fusion_function="ConcatFusion"),
+            "classification": dict(classifier="StandardClassifier", num_classes=c["num_classes"],
+                                   input_shape=[16, 49, c["multimodal"]["hidden_dim"]])}
+    cfg, ocfg = {"dropout": 0.0, "modalities": mods, "pos_weight": c["pos_weight"]}, {"lr": 1e-3}
+    ref_keys = list(G.mmimdb_shapes(c)) + ["image_criterion.pos_weight", "text_criterion.pos_weight", "fusion_criterion.pos_weight"]
+    net = MD.MMIMDBMixerMultiLoss(cfg, dict(ocfg))
+    assert list(net.state_dict().keys()) == ref_keys
+    # a reference-written checkpoint: same keys, its own pos_weight values
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    pw = torch.arange(1, c["num_classes"] + 1, dtype=torch.float32)
+    for k in ref_keys[-3:]:
+        sd[k] = pw.clone()
+    ck = tmp_path / "ref.ckpt"
+    torch.save({"state_dict": sd, "epoch": 2, "global_step": 10, "pytorch-lightning_version": "1.8.6"}, ck)
+    got = MD.MMIMDBMixerMultiLoss.load_from_checkpoint(ck, model_cfg=cfg, optimizer_cfg=dict(ocfg))      # strict=True
+    assert torch.equal(got.fusion_criterion.pos_weight, pw) and got._engine_cfg()["pos_weight"] == pw.tolist()
+    # and back: what save_checkpoint writes has exactly the reference's key list (a strict reference-side load succeeds)
+    out = got.save_checkpoint(tmp_path / "own.ckpt")
+    assert list(torch.load(out, weights_only=True)["state_dict"].keys()) == ref_keys
 
 
 def _write_avmnist(root, n_train, n_test, seed=0, learnable=False):
@@ -346,13 +387,19 @@ def test_resident_dataset_format_splits_and_sharding(tmp_path):
     assert ds.splits["val"][2].shape[0] == 20 and ds.splits["test"][2].shape[0] == 30        # 11 : 1 as 55 000 : 5 000
     raw = np.load(os.path.join(root, "image", "train_data.npy"))
     assert np.array_equal(image[:, 0].reshape(220, 784).numpy(), raw[:220])
+    # every sample is served: the reference's DataLoaders keep the ragged last batch (drop_last=False, datasets/avmnist.py:180-190)
     got = list(ds.batches("train", 50))
-    assert len(got) == 4 == ds.num_batches("train", 50)
+    assert len(got) == 5 == ds.num_batches("train", 50) and [b[2].shape[0] for b in got] == [50, 50, 50, 50, 20]
+    assert torch.equal(torch.cat([b[2] for b in got]), labels)
+    assert len(list(ds.batches("train", 50, drop_last=True))) == 4 == ds.num_batches("train", 50, drop_last=True)
     assert got[1][0].data_ptr() == image[50:100].data_ptr(), "unshuffled single-rank batches must be views"
-    # two ranks: disjoint strided shards, as DistributedSampler(shuffle=False) hands them out
-    r0 = torch.cat([b[2] for b in ResidentAVMnist(root, "cpu", 0, 2).batches("train", 55)])
-    r1 = torch.cat([b[2] for b in ResidentAVMnist(root, "cpu", 1, 2).batches("train", 55)])
+    assert [b[2].shape[0] for b in ds.batches("val", 8)] == [8, 8, 4]
+    # two ranks: disjoint strided shards that together cover the split, as DistributedSampler(shuffle=False) hands them out
+    r0 = torch.cat([b[2] for b in ResidentAVMnist(root, "cpu", 0, 2).batches("train", 50)])
+    r1 = torch.cat([b[2] for b in ResidentAVMnist(root, "cpu", 1, 2).batches("train", 50)])
     assert torch.equal(r0, labels[0::2]) and torch.equal(r1, labels[1::2])
+    three = [torch.cat([b[2] for b in ResidentAVMnist(root, "cpu", r, 3).batches("test", 4)]) for r in range(3)]
+    assert [t.shape[0] for t in three] == [10, 10, 10] and sorted(torch.cat(three).tolist()) == sorted(ds.splits["test"][2].tolist())
     # shuffled test split: a permutation
     t = torch.cat([b[2] for b in ds.batches("test", 10, shuffle=True, generator=torch.Generator().manual_seed(1))])
     assert sorted(t.tolist()) == sorted(ds.splits["test"][2].tolist())
