@@ -8,7 +8,8 @@
 Prints ONE JSON line on rank 0 (contract in the task statement): metric/value/unit/..., plus
   "roofline"     dominant kernel: algorithmic FLOPs per launch / its mean duration (HIP events on the launch
                  stream) against the dense bf16 MFMA peak,
-  "cpu_baseline" the CPU oracle's training step timed on this box's host cores (rank 0, N = 1 only).
+  "cpu_baseline" the CPU oracle's training step timed on this box's host cores (rank 0, N = 1 only); the other CPU points of
+                 BASELINE.md section 3 in "cpu_baselines_other_configs"; "eager_rocm_baseline": the same eager ops on this GPU.
 Synthetic data of the dataset's shape (image U[0,1) (B,1,28,28), audio U[0,1) (B,1,112,112), labels randint(10),
 numpy default_rng(1234 + rank)), torch-default random init under seed 42.
 """
@@ -87,45 +88,113 @@ def make_batch(cfg, B, seed, device):
     return image, audio, labels
 
 
-def cpu_baseline(cfg, B, budget_s=20.0):
-    """The CPU oracle's training step (fwd + autograd bwd + Adam, dropout masks drawn like nn.Dropout) on all
-    host cores; bounded to ~budget_s of wall-clock."""
+def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import gen_util as G
     from oracle import m2mixer_oracle as O
+    return G, O
+
+
+def host_cores():
     # the GPU box gives one job a 16-core share whatever os.cpu_count() says: oversubscribing it is pathological
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    threads = max(1, min(avail, int(os.environ.get("M2M_CPU_THREADS", "16"))))
-    torch.set_num_threads(threads)
-    shapes = G.avmnist_shapes(cfg)
-    params = dict(G.make_params(shapes, 42))
-    image, audio, labels = (t.cpu() for t in make_batch(cfg, B, 1234, "cpu"))
-    state, gen = {}, torch.Generator().manual_seed(0)
-    p = cfg["dropout"]
+    return max(1, min(avail, int(os.environ.get("M2M_CPU_THREADS", "16"))))
+
+
+def baseline_point(name, cfg, B, device, threads=None, budget_s=10.0, autocast=None):
+    """The oracle's training step (fwd + autograd bwd + Adam, dropout masks drawn like nn.Dropout) -- the restatement of
+    the reference's eager PyTorch path -- timed on `device`: the CPU (cpu_baseline, `threads` host threads) or, as
+    BASELINE config 2's "vs eager" comparator, the same eager ops on the GPU through torch-ROCm.  Bounded to ~budget_s."""
+    G, O = _oracle()
+    on_gpu = torch.device(device).type == "cuda"
+    if not on_gpu:
+        torch.set_num_threads(threads)
+    params = {k: v.to(device) for k, v in G.make_params(G.avmnist_shapes(cfg), 42).items()}
+    image, audio, labels = make_batch(cfg, B, 1234, device)
+    state, p = {}, cfg["dropout"]
+    gen = None if on_gpu else torch.Generator().manual_seed(0)
 
     def step():
-        masks = O.avmnist_random_masks(cfg, B, p, gen) if p > 0 else None
-        O.avmnist_train_step(image, audio, labels, params, cfg, state, lr=1e-2, drop_p=p, masks=masks)
+        masks = O.avmnist_random_masks(cfg, B, p, gen, device=device) if p > 0 else None
+        if autocast is not None:
+            with torch.autocast("cuda", dtype=autocast):
+                O.avmnist_train_step(image, audio, labels, params, cfg, state, lr=1e-2, drop_p=p, masks=masks)
+        else:
+            O.avmnist_train_step(image, audio, labels, params, cfg, state, lr=1e-2, drop_p=p, masks=masks)
+        if on_gpu:
+            torch.cuda.synchronize()
 
     t0 = time.perf_counter()
-    step()                                    # warm-up (allocator, thread pool)
+    step()                                    # warm-up (allocator, thread pool, kernel selection)
+    if on_gpu:
+        step()
+        t0 = time.perf_counter()
+        step()
     warm = time.perf_counter() - t0
-    log(f"cpu baseline: {threads} threads, first step {warm:.2f} s")
-    n = max(2, min(50, int(budget_s / max(warm, 1e-3))))
+    n = max(2, min(50, int(budget_s / max(warm, 1e-4))))
     t0 = time.perf_counter()
     for _ in range(n):
         step()
     dt = time.perf_counter() - t0
-    return {"value": round(B * n / dt, 2), "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": f"{n} training steps of the fp32 CPU oracle (oracle/m2mixer_oracle.py), batch {B}, "
-                      f"{dt / n * 1e3:.0f} ms/step, torch {torch.__version__} CPU"}
+    flops = total_train_flops(cfg, B)
+    what = (f"eager torch-ROCm ({'fp32' if autocast is None else 'bf16 autocast'})" if on_gpu
+            else f"fp32 CPU oracle (oracle/m2mixer_oracle.py), {threads} thread(s)")
+    return {"value": round(B * n / dt, 2), "unit": "samples/s", "cores": None if on_gpu else threads, "kind": "port",
+            "config": name, "gflops": round(flops * n / dt / 1e9, 1),
+            "sample": f"{n} training steps of the {what}, {name}, batch {B}, {dt / n * 1e3:.1f} ms/step, torch {torch.__version__}"}
+
+
+def cpu_baselines(budget_s=20.0):
+    """the north-star workload (M2-Mixer-B, batch 512) on all host cores -- the `cpu_baseline` of the
+    bench line -- plus config 1 (M2-Mixer-S, fp32, batch 32) and M2-Mixer-B at batch 32, on all cores and on one thread."""
+    cores = host_cores()
+    main = baseline_point("AV-MNIST M2-Mixer-B", CFG_B, 512, "cpu", cores, 0.55 * budget_s)
+    log(f"cpu baseline: {main['sample']}")
+    extra = []
+    for name, cfg, B, thr in (("AV-MNIST M2-Mixer-S (BASELINE config 1)", CFG_S, 32, cores), ("AV-MNIST M2-Mixer-S (BASELINE config 1)", CFG_S, 32, 1),
+                              ("AV-MNIST M2-Mixer-B", CFG_B, 32, cores), ("AV-MNIST M2-Mixer-B", CFG_B, 32, 1)):
+        extra.append(baseline_point(name, cfg, B, "cpu", thr, 0.1125 * budget_s))
+    torch.set_num_threads(cores)
+    return main, extra
 
 
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` without a torchrun environment: start N fresh rank processes (one per GPU) through
+    torch.distributed.run, BEFORE this process has made any GPU call, relay rank 0's JSON line and the ranks' stderr, and
+    return non-zero if any rank failed.  (The driver may equally start the ranks itself; then WORLD_SIZE is set and this
+    is skipped.)"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                                   # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    log(f"--gpus {n} without WORLD_SIZE: launching {n} ranks: {' '.join(cmd[1:8])} ...")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = []
+    for line in proc.stdout:
+        if line.lstrip().startswith("{"):
+            lines.append(line.strip())
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc != 0:
+        log(f"a rank failed (torch.distributed.run exit code {rc})")
+        return rc
+    if len(lines) != 1:
+        log(f"expected ONE JSON line from rank 0, got {len(lines)}")
+        return 1
+    print(lines[0], flush=True)
+    return 0
 
 
 def main():
@@ -149,14 +218,31 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--profile-steps", type=int, default=10, help="eager steps with HIP events around every launch")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous only: every rank joins the process group, the ranks agree on a MAX, rank 0 prints a JSON line "
+                         "(exercises the --gpus N launcher without a GPU: M2M_DIST_BACKEND=gloo)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))             # nothing has touched the GPU yet in this process
 
     from m2_mixer_amd import parallel
     from m2_mixer_amd.engine import AVMnistEngine
 
     rank, local_rank, world = parallel.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the job must run exactly one rank per requested GPU")
+    if world > 1:
+        assert torch.distributed.get_world_size() == args.gpus
+    if args.launch_check:
+        top = parallel.max_over_ranks(float(rank), "cpu" if torch.distributed.is_initialized() and torch.distributed.get_backend() == "gloo" else None)
+        if world > 1:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "world_size": world, "max_rank": top}), flush=True)
+        return
     dev = torch.device(f"cuda:{int(os.environ.get('M2M_FORCE_DEVICE', local_rank))}")      # override: single-GPU rehearsal of N > 1
     torch.cuda.set_device(dev)
     cfg = CFG_B if args.model == "B" else CFG_S
@@ -241,7 +327,7 @@ def main():
         "dtype": args.precision, "data": "synthetic",
         "config": {"workload": f"AV-MNIST M2-Mixer-{args.model}: fwd + bwd + Adam, dropout {cfg['dropout']}, per-GPU batch {B}, "
                                f"global batch {B * world}, {eng.n_params} params",
-                   "parallelism": f"dp{world}", "launch": "eager" if args.no_graph else ("hipGraph" if spg == 1 else f"hipGraph, {spg} steps per graph"),
+                   "parallelism": f"dp{world}", "world_size": world, "launch": "eager" if args.no_graph else ("hipGraph" if spg == 1 else f"hipGraph, {spg} steps per graph"),
                    "grad_allreduce": (compress or "fp32") if world > 1 else None, "preheat_ms": args.preheat_ms},
         "roofline": roof,
         "step_mfma_frac": round(world * B * args.steps / elapsed / world * flops_step / B / (peak * 1e12), 4),
@@ -250,8 +336,12 @@ def main():
         "final_loss": round(loss_end, 4),
     }
     if world == 1 and not args.no_cpu_baseline:
-        log("cpu baseline (oracle) ...")
-        out["cpu_baseline"] = cpu_baseline(cfg, B, args.cpu_budget)
+        # baselines, all outside the timed region: the eager path on this GPU (BASELINE config 2's comparator), then the CPU
+        log("eager torch-ROCm baseline (the oracle's ops on the GPU) ...")
+        out["eager_rocm_baseline"] = [baseline_point(f"AV-MNIST M2-Mixer-{args.model}", cfg, B, dev, budget_s=3.0, autocast=ac)
+                                      for ac in (None, torch.bfloat16)]
+        log("cpu baselines (oracle) ...")
+        out["cpu_baseline"], out["cpu_baselines_other_configs"] = cpu_baselines(args.cpu_budget)
     print(json.dumps(out), flush=True)
     finish()
 

@@ -2,7 +2,8 @@
 
 This file restates, in plain fp32/fp64 tensor arithmetic on the CPU, what the
 reference (bezirganyan/m2-mixer) computes on the training hot path.  It is the
-checker that tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+checker that tests/, __graft_entry__.smoke() and bench.py's baseline legs
+(cpu_baseline; the same eager ops timed on the GPU as the "vs eager" comparator)
 use; nothing under m2_mixer_amd/ imports it and the product path never routes
 through it.
 
@@ -313,15 +314,16 @@ def avmnist_train_step(image, audio, labels, params: Params, cfg: dict, opt_stat
     return out
 
 
-def avmnist_random_masks(cfg: dict, B: int, p: float, generator: Optional[torch.Generator] = None) -> dict:
+def avmnist_random_masks(cfg: dict, B: int, p: float, generator: Optional[torch.Generator] = None, device=None) -> dict:
     """Bernoulli keep-masks for every dropout site of the three towers (what nn.Dropout draws in the
-    reference's train mode); used by the cpu_baseline leg so that the CPU step does the same work."""
+    reference's train mode); used by bench.py's baseline legs so that the baseline step does the same work
+    (device: where to draw them -- the eager-GPU baseline draws on the GPU, as nn.Dropout would)."""
     def n_patch(c):
         return (c["image_size"][0] // c["patch_size"]) * (c["image_size"][1] // c["patch_size"])
 
     def tower(c, N):
         D, T, C = c["hidden_dim"], c["token_dim"], c["channel_dim"]
-        f = lambda *s: (torch.rand(*s, generator=generator) >= p).float()
+        f = lambda *s: (torch.rand(*s, generator=generator, device=device) >= p).float()
         return [{"tok_h": f(B, D, T), "tok_o": f(B, D, N), "ch_h": f(B, N, C), "ch_o": f(B, N, D)}
                 for _ in range(c["num_mixers"])]
 

@@ -229,6 +229,25 @@ def test_bench_cli_contract_help():
         assert flag in r.stdout
 
 
+def test_bench_gpus_n_launches_n_ranks_itself():
+    """`python bench.py --gpus 2` with no torchrun environment must start two rank processes itself (before touching the
+    GPU), relay rank 0's single JSON line and fail when a rank fails -- here over gloo, rendezvous only."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["M2M_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True,
+                       text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out == {"launch_check": True, "world_size": 2, "max_rank": 1.0}
+    # a torchrun-style environment whose world size disagrees with --gpus is refused
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True,
+                         text=True, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr
+
+
 def test_task_module_surface_and_no_cpu_path():
     """models.py mirrors the reference's task modules: built from cfg dicts through the registry, state-dict keys in the
     reference's creation order (checkpoint compatibility), optimizer as configured at models/avmnist.py:413-422 -- and,
