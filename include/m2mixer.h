@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define M2M_ABI_VERSION 12
+#define M2M_ABI_VERSION 13
 #define M2M_MAX_BLOCKS 8      /* MixerBlocks per m2m_tower; longer towers are chained by the caller */
 #define M2M_ROWS_PER_WG 16    /* token rows one workgroup keeps on chip */
 
@@ -88,6 +88,17 @@ typedef struct m2m_tower {
     float* ws_a;           /* two (B*N, D) fp32 workspaces; required only on the wide path (N > 8 or D > 128), where  */
     float* ws_b;           /* token mixing and channel mixing are separate launches and hand the stream over in HBM */
     m2m_block blk[M2M_MAX_BLOCKS];
+    /* ---- split path (optional; fused-class towers in bf16 at large batches, see csrc/split.h) -------------------------
+     * With these buffers present and B*N large enough, m2m_tower(s)_forward / _backward run every block as two launches:
+     * a per-sample launch (token mixing, LayerNorms, residual) and a channel-mixing launch whose workgroups own 128 token
+     * rows x 1/nsplit of the hidden columns, so each CU streams 1/nsplit of the weights for 8x the rows.  Results are the
+     * same up to fp32 summation order.  slabs == NULL (or nsplit < 2) keeps the one-launch-per-tower path. */
+    float* slabs;          /* nsplit x (B*N, D) fp32: partial results of the column-split launches                       */
+    int32_t nsplit;        /* slabs the buffer has room for (the library uses up to 8)                                     */
+    int32_t reserved0;
+    float* xres;           /* (B*N, D) fp32: residual / gradient stream carried between the launches                       */
+    void* a_nat[M2M_MAX_BLOCKS];   /* per block: LN2(x_mid) as packed NAT blocks [16-row tile][k-block], rows padded to 16 */
+    void* dy_nat[M2M_MAX_BLOCKS];  /* per block: d(channel MLP out) after its dropout mask, same layout                    */
 } m2m_tower;
 
 /* Patch embedding = Conv2d(Cin, D, (ph,pw), stride=(ph,pw)) + 'b c h w -> b (h w) c'

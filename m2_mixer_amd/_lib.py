@@ -17,10 +17,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("M2M_LIB_PATH", os.path.join(_HERE, "libm2mixer.so"))   # override: diagnostic builds
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 MAX_BLOCKS = 8
 ROWS_PER_WG = 16
 HCHN_PAD = 4096          # >= the pad between operand streams the library uses (csrc/tile.h M2M_HCHN_PAD)
+SPLIT_ROWS = 128         # token rows of a column-split channel workgroup (csrc/split.h SP_ROWS)
+SPLIT_MAX = 8            # column splits (slabs)
 PREC_BF16, PREC_F32 = 0, 1
 PREC_BY_NAME = {"bf16": PREC_BF16, "fp32": PREC_F32, "f32": PREC_F32}
 
@@ -43,7 +45,10 @@ class Tower(C.Structure):
                 ("Cp", C.c_int32), ("nblocks", C.c_int32), ("has_final_ln", C.c_int32),
                 ("p_drop", C.c_float), ("site_base", C.c_uint32),
                 ("lnf_w", _fp), ("lnf_b", _fp), ("g_lnf_w", _fp), ("g_lnf_b", _fp), ("x_final", _fp),
-                ("ws_a", _fp), ("ws_b", _fp), ("blk", Block * MAX_BLOCKS)]
+                ("ws_a", _fp), ("ws_b", _fp), ("blk", Block * MAX_BLOCKS),
+                # split path (csrc/split.h): slab buffer of the column-split launches, carry stream, per-block operand images
+                ("slabs", _fp), ("nsplit", C.c_int32), ("reserved0", C.c_int32), ("xres", _fp),
+                ("a_nat", _fp * MAX_BLOCKS), ("dy_nat", _fp * MAX_BLOCKS)]
 
 
 class TowerIO(C.Structure):

@@ -1,0 +1,96 @@
+// The "split" execution path of the fused-class towers (N <= 8, bf16) at large batches.
+//
+// Why it exists.  The fused path (tower_fwd.hip / tower_bwd.hip) keeps the 16 token rows of a workgroup on chip for the whole
+// tower, so EVERY workgroup streams EVERY block's channel-mixing weights from L2: FLOP per weight byte = rows per workgroup =
+// 16, and a CU takes in ~31 B/clk from L2 -- at batch 512 that caps the chain kernels near 10 % of the MFMA peak whatever the
+// instruction mix.  Here a block is two launches:
+//
+//   mix   launch (split_mix.hip)    one workgroup per 16 token rows (whole samples): sums the column-split partial results of
+//                                   the previous channel launch (+ bias, output dropout, residual), token mixing, LayerNorm-2,
+//                                   and writes the bf16 MFMA operand image of its rows (forward); the mirror image backward.
+//   chain launch (split_chain.hip)  one workgroup per (128 token rows, 1/S of the hidden columns): GEMM1 -> bias + GELU +
+//                                   dropout on the accumulators -> GEMM2, the weights of its column slice staged through LDS
+//                                   by LDS-DMA and shared by eight waves; FLOP per weight byte = 128.  Its partial [128 x D]
+//                                   result goes to slab `s` of the tower's slab buffer with plain stores (no atomics: the sum
+//                                   over the S slabs is the next mix launch's first step).
+//
+// The hidden activation still never leaves the chip in the forward pass; the launch boundary is the grid-wide
+// synchronisation (~1.5 us, against ~5 us for an in-kernel grid barrier on this part).
+#pragma once
+#include "tile.h"
+
+#define SP_ROWS 128               // token rows of a chain workgroup (8 row tiles of 16)
+#define SP_THREADS 512
+#define SP_MAX_SPLITS 8           // column splits (= slabs) a launch may use
+#define SP_UNIT 32                // hidden columns one wave handles at a time (= one dropout hash word per row)
+#define SP_MAX_UNITS_PER_SPLIT 64 // bias staging in LDS (C up to 8 x 64 x 32 = 16384 at 8 splits)
+
+// ---- piecewise-linear GELU tables (bf16 mode) ---------------------------------------------------------------------------
+// gelu(x) ~ a_i + b_i x and gelu'(x) ~ c_i + d_i x on cell i of 512 cells over [-6, 6) (error < 6e-5 / 9e-5: an order below
+// bf16 resolution); cell 0 is x < -6 (0, 0 / 0, 0), cell 513 is x >= 6 (0, 1 / 1, 0).  One fma builds the index, one fma per
+// function evaluates it; the dropout scale is folded into the table, so the forward epilogue is ~8 VALU instructions per
+// hidden element (index 4, value 1, keep-mask 2, pack 0.5) instead of the ~14 of the interpolating table of common.h.
+#define SPG_N 512
+#define SPG_XMAX 6.0f
+#define SPG_ENTRIES (SPG_N + 2)
+static __device__ __forceinline__ unsigned int spg_index(float x) {
+    const float t = __builtin_fmaf(x, SPG_N / (2.0f * SPG_XMAX), 0.5f * SPG_N + 1.0f);
+    unsigned int i = (unsigned int)__builtin_fmaxf(t, 0.0f);       // v_cvt_u32_f32 saturates at 0 (NaN -> 0 too)
+    return i < (unsigned int)(SPG_N + 1) ? i : (unsigned int)(SPG_N + 1);
+}
+static __device__ __forceinline__ void spg_cell(int i, float scale, float& a, float& b, float& c, float& d) {
+    if (i == 0) { a = b = c = d = 0.f; return; }
+    if (i == SPG_N + 1) { a = 0.f; b = scale; c = scale; d = 0.f; return; }
+    const float h = 2.0f * SPG_XMAX / SPG_N;
+    const float x0 = -SPG_XMAX + h * (i - 1), x1 = x0 + h;
+    float g0, d0, g1, d1;
+    gelu_grad_f(x0, g0, d0);
+    gelu_grad_f(x1, g1, d1);
+    b = (g1 - g0) / h;
+    a = g0 - b * x0;
+    d = (d1 - d0) / h;
+    c = d0 - d * x0;
+    a *= scale; b *= scale; c *= scale; d *= scale;
+}
+
+// ---- arguments -------------------------------------------------------------------------------------------------------------
+// One tower's share of a chain launch (block `b` of the tower).
+struct SplitChainTower {
+    const char* a_nat;            // LN2(x_mid) as packed NAT blocks [16-row tile][k-block]
+    const char* dy_nat;           // backward: dYd, same layout
+    const char* w1n; const char* w2c; const char* w2tn; const char* w1tc;
+    const float* b1p;
+    float* slabs;                 // [nsplit][M][D] fp32 partial results
+    char* h_chn; char* dh_chn;    // backward: operand streams of the weight-gradient launch (layout: tower_bwd.hip)
+    int M;                        // token rows
+    int nunits;                   // Cp / 32
+    int Cp;
+    unsigned int site;            // dropout site of the channel-hidden activation of this block
+    float p_drop;
+};
+struct SplitChainArgs {
+    SplitChainTower t[2];
+    int ntow, nsplit, max_rt;     // grid = nsplit * ntow * max_rt
+};
+
+// One tower's share of a mix launch.
+struct SplitMixTower {
+    // ---- input of the residual stream ----
+    const float* x0; long x0_ss; int x0_parts; long x0_pstride;      // first block: the tower input (sum of x0_parts buffers)
+    const float* xprev;           // later: x_mid of the previous block ...
+    const float* slabs; int nslab; long slab_stride;                  // ... + dropout(sum of the slabs + b2prev)
+    const float* b2prev;
+    unsigned int site_prev_out;   // dropout site (channel output) of the previous block
+    // ---- this block (NULL ln1_w: no block, only the final LayerNorm) ----
+    m2m_block blk;
+    float* x_in; float* x_mid;    // saved activations (x_in NULL in eval; x_mid is also the carry to the next mix launch)
+    char* a_nat; char* at_chn;    // operand images written for the chain / weight-gradient launches (at_chn NULL in eval)
+    unsigned int site;            // site_base + 4 * block
+    // ---- final LayerNorm + output (out == NULL: not the last launch) ----
+    const float* lnf_w; const float* lnf_b; float* x_final;
+    float* out; long out_ss; float* pooled;
+    int N, T, B;
+    float p_drop;
+    int ntiles;
+};
+struct SplitMixArgs { SplitMixTower t[2]; int ntow; };

@@ -61,11 +61,13 @@ def p_effective(p):
     return 1 - round((1 - p) * 65536) / 65536
 
 
-def assert_preds_match(pred, logits_ref, tol):
-    """Class predictions must be identical wherever the oracle's top-2 margin exceeds what the tolerance can flip."""
+def assert_preds_match(pred, logits_gpu, logits_ref, tol):
+    """The kernel's predictions are the argmax of its own logits, and equal the oracle's wherever the oracle's top-2
+    margin exceeds what the bf16 tolerance could flip (random-init logits sit close together: ties within 2 x tol are
+    not a class decision either implementation can be held to)."""
+    assert torch.equal(pred.cpu().long(), logits_gpu.float().cpu().argmax(1))
     top2 = logits_ref.topk(2, dim=1).values
     decided = (top2[:, 0] - top2[:, 1]) > 2 * tol
-    assert decided.float().mean() > 0.5
     assert torch.equal(pred.cpu().long()[decided], logits_ref.argmax(1)[decided])
 
 
@@ -88,7 +90,7 @@ def test_bench_instantiation_with_dropout_vs_oracle(p_drop, B, dev):
     ref = O.avmnist_train_step(image, audio, labels, dict(params), cfg, {}, lr=1e-2, drop_p=p_effective(p_drop), masks=masks)
     for i, k in enumerate(("image_logits", "audio_logits", "logits")):
         assert abserr(eng.logits[i], ref[k]) < BF16_LOGITS, k
-        assert_preds_match(eng.preds[i], ref[k], BF16_LOGITS)
+        assert_preds_match(eng.preds[i], eng.logits[i], ref[k], BF16_LOGITS)
     for i, k in enumerate(("loss_image", "loss_audio", "loss_fusion", "loss")):
         assert abs(float(eng.losses[i]) - float(ref[k])) < 2e-2, k
     for k, g in ref["grads"].items():
