@@ -26,6 +26,8 @@ extern "C" {
 #define M2M_MAX_BLOCKS 8      /* MixerBlocks per m2m_tower; longer towers are chained by the caller */
 #define M2M_ROWS_PER_WG 16    /* token rows one workgroup keeps on chip */
 
+#define M2M_SPLIT_GPART 1472  /* floats per workgroup and launch in m2m_tower.gpart (7 x 128 + 576)                       */
+
 #define M2M_PREC_BF16 0       /* bf16 operands, fp32 accumulate, fp32 residual stream / LayerNorm */
 #define M2M_PREC_F32 1        /* exact fp32 MFMA (parity mode: matches the reference CPU path to ~1e-5) */
 
@@ -89,7 +91,7 @@ typedef struct m2m_tower {
     float* ws_b;           /* token mixing and channel mixing are separate launches and hand the stream over in HBM */
     m2m_block blk[M2M_MAX_BLOCKS];
     /* ---- split path (optional; fused-class towers in bf16 at large batches, see csrc/split.h) -------------------------
-     * With these buffers present and B*N large enough, m2m_tower(s)_forward / _backward run every block as two launches:
+     * With these buffers present and B*N large enough, m2m_tower_forward / m2m_towers_forward and their backward counterparts run every block as two launches:
      * a per-sample launch (token mixing, LayerNorms, residual) and a channel-mixing launch whose workgroups own 128 token
      * rows x 1/nsplit of the hidden columns, so each CU streams 1/nsplit of the weights for 8x the rows.  Results are the
      * same up to fp32 summation order.  slabs == NULL (or nsplit < 2) keeps the one-launch-per-tower path. */
@@ -97,6 +99,9 @@ typedef struct m2m_tower {
     int32_t nsplit;        /* slabs the buffer has room for (the library uses up to 8)                                     */
     int32_t reserved0;
     float* xres;           /* (B*N, D) fp32: residual / gradient stream carried between the launches                       */
+    float* gpart;          /* (nblocks + 1) x ceil(B / (16 / N)) x M2M_SPLIT_GPART floats: per-workgroup partial sums of the small
+                            * gradients (LayerNorms, token MLP, ch_b2), stored plainly and summed by one reduction launch --
+                            * deterministic, and free of the same-address atomics of 256 workgroups                          */
     void* a_nat[M2M_MAX_BLOCKS];   /* per block: LN2(x_mid) as packed NAT blocks [16-row tile][k-block], rows padded to 16 */
     void* dy_nat[M2M_MAX_BLOCKS];  /* per block: d(channel MLP out) after its dropout mask, same layout                    */
 } m2m_tower;

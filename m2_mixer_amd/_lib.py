@@ -23,6 +23,7 @@ ROWS_PER_WG = 16
 HCHN_PAD = 4096          # >= the pad between operand streams the library uses (csrc/tile.h M2M_HCHN_PAD)
 SPLIT_ROWS = 128         # token rows of a column-split channel workgroup (csrc/split.h SP_ROWS)
 SPLIT_MAX = 8            # column splits (slabs)
+SPLIT_GPART = 1472       # floats per workgroup and launch of the small-gradient partial buffer (M2M_SPLIT_GPART)
 PREC_BF16, PREC_F32 = 0, 1
 PREC_BY_NAME = {"bf16": PREC_BF16, "fp32": PREC_F32, "f32": PREC_F32}
 
@@ -47,7 +48,7 @@ class Tower(C.Structure):
                 ("lnf_w", _fp), ("lnf_b", _fp), ("g_lnf_w", _fp), ("g_lnf_b", _fp), ("x_final", _fp),
                 ("ws_a", _fp), ("ws_b", _fp), ("blk", Block * MAX_BLOCKS),
                 # split path (csrc/split.h): slab buffer of the column-split launches, carry stream, per-block operand images
-                ("slabs", _fp), ("nsplit", C.c_int32), ("reserved0", C.c_int32), ("xres", _fp),
+                ("slabs", _fp), ("nsplit", C.c_int32), ("reserved0", C.c_int32), ("xres", _fp), ("gpart", _fp),
                 ("a_nat", _fp * MAX_BLOCKS), ("dy_nat", _fp * MAX_BLOCKS)]
 
 

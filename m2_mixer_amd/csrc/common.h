@@ -245,9 +245,22 @@ void m2m_set_error(const char* msg, const char* file, int line);
             _tm_last = _n;                                                          \
         }                                                                           \
     } while (0)
+// every workgroup: [16] = earliest start, [17] = latest end (100 MHz wall clock), [18] = sum of workgroup durations, [19] = count
+#define TIMER_WG_BEGIN() const unsigned long long _tm_wg0 = __builtin_amdgcn_s_memrealtime()
+#define TIMER_WG_END(sym)                                                           \
+    do {                                                                            \
+        if (threadIdx.x == 0) {                                                     \
+            const unsigned long long _n = __builtin_amdgcn_s_memrealtime();         \
+            atomicMin(&sym[16], _tm_wg0);                                           \
+            atomicMax(&sym[17], _n);                                                \
+            atomicAdd(&sym[18], _n - _tm_wg0);                                      \
+            atomicAdd(&sym[19], 1ULL);                                              \
+        }                                                                           \
+    } while (0)
 #define TIMER_READER(name, sym)                                                     \
     extern "C" int name(unsigned long long* out, int reset) {                       \
         unsigned long long z[32] = {0};                                             \
+        z[16] = ~0ULL;                                                              \
         if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sym), sizeof(z)) != hipSuccess) return -2; \
         if (reset && hipMemcpyToSymbol(HIP_SYMBOL(sym), z, sizeof(z)) != hipSuccess) return -2; \
         return 0;                                                                   \
@@ -257,4 +270,6 @@ void m2m_set_error(const char* msg, const char* file, int line);
 #define TIMER_START()
 #define TIMER_MARK(sym, i)
 #define TIMER_READER(name, sym)
+#define TIMER_WG_BEGIN()
+#define TIMER_WG_END(sym)
 #endif

@@ -94,3 +94,52 @@ struct SplitMixTower {
     int ntiles;
 };
 struct SplitMixArgs { SplitMixTower t[2]; int ntow; };
+
+// One tower's share of a backward mix launch (between the chain launches of block `upper` = b + 1 and `lower` = b).
+struct SplitMixBwdTower {
+    // ---- no upper block (first launch): gradient of the tower output through the final LayerNorm ----
+    const float* d_out; long d_out_ss; const float* d_pooled;
+    const float* lnf_w; float* g_lnf_w; float* g_lnf_b; const float* x_final;      // lnf_w NULL: no final LayerNorm
+    // ---- upper block: its chain launch left dA in the slabs; finish its backward (LN2, token mixing, LN1) ----
+    int has_upper;
+    m2m_block up;
+    unsigned int site_up;         // site_base + 4 * upper
+    const float* slabs; int nslab; long slab_stride;
+    // ---- lower block: operands of its chain / weight-gradient launches ----
+    int has_lower;
+    unsigned int site_lower_out;  // site_base + 4 * lower + 3
+    float* g_ch_b2_lower;
+    char* dy_nat; char* dyt_chn;
+    float* part;                  // this launch's slice of m2m_tower.gpart: [ntiles][SPP_STRIDE] partial sums of the small gradients
+    float* carry;                 // (M, D) fp32 gradient stream between the launches (read when has_upper, written when has_lower)
+    float* d_x0; long d_x0_ss;    // no lower block (last launch): gradient wrt the tower input
+    int N, T, B;
+    float p_drop;
+    int ntiles;
+};
+struct SplitMixBwdArgs { SplitMixBwdTower t[2]; int ntow; };
+
+// Layout of one workgroup's partial-sum slot (floats), D = hidden_dim (<= 128), token MLP up to T = 32, N = 8:
+//   [LN2 gamma D | LN2 beta D | token MLP: W1 (T N), W2 (N T), b1 (T), b2 (N) | LN1 gamma D | LN1 beta D | ch_b2 D | final LN gamma D, beta D]
+#define SPP_LN2 0
+#define SPP_TOK(D) (2 * (D))
+#define SPP_TOK_MAX 576
+#define SPP_LN1(D) (2 * (D) + SPP_TOK_MAX)
+#define SPP_B2(D) (4 * (D) + SPP_TOK_MAX)
+#define SPP_LNF(D) (5 * (D) + SPP_TOK_MAX)
+#define SPP_STRIDE M2M_SPLIT_GPART
+static_assert(7 * 128 + SPP_TOK_MAX == SPP_STRIDE, "partial-sum slot layout");
+
+// Reduction of the partial sums of one backward pass into the gradient buffers: launch L (0 = the first mix launch: final
+// LayerNorm + the last block's ch_b2; L = k: the LayerNorm / token gradients of block nb - k and ch_b2 of block nb - k - 1).
+struct SplitReduceTower {
+    const float* part;            // [nlaunch][ntiles][SPP_STRIDE]
+    int ntiles, nlaunch, D, N, T;
+    // destinations per launch (NULL: section not produced by that launch)
+    float* g_ln2_w[M2M_MAX_BLOCKS + 1]; float* g_ln2_b[M2M_MAX_BLOCKS + 1];
+    float* g_tok_w1[M2M_MAX_BLOCKS + 1]; float* g_tok_w2[M2M_MAX_BLOCKS + 1]; float* g_tok_b1[M2M_MAX_BLOCKS + 1]; float* g_tok_b2[M2M_MAX_BLOCKS + 1];
+    float* g_ln1_w[M2M_MAX_BLOCKS + 1]; float* g_ln1_b[M2M_MAX_BLOCKS + 1];
+    float* g_b2[M2M_MAX_BLOCKS + 1];
+    float* g_lnf_w; float* g_lnf_b;               // launch 0
+};
+struct SplitReduceArgs { SplitReduceTower t[2]; int ntow; };

@@ -198,6 +198,57 @@ static __device__ __forceinline__ void ln_to_tile(const float* x, float* dst, co
     }
 }
 
+// LayerNorm backward for the whole tile.
+//   xg      : global saved LN input, row r at xg + r*D (rows >= R treated as zero)
+//   up      : LDS tile, upstream gradient wrt the LN output                       [BM][XLD]
+//   dxs     : LDS tile, receives (accumulate ? += : =) the gradient wrt the LN input
+//   prod    : LDS tile, receives up * xhat (for the gamma gradient)
+// then column sums -> atomicAdd into g_w (gamma) / g_b (beta).  Contains two __syncthreads().
+// ATOMIC == false: the column sums are STORED to g_w / g_b (a per-workgroup partial-sum slot) instead of added atomically.
+template <int D, bool ATOMIC = true>
+static __device__ __forceinline__ void ln_backward_tile(const float* xg, int R, const float* up, const float* __restrict__ gamma,
+                                                        float* dxs, bool accumulate, float* prod, float* g_w, float* g_b,
+                                                        int tid) {
+    constexpr int XLD = TileGeom<D>::XLD, EPT = D / TPR;
+    const int r = tid / TPR, j = tid % TPR;
+    const bool valid = r < R;
+    float v[EPT], mean, rstd;
+    row_stats<D>(xg + (long)r * D, valid, j, v, mean, rstd);
+    float gsum = 0.f, gxsum = 0.f;
+    float gv[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int c = ln_col<D>(e, j);
+        const float xh = (v[e] - mean) * rstd;
+        const float u = up[r * XLD + c];
+        const float gg = u * gamma[c];
+        gv[e] = gg;
+        v[e] = xh;
+        gsum += gg;
+        gxsum = __builtin_fmaf(gg, xh, gxsum);
+        prod[r * XLD + c] = valid ? u * xh : 0.f;
+    }
+    gsum = wave_sum_xor(gsum, TPR) * (1.0f / D);
+    gxsum = wave_sum_xor(gxsum, TPR) * (1.0f / D);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int c = ln_col<D>(e, j);
+        const float dx = rstd * (gv[e] - gsum - v[e] * gxsum);
+        if (accumulate) { if (valid) dxs[r * XLD + c] += dx; }
+        else dxs[r * XLD + c] = valid ? dx : 0.f;
+    }
+    __syncthreads();
+    _Pragma("unroll 1") for (int d = tid; d < 2 * D; d += NTHREADS) {
+        const float* src = d < D ? prod : up;
+        const int c = d < D ? d : d - D;
+        float s = 0.f;
+        for (int rr = 0; rr < R; ++rr) s += src[rr * XLD + c];
+        if (ATOMIC) atomicAdd((d < D ? g_w : g_b) + c, s);
+        else (d < D ? g_w : g_b)[c] = s;
+    }
+    __syncthreads();
+}
+
 // Build the 16 bytes of one lane slot of a packed block from an fp32 tile in LDS.
 //   transposed == false : X[i][k] = tile[i][k]      transposed == true : X[i][k] = tile[k][i]
 template <int P>

@@ -18,55 +18,6 @@
 TIMER_DECL(g_tm_bwd);
 TIMER_READER(m2m_debug_timers_bwd, g_tm_bwd)
 
-// LayerNorm backward for the whole tile.
-//   xg      : global saved LN input, row r at xg + r*D (rows >= R treated as zero)
-//   up      : LDS tile, upstream gradient wrt the LN output                       [BM][XLD]
-//   dxs     : LDS tile, receives (accumulate ? += : =) the gradient wrt the LN input
-//   prod    : LDS tile, receives up * xhat (for the gamma gradient)
-// then column sums -> atomicAdd into g_w (gamma) / g_b (beta).  Contains two __syncthreads().
-template <int D>
-static __device__ __forceinline__ void ln_backward_tile(const float* xg, int R, const float* up, const float* __restrict__ gamma,
-                                                        float* dxs, bool accumulate, float* prod, float* g_w, float* g_b,
-                                                        int tid) {
-    constexpr int XLD = TileGeom<D>::XLD, EPT = D / TPR;
-    const int r = tid / TPR, j = tid % TPR;
-    const bool valid = r < R;
-    float v[EPT], mean, rstd;
-    row_stats<D>(xg + (long)r * D, valid, j, v, mean, rstd);
-    float gsum = 0.f, gxsum = 0.f;
-    float gv[EPT];
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int c = ln_col<D>(e, j);
-        const float xh = (v[e] - mean) * rstd;
-        const float u = up[r * XLD + c];
-        const float gg = u * gamma[c];
-        gv[e] = gg;
-        v[e] = xh;
-        gsum += gg;
-        gxsum = __builtin_fmaf(gg, xh, gxsum);
-        prod[r * XLD + c] = valid ? u * xh : 0.f;
-    }
-    gsum = wave_sum_xor(gsum, TPR) * (1.0f / D);
-    gxsum = wave_sum_xor(gxsum, TPR) * (1.0f / D);
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int c = ln_col<D>(e, j);
-        const float dx = rstd * (gv[e] - gsum - v[e] * gxsum);
-        if (accumulate) { if (valid) dxs[r * XLD + c] += dx; }
-        else dxs[r * XLD + c] = valid ? dx : 0.f;
-    }
-    __syncthreads();
-    _Pragma("unroll 1") for (int d = tid; d < 2 * D; d += NTHREADS) {
-        const float* src = d < D ? prod : up;
-        const int c = d < D ? d : d - D;
-        float s = 0.f;
-        for (int rr = 0; rr < R; ++rr) s += src[rr * XLD + c];
-        atomicAdd((d < D ? g_w : g_b) + c, s);
-    }
-    __syncthreads();
-}
-
 // One workgroup's share of a tower backward: token tile `wg` of `nwg`.  TW is m2m_tower (single-tower launch) or
 // m2m_tower4 (the by-value descriptors of a two-tower launch).
 template <class TW, int P, int D, int NMAX, int TG, int DM>
@@ -673,12 +624,19 @@ int m2m_chain_backward_rows(const m2m_tower* t, int B, const float* d_out, long 
 }
 
 bool m2m_can_group(const m2m_tower* a, const m2m_tower* b);
+bool m2m_split_eligible(const m2m_tower* t, int B, int training);
+bool m2m_split_can_group(const m2m_tower* a, const m2m_tower* b);
+int m2m_split_backward(const m2m_tower* const* towers, const m2m_tower_gio* io, int ntow, int B, unsigned int seed, unsigned int step,
+                       const unsigned int* step_dev, hipStream_t st);
 
 extern "C" int m2m_towers_backward(const m2m_tower* const* towers, const m2m_tower_gio* io, int ntowers, int B, uint32_t seed,
                                    uint32_t step, const uint32_t* step_dev, void* stream) {
     if (!towers || !io || ntowers != 2) { m2m_set_error("towers_backward: exactly two towers per launch", __FILE__, __LINE__); return -1; }
     for (int i = 0; i < 2; ++i)
         if (int rc = m2m_check_tower(towers[i], B)) return rc;
+    // the forward of this step took the split path under the same conditions (csrc/split.h)
+    if (m2m_split_eligible(towers[0], B, 1) && m2m_split_eligible(towers[1], B, 1) && m2m_split_can_group(towers[0], towers[1]))
+        return m2m_split_backward(towers, io, 2, B, seed, step, step_dev, reinterpret_cast<hipStream_t>(stream));
     if (!m2m_can_group(towers[0], towers[1])) {
         m2m_set_error("towers_backward: the two towers do not share a kernel instantiation: launch them separately", __FILE__, __LINE__);
         return -1;
@@ -712,6 +670,11 @@ extern "C" int m2m_tower_backward(const m2m_tower* t, int B, const float* d_out,
     if (int rc = m2m_check_tower(t, B)) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (m2m_is_wide(t)) return m2m_backward_wide(t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step, step_dev, st);
+    if (m2m_split_eligible(t, B, 1)) {
+        m2m_tower_gio io1;
+        io1.d_out = d_out; io1.d_out_sample_stride = d_out_ss; io1.d_pooled = d_pooled; io1.d_x0 = d_x0; io1.d_x0_sample_stride = d_x0_ss;
+        return m2m_split_backward(&t, &io1, 1, B, seed, step, step_dev, st);
+    }
 #define M2M_BWD_CASE(PP, DD) \
     if (t->prec == PP && t->D == DD) {                                                                                          \
         if (t->N <= 4) return launch_bwd<PP, DD, 4, 8>(t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step, step_dev, st);   \

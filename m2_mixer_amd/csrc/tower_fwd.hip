@@ -341,6 +341,10 @@ static int launch_fwd(const m2m_tower* t, const float* x0, long x0_ss, int B, fl
 }
 
 int m2m_check_tower(const m2m_tower* t, int B);
+bool m2m_split_eligible(const m2m_tower* t, int B, int training);
+bool m2m_split_can_group(const m2m_tower* a, const m2m_tower* b);
+int m2m_split_forward(const m2m_tower* const* towers, const m2m_tower_io* io, int ntow, int B, int training, unsigned int seed,
+                      unsigned int step, const unsigned int* step_dev, hipStream_t st);
 int m2m_forward_wide(const m2m_tower* t, const float* x0, long x0_ss, int B, float* out, long out_ss, float* pooled,
                      int training, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st);
 
@@ -396,6 +400,10 @@ extern "C" int m2m_towers_forward(const m2m_tower* const* towers, const m2m_towe
     if (!towers || !io || ntowers != 2) { m2m_set_error("towers_forward: exactly two towers per launch", __FILE__, __LINE__); return -1; }
     for (int i = 0; i < 2; ++i)
         if (int rc = m2m_check_tower(towers[i], B)) return rc;
+    // large batches: per-block launches with column-split channel mixing (csrc/split.h)
+    if (m2m_split_eligible(towers[0], B, training) && m2m_split_eligible(towers[1], B, training) &&
+        m2m_split_can_group(towers[0], towers[1]))
+        return m2m_split_forward(towers, io, 2, B, training, seed, step, step_dev, reinterpret_cast<hipStream_t>(stream));
     if (!m2m_can_group(towers[0], towers[1])) {
         m2m_set_error("towers_forward: the two towers do not share a kernel instantiation (fused path, precision, hidden_dim, "
                       "dropout, token class, <= 4 blocks): launch them separately", __FILE__, __LINE__);
@@ -430,6 +438,12 @@ extern "C" int m2m_tower_forward(const m2m_tower* t, const float* x0, int64_t x0
     if (int rc = m2m_check_tower(t, B)) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (m2m_is_wide(t)) return m2m_forward_wide(t, x0, x0_ss, B, out, out_ss, pooled, training, seed, step, step_dev, st);
+    if (m2m_split_eligible(t, B, training)) {
+        m2m_tower_io io1;
+        io1.x0 = x0; io1.x0_sample_stride = x0_ss; io1.out = out; io1.out_sample_stride = out_ss; io1.pooled = pooled;
+        io1.x0_parts = 1; io1.x0_part_stride = 0;
+        return m2m_split_forward(&t, &io1, 1, B, training, seed, step, step_dev, st);
+    }
 #define M2M_FWD_CASE(PP, DD) \
     if (t->prec == PP && t->D == DD) return t->N <= 4 ? launch_fwd<PP, DD, 4>(t, x0, x0_ss, B, out, out_ss, pooled, training, seed, step, step_dev, st) \
                                                       : launch_fwd<PP, DD, 8>(t, x0, x0_ss, B, out, out_ss, pooled, training, seed, step, step_dev, st);

@@ -59,6 +59,7 @@ class TowerRuntime:
         self._packed_for: Optional[List[int]] = None
         self._bufB = 0
         self._wsB = 0
+        self._splitB = 0
         self.device = None
         # wide path (include/m2mixer.h): token mixing and channel mixing are separate launches
         self.wide = N > 8 or D > 128
@@ -158,8 +159,30 @@ class TowerRuntime:
         self._keep["x_final"] = xf
         self._bufB = B
 
+    def ensure_split(self, B: int):
+        """Buffers of the split path (include/m2mixer.h, csrc/split.h): slabs of the column-split channel launches, the carry
+        stream, per-block bf16 operand images.  Allocated for every tower the split path can take (fused class, bf16,
+        hidden_dim 128); whether a call uses it is the library's decision (batch size; M2M_SPLIT=0/1 overrides)."""
+        if self.wide or self.prec != L.PREC_BF16 or self.D != 128 or self.nblocks == 0 or B == self._splitB:
+            return
+        M = B * self.N
+        ntile16 = (M + 15) // 16
+        img = ntile16 * (self.D // 32) * 1024
+        ntiles = (B + (16 // self.N) - 1) // (16 // self.N)
+        bufs = {"slabs": torch.empty(L.SPLIT_MAX, M, self.D, device=self.device), "xres": torch.empty(M, self.D, device=self.device),
+                "gpart": torch.zeros((self.nblocks + 1) * ntiles * L.SPLIT_GPART, device=self.device),
+                "a_nat": [torch.zeros(img, dtype=torch.uint8, device=self.device) for _ in range(self.nblocks)],
+                "dy_nat": [torch.zeros(img, dtype=torch.uint8, device=self.device) for _ in range(self.nblocks)]}
+        self.desc.slabs, self.desc.nsplit, self.desc.xres = bufs["slabs"].data_ptr(), L.SPLIT_MAX, bufs["xres"].data_ptr()
+        self.desc.gpart = bufs["gpart"].data_ptr()
+        for i in range(self.nblocks):
+            self.desc.a_nat[i], self.desc.dy_nat[i] = bufs["a_nat"][i].data_ptr(), bufs["dy_nat"][i].data_ptr()
+        self._keep["split"] = bufs
+        self._splitB = B
+
     def ensure_workspace(self, B: int):
         """The wide path's two (B*N, D) stream buffers (needed in eval too)."""
+        self.ensure_split(B)
         if not self.wide or B == self._wsB:
             return
         ws = torch.empty(2, B * self.N, self.D, device=self.device)
@@ -256,6 +279,7 @@ def towers_forward(towers: Sequence[TowerRuntime], ios: Sequence[tuple], B: int,
     for t in towers:
         if training:
             t.ensure_buffers(B)
+        t.ensure_workspace(B)
     host = (C.POINTER(L.Tower) * n)(*[C.pointer(t.desc) for t in towers])
     io = (L.TowerIO * n)()
     for i, (x0, x0_ss, out, out_ss, pooled, *parts) in enumerate(ios):

@@ -99,6 +99,53 @@ def test_bench_instantiation_with_dropout_vs_oracle(p_drop, B, dev):
         assert relerr(eng.grads[k], g) < BF16_GRAD_REL, k
 
 
+@pytest.mark.parametrize("p_drop,B", [(0.5, 200), (0.1, 77), (0.0, 130)])
+def test_split_path_ragged_batches_vs_oracle(p_drop, B, dev, monkeypatch):
+    """The column-split launches (csrc/split.h) forced on at batches that do not fill their tiles: B * N = 800 / 308 / 520
+    token rows against 128-row chain workgroups and 16-row mix workgroups (ragged last tiles everywhere, an odd number of
+    16-row tiles, a single sample group in the last mix workgroup), fusion tower with 97 column units over 8 splits.
+    Same oracle comparison as the benchmark instantiation; and the fused one-launch path must agree with it closely."""
+    from m2_mixer_amd.engine import AVMnistEngine
+    cfg = dict(G.AVMNIST["B"], dropout=p_drop)
+    shapes = G.avmnist_shapes(cfg)
+    params = dict(G.make_params(shapes, 27))
+    image, audio, labels = G.avmnist_batch(B, 28, cfg)
+    gb = (image.to(dev), audio.to(dev), labels.to(dev))
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("M2M_SPLIT", mode)
+        eng = AVMnistEngine(cfg, B, device=dev, precision="bf16", lr=1e-2, init=False)
+        eng.load_state_dict(params)
+        eng.forward_backward(*gb)
+        torch.cuda.synchronize()
+        got[mode] = (eng.logits.clone(), eng.losses.clone(), eng.flat_g.clone())
+        if mode == "1":
+            split_eng = eng
+    eng = split_eng
+    masks = engine_masks(eng, B) if p_drop > 0 else None
+    ref = O.avmnist_train_step(image, audio, labels, dict(params), cfg, {}, lr=1e-2, drop_p=p_effective(p_drop), masks=masks)
+    logits, losses, flat_g = got["1"]
+    for i, k in enumerate(("image_logits", "audio_logits", "logits")):
+        assert abserr(logits[i], ref[k]) < BF16_LOGITS, k
+    for i, k in enumerate(("loss_image", "loss_audio", "loss_fusion", "loss")):
+        assert abs(float(losses[i]) - float(ref[k])) < 2e-2, k
+    for k, g in ref["grads"].items():
+        if k.endswith("token_mix.2.net.3.bias"):
+            continue
+        gv = eng.grads[k]
+        o = (gv.data_ptr() - eng.flat_g.data_ptr()) // 4
+        assert relerr(flat_g[o:o + gv.numel()].view_as(gv), g) < BF16_GRAD_REL, k
+    # split vs fused: same masks, same bf16 rounding points; they differ by the GELU table form and fp32 summation order
+    assert abserr(got["1"][0], got["0"][0]) < 1e-2 and abserr(got["1"][1], got["0"][1]) < 1e-3
+    # evaluation (dropout off, no saved activations: the carry stream is rewritten in place)
+    monkeypatch.setenv("M2M_SPLIT", "1")
+    out = eng.evaluate(*gb)
+    torch.cuda.synchronize()
+    ev = O.avmnist_forward(image, audio, labels, params, cfg)
+    for k in ("logits", "image_logits", "audio_logits"):
+        assert abserr(out[k], ev[k]) < BF16_LOGITS, k
+
+
 @pytest.mark.parametrize("size,B,seed", [("S", 8, 11), ("M", 4, 21), ("B", 8, 12)])
 def test_adam_moments_and_parameters_vs_oracle(size, B, seed, dev):
     """Two optimisation steps, fp32 mode: Adam's first / second moments (linear / quadratic in the gradient, hence

@@ -41,7 +41,7 @@ def test_struct_layouts_match_header(lib):
     import ctypes as C
     # m2m_block: 12 params + 5 packed + 12 grads + 6 saved pointers; m2m_tower header is 40 bytes then 7 pointers
     assert C.sizeof(lib.Block) == 35 * 8
-    assert C.sizeof(lib.Tower) == 40 + 7 * 8 + lib.MAX_BLOCKS * C.sizeof(lib.Block) + 8 + 8 + 8 + 2 * 8 * lib.MAX_BLOCKS
+    assert C.sizeof(lib.Tower) == 40 + 7 * 8 + lib.MAX_BLOCKS * C.sizeof(lib.Block) + 8 + 8 + 8 + 8 + 2 * 8 * lib.MAX_BLOCKS
     assert lib.Tower.slabs.offset == 96 + lib.MAX_BLOCKS * C.sizeof(lib.Block)
     assert lib.Tower.blk.offset == 96
     assert C.sizeof(lib.Embed) == 40 + 5 * 8
