@@ -245,7 +245,8 @@ void m2m_set_error(const char* msg, const char* file, int line);
             _tm_last = _n;                                                          \
         }                                                                           \
     } while (0)
-// every workgroup: [16] = earliest start, [17] = latest end (100 MHz wall clock), [18] = sum of workgroup durations, [19] = count
+// every workgroup: [16] = earliest start, [17] = latest end (100 MHz wall clock), [18] = sum of workgroup durations, [19] = count,
+// [20] = latest start, [21] = earliest end
 #define TIMER_WG_BEGIN() const unsigned long long _tm_wg0 = __builtin_amdgcn_s_memrealtime()
 #define TIMER_WG_END(sym)                                                           \
     do {                                                                            \
@@ -253,6 +254,8 @@ void m2m_set_error(const char* msg, const char* file, int line);
             const unsigned long long _n = __builtin_amdgcn_s_memrealtime();         \
             atomicMin(&sym[16], _tm_wg0);                                           \
             atomicMax(&sym[17], _n);                                                \
+            atomicMax(&sym[20], _tm_wg0);                                           \
+            atomicMin(&sym[21], _n);                                                \
             atomicAdd(&sym[18], _n - _tm_wg0);                                      \
             atomicAdd(&sym[19], 1ULL);                                              \
         }                                                                           \
@@ -260,7 +263,7 @@ void m2m_set_error(const char* msg, const char* file, int line);
 #define TIMER_READER(name, sym)                                                     \
     extern "C" int name(unsigned long long* out, int reset) {                       \
         unsigned long long z[32] = {0};                                             \
-        z[16] = ~0ULL;                                                              \
+        z[16] = ~0ULL; z[21] = ~0ULL;                                               \
         if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sym), sizeof(z)) != hipSuccess) return -2; \
         if (reset && hipMemcpyToSymbol(HIP_SYMBOL(sym), z, sizeof(z)) != hipSuccess) return -2; \
         return 0;                                                                   \

@@ -226,6 +226,8 @@ __global__ __launch_bounds__(SP_THREADS, 2) void split_chain_fwd_kernel(const Sp
         const int r = idx / (D / 4), c4 = (idx % (D / 4)) * 4;
         *reinterpret_cast<f32x4_t*>(slab + ((long)rt * SP_ROWS + r) * D + c4) = *reinterpret_cast<const f32x4_t*>(outt + r * LD + c4);
     }
+    TIMER_MARK(g_tm_scf, 4);   // epilogue
+    TIMER_WG_END(g_tm_scf);
 }
 
 
