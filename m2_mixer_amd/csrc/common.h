@@ -121,52 +121,64 @@ static __device__ __forceinline__ void gelu_grad_f(float x, float& g, float& dg)
 }
 
 // ---- activation dispatch ---------------------------------------------------------------------------------
-// bf16 mode: Phi(x) and phi(x) by linear interpolation in a 512-entry LDS table over [-6, 6] (|err| < 2.5e-5
-// on gelu and gelu', an order of magnitude below bf16 resolution; 9 VALU + one ds_read_b128 per element
-// instead of ~35 VALU for the rational erf + exp).  fp32 (parity) mode: the accurate functions above.
-#define GELU_TAB_N 512
-#define GELU_TAB_XMAX 6.0f
-typedef __attribute__((ext_vector_type(4))) float gtab_t;     // {Phi_k, Phi_{k+1}-Phi_k, phi_k, phi_{k+1}-phi_k}
-static __device__ __forceinline__ void gelu_tab_fill(gtab_t* tab, int tid, int nthreads) {
-    const float h = 2.0f * GELU_TAB_XMAX / GELU_TAB_N;
-    for (int k = tid; k < GELU_TAB_N; k += nthreads) {
-        const float x0 = -GELU_TAB_XMAX + h * k, x1 = x0 + h;
-        const float P0 = 0.5f * (1.0f + erf_fast(x0 * 0.70710678118654752f));
-        const float P1 = 0.5f * (1.0f + erf_fast(x1 * 0.70710678118654752f));
-        const float p0 = 0.3989422804014327f * __expf(-0.5f * x0 * x0);
-        const float p1 = 0.3989422804014327f * __expf(-0.5f * x1 * x1);
-        tab[k] = gtab_t{P0, P1 - P0, p0, p1 - p0};
-    }
+// bf16 mode: gelu(x) ~ a_i + b_i x and gelu'(x) ~ c_i + d_i x on cell i of 512 cells over [-6, 6) (|err| < 6e-5 / 9e-5, an
+// order of magnitude below bf16 resolution); cell 0 is x < -6 (0, 0 | 0, 0), cell 513 is x >= 6 (0, 1 | 1, 0).  One fma
+// builds the index, one fma per function evaluates it, and the dropout scale 1 / (1 - p) of the launch is folded into the
+// table: ~6 VALU + one ds_read per element for gelu, ~7 for gelu and gelu' (the interpolating table this replaced: 11 / 15;
+// the rational erf + exp: ~35).  fp32 (parity) mode: the accurate functions above.
+#define PWL_N 512
+#define PWL_XMAX 6.0f
+#define GELU_TAB_N (PWL_N + 2)                                 // table entries (16 bytes each)
+typedef __attribute__((ext_vector_type(4))) float gtab_t;     // {a, b, c, d}
+static __device__ __forceinline__ unsigned int pwl_index(float x) {
+    const float t = __builtin_fmaf(x, PWL_N / (2.0f * PWL_XMAX), 0.5f * PWL_N + 1.0f);
+    const unsigned int i = (unsigned int)__builtin_fmaxf(t, 0.0f);       // v_cvt_u32_f32 saturates at 0 (NaN -> 0 too)
+    return i < (unsigned int)(PWL_N + 1) ? i : (unsigned int)(PWL_N + 1);
 }
-static __device__ __forceinline__ gtab_t gelu_tab_lookup(const gtab_t* tab, float x, float& frac) {
-    const float xc = __builtin_amdgcn_fmed3f(x, -GELU_TAB_XMAX, GELU_TAB_XMAX - 1e-3f);
-    const float t = __builtin_fmaf(xc, GELU_TAB_N / (2.0f * GELU_TAB_XMAX), 0.5f * GELU_TAB_N);
-    const unsigned int i = (unsigned int)t;          // t >= 0: truncation == floor
-    frac = t - (float)i;
-    return tab[i];
+static __device__ __forceinline__ gtab_t pwl_cell(int i, float scale) {
+    if (i <= 0) return gtab_t{0.f, 0.f, 0.f, 0.f};
+    if (i >= PWL_N + 1) return gtab_t{0.f, scale, scale, 0.f};
+    const float h = 2.0f * PWL_XMAX / PWL_N;
+    const float x0 = -PWL_XMAX + h * (i - 1), x1 = x0 + h;
+    float g0, d0, g1, d1;
+    gelu_grad_f(x0, g0, d0);
+    gelu_grad_f(x1, g1, d1);
+    const float b = (g1 - g0) / h, d = (d1 - d0) / h;
+    return gtab_t{(g0 - b * x0) * scale, b * scale, (d0 - d * x0) * scale, d * scale};
 }
+static __device__ __forceinline__ void gelu_tab_fill(gtab_t* tab, float scale, int tid, int nthreads) {
+    for (int k = tid; k < GELU_TAB_N; k += nthreads) tab[k] = pwl_cell(k, scale);
+}
+// gelu(x) * scale and gelu'(x) * scale, `scale` being the value the table was filled with (bf16) / applied here (fp32)
 template <int P> struct Act;
 template <> struct Act<PREC_BF16> {
     static constexpr bool USES_TABLE = true;
-    static __device__ __forceinline__ float gelu(const gtab_t* tab, float x) {
-        float f;
-        const gtab_t e = gelu_tab_lookup(tab, x, f);
-        return x * __builtin_fmaf(f, e[1], e[0]);
+    static __device__ __forceinline__ float gelu_scaled(const gtab_t* tab, float x, float) {
+        const gtab_t e = tab[pwl_index(x)];
+        return __builtin_fmaf(e[1], x, e[0]);
     }
-    static __device__ __forceinline__ void gelu_grad(const gtab_t* tab, float x, float& g, float& dg) {
-        float f;
-        const gtab_t e = gelu_tab_lookup(tab, x, f);
-        const float cdf = __builtin_fmaf(f, e[1], e[0]);
-        const float pdf = __builtin_fmaf(f, e[3], e[2]);
-        g = x * cdf;
-        dg = __builtin_fmaf(x, pdf, cdf);
+    static __device__ __forceinline__ void gelu_grad_scaled(const gtab_t* tab, float x, float, float& g, float& dg) {
+        const gtab_t e = tab[pwl_index(x)];
+        g = __builtin_fmaf(e[1], x, e[0]);
+        dg = __builtin_fmaf(e[3], x, e[2]);
     }
 };
 template <> struct Act<PREC_F32> {
     static constexpr bool USES_TABLE = false;
-    static __device__ __forceinline__ float gelu(const gtab_t*, float x) { return gelu_f(x); }
-    static __device__ __forceinline__ void gelu_grad(const gtab_t*, float x, float& g, float& dg) { gelu_grad_f(x, g, dg); }
+    static __device__ __forceinline__ float gelu_scaled(const gtab_t*, float x, float scale) { return gelu_f(x) * scale; }
+    static __device__ __forceinline__ void gelu_grad_scaled(const gtab_t*, float x, float scale, float& g, float& dg) {
+        gelu_grad_f(x, g, dg);
+        g *= scale;
+        dg *= scale;
+    }
 };
+// 0 / ~0 from bit k of w (v_bfe_i32): keep-masks are applied with one AND
+static __device__ __forceinline__ unsigned int bit_to_mask(unsigned int w, int k) {
+    return (unsigned int)(((int)(w << (31 - k))) >> 31);
+}
+static __device__ __forceinline__ float mask_f(float v, unsigned int m) {
+    return __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, v) & m);
+}
 
 // ---- dropout: counter-based, stateless ---------------------------------------------------------------
 // keep(element) = 16 bits of mix32(key ^ word) < thr16, two elements per 32-bit word.  The same

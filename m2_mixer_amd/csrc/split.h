@@ -25,34 +25,6 @@
 #define SP_UNIT 32                // hidden columns one wave handles at a time (= one dropout hash word per row)
 #define SP_MAX_UNITS_PER_SPLIT 64 // bias staging in LDS (C up to 8 x 64 x 32 = 16384 at 8 splits)
 
-// ---- piecewise-linear GELU tables (bf16 mode) ---------------------------------------------------------------------------
-// gelu(x) ~ a_i + b_i x and gelu'(x) ~ c_i + d_i x on cell i of 512 cells over [-6, 6) (error < 6e-5 / 9e-5: an order below
-// bf16 resolution); cell 0 is x < -6 (0, 0 / 0, 0), cell 513 is x >= 6 (0, 1 / 1, 0).  One fma builds the index, one fma per
-// function evaluates it; the dropout scale is folded into the table, so the forward epilogue is ~8 VALU instructions per
-// hidden element (index 4, value 1, keep-mask 2, pack 0.5) instead of the ~14 of the interpolating table of common.h.
-#define SPG_N 512
-#define SPG_XMAX 6.0f
-#define SPG_ENTRIES (SPG_N + 2)
-static __device__ __forceinline__ unsigned int spg_index(float x) {
-    const float t = __builtin_fmaf(x, SPG_N / (2.0f * SPG_XMAX), 0.5f * SPG_N + 1.0f);
-    unsigned int i = (unsigned int)__builtin_fmaxf(t, 0.0f);       // v_cvt_u32_f32 saturates at 0 (NaN -> 0 too)
-    return i < (unsigned int)(SPG_N + 1) ? i : (unsigned int)(SPG_N + 1);
-}
-static __device__ __forceinline__ void spg_cell(int i, float scale, float& a, float& b, float& c, float& d) {
-    if (i == 0) { a = b = c = d = 0.f; return; }
-    if (i == SPG_N + 1) { a = 0.f; b = scale; c = scale; d = 0.f; return; }
-    const float h = 2.0f * SPG_XMAX / SPG_N;
-    const float x0 = -SPG_XMAX + h * (i - 1), x1 = x0 + h;
-    float g0, d0, g1, d1;
-    gelu_grad_f(x0, g0, d0);
-    gelu_grad_f(x1, g1, d1);
-    b = (g1 - g0) / h;
-    a = g0 - b * x0;
-    d = (d1 - d0) / h;
-    c = d0 - d * x0;
-    a *= scale; b *= scale; c *= scale; d *= scale;
-}
-
 // ---- arguments -------------------------------------------------------------------------------------------------------------
 // One tower's share of a chain launch (block `b` of the tower).
 struct SplitChainTower {

@@ -34,11 +34,6 @@ static __device__ __forceinline__ unsigned int lds_addr(const void* p) {
     return (unsigned int)(unsigned long long)(const __attribute__((address_space(3))) void*)p;
 }
 
-// 0 / ~0 from bit k of w (v_bfe_i32)
-static __device__ __forceinline__ unsigned int bitmask(unsigned int w, int k) {
-    return (unsigned int)(((int)(w << (31 - k))) >> 31);
-}
-
 template <int D>
 struct ChainGeom {
     static constexpr int KD = D / 32, DT = D / 16;
@@ -57,7 +52,7 @@ static size_t chain_fwd_lds() {
     typedef ChainGeom<D> G;
     const size_t bufs = 2 * (size_t)(2 * 2 * G::UNIT);     // 2 buffers x 2 units x (W1, W2)
     const size_t body = bufs > (size_t)G::OUT_BYTES ? bufs : (size_t)G::OUT_BYTES;
-    return body + SP_MAX_UNITS_PER_SPLIT * 32 * sizeof(float) + SPG_ENTRIES * sizeof(float2);
+    return body + SP_MAX_UNITS_PER_SPLIT * 32 * sizeof(float) + GELU_TAB_N * sizeof(float2);
 }
 
 template <int D, int DM>
@@ -116,10 +111,9 @@ __global__ __launch_bounds__(SP_THREADS, 2) void split_chain_fwd_kernel(const Sp
     };
     stage(0, 0);
     for (int i = tid; i < (u1 - u0) * 32; i += SP_THREADS) biasl[i] = tw.b1p[u0 * 32 + i];
-    for (int i = tid; i < SPG_ENTRIES; i += SP_THREADS) {
-        float ta, tb, tc, td;
-        spg_cell(i, dr.scale, ta, tb, tc, td);
-        gtab[i] = make_float2(ta, tb);
+    for (int i = tid; i < GELU_TAB_N; i += SP_THREADS) {
+        const gtab_t e = pwl_cell(i, dr.scale);
+        gtab[i] = make_float2(e[0], e[1]);
     }
     // the A fragments must have arrived BEFORE the chunk loop: left to itself hipcc waits for them at their first use, inside
     // the loop, with a vmcnt(0) that also drains the (to it invisible) DMA of the next chunk on every iteration
@@ -180,9 +174,9 @@ __global__ __launch_bounds__(SP_THREADS, 2) void split_chain_fwd_kernel(const Sp
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float x = hacc[mt][t][r];
-                        const float2 e = gtab[spg_index(x)];
+                        const float2 e = gtab[pwl_index(x)];
                         const float v = __builtin_fmaf(e.y, x, e.x);
-                        hacc[mt][t][r] = DM == DM_NONE ? v : __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, v) & bitmask(word, 16 * t + r));
+                        hacc[mt][t][r] = DM == DM_NONE ? v : __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, v) & bit_to_mask(word, 16 * t + r));
                     }
                 }
                 Chain<PREC_BF16>::make(hacc[mt][0], hacc[mt][1], &hf[mt]);
@@ -241,7 +235,7 @@ static size_t chain_bwd_lds() {
     typedef ChainGeom<D> G;
     const size_t bufs = 2 * (size_t)(2 * 3 * G::UNIT);     // 2 buffers x 2 units x (W1, W2^T, W1^T)
     const size_t body = bufs > (size_t)G::OUT_BYTES ? bufs : (size_t)G::OUT_BYTES;
-    return body + SP_MAX_UNITS_PER_SPLIT * 32 * sizeof(float) + SPG_ENTRIES * sizeof(float4);
+    return body + SP_MAX_UNITS_PER_SPLIT * 32 * sizeof(float) + GELU_TAB_N * sizeof(gtab_t);
 }
 
 template <int D, int DM>
@@ -256,7 +250,7 @@ __global__ __launch_bounds__(SP_THREADS, 2) void split_chain_bwd_kernel(const Sp
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* wbuf = smem;
     float* biasl = reinterpret_cast<float*>(smem + BODY);
-    float4* gtab = reinterpret_cast<float4*>(biasl + SP_MAX_UNITS_PER_SPLIT * 32);
+    gtab_t* gtab = reinterpret_cast<gtab_t*>(biasl + SP_MAX_UNITS_PER_SPLIT * 32);
 
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, il = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -298,11 +292,7 @@ __global__ __launch_bounds__(SP_THREADS, 2) void split_chain_bwd_kernel(const Sp
     };
     stage(0, 0);
     for (int i = tid; i < (u1 - u0) * 32; i += SP_THREADS) biasl[i] = tw.b1p[u0 * 32 + i];
-    for (int i = tid; i < SPG_ENTRIES; i += SP_THREADS) {
-        float ta, tb, tc, td;
-        spg_cell(i, dr.scale, ta, tb, tc, td);
-        gtab[i] = make_float4(ta, tb, tc, td);
-    }
+    gelu_tab_fill(gtab, dr.scale, tid, SP_THREADS);
     // operand fragments in registers before the chunk loop (see the forward kernel)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -372,12 +362,12 @@ __global__ __launch_bounds__(SP_THREADS, 2) void split_chain_bwd_kernel(const Sp
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float x = hacc[mt][t][r];
-                        const float4 e = gtab[spg_index(x)];
-                        const float gl = __builtin_fmaf(e.y, x, e.x);                 // gelu(x) * scale
-                        const float dg = gacc[mt][t][r] * __builtin_fmaf(e.w, x, e.z);  // dHact * gelu'(x) * scale
+                        const gtab_t e = gtab[pwl_index(x)];
+                        const float gl = __builtin_fmaf(e[1], x, e[0]);                   // gelu(x) * scale
+                        const float dg = gacc[mt][t][r] * __builtin_fmaf(e[3], x, e[2]);  // dHact * gelu'(x) * scale
                         if (DM == DM_NONE) { hacc[mt][t][r] = gl; gacc[mt][t][r] = dg; }
                         else {
-                            const unsigned int mk = bitmask(word, 16 * t + r);
+                            const unsigned int mk = bit_to_mask(word, 16 * t + r);
                             hacc[mt][t][r] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, gl) & mk);
                             gacc[mt][t][r] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, dg) & mk);
                         }

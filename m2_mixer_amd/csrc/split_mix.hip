@@ -52,7 +52,7 @@ __global__ __launch_bounds__(NTHREADS) void split_mix_fwd_kernel(const SplitMixA
     const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
     const bool has_block = tw.blk.ln1_w != nullptr;
     TIMER_START();
-    if (has_block) gelu_tab_fill(gtab, tid, NTHREADS);
+    if (has_block) gelu_tab_fill(gtab, make_drop(training, tw.p_drop, 0u, 0u, 0u).scale, tid, NTHREADS);
 
     // ---- the residual stream entering this launch (rows >= R are zero) ----
     if (tw.xprev == nullptr) {
@@ -146,8 +146,8 @@ __global__ __launch_bounds__(NTHREADS) void split_mix_fwd_kernel(const SplitMixA
                 float h = wr[2 * NMAX];
 #pragma unroll
                 for (int n = 0; n < NMAX; ++n) h = __builtin_fmaf(wr[n], un[n], h);
-                h = Act<P>::gelu(gtab, h) * dr_th.scale;
-                h = ((wth >> t) & 1u) ? h : 0.f;
+                h = Act<P>::gelu_scaled(gtab, h, dr_th.scale);
+                h = DM == DM_NONE ? h : mask_f(h, bit_to_mask(wth, t));
 #pragma unroll
                 for (int n = 0; n < NMAX; ++n) o[n] = __builtin_fmaf(wr[NMAX + n], h, o[n]);
             }
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(NTHREADS) void split_mix_bwd_kernel(const SplitMixB
         if (tw.lnf_w) ln_backward_tile<D, false>(tw.x_final + row0 * D, R, ub, tw.lnf_w, dxs, false, xh, mypart + SPP_LNF(D), mypart + SPP_LNF(D) + D, tid);
     } else {
         const m2m_block& bk = tw.up;
-        if (Act<P>::USES_TABLE) gelu_tab_fill(gtab, tid, NTHREADS);
+        if (Act<P>::USES_TABLE) gelu_tab_fill(gtab, make_drop(true, tw.p_drop, 0u, 0u, 0u).scale, tid, NTHREADS);
         const Drop dr_th = make_drop(true, tw.p_drop, seed, step, tw.site_up + 0);
         const Drop dr_to = make_drop(true, tw.p_drop, seed, step, tw.site_up + 1);
         // ---- gradient stream carried from the previous launch; dA = sum of the column-split partial results ----
@@ -410,12 +410,11 @@ __global__ __launch_bounds__(NTHREADS) void split_mix_bwd_kernel(const SplitMixB
                         h = __builtin_fmaf(w1r[tt][n], un[n], h);
                         dh = __builtin_fmaf(w2r[n][tt], dv[n], dh);
                     }
-                    float gl, dgl;
-                    Act<P>::gelu_grad(gtab, h, gl, dgl);
+                    float gl, dgl;                                   // both carry the dropout scale
+                    Act<P>::gelu_grad_scaled(gtab, h, dr_th.scale, gl, dgl);
                     const bool keep = (wth >> (t & 31)) & 1u;
-                    const float sc = dr_th.scale;
-                    const float hact = keep ? gl * sc : 0.f;
-                    const float dhp = (keep && pv) ? dh * sc * dgl : 0.f;
+                    const float hact = keep ? gl : 0.f;
+                    const float dhp = (keep && pv) ? dh * dgl : 0.f;
                     ab1[tt] += dhp;
 #pragma unroll
                     for (int n = 0; n < NMAX; ++n) {

@@ -62,7 +62,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
     const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
 
     TIMER_START();
-    if (Act<P>::USES_TABLE) gelu_tab_fill(gtab, tid, NTHREADS);
+    if (Act<P>::USES_TABLE) gelu_tab_fill(gtab, make_drop(true, tw.p_drop, 0u, 0u, 0u).scale, tid, NTHREADS);
     // ---- upstream gradient of the tower output ----
     {
         const float invN = 1.0f / (float)N;
@@ -232,12 +232,15 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                 for (int t = 0; t < 2; ++t) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float gl, dgl;
-                        Act<P>::gelu_grad(gtab, hacc[mt][t][r], gl, dgl);
-                        const bool keep = (word >> (16 * t + r)) & 1u;
-                        const float v = gacc[mt][t][r] * dgl * dr_ch.scale;
-                        gacc[mt][t][r] = keep ? v : 0.f;
-                        hacc[mt][t][r] = keep ? gl * dr_ch.scale : 0.f;
+                        float gl, dgl;                                   // both carry the dropout scale
+                        Act<P>::gelu_grad_scaled(gtab, hacc[mt][t][r], dr_ch.scale, gl, dgl);
+                        const float v = gacc[mt][t][r] * dgl;
+                        if (DM == DM_NONE) { gacc[mt][t][r] = v; hacc[mt][t][r] = gl; }
+                        else {
+                            const unsigned int mk = bit_to_mask(word, 16 * t + r);
+                            gacc[mt][t][r] = mask_f(v, mk);
+                            hacc[mt][t][r] = mask_f(gl, mk);
+                        }
                     }
                 }
                 Chain<P>::make(gacc[mt][0], gacc[mt][1], hf[mt]);     // dHpre: operand of dA += dHpre W1
@@ -390,12 +393,11 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                             h = __builtin_fmaf(w1r[tt][n], un[n], h);
                             dh = __builtin_fmaf(w2r[n][tt], dv[n], dh);
                         }
-                        float gl, dgl;
-                        Act<P>::gelu_grad(gtab, h, gl, dgl);
+                        float gl, dgl;                                   // both carry the dropout scale
+                        Act<P>::gelu_grad_scaled(gtab, h, dr_th.scale, gl, dgl);
                         const bool keep = (wth >> (t & 31)) & 1u;
-                        const float sc = dr_th.scale;
-                        const float hact = keep ? gl * sc : 0.f;
-                        const float dhp = (keep && pv) ? dh * sc * dgl : 0.f;
+                        const float hact = keep ? gl : 0.f;
+                        const float dhp = (keep && pv) ? dh * dgl : 0.f;
                         ab1[tt] += dhp;
 #pragma unroll
                         for (int n = 0; n < NMAX; ++n) {

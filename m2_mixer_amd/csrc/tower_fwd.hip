@@ -51,7 +51,7 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
     const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
 
     TIMER_START();
-    if (Act<P>::USES_TABLE) gelu_tab_fill(gtab, tid, NTHREADS);
+    if (Act<P>::USES_TABLE) gelu_tab_fill(gtab, make_drop(training, tw.p_drop, 0u, 0u, 0u).scale, tid, NTHREADS);
     // ---- load the input tile (rows >= R are zero) ----
     _Pragma("unroll 1") for (int idx = tid; idx < BM * (D / 4); idx += NTHREADS) {
         const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
@@ -118,8 +118,8 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
                 float h = wr[2 * NMAX];
 #pragma unroll
                 for (int n = 0; n < NMAX; ++n) h = __builtin_fmaf(wr[n], un[n], h);
-                h = Act<P>::gelu(gtab, h) * dr_th.scale;
-                h = ((wth >> t) & 1u) ? h : 0.f;
+                h = Act<P>::gelu_scaled(gtab, h, dr_th.scale);
+                h = DM == DM_NONE ? h : mask_f(h, bit_to_mask(wth, t));
 #pragma unroll
                 for (int n = 0; n < NMAX; ++n) o[n] = __builtin_fmaf(wr[NMAX + n], h, o[n]);
             }
@@ -208,8 +208,8 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
                 for (int t = 0; t < 2; ++t) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float v = Act<P>::gelu(gtab, hacc[mt][t][r]) * dr_ch.scale;
-                        hacc[mt][t][r] = ((word >> (16 * t + r)) & 1u) ? v : 0.f;
+                        const float v = Act<P>::gelu_scaled(gtab, hacc[mt][t][r], dr_ch.scale);
+                        hacc[mt][t][r] = DM == DM_NONE ? v : mask_f(v, bit_to_mask(word, 16 * t + r));
                     }
                 }
                 Chain<P>::make(hacc[mt][0], hacc[mt][1], hf[mt]);
