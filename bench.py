@@ -28,14 +28,34 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense peaks, MI355X_MICROARCH.md "Chip-level parameters"
-# HBM bytes per launch (read + written) from the rocprofv3 PMC passes of this round -- FETCH_SIZE (doubled: the gfx950
-# correction) + WRITE_SIZE, M2-Mixer-B, batch 512, bf16: profiles/r01_pmc_summary.md.  PMC counters cannot be collected from
-# inside the benchmark process; refresh the table when a kernel changes.
-PMC_TRAFFIC_BYTES_B512_BF16 = {
-    "towers_bwd[image+audio]": 347.3e6, "tower_bwd[fusion]": 172.0e6,
-    "towers_fwd[image+audio]": 75.7e6, "tower_fwd[fusion]": 40.8e6,
-    "towers_wgrad[all+embeds]": 559.0e6,
-}
+# HBM bytes per launch come from the rocprofv3 PMC passes (counters cannot be collected from inside this process): the
+# summary scripts/collect_profiles.sh writes, keyed by kernel name and by the hash of the kernel sources it was taken on.
+PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc.json")
+LAUNCH_KERNEL = {"towers_bwd[image+audio]": "tower_bwd_group_kernel", "tower_bwd[fusion]": "tower_bwd_kernel",
+                 "towers_fwd[image+audio]": "tower_fwd_group_kernel", "tower_fwd[fusion]": "tower_fwd_kernel",
+                 "towers_wgrad[all+embeds]": "tower_wgrad_group_kernel", "adam": "adam_kernel", "pack_all": "pack_all_kernel",
+                 "embeds_fwd[image+audio]": "embed_fwd_group_kernel", "heads_ce": "heads_kernel"}
+
+
+def pmc_traffic(launch, model, B, precision):
+    """HBM bytes (2 x FETCH_SIZE + WRITE_SIZE) of one launch of `launch` from profiles/r02_pmc.json -- None, with a
+    warning, when the file is missing, was taken on other kernel sources, or covers another configuration."""
+    if not (model == "B" and B == 512 and precision == "bf16"):
+        return None
+    try:
+        with open(PMC_JSON) as f:
+            rec = json.load(f)
+    except OSError:
+        log(f"roofline.traffic: {PMC_JSON} not found -> null")
+        return None
+    from m2_mixer_amd import _lib
+    if rec.get("csrc_sha256") != _lib.csrc_hash():
+        log("roofline.traffic: profiles/r02_pmc.json was collected on different kernel sources (stale) -> null; "
+            "re-run scripts/collect_profiles.sh")
+        return None
+    k = rec["kernels"].get(LAUNCH_KERNEL.get(launch, ""), None)
+    return None if k is None else k["traffic_bytes"]
+
 
 # AV-MNIST M2-Mixer-B  (reference cfg/avmnist/avmnist_m2-mixer_B.yml:24-56)
 CFG_B = dict(dropout=0.5, num_classes=10,
@@ -295,7 +315,9 @@ def main():
     run_steps(args.steps)
     barrier()
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
-    loss_end = float(eng.losses[3])
+    # the last step ran through the multi-step graph (its own per-step output slots) or through the single-step graph
+    last_multi = multi is not None and args.steps >= spg and args.steps % spg == 0
+    loss_end = float((multi.losses[-1] if last_multi else eng.losses)[3])
     log(f"timed region {elapsed * 1e3:.1f} ms; profiling launches")
 
     # ---- per-launch timing (HIP events on the launch stream), eager pass of the very same step ----
@@ -318,7 +340,7 @@ def main():
     dom = max(kern.items(), key=lambda kv: kv[1]["us_per_step"])
     roof = {"bound": "mfma", "kernel": dom[0], "achieved": round(dom[1]["flops_per_launch"] / (dom[1]["us_per_launch"] * 1e-6) / 1e12, 2),
             "peak": peak, "unit": "TFLOP/s",
-            "traffic": PMC_TRAFFIC_BYTES_B512_BF16.get(dom[0]) if (args.model == "B" and B == 512 and args.precision == "bf16") else None}
+            "traffic": pmc_traffic(dom[0], args.model, B, args.precision)}
     roof["frac"] = round(roof["achieved"] / peak, 4)
     out = {
         "metric": "training samples/sec AV-MNIST M2-Mixer-%s %s" % (args.model, args.precision),

@@ -137,6 +137,18 @@ SIGNATURES = {
 _lib = None
 
 
+def csrc_hash() -> str:
+    """sha256 over the kernel sources (csrc/*.hip, *.h, the C header): identifies the code a profile was taken on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) +
+                    [os.path.join(os.path.dirname(_HERE), "include", "m2mixer.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/*.hip for gfx950 into libm2mixer.so (hipcc cross-compiles without a GPU)."""
     if force:

@@ -11,6 +11,16 @@
 #define MLP_T 256          // threads
 #define MLP_MAXW 128       // widest layer (LDS: activations + one layer's weights)
 
+// index -> (row, column) of a row-major [rows][cols] array without a runtime division when cols is a power of two (the
+// MIMIC widths are 64): 16 divisions per thread and layer were a visible share of these latency-bound kernels
+struct Div {
+    int d, sh; bool p2;
+    __device__ __forceinline__ explicit Div(int dd) : d(dd), sh(31 - __clz(dd)), p2((dd & (dd - 1)) == 0) {}
+    __device__ __forceinline__ int q(int i) const { return p2 ? i >> sh : i / d; }
+    __device__ __forceinline__ int r(int i) const { return p2 ? i & (d - 1) : i % d; }
+};
+#define MLP_U 8            // global loads a thread keeps in flight in the staging loops (one L2 round trip per batch, not per element)
+
 static __device__ __forceinline__ Drop mlp_drop(const m2m_mlp& m, int layer, int training, unsigned int seed, unsigned int step) {
     return make_drop(training != 0, m.p_drop, seed, step, m.site_base + (unsigned int)layer);
 }
@@ -39,10 +49,21 @@ __global__ __launch_bounds__(MLP_T) void mlp_fwd_kernel(const m2m_mlp m, const f
         const bool hidden = l < m.nlayers - m.has_out;
         const Drop dr = mlp_drop(m, l, training && hidden, seed, step);
         __syncthreads();
-        for (int i = tid; i < din * dout; i += MLP_T) { const int j = i / din, k = i % din; wt[k * (dout + 1) + j] = m.w[l][i]; }
+        {
+            const Div dv(din);
+            const float* __restrict__ w = m.w[l];
+            for (int i0 = tid; i0 < din * dout; i0 += MLP_U * MLP_T) {
+                float v[MLP_U];
+#pragma unroll
+                for (int u = 0; u < MLP_U; ++u) { const int i = i0 + u * MLP_T; v[u] = i < din * dout ? w[i] : 0.f; }
+#pragma unroll
+                for (int u = 0; u < MLP_U; ++u) { const int i = i0 + u * MLP_T; if (i < din * dout) wt[dv.r(i) * (dout + 1) + dv.q(i)] = v[u]; }
+            }
+        }
         __syncthreads();
+        const Div dvo(dout);
         for (int i = tid; i < MLP_S * dout; i += MLP_T) {
-            const int s = i / dout, j = i % dout;
+            const int s = dvo.q(i), j = dvo.r(i);
             float acc = m.b[l][j];
             for (int k = 0; k < din; ++k) acc = __builtin_fmaf(cur[s * LD + k], wt[k * (dout + 1) + j], acc);
             if (hidden) {
@@ -95,21 +116,46 @@ __global__ __launch_bounds__(MLP_T) void mlp_bwd_kernel(const m2m_mlp m, const f
         const bool hidden = l < m.nlayers - m.has_out;
         const float* inp = l == 0 ? x : m.act[l - 1];
         __syncthreads();
-        for (int i = tid; i < dout * din; i += MLP_T) wl[(i / din) * (din + 1) + i % din] = m.w[l][i];
-        for (int i = tid; i < MLP_S * din; i += MLP_T) {
-            const int s = i / din, k = i % din;
-            ain[s * LD + k] = s < ns ? inp[(long)(s0 + s) * din + k] : 0.f;
+        const Div dvi(din), dvo(dout);
+        {
+            const float* __restrict__ w = m.w[l];
+            for (int i0 = tid; i0 < dout * din; i0 += MLP_U * MLP_T) {
+                float v[MLP_U];
+#pragma unroll
+                for (int u = 0; u < MLP_U; ++u) { const int i = i0 + u * MLP_T; v[u] = i < dout * din ? w[i] : 0.f; }
+#pragma unroll
+                for (int u = 0; u < MLP_U; ++u) { const int i = i0 + u * MLP_T; if (i < dout * din) wl[dvi.q(i) * (din + 1) + dvi.r(i)] = v[u]; }
+            }
+            for (int i0 = tid; i0 < MLP_S * din; i0 += MLP_U * MLP_T) {
+                float v[MLP_U];
+#pragma unroll
+                for (int u = 0; u < MLP_U; ++u) {
+                    const int i = i0 + u * MLP_T, sI = dvi.q(i);
+                    v[u] = (i < MLP_S * din && sI < ns) ? inp[(long)(s0 + sI) * din + dvi.r(i)] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < MLP_U; ++u) { const int i = i0 + u * MLP_T; if (i < MLP_S * din) ain[dvi.q(i) * LD + dvi.r(i)] = v[u]; }
+            }
         }
         if (hidden) {                                  // through Dropout and ReLU
-            for (int i = tid; i < MLP_S * dout; i += MLP_T) {
-                const int s = i / dout, j = i % dout;
-                const float o = s < ns ? m.act[l][(long)(s0 + s) * dout + j] : 0.f;
-                gc[s * LD + j] = o != 0.f ? gc[s * LD + j] * scale : 0.f;
+            const float* __restrict__ actl = m.act[l];
+            for (int i0 = tid; i0 < MLP_S * dout; i0 += MLP_U * MLP_T) {
+                float o[MLP_U];
+#pragma unroll
+                for (int u = 0; u < MLP_U; ++u) {
+                    const int i = i0 + u * MLP_T, sI = dvo.q(i);
+                    o[u] = (i < MLP_S * dout && sI < ns) ? actl[(long)(s0 + sI) * dout + dvo.r(i)] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < MLP_U; ++u) {
+                    const int i = i0 + u * MLP_T;
+                    if (i < MLP_S * dout) { float* gp = gc + dvo.q(i) * LD + dvo.r(i); *gp = o[u] != 0.f ? *gp * scale : 0.f; }
+                }
             }
         }
         __syncthreads();
         for (int i = tid; i < dout * din; i += MLP_T) {      // dW[j][k] += sum_s dz[s][j] in[s][k]
-            const int j = i / din, k = i % din;
+            const int j = dvi.q(i), k = dvi.r(i);
             float a = 0.f;
             for (int s = 0; s < MLP_S; ++s) a = __builtin_fmaf(gc[s * LD + j], ain[s * LD + k], a);
             atomicAdd(m.g_w[l] + i, a);
@@ -121,7 +167,7 @@ __global__ __launch_bounds__(MLP_T) void mlp_bwd_kernel(const m2m_mlp m, const f
         }
         if (l > 0) {
             for (int i = tid; i < MLP_S * din; i += MLP_T) {  // d_in[s][k] = sum_j dz[s][j] W[j][k]
-                const int s = i / din, k = i % din;
+                const int s = dvi.q(i), k = dvi.r(i);
                 float a = 0.f;
                 for (int j = 0; j < dout; ++j) a = __builtin_fmaf(gc[s * LD + j], wl[j * (din + 1) + k], a);
                 gn[s * LD + k] = a;

@@ -47,7 +47,8 @@ def _block_tensors(block: "MixerBlock") -> dict:
 
 
 class _TowerFunction(torch.autograd.Function):
-    """x (B, N, D) -> blocks (+ final LayerNorm) -> (B, N, D)."""
+    """x (B, N, D) -> blocks (+ final LayerNorm) -> (B, N, D).  Re-entrant: every forward that will be differentiated
+    gets its own set of saved activations (TowerRuntime.fresh_saved), kept in the autograd ctx."""
 
     @staticmethod
     def forward(ctx, x, owner, need_grad, *params):
@@ -59,9 +60,12 @@ class _TowerFunction(torch.autograd.Function):
         rt.desc.p_drop = float(owner.dropout_p) if dropping else 0.0
         seed, step = config.dropout_seed(), owner._bump_step() if dropping else 0
         out = torch.empty(B, N, D, device=x.device, dtype=torch.float32)
+        rt.ensure_workspace(B)
+        ctx.saved = rt.fresh_saved(B) if need_grad else None
+        if dropping and not need_grad:
+            rt.ensure_buffers(B)            # dropout without autograd (train() under no_grad): the kernels still save
         rt.forward(x, N * D, B, out, N * D, None, need_grad or dropping, seed, step)
-        ctx.owner, ctx.B, ctx.seed, ctx.step = owner, B, seed, step
-        ctx.gen = owner._fwd_generation = owner._fwd_generation + 1
+        ctx.owner, ctx.B, ctx.seed, ctx.step, ctx.p_drop = owner, B, seed, step, rt.desc.p_drop
         ctx.nparams = len(params)
         return out
 
@@ -69,9 +73,13 @@ class _TowerFunction(torch.autograd.Function):
     def backward(ctx, dout):
         owner = ctx.owner
         rt: TowerRuntime = owner._rt
-        if ctx.gen != owner._fwd_generation:
-            raise RuntimeError("this tower ran another forward before backward; saved activations were overwritten")
+        if ctx.saved is None:
+            raise RuntimeError("backward through a tower forward that ran without gradients enabled")
         B, N, D = ctx.B, rt.N, rt.D
+        rt.ensure_buffers(B)                # operand images sized for THIS batch (a forward at another batch size may have
+        rt.ensure_workspace(B)              # re-allocated them since), then this forward's own activations
+        rt.use_saved(ctx.saved)
+        rt.desc.p_drop = ctx.p_drop
         flat = torch.zeros(rt.grad_numel(), device=dout.device, dtype=torch.float32)
         views = rt.bind_grads(flat)
         dx = torch.empty(B, N, D, device=dout.device, dtype=torch.float32)
@@ -110,7 +118,6 @@ class _HipTower(nn.Module):
         self.dropout_p = float(dropout)
         self.precision = precision
         self._rt: Optional[TowerRuntime] = None
-        self._fwd_generation = 0
         self._drop_step = 0
         self._site_base = 1024 * next(_site_counter)
 

@@ -25,9 +25,9 @@ class _MlpFunction(torch.autograd.Function):
         dropping = training and owner.dropout_p > 0
         rt.desc.p_drop = float(owner.dropout_p) if dropping else 0.0
         step = owner._bump_step() if dropping else 0
+        ctx.acts = rt.fresh_acts(B, x.device)        # this forward's own saved activations: the module path is re-entrant
         rt.forward(x, B, out, rt.dims[-1], None, True, config.dropout_seed(), step)     # training=True: keep the activations
         ctx.owner, ctx.B = owner, B
-        ctx.gen = owner._fwd_generation = owner._fwd_generation + 1
         ctx.save_for_backward(x)
         return out
 
@@ -35,11 +35,10 @@ class _MlpFunction(torch.autograd.Function):
     def backward(ctx, dout):
         owner = ctx.owner
         rt: MlpRuntime = owner._rt
-        if ctx.gen != owner._fwd_generation:
-            raise RuntimeError("this MLP ran another forward before backward; saved activations were overwritten")
         (x,) = ctx.saved_tensors
         grads = [torch.zeros_like(p) for p in owner._linear_params()]
         rt.bind(owner._param_pairs(), [(grads[2 * i], grads[2 * i + 1]) for i in range(rt.nlayers)], ctx.B)
+        rt.use_acts(ctx.acts)                        # (after bind: a batch-size change there re-allocates its own set)
         rt.backward(x, ctx.B, dout.contiguous(), rt.dims[-1], None)
         return (None, None, None) + tuple(grads)
 
@@ -57,7 +56,6 @@ class MLP(nn.Module):
         self.module_list = nn.ModuleList(layers)
         self._dims = [input_dim] + [hidden_dim] * num_blocks + ([output_dim] if output_dim is not None else [])
         self._rt: Optional[MlpRuntime] = None
-        self._fwd_generation = 0
         self._drop_step = 0
         self._site_base = 1 << 20 | (16 * next(_site_counter))
 

@@ -159,6 +159,33 @@ class TowerRuntime:
         self._keep["x_final"] = xf
         self._bufB = B
 
+    # ---- re-entrancy of the module path (torch autograd): one set of forward-saved activations per forward --------------
+    def fresh_saved(self, B: int) -> dict:
+        """A NEW set of the buffers a training forward writes and the matching backward reads (block inputs, post-token-mix
+        streams, the final LayerNorm's input; on the split path also the LN2 operand images), and the descriptor pointed at
+        it.  The autograd Function keeps the set in its ctx, so a validation forward between a training forward and its
+        backward, or gradient accumulation over several micro-batches, no longer overwrites what a pending backward needs.
+        Buffers only the backward writes (dYd images, hidden-activation operand streams) stay shared: a backward call is
+        atomic."""
+        self.ensure_buffers(B)
+        M = B * self.N
+        f = lambda: torch.empty(M, self.D, device=self.device)
+        saved = {"B": B, "x_in": [f() for _ in range(self.nblocks)], "x_mid": [f() for _ in range(self.nblocks)], "x_final": f()}
+        if "split" in self._keep and self._splitB == B:
+            sp = self._keep["split"]
+            saved["a_nat"] = [torch.zeros_like(t) for t in sp["a_nat"]]
+            saved["at_chn"] = [torch.zeros_like(self._keep[f"saved{i}"]["at_chn"]) for i in range(self.nblocks)]
+        self.use_saved(saved)
+        return saved
+
+    def use_saved(self, saved: dict):
+        for i in range(self.nblocks):
+            self.desc.blk[i].x_in, self.desc.blk[i].x_mid = saved["x_in"][i].data_ptr(), saved["x_mid"][i].data_ptr()
+            if "a_nat" in saved:
+                self.desc.a_nat[i], self.desc.blk[i].at_chn = saved["a_nat"][i].data_ptr(), saved["at_chn"][i].data_ptr()
+        self.desc.x_final = saved["x_final"].data_ptr()
+        self._keep["saved_set"] = saved
+
     def ensure_split(self, B: int):
         """Buffers of the split path (include/m2mixer.h, csrc/split.h): slabs of the column-split channel launches, the carry
         stream, per-block bf16 operand images.  Allocated for every tower the split path can take (fused class, bf16,
@@ -450,11 +477,21 @@ class MlpRuntime:
     def ensure_buffers(self, B: int, device):
         if B == self._B:
             return
+        self.use_acts([torch.zeros(B, self.dims[i + 1], device=device) for i in range(self.nlayers)])
+        self._B = B
+
+    def fresh_acts(self, B: int, device) -> list:
+        """A new set of saved hidden activations for one forward (re-entrancy of the module path, see
+        TowerRuntime.fresh_saved)."""
         acts = [torch.zeros(B, self.dims[i + 1], device=device) for i in range(self.nlayers)]
+        self.use_acts(acts)
+        self._B = B
+        return acts
+
+    def use_acts(self, acts: list):
         for i, a in enumerate(acts):
             self.desc.act[i] = a.data_ptr()
         self._keep["act"] = acts
-        self._B = B
 
     def forward(self, x: torch.Tensor, B: int, out: torch.Tensor, out_ss: int, out_dense: Optional[torch.Tensor],
                 training: bool, seed: int, step: int, step_dev: Optional[torch.Tensor] = None):

@@ -43,7 +43,11 @@ def run(task, B, steps, warmup, precision, dev):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     sps = B * steps / dt
-    return {"metric": f"training samples/sec {task} {precision}", "value": round(sps, 1), "unit": "samples/s",
+    peak = 2500.0 if precision == "bf16" else 157.3           # dense MFMA peak, TFLOP/s (MI355X_MICROARCH.md)
+    ach = sps * MFLOP_PER_SAMPLE[task] * 1e6 / 1e12
+    return {"roofline": {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 5),
+                         "traffic": None, "note": "whole step: algorithmic FLOPs (SURVEY.md section 8a) / step time"},
+            "metric": f"training samples/sec {task} {precision}", "value": round(sps, 1), "unit": "samples/s",
             "ms_per_step": round(dt / steps * 1e3, 4), "batch": B, "steps": steps, "warmup": warmup, "dtype": precision,
             "data": "synthetic", "n_params": eng.n_params,
             "achieved_tflops": round(sps * MFLOP_PER_SAMPLE[task] * 1e6 / 1e12, 3), "final_loss": round(float(eng.losses[3]), 4)}

@@ -25,6 +25,6 @@ for pass in "mfma:SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GU
 done
 cd $R
 python scripts/timeline.py $O/stats/s_kernel_trace.csv 25 > $O/step_timeline.txt
-python scripts/pmc_summary.py $O/pmc > $O/pmc_summary_table.md
+python scripts/pmc_summary.py $O/pmc $O/pmc.json > $O/pmc_summary_table.md
 python scripts/bench_configs.py > $O/secondary_configs.jsonl 2> $O/secondary.err
 echo "all done"

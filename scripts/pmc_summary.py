@@ -10,19 +10,21 @@ MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 256 CUs * 4
 import collections
 import csv
 import glob
+import json
 import os
 import sys
 
-KEEP = ("tower_", "embed_", "adam_kernel", "heads_kernel", "pack_all", "pack_tower")
+KEEP = ("tower_", "embed_", "adam_kernel", "heads_kernel", "pack_all", "pack_tower", "split_")
 
 
 def short(name):
-    name = name.split("(")[0]
+    name = name.replace("(anonymous namespace)::", "").split("(")[0]
     return name.replace("void ", "")
 
 
-def main(root):
+def main(root, json_out=None):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    kernels = {}
     for path in sorted(glob.glob(os.path.join(root, "*", "p_counter_collection.csv"))):
         for r in csv.DictReader(open(path)):
             k = short(r["Kernel_Name"])
@@ -48,7 +50,22 @@ def main(root):
         ratio = (valu - n_mfma) / n_mfma if n_mfma else float("nan")
         stall = mean.get("SQ_WAIT_INST_ANY", 0) / mean["SQ_WAVE_CYCLES"] if mean.get("SQ_WAVE_CYCLES") else 0
         print(f"| `{k}` | {grid} | {n} | {rd:.1f} | {wr:.1f} | {cyc:,.0f} | {util:.1f} | {ratio:.1f} | {stall:.2f} |")
+        base = k.split("<")[0]
+        rec = kernels.setdefault(base, {})
+        # several instantiations of one kernel (e.g. the two token classes of a tower kernel): keep the one moving most bytes
+        if rd + wr >= rec.get("traffic_bytes", -1) / 1e6:
+            rec.update({"instantiation": k, "grid_threads": int(grid), "launches_sampled": n, "hbm_read_bytes_2x_fetch_size": rd * 1e6,
+                        "hbm_write_bytes": wr * 1e6, "traffic_bytes": (rd + wr) * 1e6, "gpu_cycles": cyc,
+                        "mfma_busy_pct": round(util, 2), "valu_per_mfma": None if ratio != ratio else round(ratio, 2),
+                        "issue_stall_share": round(stall, 3)})
+    if json_out:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from m2_mixer_amd import _lib
+        with open(json_out, "w") as f:
+            json.dump({"csrc_sha256": _lib.csrc_hash(), "workload": "AV-MNIST M2-Mixer-B, bf16, per-GPU batch 512, one training step",
+                       "method": "rocprofv3 --pmc passes (scripts/collect_profiles.sh); medians per launch; FETCH_SIZE x 2 "
+                                 "(gfx950 correction) + WRITE_SIZE", "kernels": kernels}, f, indent=1)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc")
+    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc", sys.argv[2] if len(sys.argv) > 2 else None)

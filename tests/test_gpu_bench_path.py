@@ -374,3 +374,46 @@ def test_checkpoint_to_predictions_round_trip_vs_oracle(dev, tmp_path):
     assert abserr(mres["logits"], mref["logits"]) < FP32_ATOL and abs(float(mres["loss"]) - float(mref["loss"])) < FP32_ATOL
     assert torch.equal(mres["preds"].cpu().long(), mref["preds"])
     assert list(meng.state_dict().keys()) == list(sd.keys())
+
+
+def test_module_path_is_reentrant(dev):
+    """SURVEY section 8b asks for re-entrancy: a validation forward between a training forward and its backward, and
+    gradient accumulation over two micro-batches (two forwards, then the two backwards), must give the gradients of the
+    plain sequence.  Towers (fused and wide path) and the static MLP, fp32 mode, against autograd through the oracle."""
+    import m2_mixer_amd as M
+    from m2_mixer_amd import modules as MM
+    M.set_precision("fp32")
+    for case in ((4, 128, 32, 3072), (24, 64, 16, 64)):
+        N, D, T, Cc = case
+        p, x1, dy1 = G.block_case_tensors(case, 5, seed=91)
+        _, x2, dy2 = G.block_case_tensors(case, 3, seed=92)              # another batch size
+        blk = MM.MixerBlock(D, N, T, Cc, dropout=0.0).to(dev)
+        blk.load_state_dict(p)
+        blk.train()
+        a = x1.to(dev).requires_grad_(True)
+        b = x2.to(dev).requires_grad_(True)
+        ya = blk(a)
+        with torch.no_grad():
+            blk(x2.to(dev))                                              # validation-style forward in between
+        yb = blk(b)
+        (yb * dy2.to(dev)).sum().backward()                              # backwards in the opposite order
+        (ya * dy1.to(dev)).sum().backward()
+        torch.cuda.synchronize()
+        leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        r1, r2 = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+        ((O.mixer_block(r1, leaves) * dy1).sum() + (O.mixer_block(r2, leaves) * dy2).sum()).backward()
+        assert abserr(a.grad, r1.grad) < FP32_ATOL and abserr(b.grad, r2.grad) < FP32_ATOL
+        for k, prm in blk.named_parameters():
+            assert relerr(prm.grad, leaves[k].grad) < 1e-3, (case, k)
+    cs = G.MIMIC_H["static"]
+    mlp = MM.MLP(cs["input_dim"], cs["hidden_dim"], cs["num_blocks"], cs["output_dim"], dropout=0.0).to(dev)
+    xa, xb = torch.randn(7, cs["input_dim"], device=dev), torch.randn(4, cs["input_dim"], device=dev)
+    ya = mlp(xa)
+    yb = mlp(xb)
+    yb.square().sum().backward()
+    ya.square().sum().backward()
+    torch.cuda.synchronize()
+    ref = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in mlp.state_dict().items()}
+    (O.mlp(xa.cpu(), ref, "", cs["num_blocks"], True).square().sum() + O.mlp(xb.cpu(), ref, "", cs["num_blocks"], True).square().sum()).backward()
+    for k, prm in mlp.named_parameters():
+        assert relerr(prm.grad, ref[k].grad) < 1e-4, k
