@@ -33,7 +33,7 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense peaks, MI355X_MICRO
 PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc.json")
 LAUNCH_KERNEL = {"towers_bwd[image+audio]": "tower_bwd_group_kernel", "tower_bwd[fusion]": "tower_bwd_kernel",
                  "towers_fwd[image+audio]": "tower_fwd_group_kernel", "tower_fwd[fusion]": "tower_fwd_kernel",
-                 "towers_wgrad[all+embeds]": "tower_wgrad_group_kernel", "adam": "adam_kernel", "pack_all": "pack_all_kernel",
+                 "towers_wgrad[all+embeds]": "tower_wgrad_group_kernel", "adam+pack": "adam_pack_all_kernel",
                  "embeds_fwd[image+audio]": "embed_fwd_group_kernel", "heads_ce": "heads_kernel"}
 
 
@@ -400,7 +400,6 @@ def profile_launches(eng, image, audio, labels, nsteps):
         (eng.t_fus, "backward", "tower_bwd[fusion]", b_tow("fusion")),
         (E, "towers_backward", "towers_bwd[image+audio]", sum(b_tow(t) for t in two)),
         (E, "towers_wgrad", "towers_wgrad[all+embeds]", sum(alg[t]["channel"] for t in ("image", "audio", "fusion")) + emb),
-        (E, "pack_all", "pack_all", 0),
     ]
     saved = [(o, a, getattr(o, a)) for o, a, _, _ in patches]
     for o, a, name, flops in patches:
@@ -411,12 +410,9 @@ def profile_launches(eng, image, audio, labels, nsteps):
             eng._backward(image, audio)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            L.check(L.lib().m2m_adam_step(eng.flat_p.data_ptr(), eng.flat_g.data_ptr(), eng.flat_m.data_ptr(),
-                                          eng.flat_v.data_ptr(), eng.n_params, eng.adam_state.data_ptr(), eng.betas[0],
-                                          eng.betas[1], eng.eps, eng.weight_decay, -1.0, 0, L.stream_ptr()))
+            eng._update(1.0)                  # Adam + operand re-pack: one launch (m2m_adam_pack_all)
             e1.record()
-            spans.setdefault("adam", {"events": [], "flops": 0})["events"].append((e0, e1))
-            eng.pack()
+            spans.setdefault("adam+pack", {"events": [], "flops": 0})["events"].append((e0, e1))
         torch.cuda.synchronize()
     finally:
         for o, a, orig in saved:

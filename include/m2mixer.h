@@ -284,6 +284,22 @@ int m2m_adam_step_bf16(float* param, float* grad, const void* grad_bf16, float* 
                        float* state, float beta1, float beta2, float eps, float weight_decay,
                        float grad_scale, int bump_step, void* stream);
 
+/* Adam + m2m_pack_all in ONE launch: the workgroups that update a channel-mixing weight tile (or an embedding weight) emit its
+ * packed operand copies from the values they have just computed, so the re-pack does not re-read the fp32 masters; everything
+ * else (LayerNorms, token MLPs, biases, heads) is updated by plain flat workgroups of the same launch.  All parameters must
+ * live in ONE flat buffer (param / grad / exp_avg / exp_avg_sq: same indexing, n elements); gradients are consumed (cleared).
+ * m2m_adam_pack_plan fills a host struct of m2m_adam_pack_plan_bytes() bytes describing the model (which flat ranges belong to
+ * tiles, the Adam constants; |grad_scale| is applied; grad_bf16 != NULL: take the gradient values from that bf16 copy); the
+ * caller keeps a device copy of it and passes both to m2m_adam_pack_all.  Replaces optimizer.step() + zero_grad()
+ * (models/avmnist.py:413-415) and the implied refresh of the weights the next forward reads. */
+int64_t m2m_adam_pack_plan_bytes(void);
+int m2m_adam_pack_plan(const m2m_tower* const* towers, int ntowers, const m2m_embed* const* embeds, int nembeds,
+                       float* param, float* grad, const void* grad_bf16, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       const float* state, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                       void* plan_host);
+int m2m_adam_pack_all(const m2m_tower* const* towers, int ntowers, const m2m_embed* const* embeds, int nembeds,
+                      const void* plan_dev, const void* plan_host, void* stream);
+
 /* Head of a training step, ONE launch: adam_state[0] += 1 (the step count m2m_adam_step reads), *drop_counter += 1
  * (the step_dev of the tower calls), losses[0 .. nlosses) = 0.  Any pointer may be NULL. */
 int m2m_step_prologue(float* adam_state, uint32_t* drop_counter, float* losses, int nlosses, void* stream);

@@ -173,28 +173,13 @@ static_assert(sizeof(PackAllArgs) <= 4096, "kernel arguments are limited to 4 Ki
 // [32q, 32q + 32) are read ONCE, coalesced, into LDS and all four packed copies (w1n, w1tc, w2c, w2tn) plus ch_b1p are
 // written from there.  (The slot-per-thread kernels above gather every master element twice, the transposed copies with
 // 4-byte loads in 64-byte segments: 28 us for the whole model against ~100 MB of unavoidable traffic.)
-template <int P, class TW>
-static __device__ __forceinline__ void pack_block_tile(const TW& tw, int block, int q, char* smem) {
+// Second half of a tile workgroup: the four packed copies (+ ch_b1p is written by the caller) from the LDS tiles
+//   t1 [32][D + 1] = W1[32q + r][d],  t2 [D][33] = W2[d][32q + j]   (rows / columns past C are zero)
+template <int P>
+static __device__ __forceinline__ void pack_emit_tile(const m2m_block& k, int D, int q, const float* t1, const float* t2) {
     typedef Prec<P> Pr;
-    const m2m_block& k = tw.blk[block];
-    const int D = tw.D, C = tw.C, L1 = D + 1, L2 = 33;
-    float* t1 = reinterpret_cast<float*>(smem);            // [32][D + 1]   W1[32q + r][d]
-    float* t2 = t1 + 32 * L1;                               // [D][33]       W2[d][32q + j]
+    const int L1 = D + 1, L2 = 33;
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int c0 = 32 * q;
-    for (int idx = tid; idx < 32 * (D / 4); idx += nthr) {
-        const int r = idx / (D / 4), d4 = (idx % (D / 4)) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c0 + r < C) v = *reinterpret_cast<const float4*>(k.ch_w1 + (long)(c0 + r) * D + d4);
-        float* o = t1 + r * L1 + d4;
-        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
-    }
-    for (int idx = tid; idx < D * 32; idx += nthr) {
-        const int d = idx >> 5, j = idx & 31;
-        t2[d * L2 + j] = c0 + j < C ? k.ch_w2[(long)d * C + c0 + j] : 0.f;
-    }
-    if (tid < 32) k.ch_b1p[c0 + tid] = c0 + tid < C ? k.ch_b1[c0 + tid] : 0.f;
-    __syncthreads();
     const int nKB = D / Pr::KB, nIB = D / 16, CB = 32 / Pr::KB;      // k-blocks along d; 16-row blocks along d; c k-blocks per tile
     auto emit = [&](char* dst, long blk, int lane, const float (&v)[8]) {
         Frag f;
@@ -237,6 +222,30 @@ static __device__ __forceinline__ void pack_block_tile(const TW& tw, int block, 
         emit((char*)k.w1tc, blk, lane, v1);
         emit((char*)k.w2c, blk, lane, v2);
     }
+}
+
+template <int P, class TW>
+static __device__ __forceinline__ void pack_block_tile(const TW& tw, int block, int q, char* smem) {
+    const m2m_block& k = tw.blk[block];
+    const int D = tw.D, C = tw.C, L1 = D + 1, L2 = 33;
+    float* t1 = reinterpret_cast<float*>(smem);            // [32][D + 1]   W1[32q + r][d]
+    float* t2 = t1 + 32 * L1;                               // [D][33]       W2[d][32q + j]
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int c0 = 32 * q;
+    for (int idx = tid; idx < 32 * (D / 4); idx += nthr) {
+        const int r = idx / (D / 4), d4 = (idx % (D / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c0 + r < C) v = *reinterpret_cast<const float4*>(k.ch_w1 + (long)(c0 + r) * D + d4);
+        float* o = t1 + r * L1 + d4;
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
+    for (int idx = tid; idx < D * 32; idx += nthr) {
+        const int d = idx >> 5, j = idx & 31;
+        t2[d * L2 + j] = c0 + j < C ? k.ch_w2[(long)d * C + c0 + j] : 0.f;
+    }
+    if (tid < 32) k.ch_b1p[c0 + tid] = c0 + tid < C ? k.ch_b1[c0 + tid] : 0.f;
+    __syncthreads();
+    pack_emit_tile<P>(k, D, q, t1, t2);
 }
 
 // blockIdx.x: the towers' (block, column group) tiles first -- tower t owns tile_end[t - 1] .. tile_end[t] -- then the
@@ -378,6 +387,264 @@ extern "C" int m2m_adam_step_bf16(float* param, float* grad, const void* grad_bf
                                   int bump_step, void* stream) {
     if (!grad_bf16) { m2m_set_error("adam_step_bf16: null bf16 gradient", __FILE__, __LINE__); return -1; }
     return adam_launch(param, grad, grad_bf16, exp_avg, exp_avg_sq, n, state, beta1, beta2, eps, weight_decay, grad_scale, bump_step, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Adam + operand re-pack of a whole model in ONE launch (replaces m2m_adam_step over the flat buffers followed by
+// m2m_pack_all): the re-pack no longer re-reads the 33 MB of fp32 masters Adam has just written, and the step loses a launch.
+//   tile workgroups  (tower, block, 32-column group q): Adam on W1 rows [32q, 32q + 32), W2 columns [32q, 32q + 32) and
+//                    ch_b1[32q ..]; the updated values go to memory AND into the LDS tiles the four packed copies are
+//                    emitted from (pack_emit_tile);
+//   embed workgroups 256 packed slots each: Adam on the 8 weights of a slot (one 128-byte line per 16-row block row),
+//                    then the slot's packed bf16 / fp32 image;
+//   flat workgroups  1024 elements each of everything else (LayerNorms, token MLPs, ch_b2, embedding biases, heads).
+// The plan (which flat ranges are "everything else", the Adam constants, the flat buffers) is a device-resident struct the
+// host builds once (m2m_adam_pack_plan): with the three by-value tower descriptors the kernel arguments are at the 4 KiB limit.
+// ---------------------------------------------------------------------------------------------------
+#define M2M_AP_MAXSEG 96
+struct AdamPackPlan {
+    float* p; float* g; const unsigned short* gb; float* m; float* v; const float* state;
+    float b1, b2, eps, wd, gscale;
+    int nseg;
+    long seg_lo[M2M_AP_MAXSEG], seg_hi[M2M_AP_MAXSEG];
+    int seg_wg0[M2M_AP_MAXSEG + 1];          // first flat workgroup of each segment (1024 elements per workgroup)
+};
+struct AdamConsts { float b1, b2, eps, wd, gscale, step_size, inv_sqrt_bc2; };
+static __device__ __forceinline__ AdamConsts adam_consts(const AdamPackPlan& pl) {
+    AdamConsts c;
+    c.b1 = pl.b1; c.b2 = pl.b2; c.eps = pl.eps; c.wd = pl.wd; c.gscale = pl.gscale;
+    const float stepf = pl.state[0], lr = pl.state[1];
+    c.step_size = lr / (1.0f - powf(pl.b1, stepf));
+    c.inv_sqrt_bc2 = 1.0f / sqrtf(1.0f - powf(pl.b2, stepf));
+    return c;
+}
+// one element: reads p, g (or its bf16 copy), m, v at flat index i; writes p, m, v, g = 0; returns the new parameter
+template <bool LOWP>
+static __device__ __forceinline__ float adam_elem(const AdamPackPlan& pl, const AdamConsts& c, long i) {
+    float g = (LOWP ? __uint_as_float((unsigned int)pl.gb[i] << 16) : pl.g[i]) * c.gscale;
+    pl.g[i] = 0.f;
+    const float pv = pl.p[i];
+    if (c.wd != 0.f) g = __builtin_fmaf(c.wd, pv, g);
+    const float mi = c.b1 * pl.m[i] + (1.0f - c.b1) * g;
+    const float vi = c.b2 * pl.v[i] + (1.0f - c.b2) * g * g;
+    pl.m[i] = mi;
+    pl.v[i] = vi;
+    const float pn = pv - c.step_size * (mi / (sqrtf(vi) * c.inv_sqrt_bc2 + c.eps));
+    pl.p[i] = pn;
+    return pn;
+}
+// four consecutive elements (any 4-byte alignment: the flat offsets of the tensors are not multiples of 4 everywhere)
+template <bool LOWP>
+static __device__ __forceinline__ float4 adam_elem4(const AdamPackPlan& pl, const AdamConsts& c, long i) {
+    const float4 pv = *reinterpret_cast<const float4*>(pl.p + i), mv = *reinterpret_cast<const float4*>(pl.m + i);
+    const float4 vv = *reinterpret_cast<const float4*>(pl.v + i);
+    float gg[4];
+    if (LOWP) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gg[e] = __uint_as_float((unsigned int)pl.gb[i + e] << 16);      // (i may be odd: 2-byte loads)
+    } else {
+        const float4 gv = *reinterpret_cast<const float4*>(pl.g + i);
+        gg[0] = gv.x; gg[1] = gv.y; gg[2] = gv.z; gg[3] = gv.w;
+    }
+    const float pp[4] = {pv.x, pv.y, pv.z, pv.w}, mm[4] = {mv.x, mv.y, mv.z, mv.w}, vq[4] = {vv.x, vv.y, vv.z, vv.w};
+    float pn[4], mn[4], vn[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float g = gg[e] * c.gscale;
+        if (c.wd != 0.f) g = __builtin_fmaf(c.wd, pp[e], g);
+        mn[e] = c.b1 * mm[e] + (1.0f - c.b1) * g;
+        vn[e] = c.b2 * vq[e] + (1.0f - c.b2) * g * g;
+        pn[e] = pp[e] - c.step_size * (mn[e] / (sqrtf(vn[e]) * c.inv_sqrt_bc2 + c.eps));
+    }
+    *reinterpret_cast<float4*>(pl.p + i) = make_float4(pn[0], pn[1], pn[2], pn[3]);
+    *reinterpret_cast<float4*>(pl.m + i) = make_float4(mn[0], mn[1], mn[2], mn[3]);
+    *reinterpret_cast<float4*>(pl.v + i) = make_float4(vn[0], vn[1], vn[2], vn[3]);
+    *reinterpret_cast<float4*>(pl.g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    return make_float4(pn[0], pn[1], pn[2], pn[3]);
+}
+
+template <int P, bool LOWP>
+__global__ __launch_bounds__(256) void adam_pack_all_kernel(const PackAllArgs a, const AdamPackPlan* __restrict__ plan, int embed_wgs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const AdamPackPlan& pl = *plan;
+    const AdamConsts c = adam_consts(pl);
+    int id = blockIdx.x;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    if (id < a.tile_end[M2M_PACK_TOWERS - 1]) {
+        int t = 0;
+        while (id >= a.tile_end[t]) ++t;
+        if (t) id -= a.tile_end[t - 1];
+        const m2m_tower4& tw = a.tw[t];
+        const int nq = tw.Cp >> 5, block = id / nq, q = id % nq;
+        const m2m_block& k = tw.blk[block];
+        const int D = tw.D, C = tw.C, L1 = D + 1, L2 = 33, c0 = 32 * q;
+        float* t1 = reinterpret_cast<float*>(smem);
+        float* t2 = t1 + 32 * L1;
+        const long o1 = k.ch_w1 - pl.p, o2 = k.ch_w2 - pl.p, ob = k.ch_b1 - pl.p;       // flat offsets of this block's tensors
+        for (int idx = tid; idx < 32 * (D / 4); idx += nthr) {
+            const int r = idx / (D / 4), d4 = (idx % (D / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c0 + r < C) v = adam_elem4<LOWP>(pl, c, o1 + (long)(c0 + r) * D + d4);
+            float* o = t1 + r * L1 + d4;
+            o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        }
+        for (int idx = tid; idx < D * 32; idx += nthr) {
+            const int d = idx >> 5, j = idx & 31;
+            t2[d * L2 + j] = c0 + j < C ? adam_elem<LOWP>(pl, c, o2 + (long)d * C + c0 + j) : 0.f;
+        }
+        if (tid < 32) k.ch_b1p[c0 + tid] = c0 + tid < C ? adam_elem<LOWP>(pl, c, ob + c0 + tid) : 0.f;
+        __syncthreads();
+        pack_emit_tile<P>(k, D, q, t1, t2);
+        return;
+    }
+    id -= a.tile_end[M2M_PACK_TOWERS - 1];
+    if (id < embed_wgs) {
+        typedef Prec<P> Pr;
+        const int e = id < a.embed_wgs0 ? 0 : 1;
+        if (e) id -= a.embed_wgs0;
+        const m2m_embed& em = a.em[e];
+        const long nIB = em.D / 16, nKB = em.Kp / Pr::KB;
+        const long slot = (long)id * 256 + tid;
+        if (slot >= nIB * nKB * 64) return;
+        const long blk = slot >> 6;
+        const int lane = (int)(slot & 63), g = lane >> 4, il = lane & 15;
+        const long ib = blk / nKB, kb = blk % nKB;                 // NAT, i-major: m2m_pack_embed's layout
+        const long i = ib * 16 + il, o = em.w - pl.p;
+        float v[8];
+#pragma unroll
+        for (int x = 0; x < Pr::EPL; ++x) {
+            const long kk = kb * Pr::KB + Pr::kmap(PACK_NAT, g, x);
+            v[x] = (i < em.D && kk < em.K) ? adam_elem<LOWP>(pl, c, o + i * em.K + kk) : 0.f;
+        }
+        Frag f;
+        if (P == PREC_BF16) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) f.u[x] = pack_bf2(v[2 * x], v[2 * x + 1]);
+        } else {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) f.f[x] = v[x];
+        }
+        *reinterpret_cast<u32x4_t*>((char*)em.wn + slot * 16) = f.u;
+        return;
+    }
+    id -= embed_wgs;
+    int sgm = 0;
+    while (sgm + 1 < pl.nseg && id >= pl.seg_wg0[sgm + 1]) ++sgm;
+    const long lo = pl.seg_lo[sgm] + (long)(id - pl.seg_wg0[sgm]) * 1024, hi = pl.seg_hi[sgm];
+    for (long i = lo + tid; i < hi && i < lo + 1024; i += nthr) adam_elem<LOWP>(pl, c, i);
+}
+
+// Fills `plan_host` (sizeof == m2m_adam_pack_plan_bytes()) for the given model; the caller copies it to device memory and
+// passes that copy to m2m_adam_pack_all.  grad_bf16 != NULL: gradient values come from that bf16 copy of `grad`.
+extern "C" int64_t m2m_adam_pack_plan_bytes(void) { return (int64_t)sizeof(AdamPackPlan); }
+extern "C" int m2m_adam_pack_plan(const m2m_tower* const* towers, int ntowers, const m2m_embed* const* embeds, int nembeds,
+                                  float* param, float* grad, const void* grad_bf16, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                  const float* state, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                                  void* plan_host) {
+    if (!plan_host || !param || !grad || !exp_avg || !exp_avg_sq || !state || n <= 0) { m2m_set_error("adam_pack_plan: null argument", __FILE__, __LINE__); return -1; }
+    AdamPackPlan pl;
+    memset(&pl, 0, sizeof(pl));
+    pl.p = param; pl.g = grad; pl.gb = reinterpret_cast<const unsigned short*>(grad_bf16); pl.m = exp_avg; pl.v = exp_avg_sq; pl.state = state;
+    pl.b1 = beta1; pl.b2 = beta2; pl.eps = eps; pl.wd = weight_decay; pl.gscale = grad_scale < 0.f ? -grad_scale : grad_scale;
+    // the ranges the tile / embed workgroups own, sorted; the flat workgroups take the complement
+    struct R { long lo, hi; };
+    R own[3 * M2M_PACK_TOWERS * M2M_GROUP_BLOCKS + M2M_PACK_EMBEDS];
+    int no = 0;
+    auto add = [&](const float* ptr, long cnt) -> bool {
+        const long lo = ptr - param;
+        if (lo < 0 || lo + cnt > n) return false;
+        own[no].lo = lo; own[no].hi = lo + cnt; ++no;
+        return true;
+    };
+    for (int i = 0; i < ntowers; ++i) {
+        const m2m_tower* t = towers[i];
+        if (t->nblocks > M2M_GROUP_BLOCKS) { m2m_set_error("adam_pack_plan: towers of <= 4 blocks", __FILE__, __LINE__); return -1; }
+        for (int b = 0; b < t->nblocks; ++b) {
+            const m2m_block& k = t->blk[b];
+            if (!add(k.ch_w1, (long)t->C * t->D) || !add(k.ch_w2, (long)t->C * t->D) || !add(k.ch_b1, t->C)) {
+                m2m_set_error("adam_pack_plan: a channel-mixing weight is not inside the flat parameter buffer", __FILE__, __LINE__);
+                return -1;
+            }
+        }
+    }
+    for (int i = 0; i < nembeds; ++i)
+        if (!add(embeds[i]->w, (long)embeds[i]->D * embeds[i]->K)) { m2m_set_error("adam_pack_plan: an embedding weight is not inside the flat parameter buffer", __FILE__, __LINE__); return -1; }
+    std::sort(own, own + no, [](const R& x, const R& y) { return x.lo < y.lo; });
+    long cur = 0;
+    int wg = 0;
+    for (int i = 0; i <= no; ++i) {
+        const long lo = cur, hi = i < no ? own[i].lo : (long)n;
+        if (i < no && own[i].lo < cur) { m2m_set_error("adam_pack_plan: overlapping parameter tensors", __FILE__, __LINE__); return -1; }
+        if (hi > lo) {
+            if (pl.nseg >= M2M_AP_MAXSEG) { m2m_set_error("adam_pack_plan: too many parameter segments", __FILE__, __LINE__); return -1; }
+            pl.seg_lo[pl.nseg] = lo; pl.seg_hi[pl.nseg] = hi; pl.seg_wg0[pl.nseg] = wg;
+            wg += (int)ceil_div(hi - lo, 1024);
+            ++pl.nseg;
+        }
+        if (i < no) cur = own[i].hi;
+    }
+    pl.seg_wg0[pl.nseg] = wg;
+    memcpy(plan_host, &pl, sizeof(pl));
+    return 0;
+}
+
+extern "C" int m2m_adam_pack_all(const m2m_tower* const* towers, int ntowers, const m2m_embed* const* embeds, int nembeds,
+                                 const void* plan_dev, const void* plan_host, void* stream) {
+    if (ntowers < 1 || ntowers > M2M_PACK_TOWERS || nembeds < 0 || nembeds > M2M_PACK_EMBEDS || !towers || (nembeds && !embeds) ||
+        !plan_dev || !plan_host) {
+        m2m_set_error("adam_pack_all: up to 3 towers and 2 embeddings, and a plan", __FILE__, __LINE__);
+        return -1;
+    }
+    const AdamPackPlan* ph = reinterpret_cast<const AdamPackPlan*>(plan_host);
+    PackAllArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nt = ntowers; a.ne = nembeds;
+    int prec = -1, tiles = 0, maxD = 0;
+    for (int i = 0; i < M2M_PACK_TOWERS; ++i) {
+        if (i < ntowers) {
+            if (int rc = m2m_check_tower(towers[i], 1)) return rc;
+            if (towers[i]->nblocks > M2M_GROUP_BLOCKS) { m2m_set_error("adam_pack_all: towers of <= 4 blocks", __FILE__, __LINE__); return -1; }
+            if (prec < 0) prec = towers[i]->prec;
+            if (towers[i]->prec != prec) { m2m_set_error("adam_pack_all: one precision per launch", __FILE__, __LINE__); return -1; }
+            a.tw[i] = m2m_shrink(towers[i]);
+            tiles += towers[i]->nblocks * (towers[i]->Cp / 32);
+            maxD = std::max(maxD, (int)towers[i]->D);
+        }
+        a.tile_end[i] = tiles;
+    }
+    int embed_wgs = 0;
+    for (int i = 0; i < nembeds; ++i) {
+        const m2m_embed* e = embeds[i];
+        if (!e || !e->w || !e->wn || e->prec != prec) { m2m_set_error("adam_pack_all: bad embed", __FILE__, __LINE__); return -1; }
+        const long KB = prec == PREC_BF16 ? 32 : 16;
+        a.em[i] = *e;
+        const int wgs = (int)ceil_div((long)(e->D / 16) * (e->Kp / KB) * 64, 256);
+        if (i == 0) a.embed_wgs0 = wgs;
+        embed_wgs += wgs;
+    }
+    const int flat_wgs = ph->seg_wg0[ph->nseg];
+    const size_t lds = (size_t)(32 * (maxD + 1) + maxD * 33) * sizeof(float);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bool lowp = ph->gb != nullptr;
+    const void* fn = prec == PREC_BF16 ? (lowp ? reinterpret_cast<const void*>(adam_pack_all_kernel<PREC_BF16, true>) : reinterpret_cast<const void*>(adam_pack_all_kernel<PREC_BF16, false>))
+                                       : (lowp ? reinterpret_cast<const void*>(adam_pack_all_kernel<PREC_F32, true>) : reinterpret_cast<const void*>(adam_pack_all_kernel<PREC_F32, false>));
+    static size_t attr_lds[4] = {0, 0, 0, 0};
+    const int pi = (prec == PREC_BF16 ? 0 : 2) + (lowp ? 1 : 0);
+    if (lds > attr_lds[pi]) {
+        M2M_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds[pi] = lds;
+    }
+    const dim3 grid((unsigned)(tiles + embed_wgs + flat_wgs));
+    const AdamPackPlan* pd = reinterpret_cast<const AdamPackPlan*>(plan_dev);
+    if (prec == PREC_BF16) {
+        if (lowp) hipLaunchKernelGGL((adam_pack_all_kernel<PREC_BF16, true>), grid, dim3(256), lds, st, a, pd, embed_wgs);
+        else hipLaunchKernelGGL((adam_pack_all_kernel<PREC_BF16, false>), grid, dim3(256), lds, st, a, pd, embed_wgs);
+    } else {
+        if (lowp) hipLaunchKernelGGL((adam_pack_all_kernel<PREC_F32, true>), grid, dim3(256), lds, st, a, pd, embed_wgs);
+        else hipLaunchKernelGGL((adam_pack_all_kernel<PREC_F32, false>), grid, dim3(256), lds, st, a, pd, embed_wgs);
+    }
+    M2M_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 // One tiny launch at the head of a training step instead of three scattered through it (each tiny kernel costs

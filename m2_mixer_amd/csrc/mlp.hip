@@ -7,8 +7,9 @@
 // non-zero exactly where the gradient passes, so dz = d_out * scale * [out != 0].
 #include "tile.h"
 
-#define MLP_S 32           // samples per workgroup
-#define MLP_T 256          // threads
+// Workgroup shape (template parameters S = samples per workgroup, T = threads): the kernels are pure latency (dependent LDS
+// reads), a workgroup's time is proportional to its samples, and every workgroup adds its weight-gradient partials with
+// atomics: 8 samples x 128 threads spreads the cfg batch (128) over 16 CUs; 32 x 256 keeps the atomics of a large batch down.
 #define MLP_MAXW 128       // widest layer (LDS: activations + one layer's weights)
 
 // index -> (row, column) of a row-major [rows][cols] array without a runtime division when cols is a power of two (the
@@ -19,15 +20,18 @@ struct Div {
     __device__ __forceinline__ int q(int i) const { return p2 ? i >> sh : i / d; }
     __device__ __forceinline__ int r(int i) const { return p2 ? i & (d - 1) : i % d; }
 };
-#define MLP_U 8            // global loads a thread keeps in flight in the staging loops (one L2 round trip per batch, not per element)
+// MLP_U: outputs a thread accumulates at a time (independent fma chains) = S * 64 / T
+#define MLP_SU 16          // global loads a thread keeps in flight in the staging loops (one L2 round trip per batch, not per element)
 
 static __device__ __forceinline__ Drop mlp_drop(const m2m_mlp& m, int layer, int training, unsigned int seed, unsigned int step) {
     return make_drop(training != 0, m.p_drop, seed, step, m.site_base + (unsigned int)layer);
 }
 
+template <int MLP_S, int MLP_T>
 __global__ __launch_bounds__(MLP_T) void mlp_fwd_kernel(const m2m_mlp m, const float* __restrict__ x, int B, float* __restrict__ out,
                                                         long out_ss, float* __restrict__ out2, int training, unsigned int seed,
                                                         unsigned int step_host, const unsigned int* __restrict__ step_dev) {
+    constexpr int MLP_U = MLP_S * 64 / MLP_T;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* a0 = sm;                                   // [MLP_S][MLP_MAXW + 1]
     float* a1 = a0 + MLP_S * (MLP_MAXW + 1);
@@ -52,26 +56,46 @@ __global__ __launch_bounds__(MLP_T) void mlp_fwd_kernel(const m2m_mlp m, const f
         {
             const Div dv(din);
             const float* __restrict__ w = m.w[l];
-            for (int i0 = tid; i0 < din * dout; i0 += MLP_U * MLP_T) {
-                float v[MLP_U];
+            for (int i0 = tid; i0 < din * dout; i0 += MLP_SU * MLP_T) {
+                float v[MLP_SU];
 #pragma unroll
-                for (int u = 0; u < MLP_U; ++u) { const int i = i0 + u * MLP_T; v[u] = i < din * dout ? w[i] : 0.f; }
+                for (int u = 0; u < MLP_SU; ++u) { const int i = i0 + u * MLP_T; v[u] = i < din * dout ? w[i] : 0.f; }
 #pragma unroll
-                for (int u = 0; u < MLP_U; ++u) { const int i = i0 + u * MLP_T; if (i < din * dout) wt[dv.r(i) * (dout + 1) + dv.q(i)] = v[u]; }
+                for (int u = 0; u < MLP_SU; ++u) { const int i = i0 + u * MLP_T; if (i < din * dout) wt[dv.r(i) * (dout + 1) + dv.q(i)] = v[u]; }
             }
         }
         __syncthreads();
+        // MLP_U outputs per thread at a time: one dependent fma chain per output left every LDS read latency exposed
+        // (~100 cycles per step of a 64-step chain, 24 chains per thread: most of this kernel's 50 us)
         const Div dvo(dout);
-        for (int i = tid; i < MLP_S * dout; i += MLP_T) {
-            const int s = dvo.q(i), j = dvo.r(i);
-            float acc = m.b[l][j];
-            for (int k = 0; k < din; ++k) acc = __builtin_fmaf(cur[s * LD + k], wt[k * (dout + 1) + j], acc);
-            if (hidden) {
-                acc = acc > 0.f ? acc : 0.f;
-                acc = drop_keep(dr, (unsigned int)(s0 + s) * dout + j) ? acc * dr.scale : 0.f;
-                if (training && s < ns) m.act[l][(long)(s0 + s) * dout + j] = acc;
+        for (int i0 = tid; i0 < MLP_S * dout; i0 += MLP_U * MLP_T) {
+            int so[MLP_U], jo[MLP_U];
+            float acc[MLP_U];
+#pragma unroll
+            for (int u = 0; u < MLP_U; ++u) {
+                const int i = min(i0 + u * MLP_T, MLP_S * dout - 1);
+                so[u] = dvo.q(i) * LD; jo[u] = dvo.r(i);
+                acc[u] = m.b[l][jo[u]];
             }
-            nxt[s * LD + j] = acc;
+#pragma unroll 8
+            for (int k = 0; k < din; ++k) {
+#pragma unroll
+                for (int u = 0; u < MLP_U; ++u) acc[u] = __builtin_fmaf(cur[so[u] + k], wt[k * (dout + 1) + jo[u]], acc[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < MLP_U; ++u) {
+                const int i = i0 + u * MLP_T;
+                if (i < MLP_S * dout) {
+                    const int s = so[u] / LD, j = jo[u];
+                    float a = acc[u];
+                    if (hidden) {
+                        a = a > 0.f ? a : 0.f;
+                        a = drop_keep(dr, (unsigned int)(s0 + s) * dout + j) ? a * dr.scale : 0.f;
+                        if (training && s < ns) m.act[l][(long)(s0 + s) * dout + j] = a;
+                    }
+                    nxt[so[u] + j] = a;
+                }
+            }
         }
         float* t = cur; cur = nxt; nxt = t;
     }
@@ -85,9 +109,11 @@ __global__ __launch_bounds__(MLP_T) void mlp_fwd_kernel(const m2m_mlp m, const f
     }
 }
 
+template <int MLP_S, int MLP_T>
 __global__ __launch_bounds__(MLP_T) void mlp_bwd_kernel(const m2m_mlp m, const float* __restrict__ x, int B,
                                                         const float* __restrict__ d_out, long d_out_ss,
                                                         const float* __restrict__ d_out2) {
+    constexpr int MLP_U = MLP_S * 64 / MLP_T;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int LD = MLP_MAXW + 1;
     float* g0 = sm;                                   // gradient wrt the current layer's output [MLP_S][LD]
@@ -119,46 +145,56 @@ __global__ __launch_bounds__(MLP_T) void mlp_bwd_kernel(const m2m_mlp m, const f
         const Div dvi(din), dvo(dout);
         {
             const float* __restrict__ w = m.w[l];
-            for (int i0 = tid; i0 < dout * din; i0 += MLP_U * MLP_T) {
-                float v[MLP_U];
+            for (int i0 = tid; i0 < dout * din; i0 += MLP_SU * MLP_T) {
+                float v[MLP_SU];
 #pragma unroll
-                for (int u = 0; u < MLP_U; ++u) { const int i = i0 + u * MLP_T; v[u] = i < dout * din ? w[i] : 0.f; }
+                for (int u = 0; u < MLP_SU; ++u) { const int i = i0 + u * MLP_T; v[u] = i < dout * din ? w[i] : 0.f; }
 #pragma unroll
-                for (int u = 0; u < MLP_U; ++u) { const int i = i0 + u * MLP_T; if (i < dout * din) wl[dvi.q(i) * (din + 1) + dvi.r(i)] = v[u]; }
+                for (int u = 0; u < MLP_SU; ++u) { const int i = i0 + u * MLP_T; if (i < dout * din) wl[dvi.q(i) * (din + 1) + dvi.r(i)] = v[u]; }
             }
-            for (int i0 = tid; i0 < MLP_S * din; i0 += MLP_U * MLP_T) {
-                float v[MLP_U];
+            for (int i0 = tid; i0 < MLP_S * din; i0 += MLP_SU * MLP_T) {
+                float v[MLP_SU];
 #pragma unroll
-                for (int u = 0; u < MLP_U; ++u) {
+                for (int u = 0; u < MLP_SU; ++u) {
                     const int i = i0 + u * MLP_T, sI = dvi.q(i);
                     v[u] = (i < MLP_S * din && sI < ns) ? inp[(long)(s0 + sI) * din + dvi.r(i)] : 0.f;
                 }
 #pragma unroll
-                for (int u = 0; u < MLP_U; ++u) { const int i = i0 + u * MLP_T; if (i < MLP_S * din) ain[dvi.q(i) * LD + dvi.r(i)] = v[u]; }
+                for (int u = 0; u < MLP_SU; ++u) { const int i = i0 + u * MLP_T; if (i < MLP_S * din) ain[dvi.q(i) * LD + dvi.r(i)] = v[u]; }
             }
         }
         if (hidden) {                                  // through Dropout and ReLU
             const float* __restrict__ actl = m.act[l];
-            for (int i0 = tid; i0 < MLP_S * dout; i0 += MLP_U * MLP_T) {
-                float o[MLP_U];
+            for (int i0 = tid; i0 < MLP_S * dout; i0 += MLP_SU * MLP_T) {
+                float o[MLP_SU];
 #pragma unroll
-                for (int u = 0; u < MLP_U; ++u) {
+                for (int u = 0; u < MLP_SU; ++u) {
                     const int i = i0 + u * MLP_T, sI = dvo.q(i);
                     o[u] = (i < MLP_S * dout && sI < ns) ? actl[(long)(s0 + sI) * dout + dvo.r(i)] : 0.f;
                 }
 #pragma unroll
-                for (int u = 0; u < MLP_U; ++u) {
+                for (int u = 0; u < MLP_SU; ++u) {
                     const int i = i0 + u * MLP_T;
                     if (i < MLP_S * dout) { float* gp = gc + dvo.q(i) * LD + dvo.r(i); *gp = o[u] != 0.f ? *gp * scale : 0.f; }
                 }
             }
         }
         __syncthreads();
-        for (int i = tid; i < dout * din; i += MLP_T) {      // dW[j][k] += sum_s dz[s][j] in[s][k]
-            const int j = dvi.q(i), k = dvi.r(i);
-            float a = 0.f;
-            for (int s = 0; s < MLP_S; ++s) a = __builtin_fmaf(gc[s * LD + j], ain[s * LD + k], a);
-            atomicAdd(m.g_w[l] + i, a);
+        for (int i0 = tid; i0 < dout * din; i0 += MLP_U * MLP_T) {      // dW[j][k] += sum_s dz[s][j] in[s][k]
+            int jo[MLP_U], ko[MLP_U];
+            float a[MLP_U];
+#pragma unroll
+            for (int u = 0; u < MLP_U; ++u) {
+                const int i = min(i0 + u * MLP_T, dout * din - 1);
+                jo[u] = dvi.q(i); ko[u] = dvi.r(i); a[u] = 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < MLP_S; ++s) {
+#pragma unroll
+                for (int u = 0; u < MLP_U; ++u) a[u] = __builtin_fmaf(gc[s * LD + jo[u]], ain[s * LD + ko[u]], a[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < MLP_U; ++u) { const int i = i0 + u * MLP_T; if (i < dout * din) atomicAdd(m.g_w[l] + i, a[u]); }
         }
         for (int j = tid; j < dout; j += MLP_T) {
             float a = 0.f;
@@ -166,11 +202,21 @@ __global__ __launch_bounds__(MLP_T) void mlp_bwd_kernel(const m2m_mlp m, const f
             atomicAdd(m.g_b[l] + j, a);
         }
         if (l > 0) {
-            for (int i = tid; i < MLP_S * din; i += MLP_T) {  // d_in[s][k] = sum_j dz[s][j] W[j][k]
-                const int s = dvi.q(i), k = dvi.r(i);
-                float a = 0.f;
-                for (int j = 0; j < dout; ++j) a = __builtin_fmaf(gc[s * LD + j], wl[j * (din + 1) + k], a);
-                gn[s * LD + k] = a;
+            for (int i0 = tid; i0 < MLP_S * din; i0 += MLP_U * MLP_T) {  // d_in[s][k] = sum_j dz[s][j] W[j][k]
+                int so[MLP_U], ko[MLP_U];
+                float a[MLP_U];
+#pragma unroll
+                for (int u = 0; u < MLP_U; ++u) {
+                    const int i = min(i0 + u * MLP_T, MLP_S * din - 1);
+                    so[u] = dvi.q(i) * LD; ko[u] = dvi.r(i); a[u] = 0.f;
+                }
+#pragma unroll 8
+                for (int j = 0; j < dout; ++j) {
+#pragma unroll
+                    for (int u = 0; u < MLP_U; ++u) a[u] = __builtin_fmaf(gc[so[u] + j], wl[j * (din + 1) + ko[u]], a[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < MLP_U; ++u) { const int i = i0 + u * MLP_T; if (i < MLP_S * din) gn[so[u] + ko[u]] = a[u]; }
             }
         }
         float* t = gc; gc = gn; gn = t;
@@ -185,26 +231,42 @@ static int check_mlp(const m2m_mlp* m, int B) {
     return 0;
 }
 
+template <int S, int T>
+static int launch_mlp_fwd(const m2m_mlp* m, const float* x, int B, float* out, long out_ss, float* out_dense, int training,
+                          unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
+    const size_t lds = sizeof(float) * ((size_t)2 * S * (MLP_MAXW + 1) + (size_t)MLP_MAXW * (MLP_MAXW + 1));
+    auto kern = mlp_fwd_kernel<S, T>;
+    static bool done = false;
+    if (!done) { M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+    hipLaunchKernelGGL(kern, dim3((B + S - 1) / S), dim3(T), lds, st, *m, x, B, out, out_ss, out_dense, training, seed, step, step_dev);
+    M2M_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+template <int S, int T>
+static int launch_mlp_bwd(const m2m_mlp* m, const float* x, int B, const float* d_out, long d_out_ss, const float* d_out_dense,
+                          hipStream_t st) {
+    const size_t lds = sizeof(float) * ((size_t)3 * S * (MLP_MAXW + 1) + (size_t)MLP_MAXW * (MLP_MAXW + 1));
+    auto kern = mlp_bwd_kernel<S, T>;
+    static bool done = false;
+    if (!done) { M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+    hipLaunchKernelGGL(kern, dim3((B + S - 1) / S), dim3(T), lds, st, *m, x, B, d_out, d_out_ss, d_out_dense);
+    M2M_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+#define MLP_SMALL_BATCH 1024      // up to here 8 samples per workgroup
+
 extern "C" int m2m_mlp_forward(const m2m_mlp* m, const float* x, int B, float* out, int64_t out_sample_stride, float* out_dense,
                                int training, uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream) {
     if (int rc = check_mlp(m, B)) return rc;
-    const size_t lds = sizeof(float) * ((size_t)2 * MLP_S * (MLP_MAXW + 1) + (size_t)MLP_MAXW * (MLP_MAXW + 1));
-    static bool done = false;
-    if (!done) { M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); done = true; }
-    hipLaunchKernelGGL(mlp_fwd_kernel, dim3((B + MLP_S - 1) / MLP_S), dim3(MLP_T), lds, reinterpret_cast<hipStream_t>(stream), *m, x, B,
-                       out, (long)out_sample_stride, out_dense, training, seed, step, step_dev);
-    M2M_CHECK_HIP(hipGetLastError());
-    return 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (B <= MLP_SMALL_BATCH) return launch_mlp_fwd<8, 128>(m, x, B, out, (long)out_sample_stride, out_dense, training, seed, step, step_dev, st);
+    return launch_mlp_fwd<32, 256>(m, x, B, out, (long)out_sample_stride, out_dense, training, seed, step, step_dev, st);
 }
 
 extern "C" int m2m_mlp_backward(const m2m_mlp* m, const float* x, int B, const float* d_out, int64_t d_out_sample_stride,
                                 const float* d_out_dense, void* stream) {
     if (int rc = check_mlp(m, B)) return rc;
-    const size_t lds = sizeof(float) * ((size_t)3 * MLP_S * (MLP_MAXW + 1) + (size_t)MLP_MAXW * (MLP_MAXW + 1));
-    static bool done = false;
-    if (!done) { M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); done = true; }
-    hipLaunchKernelGGL(mlp_bwd_kernel, dim3((B + MLP_S - 1) / MLP_S), dim3(MLP_T), lds, reinterpret_cast<hipStream_t>(stream), *m, x, B,
-                       d_out, (long)d_out_sample_stride, d_out_dense);
-    M2M_CHECK_HIP(hipGetLastError());
-    return 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (B <= MLP_SMALL_BATCH) return launch_mlp_bwd<8, 128>(m, x, B, d_out, (long)d_out_sample_stride, d_out_dense, st);
+    return launch_mlp_bwd<32, 256>(m, x, B, d_out, (long)d_out_sample_stride, d_out_dense, st);
 }

@@ -24,9 +24,18 @@ import torch
 
 from . import _lib as L
 from . import config
-from .runtime import (BLOCK_FIELDS, BLOCK_KEYS, EmbedRuntime, MlpRuntime, TowerRuntime, block_param_shapes, heads_bce,
+from .runtime import (AdamPackPlan, BLOCK_FIELDS, BLOCK_KEYS, EmbedRuntime, MlpRuntime, TowerRuntime, block_param_shapes, heads_bce,
                       heads_ce, can_group, can_group_embeds, can_pack_all, embeds_forward, pack_all,
                       towers_backward, towers_forward, towers_wgrad)
+
+
+def config_fused_update() -> bool:
+    """M2M_FUSED_UPDATE=1: Adam and the operand re-pack as ONE launch (m2m_adam_pack_all).  Off by default: measured on
+    M2-Mixer-B it is slower (97 us against 45 + 19 us for the flat Adam launch followed by m2m_pack_all) -- the tile
+    workgroups that must own a 32-column group of both weight matrices update W2 through 128-byte row segments with few
+    loads in flight, the flat grid-stride Adam streams at the HBM roofline (profiles/)."""
+    import os
+    return os.environ.get("M2M_FUSED_UPDATE", "0") == "1"
 
 
 def _num_patch(c: dict) -> int:
@@ -160,6 +169,7 @@ class _FlatEngine:
         self.losses = torch.zeros(4, device=dev)
         self._graph = None
         self._static = None
+        self._adam_plans: Dict[tuple, AdamPackPlan] = {}
         # side streams for the paths whose towers cannot share a launch (wide towers, mixed shapes, the MIMIC static MLP): the
         # second modality runs beside the first.  The AV-MNIST step needs none of them: nine launches on the main stream.
         self.s_b = torch.cuda.Stream(device=dev)
@@ -308,9 +318,31 @@ class _FlatEngine:
         self._backward(*batch[:-1], fused_update=True)
         return self.losses
 
+    def _adam_pack_modules(self):
+        """(towers, embeds) whose parameters all live in the flat buffers and whose operand copies one m2m_adam_pack_all
+        launch can rebuild -- None: the model needs the two-launch form (Adam, then pack())."""
+        return None
+
+    def _update(self, grad_scale: float = 1.0, grad_bf16: Optional[torch.Tensor] = None):
+        """Adam over every parameter + operand re-pack.  One launch (m2m_adam_pack_all) where the model allows it: the
+        re-pack then takes the updated weights from the workgroup that computed them instead of re-reading the masters."""
+        mods = self._adam_pack_modules() if config_fused_update() else None
+        if mods is None:
+            self._adam(0, self.n_params, grad_scale, False, grad_bf16)        # negative scale inside: clears the gradients
+            self.pack()
+            return
+        key = (abs(float(grad_scale)), 0 if grad_bf16 is None else grad_bf16.data_ptr())
+        plan = self._adam_plans.get(key)
+        if plan is None:
+            if grad_bf16 is not None and (grad_bf16.dtype != torch.bfloat16 or grad_bf16.numel() != self.n_params or not grad_bf16.is_cuda):
+                raise RuntimeError("grad_bf16 must be a bf16 device copy of the whole flat gradient")
+            plan = AdamPackPlan(mods[0], mods[1], self.flat_p, self.flat_g, grad_bf16, self.flat_m, self.flat_v, self.adam_state,
+                                self.betas, self.eps, self.weight_decay, grad_scale)
+            self._adam_plans[key] = plan
+        plan.run()
+
     def optimizer_step(self, grad_scale: float = 1.0, grad_bf16: Optional[torch.Tensor] = None):
-        self._adam(0, self.n_params, grad_scale, False, grad_bf16)            # negative scale inside: clears the gradients
-        self.pack()                                                            # (the step counters were advanced by _prologue)
+        self._update(grad_scale, grad_bf16)                                    # (the step counters were advanced by _prologue)
 
     def train_step(self, *batch, grad_sync=None):
         """One optimisation step.  grad_sync: optional callable(flat_grad) doing the data-parallel
@@ -549,8 +581,11 @@ class _TwoTowerEngine(_FlatEngine):
             towers_wgrad([self.t_fus, self.t_a, self.t_b], B)
             main.wait_stream(s_e)
         if fused_update:
-            self._adam(0, self.n_params, 1.0, False)
-            self.pack()
+            self._update(1.0)
+
+    def _adam_pack_modules(self):
+        towers, embeds = [self.t_a, self.t_b, self.t_fus], [self.e_a, self.e_b]
+        return (towers, embeds) if can_pack_all(towers, embeds) else None
 
     @torch.no_grad()
     def evaluate(self, xa, xb, labels):

@@ -359,6 +359,32 @@ def pack_all(towers: Sequence[TowerRuntime], embeds: Sequence["EmbedRuntime"]):
         e.mark_packed()
 
 
+class AdamPackPlan:
+    """Host + device copies of the plan of m2m_adam_pack_all (Adam and the operand re-pack of a whole model in one launch)."""
+
+    def __init__(self, towers: Sequence[TowerRuntime], embeds: Sequence["EmbedRuntime"], flat_p, flat_g, grad_bf16, flat_m, flat_v,
+                 state, betas, eps: float, weight_decay: float, grad_scale: float):
+        self.towers, self.embeds = list(towers), list(embeds)
+        nt, ne = len(towers), len(embeds)
+        self._tp = (C.POINTER(L.Tower) * max(nt, 1))(*[C.pointer(t.desc) for t in towers])
+        self._ep = (C.POINTER(L.Embed) * max(ne, 1))(*[C.pointer(e.desc) for e in embeds])
+        nbytes = int(L.lib().m2m_adam_pack_plan_bytes())
+        self.host = C.create_string_buffer(nbytes)
+        L.check(L.lib().m2m_adam_pack_plan(self._tp, nt, self._ep, ne, flat_p.data_ptr(), flat_g.data_ptr(), L.ptr(grad_bf16),
+                                           flat_m.data_ptr(), flat_v.data_ptr(), flat_p.numel(), state.data_ptr(), betas[0], betas[1],
+                                           eps, weight_decay, abs(grad_scale), self.host), "adam_pack_plan")
+        self.dev = torch.frombuffer(bytearray(self.host.raw), dtype=torch.uint8).to(flat_p.device)
+        self._keep = (flat_p, flat_g, grad_bf16, flat_m, flat_v, state)
+
+    def run(self):
+        L.check(L.lib().m2m_adam_pack_all(self._tp, len(self.towers), self._ep, len(self.embeds), self.dev.data_ptr(), self.host,
+                                          L.stream_ptr()), "adam_pack_all")
+        for t in self.towers:
+            t.mark_packed()
+        for e in self.embeds:
+            e.mark_packed()
+
+
 class EmbedRuntime:
     """m2m_embed: Conv2d(Cin, D, (ph, pw), stride=(ph, pw)) + rearrange, or Linear(K, D) on (B, N, K) rows."""
 

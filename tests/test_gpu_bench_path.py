@@ -146,13 +146,16 @@ def test_split_path_ragged_batches_vs_oracle(p_drop, B, dev, monkeypatch):
         assert abserr(out[k], ev[k]) < BF16_LOGITS, k
 
 
+@pytest.mark.parametrize("fused_update", ["0", "1"])
 @pytest.mark.parametrize("size,B,seed", [("S", 8, 11), ("M", 4, 21), ("B", 8, 12)])
-def test_adam_moments_and_parameters_vs_oracle(size, B, seed, dev):
+def test_adam_moments_and_parameters_vs_oracle(size, B, seed, fused_update, dev, monkeypatch):
     """Two optimisation steps, fp32 mode: Adam's first / second moments (linear / quadratic in the gradient, hence
     well-conditioned) against the oracle's optimizer state, and the parameters wherever the gradient is not ~0 (Adam's
     first step moves a parameter by lr * g / (|g| + eps): at |g| ~ eps that is noise).  A no-op or mis-scaled update
-    moves the parameters by up to lr = 1e-2 from the oracle's: the tolerance is 2 % of that."""
+    moves the parameters by up to lr = 1e-2 from the oracle's: the tolerance is 2 % of that.  Both forms of the update:
+    the flat Adam launch followed by the re-pack, and the one-launch m2m_adam_pack_all (M2M_FUSED_UPDATE=1)."""
     from m2_mixer_amd.engine import AVMnistEngine
+    monkeypatch.setenv("M2M_FUSED_UPDATE", fused_update)
     cfg = dict(G.AVMNIST[size], dropout=0.0)
     eng = AVMnistEngine(cfg, B, device=dev, precision="fp32", lr=1e-2, init=False)
     shapes = G.avmnist_shapes(cfg)
