@@ -48,44 +48,58 @@ def _block_tensors(block: "MixerBlock") -> dict:
 
 class _TowerFunction(torch.autograd.Function):
     """x (B, N, D) -> blocks (+ final LayerNorm) -> (B, N, D).  Re-entrant: every forward that will be differentiated
-    gets its own set of saved activations (TowerRuntime.fresh_saved), kept in the autograd ctx."""
+    gets its own set of saved activations (TowerRuntime.fresh_saved), kept in the autograd ctx.  Towers deeper than one
+    m2m_tower holds are a chain of runtimes (owner._rts)."""
 
     @staticmethod
     def forward(ctx, x, owner, need_grad, *params):
         # NB: grad mode is switched off inside Function.forward, so the caller decides `need_grad`
-        rt: TowerRuntime = owner._rt
+        rts: List[TowerRuntime] = owner._rts
         B = x.shape[0]
-        N, D = rt.N, rt.D
+        N, D = rts[0].N, rts[0].D
         dropping = owner.training and owner.dropout_p > 0
-        rt.desc.p_drop = float(owner.dropout_p) if dropping else 0.0
         seed, step = config.dropout_seed(), owner._bump_step() if dropping else 0
-        out = torch.empty(B, N, D, device=x.device, dtype=torch.float32)
-        rt.ensure_workspace(B)
-        ctx.saved = rt.fresh_saved(B) if need_grad else None
-        if dropping and not need_grad:
-            rt.ensure_buffers(B)            # dropout without autograd (train() under no_grad): the kernels still save
-        rt.forward(x, N * D, B, out, N * D, None, need_grad or dropping, seed, step)
-        ctx.owner, ctx.B, ctx.seed, ctx.step, ctx.p_drop = owner, B, seed, step, rt.desc.p_drop
+        p_drop = float(owner.dropout_p) if dropping else 0.0
+        saved = []
+        cur = x
+        for rt in rts:
+            rt.desc.p_drop = p_drop
+            out = torch.empty(B, N, D, device=x.device, dtype=torch.float32)
+            rt.ensure_workspace(B)
+            saved.append(rt.fresh_saved(B) if need_grad else None)
+            if dropping and not need_grad:
+                rt.ensure_buffers(B)        # dropout without autograd (train() under no_grad): the kernels still save
+            rt.forward(cur, N * D, B, out, N * D, None, need_grad or dropping, seed, step)
+            cur = out
+        ctx.saved = saved if need_grad else None
+        ctx.owner, ctx.B, ctx.seed, ctx.step, ctx.p_drop = owner, B, seed, step, p_drop
         ctx.nparams = len(params)
-        return out
+        return cur
 
     @staticmethod
     def backward(ctx, dout):
         owner = ctx.owner
-        rt: TowerRuntime = owner._rt
+        rts: List[TowerRuntime] = owner._rts
         if ctx.saved is None:
             raise RuntimeError("backward through a tower forward that ran without gradients enabled")
-        B, N, D = ctx.B, rt.N, rt.D
-        rt.ensure_buffers(B)                # operand images sized for THIS batch (a forward at another batch size may have
-        rt.ensure_workspace(B)              # re-allocated them since), then this forward's own activations
-        rt.use_saved(ctx.saved)
-        rt.desc.p_drop = ctx.p_drop
-        flat = torch.zeros(rt.grad_numel(), device=dout.device, dtype=torch.float32)
-        views = rt.bind_grads(flat)
-        dx = torch.empty(B, N, D, device=dout.device, dtype=torch.float32)
-        rt.backward(B, dout.contiguous(), N * D, None, dx, N * D, ctx.seed, ctx.step)
-        rt.wgrad(B, ctx.seed, ctx.step)
-        return (dx, None, None) + tuple(views)
+        B, N, D = ctx.B, rts[0].N, rts[0].D
+        grads_per_chunk = []
+        g = dout.contiguous()
+        for rt, saved in zip(reversed(rts), reversed(ctx.saved)):
+            rt.ensure_buffers(B)            # operand images sized for THIS batch (a forward at another batch size may have
+            rt.ensure_workspace(B)          # re-allocated them since), then this forward's own activations
+            rt.use_saved(saved)
+            rt.desc.p_drop = ctx.p_drop
+            flat = torch.zeros(rt.grad_numel(), device=dout.device, dtype=torch.float32)
+            views = rt.bind_grads(flat)
+            dx = torch.empty(B, N, D, device=dout.device, dtype=torch.float32)
+            rt.backward(B, g, N * D, None, dx, N * D, ctx.seed, ctx.step)
+            rt.wgrad(B, ctx.seed, ctx.step)
+            grads_per_chunk.append(views)
+            g = dx
+        # parameter order of _run_tower: the blocks' fields chunk by chunk, then the final LayerNorm (in the last chunk's views)
+        views = [v for chunk in reversed(grads_per_chunk) for v in chunk]
+        return (g, None, None) + tuple(views)
 
 
 class _EmbedFunction(torch.autograd.Function):
@@ -118,6 +132,7 @@ class _HipTower(nn.Module):
         self.dropout_p = float(dropout)
         self.precision = precision
         self._rt: Optional[TowerRuntime] = None
+        self._rts: Optional[List[TowerRuntime]] = None
         self._drop_step = 0
         self._site_base = 1024 * next(_site_counter)
 
@@ -132,17 +147,32 @@ class _HipTower(nn.Module):
         return getattr(self, "layer_norm", None)
 
     def _runtime(self) -> TowerRuntime:
-        blocks = [_block_tensors(b) for b in self._tower_blocks()]
+        """The tower's TowerRuntime(s).  One m2m_tower holds at most L.MAX_BLOCKS MixerBlocks; a deeper tower (the reference's
+        sweeps go to 16 mixers, sweeps/avmnist_mixer.yaml:19-35) is a chain of them -- `_rts`: consecutive chunks of blocks,
+        the final LayerNorm on the last chunk -- and forward / backward walk the chain.  `_rt` stays the first chunk."""
+        all_blocks = [_block_tensors(b) for b in self._tower_blocks()]
         ln = self._final_ln()
         lnf = (ln.weight, ln.bias) if ln is not None else None
         prec = config.prec_id(self.precision)
-        if self._rt is None or self._rt.prec != prec:
-            self._rt = TowerRuntime(self.hidden_dim, self.num_patch, self.token_dim, self.channel_dim, len(blocks),
-                                    ln is not None, self.dropout_p, prec, self._site_base)
-            self._rt.bind_params(blocks, lnf)
-        elif self._rt.params_changed(blocks, lnf):
-            self._rt.bind_params(blocks, lnf)
-        self._rt.pack()
+        chunks = [all_blocks[i:i + L.MAX_BLOCKS] for i in range(0, len(all_blocks), L.MAX_BLOCKS)] or [[]]
+        rts = getattr(self, "_rts", None)
+        if rts is None or len(rts) != len(chunks) or rts[0].prec != prec:
+            rts = []
+            for ci, blocks in enumerate(chunks):
+                last = ci == len(chunks) - 1
+                rt = TowerRuntime(self.hidden_dim, self.num_patch, self.token_dim, self.channel_dim, len(blocks),
+                                  ln is not None and last, self.dropout_p, prec, self._site_base + 4 * L.MAX_BLOCKS * ci)
+                rt.bind_params(blocks, lnf if last else None)
+                rts.append(rt)
+            self._rts = rts
+        else:
+            for ci, (rt, blocks) in enumerate(zip(rts, chunks)):
+                l = lnf if ci == len(chunks) - 1 else None
+                if rt.params_changed(blocks, l):
+                    rt.bind_params(blocks, l)
+        for rt in self._rts:
+            rt.pack()
+        self._rt = self._rts[0]
         return self._rt
 
     def _run_tower(self, x: torch.Tensor) -> torch.Tensor:

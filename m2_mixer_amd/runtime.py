@@ -42,7 +42,8 @@ class TowerRuntime:
     def __init__(self, D: int, N: int, T: int, Cc: int, nblocks: int, has_final_ln: bool, p_drop: float,
                  prec: int, site_base: int = 0):
         if nblocks > L.MAX_BLOCKS:
-            raise RuntimeError(f"a tower holds at most {L.MAX_BLOCKS} blocks; chain towers for more")
+            raise RuntimeError(f"one m2m_tower holds at most {L.MAX_BLOCKS} blocks; deeper towers are a chain of them "
+                               "(modules/mixer.py does that; the fused engines take towers of up to 8 blocks)")
         self.D, self.N, self.T, self.C, self.nblocks = D, N, T, Cc, nblocks
         self.Cp = (Cc + 31) // 32 * 32
         self.prec = prec

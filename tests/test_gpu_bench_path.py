@@ -420,3 +420,34 @@ def test_module_path_is_reentrant(dev):
     (O.mlp(xa.cpu(), ref, "", cs["num_blocks"], True).square().sum() + O.mlp(xb.cpu(), ref, "", cs["num_blocks"], True).square().sum()).backward()
     for k, prm in mlp.named_parameters():
         assert relerr(prm.grad, ref[k].grad) < 1e-4, k
+
+
+def test_towers_deeper_than_one_descriptor(dev):
+    """The reference's sweeps go to 16 mixers per tower (sweeps/avmnist_mixer.yaml:19-35); one m2m_tower holds 8 blocks, so
+    the module path chains descriptors.  11 blocks (8 + 3), fp32, dropout on (masks exported per chunk), against autograd
+    through the oracle."""
+    import m2_mixer_amd as M
+    from m2_mixer_amd import modules as MM
+    M.set_precision("fp32")
+    cfg = dict(hidden_dim=32, token_dim=16, channel_dim=64, num_mixers=11)
+    N, B = 8, 5
+    tower = MM.get_block_by_name(block_type="FusionMixer", num_patches=N, dropout=0.0, **cfg).to(dev)
+    shapes = G.tower_shapes("", cfg, N, "none")
+    params = G.make_params(shapes, 95)
+    tower.load_state_dict(params)
+    assert len(tower.mixer_blocks) == 11
+    x = torch.randn(B, N, cfg["hidden_dim"])
+    xg = x.to(dev).requires_grad_(True)
+    y = tower(xg)
+    y.square().sum().backward()
+    torch.cuda.synchronize()
+    assert len(tower._rts) == 2 and [rt.nblocks for rt in tower._rts] == [8, 3]
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    xr = x.clone().requires_grad_(True)
+    yo = O.fusion_mixer(xr, leaves, "", 11)
+    yo.square().sum().backward()
+    assert abserr(y, yo) < FP32_ATOL and abserr(xg.grad, xr.grad) < 2e-3
+    for k, prm in tower.named_parameters():
+        if k.endswith("token_mix.2.net.3.bias"):
+            continue
+        assert relerr(prm.grad, leaves[k].grad) < 2e-3, k
