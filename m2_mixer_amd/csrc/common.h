@@ -249,13 +249,37 @@ void m2m_set_error(const char* msg, const char* file, int line);
 #ifdef M2M_TIMERS
 #define TIMER_DECL(sym) static __device__ unsigned long long sym[32]
 #define TIMER_START() unsigned long long _tm_last = __builtin_amdgcn_s_memrealtime()
+// The mark is taken by the WHOLE first wave of workgroup 0 behind a wave-uniform (scalar) branch, lanes other than 0 adding
+// zero: an exec-masked single-lane read-modify-write here was miscompiled once the kernels grew (the store's zero offset
+// register was materialised under a different exec mask and lane 0 wrote through garbage: "write access to a read-only page").
 #define TIMER_MARK(sym, i)                                                          \
+    do {                                                                            \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 &&                \
+            __builtin_amdgcn_readfirstlane((int)threadIdx.x) == 0) {                \
+            const unsigned long long _n = __builtin_amdgcn_s_memrealtime();         \
+            atomicAdd(&sym[i], (threadIdx.x & 63) == 0 ? _n - _tm_last : 0ULL);     \
+            _tm_last = _n;                                                          \
+        }                                                                           \
+    } while (0)
+// Cheap flavour for kernels with many marks (the tower chains): thread 0 of workgroup 0 accumulates into LDS, one flush of
+// the 32 slots at the end of the kernel.  (A mark of the flavour above costs ~2.5 us: its atomic is waited for by the next
+// vmcnt(0) of the wave.)
+#define TIMER_LSTART()                                                              \
+    __shared__ unsigned long long _tm_lds[32];                                      \
+    if (threadIdx.x < 32) _tm_lds[threadIdx.x] = 0ULL;                              \
+    unsigned long long _tm_last = __builtin_amdgcn_s_memrealtime()
+#define TIMER_LMARK(i)                                                              \
     do {                                                                            \
         if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) { \
             const unsigned long long _n = __builtin_amdgcn_s_memrealtime();         \
-            sym[i] += _n - _tm_last;                                                \
+            _tm_lds[i] += _n - _tm_last;                                            \
             _tm_last = _n;                                                          \
         }                                                                           \
+    } while (0)
+#define TIMER_LFLUSH(sym)                                                           \
+    do {                                                                            \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 32) \
+            atomicAdd(&sym[threadIdx.x], _tm_lds[threadIdx.x]);                     \
     } while (0)
 // every workgroup: [16] = earliest start, [17] = latest end (100 MHz wall clock), [18] = sum of workgroup durations, [19] = count,
 // [20] = latest start, [21] = earliest end
@@ -284,6 +308,9 @@ void m2m_set_error(const char* msg, const char* file, int line);
 #define TIMER_DECL(sym)
 #define TIMER_START()
 #define TIMER_MARK(sym, i)
+#define TIMER_LSTART()
+#define TIMER_LMARK(i)
+#define TIMER_LFLUSH(sym)
 #define TIMER_READER(name, sym)
 #define TIMER_WG_BEGIN()
 #define TIMER_WG_END(sym)

@@ -14,6 +14,8 @@
 // tower_wgrad.hip; this kernel writes the operands it contracts: A^T, dYd^T per token tile and, per hidden column
 // tile, Hact^T and dHpre^T (the hidden activation and its gradient leave the chip ONCE, in operand precision, here).
 #include "tile.h"
+#include "token_mfma.h"
+#include <algorithm>
 
 TIMER_DECL(g_tm_bwd);
 TIMER_READER(m2m_debug_timers_bwd, g_tm_bwd)
@@ -44,12 +46,16 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
     float* rstd_s = slabs + 4 * SF;                      // [BM]
     float* dasum = rstd_s + BM;                          // [BM][XLD] summed dA (row-major)
     gtab_t* gtab = reinterpret_cast<gtab_t*>(dasum + TILE_F);   // [GELU_TAB_N] (bf16 mode only)
-    constexpr int RED_LD = ((32 / TG) * (1 + 2 * NM) + NM) * TG;       // token-grad slots per wave
+    constexpr int RED_LD0 = ((32 / TG) * (1 + 2 * NM) + NM) * TG;      // token-grad slots per wave (VALU form)
+    constexpr int RED_LD = RED_LD0 > TokRed<NM>::LD ? RED_LD0 : TokRed<NM>::LD;
     float* red = reinterpret_cast<float*>(gtab + GELU_TAB_N);    // [NWAVES][RED_LD]
     constexpr int TW_LD = 2 * NM + 4;
     float* tokw = red + NWAVES * RED_LD;                         // [32][TW_LD] zero-padded token-MLP weights
+    unsigned int* wth = reinterpret_cast<unsigned int*>(tokw + 32 * TW_LD);   // [BM * D] keep-words of the token-hidden site (bf16 mode)
+    float* dov = dasum;                                          // dO' tile of the MFMA token path (dasum is dead by then)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, il = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: scalar loop control in the column loop
     const int N = tw.N, T = tw.T, Cp = tw.Cp;
     const int SPW = TOK ? BM / N : 0;
     const int s0 = wg * SPW;
@@ -61,7 +67,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
     const int tile_in_pair = wg % TPP;
     const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
 
-    TIMER_START();
+    TIMER_LSTART();
     if (Act<P>::USES_TABLE) gelu_tab_fill(gtab, make_drop(true, tw.p_drop, 0u, 0u, 0u).scale, tid, NTHREADS);
     // ---- upstream gradient of the tower output ----
     {
@@ -84,7 +90,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
             ln_backward_tile<D>(tw.x_final + row0 * D, R, ub, tw.lnf_w, dxs, false, xh, tw.g_lnf_w, tw.g_lnf_b, tid);
     }
 
-    TIMER_MARK(g_tm_bwd, 0);       // upstream + final LN backward
+    TIMER_LMARK(0);       // upstream + final LN backward
     for (int b = tw.nblocks - 1; b >= 0; --b) {
         const m2m_block& bk = tw.blk[b];
         const unsigned int site = tw.site_base + 4u * b;
@@ -93,28 +99,35 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
         const Drop dr_ch = make_drop(true, tw.p_drop, seed, step, site + 2);
         const Drop dr_co = make_drop(true, tw.p_drop, seed, step, site + 3);
 
+        // Per-phase copies of the thread index behind an opaque asm: the phases' index arithmetic is then recomputed where it
+        // is used instead of being hoisted out of the block loop and kept live across the hidden-column loop, which needs
+        // every register it can get (the hoisted values were spilled to scratch and reloaded at L2 latency in each phase).
+        int tb1 = tid;
+        asm volatile("" : "+v"(tb1));
         // ================= channel mixing backward =================
         // (C1) dYd = dY * mask_out -> fp32 temp (ub)
-        _Pragma("unroll 1") for (int idx = tid; idx < BM * D; idx += NTHREADS) {
+        _Pragma("unroll 1") for (int idx = tb1; idx < BM * D; idx += NTHREADS) {
             const int r = idx / D, d = idx % D;
             float v = dxs[r * XLD + d];
             v = drop_keep_elem<DM>(dr_co, (unsigned int)(row0 + r) * D + d) ? v * dr_co.scale : 0.f;
             ub[r * XLD + d] = (r < R) ? v : 0.f;
         }
         __syncthreads();
+        TIMER_LMARK(8);   // C1a: dYd
         // ch_b2 gradient: column sums of dYd
-        _Pragma("unroll 1") for (int d = tid; d < D; d += NTHREADS) {
+        _Pragma("unroll 1") for (int d = tb1; d < D; d += NTHREADS) {
             float s = 0.f;
             for (int r = 0; r < R; ++r) s += ub[r * XLD + d];
             atomicAdd(bk.g_ch_b2 + d, s);
         }
         // pack dYd: NAT [m][d] (LDS image + global copy) and CHN [d][m] (global, for the weight gradients)
-        pack_tile_nat<P, D>(ub, dyp, tid);
-        pack_tile_chn_t<P, D>(ub, reinterpret_cast<char*>(bk.dyt_chn) + pair_off, tile_in_pair, tid);
+        pack_tile_nat<P, D>(ub, dyp, tb1);
+        pack_tile_chn_t<P, D>(ub, reinterpret_cast<char*>(bk.dyt_chn) + pair_off, tile_in_pair, tb1);
         __syncthreads();
+        TIMER_LMARK(9);   // C1b: b2 sums, packs
         // (C2) A = LN2(x_mid) -> fp32 tile (ub) -> packed images
         {
-            const int r = tid / TPR, j = tid % TPR;
+            const int r = tb1 / TPR, j = tb1 % TPR;
             float v[D / TPR], mean, rstd;
             row_stats<D>(bk.x_mid + (row0 + r) * D, r < R, j, v, mean, rstd);
 #pragma unroll
@@ -124,11 +137,12 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
             }
         }
         __syncthreads();
-        pack_tile_nat<P, D>(ub, at, tid);
-        pack_tile_chn_t<P, D>(ub, reinterpret_cast<char*>(bk.at_chn) + pair_off, tile_in_pair, tid);
+        TIMER_LMARK(10);  // C2a: LN2 recompute
+        pack_tile_nat<P, D>(ub, at, tb1);
+        pack_tile_chn_t<P, D>(ub, reinterpret_cast<char*>(bk.at_chn) + pair_off, tile_in_pair, tb1);
         __syncthreads();
 
-        TIMER_MARK(g_tm_bwd, 1);   // C1 + C2: dYd, A, packing, global copies
+        TIMER_LMARK(1);   // C1 + C2: dYd, A, packing, global copies
         // (C3) hidden-column loop
         f32x4_t dacc[MT][DT];
 #pragma unroll
@@ -257,13 +271,23 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                 f32x4_t od[2], oa[2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    Frag id;
-                    if (P == PREC_BF16) id.u = t == 0 ? u32x4_t{id_a, id_b, 0u, 0u} : u32x4_t{0u, 0u, id_a, id_b};
-                    else id.f = f32x4_t{4 * g + 0 == il ? 1.f : 0.f, 4 * g + 1 == il ? 1.f : 0.f, 4 * g + 2 == il ? 1.f : 0.f, 4 * g + 3 == il ? 1.f : 0.f};
                     od[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
                     oa[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                    Pr::mma(od[t], hf[mt][P == PREC_BF16 ? 0 : t], id);
-                    Pr::mma(oa[t], af[mt][P == PREC_BF16 ? 0 : t], id);
+                    if constexpr (P == PREC_BF16) {
+                        // half t of the chained fragment = accumulator tile t, rows 4g + j: the natural k order of the
+                        // 16x16x16 form, so ONE two-register identity serves both halves (the 16x16x32 form needs two
+                        // four-register selectors, and the column loop has no registers to spare)
+                        typedef short s16x4 __attribute__((ext_vector_type(4)));
+                        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                        const s16x4 id16 = __builtin_bit_cast(s16x4, u32x2{id_a, id_b});
+                        od[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, u32x2{hf[mt][0].u[2 * t], hf[mt][0].u[2 * t + 1]}), id16, od[t], 0, 0, 0);
+                        oa[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, u32x2{af[mt][0].u[2 * t], af[mt][0].u[2 * t + 1]}), id16, oa[t], 0, 0, 0);
+                    } else {
+                        Frag id;
+                        id.f = f32x4_t{4 * g + 0 == il ? 1.f : 0.f, 4 * g + 1 == il ? 1.f : 0.f, 4 * g + 2 == il ? 1.f : 0.f, 4 * g + 3 == il ? 1.f : 0.f};
+                        Pr::mma(od[t], hf[mt][t], id);
+                        Pr::mma(oa[t], af[mt][t], id);
+                    }
                     // od[t][r] = dHpre[m = 16u + 4g + r][c = 32q + 16t + il]
                 }
                 // streamed out once and read once by the weight-gradient pass: non-temporal, so that the 100 MB per
@@ -296,24 +320,32 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) Pr::mma(dacc[mt][dt], hf[mt][f], w3f[f][dt]);
         }
-        TIMER_MARK(g_tm_bwd, 2);   // C3 hidden-column loop (wave 0)
+        TIMER_LMARK(2);   // C3 hidden-column loop (wave 0)
         __syncthreads();   // every wave is done reading the packed images that xh aliases
+        TIMER_LMARK(11);  // wave 0 waiting for the other waves' loops
+        int tb2 = tid;
+        asm volatile("" : "+v"(tb2));
         // (C4) dA = sum of the eight waves' partials (through the four slabs) -> ub
         reduce_waves_to_slabs<D>(dacc, slabs, wave, g, il);
-        _Pragma("unroll 1") for (int idx = tid; idx < BM * D; idx += NTHREADS) {
+        TIMER_LMARK(12);  // C4a: slabs
+        _Pragma("unroll 1") for (int idx = tb2; idx < BM * D; idx += NTHREADS) {
             const int d = idx / BM, r = idx % BM;
             dasum[r * XLD + d] = slab_sum<D>(slabs, r, d);
         }
         __syncthreads();
+        TIMER_LMARK(13);  // C4b: slab sum
         // (C5) LayerNorm-2 backward; dx_mid = dY + LN2'(dA)
-        ln_backward_tile<D>(bk.x_mid + row0 * D, R, dasum, bk.ln2_w, dxs, true, xh, bk.g_ln2_w, bk.g_ln2_b, tid);
+        ln_backward_tile<D>(bk.x_mid + row0 * D, R, dasum, bk.ln2_w, dxs, true, xh, bk.g_ln2_w, bk.g_ln2_b, tb2);
 
-        TIMER_MARK(g_tm_bwd, 3);   // C4 + C5: reduction, LN2 backward
+        TIMER_LMARK(3);   // C4 + C5: reduction, LN2 backward
         if constexpr (TOK) {
         // ================= token mixing backward =================
+        int tb3 = tid;
+        asm volatile("" : "+v"(tb3));
+        const int lane3 = tb3 & 63;
         // (T1) xhat1 -> xh, U = LN1(x_in) -> ub, rstd -> rstd_s; token-MLP weights -> LDS, zero-padded:
         //   tokw[t][0..NMAX) = W1[t][n]   tokw[t][NMAX..2NMAX) = W2[n][t]   tokw[t][2NMAX] = b1[t]   (t < 32)
-        _Pragma("unroll 1") for (int idx = tid; idx < 32 * TW_LD; idx += NTHREADS) {
+        _Pragma("unroll 1") for (int idx = tb3; idx < 32 * TW_LD; idx += NTHREADS) {
             const int t = idx / TW_LD, j = idx % TW_LD;
             float v = 0.f;
             if (t < T) {
@@ -324,7 +356,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
             tokw[idx] = v;
         }
         {
-            const int r = tid / TPR, j = tid % TPR;
+            const int r = tb3 / TPR, j = tb3 % TPR;
             float v[D / TPR], mean, rstd;
             row_stats<D>(bk.x_in + (row0 + r) * D, r < R, j, v, mean, rstd);
             if (j == 0) rstd_s[r] = rstd;
@@ -336,10 +368,48 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                 ub[r * XLD + c] = xhv * bk.ln1_w[c] + bk.ln1_b[c];
             }
         }
+        if constexpr (P == PREC_BF16) {
+            // operands of the MFMA token path (token_mfma.h): keep-words of the hidden site, dO' = dropout'(dx_mid)
+            _Pragma("unroll 1") for (int p = tb3; p < SPW * D; p += NTHREADS) {
+                const int sl = p / D, d = p % D;
+                const bool v = sl < ns;
+                const unsigned int bd = (unsigned int)(s0 + sl) * D + d;
+                unsigned int wto = 0xFFFFFFFFu;
+                if (DM != DM_NONE) {
+                    wth[p] = v ? drop_row_bits<DM>(dr_th, bd, T) : 0u;
+                    wto = drop_row_bits<DM>(dr_to, bd, N);
+                }
+                if (v) {
+                    for (int n = 0; n < N; ++n) {
+                        const float x = dxs[(sl * N + n) * XLD + d] * dr_to.scale;
+                        dov[(sl * N + n) * XLD + d] = ((wto >> n) & 1u) ? x : 0.f;
+                    }
+                }
+            }
+        }
         __syncthreads();
-        {
+        TIMER_LMARK(14);  // T0: token weights, LN1 recompute, operands of the MFMA token path
+        if constexpr (P == PREC_BF16) {
+            token_bwd_mfma<D, NM, DM>(ub, dov, tokw, gtab, wth, red, N, ns, dr_th.scale, wave, lane3);
+            __syncthreads();
+            TIMER_LMARK(4);   // T1: token MLP backward (MFMA form)
+            // sum the waves' partial token-weight gradients (layout: TokRed), ONE global atomic per value per workgroup
+            const int nred = 2 * T * N + T + N;
+            for (int i = tb3; i < nred; i += NTHREADS) {
+                int slot;
+                float* dst;
+                if (i < T * N)              { slot = (i % N) * 32 + i / N; dst = bk.g_tok_w1 + i; }
+                else if (i < 2 * T * N)     { const int j = i - T * N; slot = (NM + 1 + j / T) * 32 + j % T; dst = bk.g_tok_w2 + j; }
+                else if (i < 2 * T * N + T) { const int t = i - 2 * T * N; slot = N * 32 + t; dst = bk.g_tok_b1 + t; }
+                else                        { const int n = i - 2 * T * N - T; slot = 2 * (NM + 1) * 32 + n; dst = bk.g_tok_b2 + n; }
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < NWAVES; ++w) v += red[w * TokRed<NM>::LD + slot];
+                atomicAdd(dst, v);
+            }
+        } else {
             constexpr int TTMAX = 32 / TG;                 // hidden units per lane (T <= 32)
-            const int tg = tid % TG, pl = tid / TG;        // TG lanes share a column and split its T hidden units
+            const int tg = tb3 % TG, pl = tb3 / TG;        // TG lanes share a column and split its T hidden units
             const int TT = T / TG;
             float w1r[TTMAX][NMAX], w2r[NMAX][TTMAX], b1r[TTMAX];
             float aw1[TTMAX][NMAX], aw2[NMAX][TTMAX], ab1[TTMAX], ab2[NMAX];
@@ -418,7 +488,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                     }
                 }
             }
-            TIMER_MARK(g_tm_bwd, 4);   // T1: LN1 recompute + token MLP backward pair loop
+            TIMER_LMARK(4);   // T1: LN1 recompute + token MLP backward pair loop
             // reduce the token-weight gradients: over the columns a wave handles concurrently (VALU cross-lane
             // sums), over the 8 waves (per-wave LDS slots written in REGISTER order -- slot (k, tg) at k*TG + tg
             // from one base address, so no per-value address arithmetic stays live), then ONE global atomic
@@ -445,9 +515,9 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                 if (lane < TG) myred[(TTMAX * KS + n) * TG] = s;
             }
             __syncthreads();
-            TIMER_MARK(g_tm_bwd, 6);   // T1b: token-grad cross-lane sums + per-wave LDS slots
+            TIMER_LMARK(6);   // T1b: token-grad cross-lane sums + per-wave LDS slots
             const int nred = 2 * T * N + T + N;
-            for (int i = tid; i < nred; i += NTHREADS) {
+            for (int i = tb3; i < nred; i += NTHREADS) {
                 int t, k;
                 float* dst;
                 if (i < T * N)              { t = i / N; k = 1 + i % N; dst = bk.g_tok_w1 + i; }
@@ -462,10 +532,10 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
             }
         }
         __syncthreads();
-        TIMER_MARK(g_tm_bwd, 7);       // T1c: global atomics of the token grads
+        TIMER_LMARK(7);       // T1c: global atomics of the token grads
         // (T2) LayerNorm-1 backward: dx_in = dx_mid + LN1'(dU); gamma/beta gradients
         {
-            const int r = tid / TPR, j = tid % TPR;
+            const int r = tb3 / TPR, j = tb3 % TPR;
             const bool valid = r < R;
             const float rstd = rstd_s[r];
             float gv[D / TPR], xv[D / TPR];
@@ -492,7 +562,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
             }
         }
         __syncthreads();
-        _Pragma("unroll 1") for (int d = tid; d < 2 * D; d += NTHREADS) {
+        _Pragma("unroll 1") for (int d = tb3; d < 2 * D; d += NTHREADS) {
             const float* src = d < D ? xh : ub;
             const int c = d < D ? d : d - D;
             float s = 0.f;
@@ -500,7 +570,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
             atomicAdd((d < D ? bk.g_ln1_w : bk.g_ln1_b) + c, s);
         }
         __syncthreads();
-        TIMER_MARK(g_tm_bwd, 5);   // T2: LN1 backward
+        TIMER_LMARK(5);   // T2: LN1 backward
         }   // TOK
     }
 
@@ -511,6 +581,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
         *reinterpret_cast<float4*>(d_x0 + (gr / N) * d_x0_ss + (gr % N) * D + c) =
             *reinterpret_cast<const float4*>(dxs + r * XLD + c);
     }
+    TIMER_LFLUSH(g_tm_bwd);
 }
 
 template <int P, int D, int NMAX, int TG, int DM>
@@ -553,7 +624,8 @@ static size_t bwd_lds_bytes() {
     constexpr int NM = NMAX > 0 ? NMAX : 1;
     const size_t tile_b = (size_t)BM * TileGeom<D>::XLD * sizeof(float);
     return 2 * tile_b + 4 * SlabGeom<D>::FLOATS * sizeof(float) + BM * sizeof(float) + GELU_TAB_N * 16 +
-           (size_t)NWAVES * ((32 / TG) * (1 + 2 * NM) + NM) * TG * sizeof(float) + 32 * (2 * NM + 4) * sizeof(float);
+           (size_t)NWAVES * std::max(((32 / TG) * (1 + 2 * NM) + NM) * TG, TokRed<NM>::LD) * sizeof(float) + 32 * (2 * NM + 4) * sizeof(float) +
+           (size_t)BM * D * sizeof(unsigned int);
 }
 
 template <int P, int D, int NMAX, int TG, int DM>

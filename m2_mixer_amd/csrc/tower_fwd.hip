@@ -13,6 +13,7 @@
 //                  -- the hidden activation never leaves registers.
 //   the eight waves' partial Y are summed through LDS slabs, then bias + dropout + residual.
 #include "tile.h"
+#include "token_mfma.h"
 
 TIMER_DECL(g_tm_fwd);
 TIMER_READER(m2m_debug_timers_fwd, g_tm_fwd)
@@ -40,6 +41,8 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
     float* tokw = reinterpret_cast<float*>(at + BM * D * Pr::ESZ);   // [T <= 32][TW_LD]
     float* tokb2 = tokw + 32 * TW_LD;                             // [NM]
     gtab_t* gtab = reinterpret_cast<gtab_t*>(tokb2 + 8);          // [GELU_TAB_N] (bf16 mode only)
+    unsigned int* wth = reinterpret_cast<unsigned int*>(gtab + GELU_TAB_N);   // [BM * D] keep-words of the token sites, one per column
+    unsigned int* wto = wth + BM * D;                             //   (bf16 mode with dropout only: token_mfma.h)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
     const int N = tw.N, T = tw.T, Cp = tw.Cp;
@@ -50,7 +53,7 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
     const int R = TOK ? ns * N : (int)min((long)BM, (long)B * N - row0);
     const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
 
-    TIMER_START();
+    TIMER_LSTART();
     if (Act<P>::USES_TABLE) gelu_tab_fill(gtab, make_drop(training, tw.p_drop, 0u, 0u, 0u).scale, tid, NTHREADS);
     // ---- load the input tile (rows >= R are zero) ----
     _Pragma("unroll 1") for (int idx = tid; idx < BM * (D / 4); idx += NTHREADS) {
@@ -86,20 +89,27 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
                 *reinterpret_cast<float4*>(bk.x_in + (row0 + r) * D + c) = *reinterpret_cast<const float4*>(xs + r * XLD + c);
             }
         }
-        _Pragma("unroll 1") for (int idx = tid; idx < T * TW_LD; idx += NTHREADS) {
+        _Pragma("unroll 1") for (int idx = tid; idx < 32 * TW_LD; idx += NTHREADS) {      // rows t >= T are zero
             const int t = idx / TW_LD, j = idx % TW_LD;
             float v = 0.f;
-            if (j < NMAX) { if (j < N) v = bk.tok_w1[t * N + j]; }
-            else if (j < 2 * NMAX) { if (j - NMAX < N) v = bk.tok_w2[(j - NMAX) * T + t]; }
-            else if (j == 2 * NMAX) v = bk.tok_b1[t];
+            if (t < T) {
+                if (j < NMAX) { if (j < N) v = bk.tok_w1[t * N + j]; }
+                else if (j < 2 * NMAX) { if (j - NMAX < N) v = bk.tok_w2[(j - NMAX) * T + t]; }
+                else if (j == 2 * NMAX) v = bk.tok_b1[t];
+            }
             tokw[idx] = v;
         }
-        if (tid < NMAX) tokb2[tid] = tid < N ? bk.tok_b2[tid] : 0.f;
+        if (tid < 8) tokb2[tid] = tid < N ? bk.tok_b2[tid] : 0.f;
+        if constexpr (P == PREC_BF16) token_keep_words<D, DM>(wth, wto, dr_th, dr_to, s0, ns, SPW, N, T, tid);
         ln_to_tile<D>(xs, ub, bk.ln1_w, bk.ln1_b, tid);
         __syncthreads();
-        TIMER_MARK(g_tm_fwd, 0);   // load / save / LN1
+        TIMER_LMARK(0);   // load / save / LN1
 
-        // ---- token mixing: one thread per (sample, channel) column (modules/mixer.py:30-35) ----
+        // ---- token mixing (modules/mixer.py:30-35): bf16 mode on the matrix pipe (token_mfma.h), fp32 mode one thread
+        //      per (sample, channel) column ----
+        if constexpr (P == PREC_BF16) {
+            token_fwd_mfma<D, NMAX, DM>(ub, xs, tokw, tokb2, gtab, wth, wto, N, ns, dr_th.scale, dr_to.scale, wave, lane);
+        } else
         _Pragma("unroll 1") for (int p = tid; p < ns * D; p += NTHREADS) {
             const int sl = p / D, d = p % D;
             const unsigned int bd = (unsigned int)(s0 + sl) * D + d;
@@ -131,7 +141,7 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
             }
         }
         __syncthreads();
-        TIMER_MARK(g_tm_fwd, 1);   // token mixing
+        TIMER_LMARK(1);   // token mixing
         }   // TOK
 
         // ---- save x_mid, LN2 -> packed operand image (wide path: the input IS the saved x_mid) ----
@@ -145,7 +155,7 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
         __syncthreads();
         pack_tile_nat<P, D>(ub, at, tid);
         __syncthreads();
-        TIMER_MARK(g_tm_fwd, 2);   // save x_mid, LN2, pack
+        TIMER_LMARK(2);   // save x_mid, LN2, pack
 
         // ---- channel mixing (modules/mixer.py:37-40), each wave owns 32 hidden columns per step ----
         f32x4_t yacc[MT][DT];
@@ -221,7 +231,7 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) Pr::mma(yacc[mt][dt], hf[mt][f], w2f[f][dt]);
         }
-        TIMER_MARK(g_tm_fwd, 3);   // hidden-column loop (wave 0)
+        TIMER_LMARK(3);   // hidden-column loop (wave 0)
 
         // ---- sum the eight waves' partial Y (deterministic order), then + bias, dropout, residual ----
         __syncthreads();           // every wave is done with `at` / ub before the slabs are overwritten
@@ -235,7 +245,7 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
             }
         }
         __syncthreads();
-        TIMER_MARK(g_tm_fwd, 4);   // wave reduction + bias/dropout/residual
+        TIMER_LMARK(4);   // wave reduction + bias/dropout/residual
     }
 
     // ---- final LayerNorm (modules/mixer.py:131,161,185), output + token mean ----
@@ -266,7 +276,8 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
             pooled[(long)(s0 + sl) * D + d] = s * inv;
         }
     }
-    TIMER_MARK(g_tm_fwd, 5);       // final LN, output, pooled
+    TIMER_LMARK(5);       // final LN, output, pooled
+    TIMER_LFLUSH(g_tm_fwd);
 }
 
 template <int P, int D, int NMAX, int DM>
@@ -310,7 +321,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_group_kernel(const FwdGrou
 
 template <int P, int D>
 static size_t fwd_lds_bytes() {
-    return (size_t)(BM * TileGeom<D>::XLD + 4 * SlabGeom<D>::FLOATS) * sizeof(float) + (size_t)BM * D * Prec<P>::ESZ + (32 * 20 + 8) * sizeof(float) + GELU_TAB_N * 16;
+    return (size_t)(BM * TileGeom<D>::XLD + 4 * SlabGeom<D>::FLOATS) * sizeof(float) + (size_t)BM * D * Prec<P>::ESZ + (32 * 20 + 8) * sizeof(float) + GELU_TAB_N * 16 + 2 * (size_t)BM * D * sizeof(unsigned int);
 }
 
 template <int P, int D, int NMAX, int DM>

@@ -40,6 +40,20 @@ def abserr(a, b):
     return float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max())
 
 
+def assert_preds_bf16(pred, logits_gpu, logits_ref):
+    """bf16 mode: the kernel's predictions are the argmax of its own logits, and equal the oracle's on every sample whose
+    top-2 margin in the oracle exceeds twice the logit error observed in this very comparison (if |l - ref| <= e everywhere,
+    the argmax can only differ where the margin is <= 2e; random-init logits do produce such near-ties: one sample of the
+    B = 40 case has a margin of 3e-4).  fp32 mode asserts bit-exact predictions instead."""
+    lg = logits_gpu.detach().float().cpu()
+    assert torch.equal(pred.cpu().long(), lg.argmax(1))
+    e = float((lg - logits_ref).abs().max())
+    top2 = logits_ref.topk(2, dim=1).values
+    decided = (top2[:, 0] - top2[:, 1]) > 2 * e
+    assert float(decided.float().mean()) >= 0.75, "too many near-ties for the prediction check to mean anything"
+    assert torch.equal(pred.cpu().long()[decided], logits_ref.argmax(1)[decided])
+
+
 def run_block(case, B, prec, dev, p_drop=0.0, seed=0):
     import m2_mixer_amd as M
     from m2_mixer_amd import modules as MM
@@ -187,7 +201,9 @@ def test_avmnist_step_bf16_vs_oracle(size, B, dev):
     assert abserr(eng.logits[0], ref["image_logits"]) < BF16_REL
     assert abserr(eng.logits[1], ref["audio_logits"]) < BF16_REL
     assert abs(float(eng.losses[3]) - float(ref["loss"])) < 1e-2
-    assert torch.equal(eng.preds[2].cpu().long(), ref["preds"])
+    assert_preds_bf16(eng.preds[2], eng.logits[2], ref["logits"])
+    assert_preds_bf16(eng.preds[0], eng.logits[0], ref["image_logits"])
+    assert_preds_bf16(eng.preds[1], eng.logits[1], ref["audio_logits"])
     for k, g in ref["grads"].items():
         if k.endswith("token_mix.2.net.3.bias"):
             continue
