@@ -70,6 +70,24 @@ static __device__ __forceinline__ Frag ld_frag_global(const void* base, long blo
     f.u = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(base) + block * 1024 + lane * 16);
     return f;
 }
+// Global-memory pointer type for values that pass through an opaque asm (which strips the address-space inference: a plain
+// pointer would come back as FLAT, and flat loads also tick lgkmcnt).
+typedef const __attribute__((address_space(1))) char* gptr_t;
+typedef __attribute__((address_space(1))) char* gptr_w_t;
+// (the value is wave-uniform by construction -- a descriptor field -- and is made so for the compiler too: readfirstlane of
+//  both halves, free when it already sits in SGPRs)
+static __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+    const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v), hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+static __device__ __forceinline__ gptr_t to_gptr(const void* p) { return (gptr_t)uniform_u64((unsigned long long)p); }
+static __device__ __forceinline__ gptr_w_t to_gptr_w(void* p) { return (gptr_w_t)uniform_u64((unsigned long long)p); }
+// fragment load with a wave-uniform block index: scalar base + one 32-bit per-lane offset shared by every load of the loop
+static __device__ __forceinline__ Frag ld_frag_global_u(gptr_t base, long block_uniform, unsigned int lane16) {
+    Frag f;
+    f.u = *reinterpret_cast<const __attribute__((address_space(1))) u32x4_t*>(base + block_uniform * 1024 + lane16);
+    return f;
+}
 static __device__ __forceinline__ Frag ld_frag_lds(const char* base, int block, int lane) {
     Frag f;
     f.u = *reinterpret_cast<const u32x4_t*>(base + block * 1024 + lane * 16);

@@ -369,3 +369,118 @@ static __device__ __forceinline__ float slab_sum(const float* slabs, int r, int 
     constexpr int F = SlabGeom<D>::FLOATS;
     return (s[0] + s[F]) + (s[2 * F] + s[3 * F]);
 }
+
+// ---- row-wise phases on registers (round 2) ---------------------------------------------------------------------
+// Thread (r = tid / TPR, j = tid % TPR) owns the EPT = D / TPR elements ln_col<D>(e, j) of row r.  The helpers below keep a
+// phase's values in registers from the LDS / global read to the last write, so that neighbouring phases (sum of the waves'
+// partial results -> residual -> LayerNorm -> packed operand image) need no LDS round trip and no barrier between them.
+template <int D>
+static __device__ __forceinline__ void ld_row(const float* row, int j, float v[D / TPR]) {
+    constexpr int EPT = D / TPR;
+    if constexpr (EPT >= 4) {
+#pragma unroll
+        for (int i = 0; i < EPT / 4; ++i) {
+            const f32x4_t q = *reinterpret_cast<const f32x4_t*>(row + 4 * TPR * i + 4 * j);
+            v[4 * i + 0] = q[0]; v[4 * i + 1] = q[1]; v[4 * i + 2] = q[2]; v[4 * i + 3] = q[3];
+        }
+    } else if constexpr (EPT == 2) {
+        const float2 q = *reinterpret_cast<const float2*>(row + 2 * j);
+        v[0] = q.x; v[1] = q.y;
+    } else {
+        v[0] = row[j];
+    }
+}
+template <int D>
+static __device__ __forceinline__ void st_row(float* row, int j, const float v[D / TPR]) {
+    constexpr int EPT = D / TPR;
+    if constexpr (EPT >= 4) {
+#pragma unroll
+        for (int i = 0; i < EPT / 4; ++i)
+            *reinterpret_cast<f32x4_t*>(row + 4 * TPR * i + 4 * j) = f32x4_t{v[4 * i + 0], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+    } else if constexpr (EPT == 2) {
+        *reinterpret_cast<float2*>(row + 2 * j) = make_float2(v[0], v[1]);
+    } else {
+        row[j] = v[0];
+    }
+}
+// mean and 1 / std (biased variance, eps 1e-5) of a row held by its TPR threads
+template <int D>
+static __device__ __forceinline__ void reg_stats(const float v[D / TPR], float& mean, float& rstd) {
+    constexpr int EPT = D / TPR;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) s += v[i];
+    s = wave_sum_xor(s, TPR);
+    mean = s * (1.0f / D);
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) { const float c = v[i] - mean; s2 = __builtin_fmaf(c, c, s2); }
+    s2 = wave_sum_xor(s2, TPR);
+    const float vv = s2 * (1.0f / D) + 1e-5f;
+    rstd = __builtin_amdgcn_rsqf(vv);
+    rstd = rstd * (1.5f - 0.5f * vv * rstd * rstd);
+}
+// this thread's elements of row r -> packed NAT operand image X[i = row][k = column] (blocks [mt][kb], see pack_tile_nat)
+template <int P, int D>
+static __device__ __forceinline__ void pack_row_nat(char* img, int r, int j, const float y[D / TPR]) {
+    typedef Prec<P> Pr;
+    constexpr int EPT = D / TPR, KD = D / Pr::KB;
+    const int mt = r >> 4, il = r & 15;
+    if constexpr (P == PREC_BF16 && EPT >= 4) {
+#pragma unroll
+        for (int i = 0; i < EPT / 4; ++i) {
+            const int c = 4 * TPR * i + 4 * j, kb = c >> 5, kk = c & 31;          // 4 consecutive k inside one lane slot
+            uint2 o;
+            o.x = pack_bf2(y[4 * i + 0], y[4 * i + 1]);
+            o.y = pack_bf2(y[4 * i + 2], y[4 * i + 3]);
+            *reinterpret_cast<uint2*>(img + (((mt * KD + kb) * 64 + (kk >> 3) * 16 + il) * 16 + (kk & 7) * 2)) = o;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int c = ln_col<D>(e, j), kb = c / Pr::KB, kk = c % Pr::KB;
+            if constexpr (P == PREC_BF16) {
+                *reinterpret_cast<unsigned short*>(img + (((mt * KD + kb) * 64 + (kk >> 3) * 16 + il) * 16 + (kk & 7) * 2)) = f2bf(y[e]);
+            } else {
+                *reinterpret_cast<float*>(img + (((mt * KD + kb) * 64 + (kk & 3) * 16 + il) * 16 + (kk >> 2) * 4)) = y[e];
+            }
+        }
+    }
+}
+// accumulator set of a wave -> its row-major fp32 slab [BM][XLD]: element (row 16 mt + 4 g + r, column 16 dt + il)
+template <int D>
+static __device__ __forceinline__ void acc_to_slab(const f32x4_t (&acc)[MT][D / 16], float* slab, int g, int il) {
+    constexpr int XLD = TileGeom<D>::XLD;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[(mt * 16 + 4 * g + r) * XLD + dt * 16 + il] = acc[mt][dt][r];
+}
+template <int D>
+static __device__ __forceinline__ void acc_add_slab(const f32x4_t (&acc)[MT][D / 16], float* slab, int g, int il) {
+    constexpr int XLD = TileGeom<D>::XLD;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[(mt * 16 + 4 * g + r) * XLD + dt * 16 + il] += acc[mt][dt][r];
+}
+// number of row-major slabs the chain kernels keep: one per wave where LDS allows it (hidden_dim <= 128), else four (waves
+// 4-7 add into the slabs of waves 0-3 behind a barrier)
+template <int D> struct RowSlabs { static constexpr int N = D <= 128 ? NWAVES : 4; };
+// this thread's elements of row r, summed over the slabs
+template <int D>
+static __device__ __forceinline__ void slab_row_sum(const float* slabs, int r, int j, float v[D / TPR]) {
+    constexpr int EPT = D / TPR, XLD = TileGeom<D>::XLD;
+    ld_row<D>(slabs + r * XLD, j, v);
+#pragma unroll
+    for (int w = 1; w < RowSlabs<D>::N; ++w) {
+        float u[EPT];
+        ld_row<D>(slabs + (w * BM + r) * XLD, j, u);
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) v[e] += u[e];
+    }
+}

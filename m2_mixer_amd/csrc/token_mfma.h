@@ -83,7 +83,7 @@ static __device__ __forceinline__ void token_fwd_mfma(const float* ub, float* xs
     for (int r = 0; r < 4; ++r) b2v[r] = (4 * g + r < NMAX) ? tokb2[(4 * g + r) & 7] : 0.f;
 
     // TU tiles per pass, stage by stage, so that the LDS round trips (operand, table, read-modify-write) of the tiles overlap
-    constexpr int TU = 2;
+    constexpr int TU = NMAX == 4 ? 4 : 2;
     const int ntile = ns * CT;
     for (int p0 = wave; p0 < ntile; p0 += NWAVES * TU) {
         int sl[TU], d0[TU];

@@ -17,6 +17,27 @@
 #include "token_mfma.h"
 #include <algorithm>
 
+// LDS budget of the backward chain kernel (bytes): FIXED + nblocks * PB * 4
+template <int P, int D, int NMAX, int TG> struct BwdLds {
+    static constexpr bool TOK = NMAX > 0;
+    static constexpr int NM = TOK ? NMAX : 1, TW_LD = 2 * NM + 4, XLD = D + 4;
+    static constexpr int RED_LD0 = ((32 / TG) * (1 + 2 * NM) + NM) * TG;      // token-grad slots per wave (VALU form, fp32 mode)
+    static constexpr int RED_LD = RED_LD0 > TokRed<NM>::LD ? RED_LD0 : TokRed<NM>::LD;
+    static constexpr int PB = 4 * D + (TOK ? 32 * TW_LD : 0);                  // floats of one block's small parameters
+    static constexpr size_t FIXED = (size_t)BM * XLD * sizeof(float) * (1 + RowSlabs<D>::N + 2) + 2 * (size_t)BM * D * Prec<P>::ESZ +
+                                    GELU_TAB_N * 16 + (TOK ? (size_t)NWAVES * RED_LD * sizeof(float) : 0);
+    // + keep-words of the token-hidden site (one per column of the workgroup's SPW = BM / N samples) + hidden bias of one block
+    static size_t bytes(int nblocks, int N, int Cp) {
+        return FIXED + (TOK ? (size_t)(BM / N) * D * sizeof(unsigned int) : 0) + (size_t)nblocks * PB * sizeof(float) +
+               (size_t)Cp * sizeof(float);
+    }
+};
+#ifdef M2M_TIMERS
+#define M2M_LDS_MAX (163840 - 1024)     // the diagnostic build keeps its timer slots in static LDS
+#else
+#define M2M_LDS_MAX 163840
+#endif
+
 TIMER_DECL(g_tm_bwd);
 TIMER_READER(m2m_debug_timers_bwd, g_tm_bwd)
 
@@ -29,33 +50,38 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                                                       const unsigned int* __restrict__ step_dev, int wg, int nwg, char* smem) {
     typedef Prec<P> Pr;
     typedef TileGeom<D> G;
+    typedef BwdLds<P, D, NMAX, TG> L;
     constexpr int XLD = G::XLD, DT = G::DT, KD = D / Pr::KB, NF = Chain<P>::NF;
     constexpr bool TOK = NMAX > 0;                      // false: wide path, channel mixing only (rows independent)
     constexpr int NM = TOK ? NMAX : 1;
     constexpr int TILE_F = BM * XLD;                    // floats in one fp32 tile
     constexpr int IMG_B = BM * D * Pr::ESZ;             // bytes of one packed BM-row image
+    constexpr int EPT = D / TPR, NSL = RowSlabs<D>::N;
+    constexpr int TW_LD = 2 * NM + 4, RED_LD = L::RED_LD, PB = L::PB;
+    constexpr int O_LN1W = 0, O_LN1B = D, O_LN2W = 2 * D, O_LN2B = 3 * D, O_TOKW = 4 * D;
 
-    constexpr int SF = SlabGeom<D>::FLOATS;             // floats in one (transposed) reduction slab, >= TILE_F
-    static_assert(IMG_B <= SF * 4 && TILE_F <= SF, "packed image / fp32 tile must fit the slab it aliases");
+    // LDS: gradient stream | one row-major partial-dA slab per wave (RowSlabs); after the row threads have summed them, slabs
+    //      0-3 are reused in place as fp32 tiles (each thread rewrites only the elements it alone has read) | dYd / A tiles
+    //      (sources of the transposed operand copies) | packed A / dYd images | GELU table | token-gradient partial sums |
+    //      keep-words | the small parameters of every block (loaded once)
     float* dxs = reinterpret_cast<float*>(smem);        // gradient stream
-    float* slabs = dxs + TILE_F;                         // 4 slabs: S0 = ub (scratch), S1 = xh (scratch),
-    float* ub = slabs;                                   //   S2 / S3 hold the packed A / dYd images during the
-    float* xh = slabs + SF;                              //   hidden-column loop, then all four receive the waves'
-    char* at = reinterpret_cast<char*>(slabs + 2 * SF);  //   partial dA
-    char* dyp = reinterpret_cast<char*>(slabs + 3 * SF);
-    float* rstd_s = slabs + 4 * SF;                      // [BM]
-    float* dasum = rstd_s + BM;                          // [BM][XLD] summed dA (row-major)
-    gtab_t* gtab = reinterpret_cast<gtab_t*>(dasum + TILE_F);   // [GELU_TAB_N] (bf16 mode only)
-    constexpr int RED_LD0 = ((32 / TG) * (1 + 2 * NM) + NM) * TG;      // token-grad slots per wave (VALU form)
-    constexpr int RED_LD = RED_LD0 > TokRed<NM>::LD ? RED_LD0 : TokRed<NM>::LD;
-    float* red = reinterpret_cast<float*>(gtab + GELU_TAB_N);    // [NWAVES][RED_LD]
-    constexpr int TW_LD = 2 * NM + 4;
-    float* tokw = red + NWAVES * RED_LD;                         // [32][TW_LD] zero-padded token-MLP weights
-    unsigned int* wth = reinterpret_cast<unsigned int*>(tokw + 32 * TW_LD);   // [BM * D] keep-words of the token-hidden site (bf16 mode)
-    float* dov = dasum;                                          // dO' tile of the MFMA token path (dasum is dead by then)
+    float* slabs = dxs + TILE_F;
+    float* t_prod = slabs;                               // LayerNorm gamma-gradient products (column-summed one phase later)
+    float* t_up = slabs + TILE_F;                        // LayerNorm beta-gradient source
+    float* ub = slabs + 2 * TILE_F;                      // token path: U = LN1 output in, dU out
+    float* dov = slabs + 3 * TILE_F;                     // token path: dO' = dropout'(dx_mid)
+    float* tdy = slabs + NSL * TILE_F;                   // dYd (fp32)
+    float* ta = tdy + TILE_F;                            // A = LN2(x_mid) (fp32)
+    char* at = reinterpret_cast<char*>(ta + TILE_F);
+    char* dyp = at + IMG_B;
+    gtab_t* gtab = reinterpret_cast<gtab_t*>(dyp + IMG_B);       // [GELU_TAB_N] (bf16 mode only)
+    float* red = reinterpret_cast<float*>(gtab + GELU_TAB_N);    // [NWAVES][RED_LD] (token path)
+    unsigned int* wth = reinterpret_cast<unsigned int*>(red + (TOK ? NWAVES * RED_LD : 0));   // [BM * D] (token path)
+    float* par = reinterpret_cast<float*>(wth + (TOK ? (BM / tw.N) * D : 0));                 // [nblocks][PB]
+    float* bias_s = par + tw.nblocks * PB;                                                    // [Cp] hidden bias of the block in flight
 
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, il = lane & 15;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: scalar loop control in the column loop
+    const int wave = tid >> 6;
     const int N = tw.N, T = tw.T, Cp = tw.Cp;
     const int SPW = TOK ? BM / N : 0;
     const int s0 = wg * SPW;
@@ -69,6 +95,55 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
 
     TIMER_LSTART();
     if (Act<P>::USES_TABLE) gelu_tab_fill(gtab, make_drop(true, tw.p_drop, 0u, 0u, 0u).scale, tid, NTHREADS);
+    constexpr int MAXB = (int)(sizeof(tw.blk) / sizeof(tw.blk[0]));       // blocks the descriptor type can hold
+    // ---- the small parameters of every block -> LDS.  The block index stays wave-uniform (a per-thread index into the
+    //      by-value descriptor would turn every later descriptor read into a vector load); all blocks' loads are issued
+    //      before the first LDS write, so the whole preload costs one memory round trip ----
+    _Pragma("unroll 1") for (int i = tid; i < D; i += NTHREADS) {
+        float v[MAXB][4];
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b)
+            if (b < tw.nblocks) {
+                const m2m_block& bk = tw.blk[b];
+                v[b][0] = TOK ? bk.ln1_w[i] : 0.f; v[b][1] = TOK ? bk.ln1_b[i] : 0.f;
+                v[b][2] = bk.ln2_w[i]; v[b][3] = bk.ln2_b[i];
+            }
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b)
+            if (b < tw.nblocks) {
+                float* pb = par + b * PB;
+                if (TOK) { pb[O_LN1W + i] = v[b][0]; pb[O_LN1B + i] = v[b][1]; }
+                pb[O_LN2W + i] = v[b][2]; pb[O_LN2B + i] = v[b][3];
+            }
+    }
+    if constexpr (TOK) {
+        // zero-padded token weights: tokw[t][0..NMAX) = W1[t][n]  tokw[t][NMAX..2NMAX) = W2[n][t]  tokw[t][2NMAX] = b1[t]  (t < 32)
+        _Pragma("unroll 1") for (int idx = tid; idx < 32 * TW_LD; idx += NTHREADS) {
+            const int t = idx / TW_LD, j = idx % TW_LD;
+            float v[MAXB];
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b) {
+                v[b] = 0.f;
+                if (b < tw.nblocks && t < T) {
+                    const m2m_block& bk = tw.blk[b];
+                    if (j < NMAX) { if (j < N) v[b] = bk.tok_w1[t * N + j]; }
+                    else if (j < 2 * NMAX) { if (j - NMAX < N) v[b] = bk.tok_w2[(j - NMAX) * T + t]; }
+                    else if (j == 2 * NMAX) v[b] = bk.tok_b1[t];
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b)
+                if (b < tw.nblocks) par[b * PB + O_TOKW + idx] = v[b];
+        }
+    }
+    // x_mid of the last block: its rows are requested now and used by the first phase of the block loop
+    float xm[EPT];
+    {
+        const int r = tid / TPR, j = tid % TPR;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) xm[e] = 0.f;
+        if (r < R) ld_row<D>(tw.blk[tw.nblocks - 1].x_mid + (row0 + r) * D, j, xm);
+    }
     // ---- upstream gradient of the tower output ----
     {
         const float invN = 1.0f / (float)N;
@@ -83,16 +158,29 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                     v.x += p.x * invN; v.y += p.y * invN; v.z += p.z * invN; v.w += p.w * invN;
                 }
             }
-            *reinterpret_cast<float4*>((tw.has_final_ln ? ub : dxs) + r * XLD + c) = v;
+            *reinterpret_cast<float4*>((tw.has_final_ln ? tdy : dxs) + r * XLD + c) = v;
         }
         __syncthreads();
         if (tw.has_final_ln)
-            ln_backward_tile<D>(tw.x_final + row0 * D, R, ub, tw.lnf_w, dxs, false, xh, tw.g_lnf_w, tw.g_lnf_b, tid);
+            ln_backward_tile<D>(tw.x_final + row0 * D, R, tdy, tw.lnf_w, dxs, false, ta, tw.g_lnf_w, tw.g_lnf_b, tid);
     }
 
-    TIMER_LMARK(0);       // upstream + final LN backward
+    TIMER_LMARK(0);       // parameters, upstream + final LN backward
+    int pend = -1;        // block whose LayerNorm-1 parameter gradients are still to be column-summed (from t_prod / ub)
+    // column sums of two tiles -> global atomics (gamma gradient from `pw`, beta gradient from `pb_`); rows >= R hold zeros
+    auto colsums = [&](const float* pw, const float* pb_, float* gw, float* gb, int t0) {
+        _Pragma("unroll 1") for (int d = t0; d < 2 * D; d += NTHREADS) {
+            const float* src = d < D ? pw : pb_;
+            const int c = d < D ? d : d - D;
+            float s_ = 0.f;
+#pragma unroll 4
+            for (int r = 0; r < BM; ++r) s_ += src[r * XLD + c];
+            atomicAdd((d < D ? gw : gb) + c, s_);
+        }
+    };
     for (int b = tw.nblocks - 1; b >= 0; --b) {
         const m2m_block& bk = tw.blk[b];
+        const float* pb = par + b * PB;
         const unsigned int site = tw.site_base + 4u * b;
         const Drop dr_th = make_drop(true, tw.p_drop, seed, step, site + 0);
         const Drop dr_to = make_drop(true, tw.p_drop, seed, step, site + 1);
@@ -105,44 +193,57 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
         int tb1 = tid;
         asm volatile("" : "+v"(tb1));
         // ================= channel mixing backward =================
-        // (C1) dYd = dY * mask_out -> fp32 temp (ub)
-        _Pragma("unroll 1") for (int idx = tb1; idx < BM * D; idx += NTHREADS) {
-            const int r = idx / D, d = idx % D;
-            float v = dxs[r * XLD + d];
-            v = drop_keep_elem<DM>(dr_co, (unsigned int)(row0 + r) * D + d) ? v * dr_co.scale : 0.f;
-            ub[r * XLD + d] = (r < R) ? v : 0.f;
-        }
-        __syncthreads();
-        TIMER_LMARK(8);   // C1a: dYd
-        // ch_b2 gradient: column sums of dYd
-        _Pragma("unroll 1") for (int d = tb1; d < D; d += NTHREADS) {
-            float s = 0.f;
-            for (int r = 0; r < R; ++r) s += ub[r * XLD + d];
-            atomicAdd(bk.g_ch_b2 + d, s);
-        }
-        // pack dYd: NAT [m][d] (LDS image + global copy) and CHN [d][m] (global, for the weight gradients)
-        pack_tile_nat<P, D>(ub, dyp, tb1);
-        pack_tile_chn_t<P, D>(ub, reinterpret_cast<char*>(bk.dyt_chn) + pair_off, tile_in_pair, tb1);
-        __syncthreads();
-        TIMER_LMARK(9);   // C1b: b2 sums, packs
-        // (C2) A = LN2(x_mid) -> fp32 tile (ub) -> packed images
+        // (X1) on the row thread's registers: dYd = dY * mask_out and A = LN2(x_mid), each to its fp32 tile (source of the
+        //      transposed operand copy and of the ch_b2 gradient) and straight into its packed NAT image.  The previous
+        //      block's LayerNorm-1 parameter gradients are column-summed beside it (other tiles).
         {
-            const int r = tb1 / TPR, j = tb1 % TPR;
-            float v[D / TPR], mean, rstd;
-            row_stats<D>(bk.x_mid + (row0 + r) * D, r < R, j, v, mean, rstd);
+            // this block's hidden bias -> LDS: requested first, written at the end of the phase (the column loop reads it from
+            // there: a global load of it at the top of every step was waited for at once, and with it -- the memory counter is
+            // in order -- everything requested before it)
+            constexpr int BPT = 8;                                  // Cp <= BPT * NTHREADS (checked by the host)
+            float nb[BPT];
 #pragma unroll
-            for (int e = 0; e < D / TPR; ++e) {
-                const int c = ln_col<D>(e, j);
-                ub[r * XLD + c] = (v[e] - mean) * rstd * bk.ln2_w[c] + bk.ln2_b[c];
+            for (int k = 0; k < BPT; ++k) {
+                nb[k] = 0.f;
+                if (tb1 + k * NTHREADS < Cp) nb[k] = bk.ch_b1p[tb1 + k * NTHREADS];
             }
+            const int r = tb1 / TPR, j = tb1 % TPR;
+            float dy[EPT], a[EPT], mean, rstd;
+            ld_row<D>(dxs + r * XLD, j, dy);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const int c = ln_col<D>(e, j);
+                const float v = drop_keep_elem<DM>(dr_co, (unsigned int)(row0 + r) * D + c) ? dy[e] * dr_co.scale : 0.f;
+                dy[e] = r < R ? v : 0.f;
+            }
+            st_row<D>(tdy + r * XLD, j, dy);
+            pack_row_nat<P, D>(dyp, r, j, dy);
+            reg_stats<D>(xm, mean, rstd);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const int c = ln_col<D>(e, j);
+                a[e] = (xm[e] - mean) * rstd * pb[O_LN2W + c] + pb[O_LN2B + c];
+            }
+            st_row<D>(ta + r * XLD, j, a);
+            pack_row_nat<P, D>(at, r, j, a);
+            if (TOK && pend >= 0) colsums(t_prod, ub, tw.blk[pend].g_ln1_w, tw.blk[pend].g_ln1_b, tb1);
+#pragma unroll
+            for (int k = 0; k < BPT; ++k)
+                if (tb1 + k * NTHREADS < Cp) bias_s[tb1 + k * NTHREADS] = nb[k];
         }
         __syncthreads();
-        TIMER_LMARK(10);  // C2a: LN2 recompute
-        pack_tile_nat<P, D>(ub, at, tb1);
-        pack_tile_chn_t<P, D>(ub, reinterpret_cast<char*>(bk.at_chn) + pair_off, tile_in_pair, tb1);
-        __syncthreads();
+        TIMER_LMARK(1);   // X1: dYd, A, packed images (+ previous block's LN1 column sums)
+        // (X2) ch_b2 gradient (column sums of dYd) and the transposed (CHN) operand copies for the weight gradients: global
+        //      writes from tiles nothing rewrites before the next block -- no barrier between here and the column loop
+        _Pragma("unroll 1") for (int d = tb1; d < D; d += NTHREADS) {
+            float s_ = 0.f;
+#pragma unroll 4
+            for (int r = 0; r < BM; ++r) s_ += tdy[r * XLD + d];
+            atomicAdd(bk.g_ch_b2 + d, s_);
+        }
+        pack_tile_chn_t<P, D>(tdy, reinterpret_cast<char*>(bk.dyt_chn) + pair_off, tile_in_pair, tb1);
+        pack_tile_chn_t<P, D>(ta, reinterpret_cast<char*>(bk.at_chn) + pair_off, tile_in_pair, tb1);
 
-        TIMER_LMARK(1);   // C1 + C2: dYd, A, packing, global copies
         // (C3) hidden-column loop
         f32x4_t dacc[MT][DT];
 #pragma unroll
@@ -150,6 +251,13 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) dacc[mt][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         const int npairs = Cp >> 5;
+        // The loop's six streams as scalar (SGPR) base pointers behind an opaque asm: under register pressure hipcc otherwise
+        // re-reads them from the descriptor INSIDE the loop (two global_load_dwordx2 + vmcnt(0) per step, which drains the
+        // weight prefetch in flight).
+        gptr_t p_w1n = to_gptr(bk.w1n), p_w2tn = to_gptr(bk.w2tn), p_w1tc = to_gptr(bk.w1tc);
+        gptr_w_t p_dh = to_gptr_w(bk.dh_chn), p_h = to_gptr_w(bk.h_chn);
+        asm volatile("" : "+s"(p_w1n), "+s"(p_w2tn), "+s"(p_w1tc), "+s"(p_dh), "+s"(p_h));
+        const unsigned int lane16 = (unsigned int)lane * 16u;
         // identity block of the transposing MFMA (bf16): lane (g, il) is non-zero iff g == il >> 2, at element il & 3
         const unsigned int id_sel = (g == (il >> 2)) ? ((il & 1) ? 0x3F800000u : 0x00003F80u) : 0u;
         const unsigned int id_a = (il & 2) ? 0u : id_sel, id_b = (il & 2) ? id_sel : 0u;
@@ -158,20 +266,35 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
         // the third product -- the kernel spilled ~200 -- and such towers have few steps per wave (C = 512: two), so there the
         // first two products stream their fragments two k-blocks at a time, nothing held across steps.
         constexpr bool HOLD = D <= 128;
+        // bf16, hidden_dim <= 128: the third product takes its W1 operand (k = hidden column) from THIS step's W1 fragments,
+        // parked in the wave's LDS slot as 32 rows of 256 bytes and read back transposed (ds_read_b64_tr_b16): the W1^T copy is
+        // not streamed at all (a third less traffic on the CU's vector-memory path, which paces this loop) and its 32
+        // registers are free.  Rows are XOR-swizzled by 16-byte chunk (chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))) so that
+        // both the 16-byte fragment writes and the 8-byte transposed reads spread over the banks.  The slot lies inside the
+        // wave's own slab (dead until the wave leaves the loop).
+#ifndef M2M_W1LDS
+#define M2M_W1LDS 1
+#endif
+        constexpr bool W1LDS = M2M_W1LDS && D == 128 && P == PREC_BF16;      // (256-byte rows: hidden_dim 128)
+        char* w1slot = reinterpret_cast<char*>(slabs + wave * TILE_F);
+        const int swz_w = ((il & 3) << 2) | ((il >> 2) & 3);                       // writer: row 16 t + il, chunk 4 kb + g
+        char* w1_wr = w1slot + 256 * il + 16 * (g ^ (swz_w & 3));
+        const int swz_r = ((il >> 2) << 2) | g;                                    // reader: row 16 t + 4 g + (il >> 2)
+        const char* w1_rd = w1slot + 256 * (4 * g + (il >> 2)) + 8 * (il & 1) + 16 * (((il >> 1) & 1) ^ (swz_r & 1));
         Frag w1f[2][HOLD ? KD : 1], w2f[2][HOLD ? KD : 1];
         if (HOLD && wave < npairs) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int kb = 0; kb < KD; ++kb) {
-                    w1f[t][kb] = ld_frag_global(bk.w1n, (long)(2 * wave + t) * KD + kb, lane);
-                    w2f[t][kb] = ld_frag_global(bk.w2tn, (long)(2 * wave + t) * KD + kb, lane);
+                    w1f[t][kb] = ld_frag_global_u(p_w1n, (long)(2 * wave + t) * KD + kb, lane16);
+                    w2f[t][kb] = ld_frag_global_u(p_w2tn, (long)(2 * wave + t) * KD + kb, lane16);
                 }
         }
         for (int q = wave; q < npairs; q += NWAVES) {
             f32x4_t bias[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) bias[t] = *reinterpret_cast<const f32x4_t*>(bk.ch_b1p + 32 * q + 16 * t + 4 * g);
+            for (int t = 0; t < 2; ++t) bias[t] = *reinterpret_cast<const f32x4_t*>(bias_s + 32 * q + 16 * t + 4 * g);
             f32x4_t hacc[MT][2], gacc[MT][2];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -181,6 +304,13 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                 gacc[mt][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             }
             if constexpr (HOLD) {
+            if constexpr (W1LDS) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int kb = 0; kb < KD; ++kb)
+                        *reinterpret_cast<u32x4_t*>(w1_wr + 4096 * t + 16 * ((4 * kb) ^ (swz_w & 12))) = w1f[t][kb].u;
+            }
 #pragma unroll
             for (int kb = 0; kb < KD; ++kb) {
 #pragma unroll
@@ -202,8 +332,8 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                     for (int t = 0; t < 2; ++t)
 #pragma unroll
                         for (int kk = 0; kk < KG; ++kk) {
-                            u1[t][kk] = ld_frag_global(bk.w1n, (long)(2 * q + t) * KD + k0 + kk, lane);
-                            u2[t][kk] = ld_frag_global(bk.w2tn, (long)(2 * q + t) * KD + k0 + kk, lane);
+                            u1[t][kk] = ld_frag_global_u(p_w1n, (long)(2 * q + t) * KD + k0 + kk, lane16);
+                            u2[t][kk] = ld_frag_global_u(p_w2tn, (long)(2 * q + t) * KD + k0 + kk, lane16);
                         }
 #pragma unroll
                     for (int kk = 0; kk < KG; ++kk) {
@@ -223,18 +353,20 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
             // during the epilogue.  The scheduling barrier keeps the compiler from hoisting these loads above
             // the MFMAs that still read the current fragments (which would double the live registers).
             __builtin_amdgcn_sched_barrier(0);
-            Frag w3f[NF][DT];
+            Frag w3f[W1LDS ? 1 : NF][W1LDS ? 1 : DT];
+            if constexpr (!W1LDS) {
 #pragma unroll
             for (int f = 0; f < NF; ++f)
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) w3f[f][dt] = ld_frag_global(bk.w1tc, (long)(q * NF + f) * DT + dt, lane);
+                for (int dt = 0; dt < DT; ++dt) w3f[f][dt] = ld_frag_global_u(p_w1tc, (long)(q * NF + f) * DT + dt, lane16);
+            }
             if (HOLD && q + NWAVES < npairs) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int kb = 0; kb < KD; ++kb) {
-                        w1f[t][kb] = ld_frag_global(bk.w1n, (long)(2 * (q + NWAVES) + t) * KD + kb, lane);
-                        w2f[t][kb] = ld_frag_global(bk.w2tn, (long)(2 * (q + NWAVES) + t) * KD + kb, lane);
+                        w1f[t][kb] = ld_frag_global_u(p_w1n, (long)(2 * (q + NWAVES) + t) * KD + kb, lane16);
+                        w2f[t][kb] = ld_frag_global_u(p_w2tn, (long)(2 * (q + NWAVES) + t) * KD + kb, lane16);
                     }
             }
             Frag hf[MT][NF], af[MT][NF];
@@ -299,100 +431,141 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                     const long off = (long)q * m2m_hchn_stride(npair) + (pair * 2 + u) * 1024 + lane * 16;
                     __builtin_nontemporal_store(u32x4_t{pack_bf2(od[0][0], od[0][1]), pack_bf2(od[0][2], od[0][3]),
                                                         pack_bf2(od[1][0], od[1][1]), pack_bf2(od[1][2], od[1][3])},
-                                                reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(bk.dh_chn) + off));
+                                                reinterpret_cast<__attribute__((address_space(1))) u32x4_t*>(p_dh + off));
                     __builtin_nontemporal_store(u32x4_t{pack_bf2(oa[0][0], oa[0][1]), pack_bf2(oa[0][2], oa[0][3]),
                                                         pack_bf2(oa[1][0], oa[1][1]), pack_bf2(oa[1][2], oa[1][3])},
-                                                reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(bk.h_chn) + off));
+                                                reinterpret_cast<__attribute__((address_space(1))) u32x4_t*>(p_h + off));
                 } else {
                     // fp32: a 16-row half is a whole k-block: [column tile][32-row pair][half][lane][16 bytes]
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         const long off = (long)(2 * q + t) * m2m_hchn_stride(npair) + (pair * 2 + u) * 1024 + lane * 16;
-                        __builtin_nontemporal_store(od[t], reinterpret_cast<f32x4_t*>(reinterpret_cast<char*>(bk.dh_chn) + off));
-                        __builtin_nontemporal_store(oa[t], reinterpret_cast<f32x4_t*>(reinterpret_cast<char*>(bk.h_chn) + off));
+                        __builtin_nontemporal_store(od[t], reinterpret_cast<__attribute__((address_space(1))) f32x4_t*>(p_dh + off));
+                        __builtin_nontemporal_store(oa[t], reinterpret_cast<__attribute__((address_space(1))) f32x4_t*>(p_h + off));
                     }
                 }
             }
+            if constexpr (W1LDS) {
+                typedef short s16x4 __attribute__((ext_vector_type(4)));
+                typedef __attribute__((address_space(3))) s16x4* lds_s16x4_p;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    // B[k = hidden column, chained order][n = 16 dt + il]: rows 4g .. 4g+3 of tile 0, then of tile 1
+                    const char* pr = w1_rd + 16 * ((2 * dt) ^ (swz_r & 14));
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(pr));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(pr + 4096));
+                    Frag wf;
+                    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                    wf.u = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) Pr::mma(dacc[mt][dt], hf[mt][0], wf);
+                }
+            } else {
 #pragma unroll
             for (int f = 0; f < NF; ++f)
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) Pr::mma(dacc[mt][dt], hf[mt][f], w3f[f][dt]);
+            }
         }
         TIMER_LMARK(2);   // C3 hidden-column loop (wave 0)
-        __syncthreads();   // every wave is done reading the packed images that xh aliases
-        TIMER_LMARK(11);  // wave 0 waiting for the other waves' loops
         int tb2 = tid;
         asm volatile("" : "+v"(tb2));
-        // (C4) dA = sum of the eight waves' partials (through the four slabs) -> ub
-        reduce_waves_to_slabs<D>(dacc, slabs, wave, g, il);
-        TIMER_LMARK(12);  // C4a: slabs
-        _Pragma("unroll 1") for (int idx = tb2; idx < BM * D; idx += NTHREADS) {
-            const int d = idx / BM, r = idx % BM;
-            dasum[r * XLD + d] = slab_sum<D>(slabs, r, d);
-        }
-        __syncthreads();
-        TIMER_LMARK(13);  // C4b: slab sum
-        // (C5) LayerNorm-2 backward; dx_mid = dY + LN2'(dA)
-        ln_backward_tile<D>(bk.x_mid + row0 * D, R, dasum, bk.ln2_w, dxs, true, xh, bk.g_ln2_w, bk.g_ln2_b, tb2);
-
-        TIMER_LMARK(3);   // C4 + C5: reduction, LN2 backward
-        if constexpr (TOK) {
-        // ================= token mixing backward =================
-        int tb3 = tid;
-        asm volatile("" : "+v"(tb3));
-        const int lane3 = tb3 & 63;
-        // (T1) xhat1 -> xh, U = LN1(x_in) -> ub, rstd -> rstd_s; token-MLP weights -> LDS, zero-padded:
-        //   tokw[t][0..NMAX) = W1[t][n]   tokw[t][NMAX..2NMAX) = W2[n][t]   tokw[t][2NMAX] = b1[t]   (t < 32)
-        _Pragma("unroll 1") for (int idx = tb3; idx < 32 * TW_LD; idx += NTHREADS) {
-            const int t = idx / TW_LD, j = idx % TW_LD;
-            float v = 0.f;
-            if (t < T) {
-                if (j < NMAX) { if (j < N) v = bk.tok_w1[t * N + j]; }
-                else if (j < 2 * NMAX) { if (j - NMAX < N) v = bk.tok_w2[(j - NMAX) * T + t]; }
-                else if (j == 2 * NMAX) v = bk.tok_b1[t];
-            }
-            tokw[idx] = v;
-        }
-        {
-            const int r = tb3 / TPR, j = tb3 % TPR;
-            float v[D / TPR], mean, rstd;
-            row_stats<D>(bk.x_in + (row0 + r) * D, r < R, j, v, mean, rstd);
-            if (j == 0) rstd_s[r] = rstd;
+        const int r2 = tb2 / TPR, j2 = tb2 % TPR;
+        // rows of x_mid (LayerNorm-2 backward) and x_in (LayerNorm-1 recompute): requested now, used behind the next barrier
+        float xm2[EPT], xi[EPT];
 #pragma unroll
-            for (int e = 0; e < D / TPR; ++e) {
-                const int c = ln_col<D>(e, j);
-                const float xhv = (v[e] - mean) * rstd;
-                xh[r * XLD + c] = xhv;
-                ub[r * XLD + c] = xhv * bk.ln1_w[c] + bk.ln1_b[c];
-            }
+        for (int e = 0; e < EPT; ++e) { xm2[e] = 0.f; xi[e] = 0.f; }
+        if (r2 < R) {
+            ld_row<D>(bk.x_mid + (row0 + r2) * D, j2, xm2);
+            if (TOK) ld_row<D>(bk.x_in + (row0 + r2) * D, j2, xi);
         }
-        if constexpr (P == PREC_BF16) {
-            // operands of the MFMA token path (token_mfma.h): keep-words of the hidden site, dO' = dropout'(dx_mid)
-            _Pragma("unroll 1") for (int p = tb3; p < SPW * D; p += NTHREADS) {
-                const int sl = p / D, d = p % D;
-                const bool v = sl < ns;
-                const unsigned int bd = (unsigned int)(s0 + sl) * D + d;
-                unsigned int wto = 0xFFFFFFFFu;
-                if (DM != DM_NONE) {
-                    wth[p] = v ? drop_row_bits<DM>(dr_th, bd, T) : 0u;
-                    wto = drop_row_bits<DM>(dr_to, bd, N);
+        // (C4) the waves' partial dA -> row-major slabs (nothing else lives there: no barrier in front)
+        if (NSL == NWAVES || wave < NSL) acc_to_slab<D>(dacc, slabs + (wave % NSL) * TILE_F, g, il);
+        __syncthreads();
+        if (NSL < NWAVES) {
+            if (wave >= NSL) acc_add_slab<D>(dacc, slabs + (wave % NSL) * TILE_F, g, il);
+            __syncthreads();
+        }
+        TIMER_LMARK(3);   // C4: slabs (wave 0 waits here for the other waves' loops)
+        // (R1) on the row thread's registers: dA = sum of the slabs; LayerNorm-2 backward, dx_mid = dY + LN2'(dA); sources of
+        //      the LN2 parameter gradients; token path: LayerNorm-1 recompute (U -> ub, xhat / rstd stay in registers for
+        //      R3), dO' = dropout'(dx_mid) and the keep-words of the hidden site
+        float xh1[EPT], rstd1 = 0.f;
+        {
+            float dA[EPT], dx[EPT], mean, rstd;
+            slab_row_sum<D>(slabs, r2, j2, dA);
+            reg_stats<D>(xm2, mean, rstd);
+            float gg[EPT], xh2[EPT], gsum = 0.f, gxsum = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const int c = ln_col<D>(e, j2);
+                xh2[e] = (xm2[e] - mean) * rstd;
+                gg[e] = dA[e] * pb[O_LN2W + c];
+                gsum += gg[e];
+                gxsum = __builtin_fmaf(gg[e], xh2[e], gxsum);
+            }
+            gsum = wave_sum_xor(gsum, TPR) * (1.0f / D);
+            gxsum = wave_sum_xor(gxsum, TPR) * (1.0f / D);
+            ld_row<D>(dxs + r2 * XLD, j2, dx);
+            float pr[EPT], up[EPT];
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const bool valid = r2 < R;
+                if (valid) dx[e] += rstd * (gg[e] - gsum - xh2[e] * gxsum);
+                pr[e] = valid ? dA[e] * xh2[e] : 0.f;
+                up[e] = valid ? dA[e] : 0.f;
+            }
+            st_row<D>(dxs + r2 * XLD, j2, dx);
+            st_row<D>(t_prod + r2 * XLD, j2, pr);
+            st_row<D>(t_up + r2 * XLD, j2, up);
+            if constexpr (TOK) {
+                float u[EPT], mean1;
+                reg_stats<D>(xi, mean1, rstd1);
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) {
+                    const int c = ln_col<D>(e, j2);
+                    xh1[e] = (xi[e] - mean1) * rstd1;
+                    u[e] = xh1[e] * pb[O_LN1W + c] + pb[O_LN1B + c];
                 }
-                if (v) {
-                    for (int n = 0; n < N; ++n) {
-                        const float x = dxs[(sl * N + n) * XLD + d] * dr_to.scale;
-                        dov[(sl * N + n) * XLD + d] = ((wto >> n) & 1u) ? x : 0.f;
+                st_row<D>(ub + r2 * XLD, j2, u);
+                if constexpr (P == PREC_BF16) {
+                    float o[EPT];
+                    const int sl = r2 / N, n = r2 % N;
+#pragma unroll
+                    for (int e = 0; e < EPT; ++e) {
+                        const int c = ln_col<D>(e, j2);
+                        const bool keep = r2 < R && drop_row_keep<DM>(dr_to, (unsigned int)(s0 + sl) * D + c, (unsigned int)N, (unsigned int)n);
+                        o[e] = keep ? dx[e] * dr_to.scale : 0.f;
+                    }
+                    st_row<D>(dov + r2 * XLD, j2, o);
+                    if (DM != DM_NONE) {
+                        _Pragma("unroll 1") for (int p = tb2; p < SPW * D; p += NTHREADS) {
+                            const int slp = p / D;
+                            wth[p] = slp < ns ? drop_row_bits<DM>(dr_th, (unsigned int)(s0 + slp) * D + p % D, T) : 0u;
+                        }
                     }
                 }
             }
         }
         __syncthreads();
-        TIMER_LMARK(14);  // T0: token weights, LN1 recompute, operands of the MFMA token path
+        TIMER_LMARK(4);   // R1: slab sum, LN2 backward, LN1 recompute, token operands
+        // (R2) LayerNorm-2 parameter gradients (column sums of t_prod / t_up) beside the token MLP backward
+        int tb3 = tid;
+        asm volatile("" : "+v"(tb3));
+        const int lane3 = tb3 & 63;
+        if constexpr (!TOK) {
+            colsums(t_prod, t_up, bk.g_ln2_w, bk.g_ln2_b, tb3);
+        } else {
+        // ================= token mixing backward =================
+        const float* tokw = pb + O_TOKW;
         if constexpr (P == PREC_BF16) {
             token_bwd_mfma<D, NM, DM>(ub, dov, tokw, gtab, wth, red, N, ns, dr_th.scale, wave, lane3);
+            colsums(t_prod, t_up, bk.g_ln2_w, bk.g_ln2_b, tb3);
             __syncthreads();
-            TIMER_LMARK(4);   // T1: token MLP backward (MFMA form)
+            TIMER_LMARK(5);   // R2: token MLP backward (MFMA form) + LN2 column sums
             // sum the waves' partial token-weight gradients (layout: TokRed), ONE global atomic per value per workgroup
             const int nred = 2 * T * N + T + N;
             for (int i = tb3; i < nred; i += NTHREADS) {
@@ -408,6 +581,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                 atomicAdd(dst, v);
             }
         } else {
+            colsums(t_prod, t_up, bk.g_ln2_w, bk.g_ln2_b, tb3);
             constexpr int TTMAX = 32 / TG;                 // hidden units per lane (T <= 32)
             const int tg = tb3 % TG, pl = tb3 / TG;        // TG lanes share a column and split its T hidden units
             const int TT = T / TG;
@@ -488,7 +662,6 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                     }
                 }
             }
-            TIMER_LMARK(4);   // T1: LN1 recompute + token MLP backward pair loop
             // reduce the token-weight gradients: over the columns a wave handles concurrently (VALU cross-lane
             // sums), over the 8 waves (per-wave LDS slots written in REGISTER order -- slot (k, tg) at k*TG + tg
             // from one base address, so no per-value address arithmetic stays live), then ONE global atomic
@@ -515,7 +688,6 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                 if (lane < TG) myred[(TTMAX * KS + n) * TG] = s;
             }
             __syncthreads();
-            TIMER_LMARK(6);   // T1b: token-grad cross-lane sums + per-wave LDS slots
             const int nred = 2 * T * N + T + N;
             for (int i = tb3; i < nred; i += NTHREADS) {
                 int t, k;
@@ -531,48 +703,47 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                 atomicAdd(dst, v);
             }
         }
-        __syncthreads();
-        TIMER_LMARK(7);       // T1c: global atomics of the token grads
-        // (T2) LayerNorm-1 backward: dx_in = dx_mid + LN1'(dU); gamma/beta gradients
+        // (R3) LayerNorm-1 backward on the row thread's registers: dx_in = dx_mid + LN1'(dU); the sources of the LN1 parameter
+        //      gradients go to t_prod (dU * xhat) and stay in ub (dU): column-summed during the next block's first phase
         {
             const int r = tb3 / TPR, j = tb3 % TPR;
-            const bool valid = r < R;
-            const float rstd = rstd_s[r];
-            float gv[D / TPR], xv[D / TPR];
-            float gsum = 0.f, gxsum = 0.f;
+            float du[EPT], dx[EPT], gg[EPT], gsum = 0.f, gxsum = 0.f;
+            ld_row<D>(ub + r * XLD, j, du);
 #pragma unroll
-            for (int e = 0; e < D / TPR; ++e) {
+            for (int e = 0; e < EPT; ++e) {
                 const int c = ln_col<D>(e, j);
-                const float u = ub[r * XLD + c];
-                const float xhv = xh[r * XLD + c];
-                const float gg = u * bk.ln1_w[c];
-                gv[e] = gg; xv[e] = xhv;
-                gsum += gg;
-                gxsum = __builtin_fmaf(gg, xhv, gxsum);
-                xh[r * XLD + c] = valid ? u * xhv : 0.f;       // product tile for the gamma gradient
+                gg[e] = du[e] * pb[O_LN1W + c];
+                gsum += gg[e];
+                gxsum = __builtin_fmaf(gg[e], xh1[e], gxsum);
             }
             gsum = wave_sum_xor(gsum, TPR) * (1.0f / D);
             gxsum = wave_sum_xor(gxsum, TPR) * (1.0f / D);
-            if (valid) {
+            ld_row<D>(dxs + r * XLD, j, dx);
+            float pr[EPT];
 #pragma unroll
-                for (int e = 0; e < D / TPR; ++e) {
-                    const int c = ln_col<D>(e, j);
-                    dxs[r * XLD + c] += rstd * (gv[e] - gsum - xv[e] * gxsum);
-                }
+            for (int e = 0; e < EPT; ++e) {
+                const bool valid = r < R;
+                if (valid) dx[e] += rstd1 * (gg[e] - gsum - xh1[e] * gxsum);
+                pr[e] = valid ? du[e] * xh1[e] : 0.f;
+                if (!valid) du[e] = 0.f;
             }
+            st_row<D>(dxs + r * XLD, j, dx);
+            st_row<D>(t_prod + r * XLD, j, pr);
+            st_row<D>(ub + r * XLD, j, du);
+            pend = b;
         }
-        __syncthreads();
-        _Pragma("unroll 1") for (int d = tb3; d < 2 * D; d += NTHREADS) {
-            const float* src = d < D ? xh : ub;
-            const int c = d < D ? d : d - D;
-            float s = 0.f;
-            for (int rr = 0; rr < R; ++rr) s += src[rr * XLD + c];
-            atomicAdd((d < D ? bk.g_ln1_w : bk.g_ln1_b) + c, s);
-        }
-        __syncthreads();
-        TIMER_LMARK(5);   // T2: LN1 backward
         }   // TOK
+        // the next block's x_mid rows: requested here, used in its first phase
+        if (b > 0) {
+            const int r = tb3 / TPR, j = tb3 % TPR;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) xm[e] = 0.f;
+            if (r < R) ld_row<D>(tw.blk[b - 1].x_mid + (row0 + r) * D, j, xm);
+        }
+        __syncthreads();
+        TIMER_LMARK(6);   // R3: token-gradient atomics, LN1 backward
     }
+    if (TOK && pend >= 0) colsums(t_prod, ub, tw.blk[pend].g_ln1_w, tw.blk[pend].g_ln1_b, tid);
 
     // ---- gradient wrt the tower input ----
     _Pragma("unroll 1") for (int idx = tid; idx < R * (D / 4); idx += NTHREADS) {
@@ -620,22 +791,21 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_group_kernel(const BwdGrou
 }
 
 template <int P, int D, int NMAX, int TG>
-static size_t bwd_lds_bytes() {
-    constexpr int NM = NMAX > 0 ? NMAX : 1;
-    const size_t tile_b = (size_t)BM * TileGeom<D>::XLD * sizeof(float);
-    return 2 * tile_b + 4 * SlabGeom<D>::FLOATS * sizeof(float) + BM * sizeof(float) + GELU_TAB_N * 16 +
-           (size_t)NWAVES * std::max(((32 / TG) * (1 + 2 * NM) + NM) * TG, TokRed<NM>::LD) * sizeof(float) + 32 * (2 * NM + 4) * sizeof(float) +
-           (size_t)BM * D * sizeof(unsigned int);
-}
+static size_t bwd_lds_bytes(int nblocks, int N, int Cp) { return BwdLds<P, D, NMAX, TG>::bytes(nblocks, N, Cp); }
 
 template <int P, int D, int NMAX, int TG, int DM>
 static int launch_bwd_group_dm(const BwdGroupArgs& a, int B, unsigned int seed, unsigned int step, const unsigned int* step_dev,
                                hipStream_t st) {
-    const size_t lds = bwd_lds_bytes<P, D, NMAX, TG>();
+    const size_t lds = std::max(bwd_lds_bytes<P, D, NMAX, TG>(a.tw[0].nblocks, a.tw[0].N, a.tw[0].Cp),
+                                bwd_lds_bytes<P, D, NMAX, TG>(a.tw[1].nblocks, a.tw[1].N, a.tw[1].Cp));
+    if (lds > M2M_LDS_MAX || a.tw[0].Cp > 8 * NTHREADS || a.tw[1].Cp > 8 * NTHREADS) {
+        m2m_set_error("towers_backward: blocks x channel_dim exceed the workgroup's LDS", __FILE__, __LINE__);
+        return -1;
+    }
     auto kern = tower_bwd_group_kernel<P, D, NMAX, TG, DM>;
     static bool attr_done = false;
     if (!attr_done) {
-        M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, M2M_LDS_MAX));
         attr_done = true;
     }
     const int mx = a.ntiles[0] > a.ntiles[1] ? a.ntiles[0] : a.ntiles[1];
@@ -659,11 +829,12 @@ static int launch_bwd_dm(const m2m_tower* t, int B, const float* d_out, long d_o
                       long d_x0_ss, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
     const int SPW = NMAX > 0 ? BM / t->N : 1;
     const int grid = NMAX > 0 ? (B + SPW - 1) / SPW : (int)(((long)B * t->N + BM - 1) / BM);
-    const size_t lds = bwd_lds_bytes<P, D, NMAX, TG>();
+    const size_t lds = bwd_lds_bytes<P, D, NMAX, TG>(t->nblocks, t->N, t->Cp);
+    if (lds > M2M_LDS_MAX || t->Cp > 8 * NTHREADS) { m2m_set_error("tower_backward: blocks x channel_dim exceed the workgroup's LDS", __FILE__, __LINE__); return -1; }
     auto kern = tower_bwd_kernel<P, D, NMAX, TG, DM>;
     static bool attr_done = false;
     if (!attr_done) {
-        M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, M2M_LDS_MAX));
         attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, st, *t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step, step_dev);

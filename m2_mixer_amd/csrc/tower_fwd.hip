@@ -14,6 +14,26 @@
 //   the eight waves' partial Y are summed through LDS slabs, then bias + dropout + residual.
 #include "tile.h"
 #include "token_mfma.h"
+#include <algorithm>
+
+// LDS budget of the forward chain kernel (bytes): FIXED + nblocks * PB * 4
+template <int P, int D, int NMAX> struct FwdLds {
+    static constexpr bool TOK = NMAX > 0;
+    static constexpr int NM = TOK ? NMAX : 1, TW_LD = 2 * NM + 4, XLD = D + 4;
+    static constexpr int PB = 5 * D + (TOK ? 32 * TW_LD + 8 : 0);          // floats of one block's small parameters
+    static constexpr size_t FIXED = (size_t)BM * XLD * sizeof(float) * (1 + (TOK ? 1 : 0) + RowSlabs<D>::N) +
+                                    (size_t)BM * D * Prec<P>::ESZ + GELU_TAB_N * 16;
+    // + keep-words of the token sites (two per column of the workgroup's SPW = BM / N samples) + hidden bias of one block
+    static size_t bytes(int nblocks, int N, int Cp) {
+        return FIXED + (TOK ? 2 * (size_t)(BM / N) * D * sizeof(unsigned int) : 0) + (size_t)nblocks * PB * sizeof(float) +
+               (size_t)Cp * sizeof(float);
+    }
+};
+#ifdef M2M_TIMERS
+#define M2M_LDS_MAX (163840 - 1024)     // the diagnostic build keeps its timer slots in static LDS
+#else
+#define M2M_LDS_MAX 163840
+#endif
 
 TIMER_DECL(g_tm_fwd);
 TIMER_READER(m2m_debug_timers_fwd, g_tm_fwd)
@@ -33,16 +53,22 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
     constexpr int NM = TOK ? NMAX : 1;
     constexpr int TW_LD = 2 * NM + 4;                            // token-weight row: W1 | W2^T | b1 | pad
 
+    // LDS: residual stream | LN1 output (token path) | one row-major partial-Y slab per wave (RowSlabs) | packed A image |
+    //      GELU table | keep-words of the token sites | the small parameters of EVERY block (loaded once: no phase of the
+    //      block loop waits for a global load of a parameter)
+    typedef FwdLds<P, D, NMAX> L;
     float* xs = reinterpret_cast<float*>(smem);                  // residual stream  [BM][XLD]
-    float* slabs = xs + BM * XLD;                                 // 4 transposed slabs [D][SLD]; slab 0 doubles as scratch `ub`
-    float* ub = slabs;
-    static_assert(SlabGeom<D>::FLOATS >= BM * XLD, "scratch tile must fit in slab 0");
-    char* at = reinterpret_cast<char*>(slabs + 4 * SlabGeom<D>::FLOATS);   // packed A image   BM*D*ESZ bytes
-    float* tokw = reinterpret_cast<float*>(at + BM * D * Pr::ESZ);   // [T <= 32][TW_LD]
-    float* tokb2 = tokw + 32 * TW_LD;                             // [NM]
-    gtab_t* gtab = reinterpret_cast<gtab_t*>(tokb2 + 8);          // [GELU_TAB_N] (bf16 mode only)
-    unsigned int* wth = reinterpret_cast<unsigned int*>(gtab + GELU_TAB_N);   // [BM * D] keep-words of the token sites, one per column
-    unsigned int* wto = wth + BM * D;                             //   (bf16 mode with dropout only: token_mfma.h)
+    float* ub = xs + BM * XLD;                                    // LN1 output       [BM][XLD] (token path only)
+    float* slabs = ub + (TOK ? BM * XLD : 0);                     // [RowSlabs<D>::N][BM][XLD]
+    char* at = reinterpret_cast<char*>(slabs + RowSlabs<D>::N * BM * XLD);   // packed A image   BM*D*ESZ bytes
+    gtab_t* gtab = reinterpret_cast<gtab_t*>(at + BM * D * Pr::ESZ);          // [GELU_TAB_N] (bf16 mode only)
+    unsigned int* wth = reinterpret_cast<unsigned int*>(gtab + GELU_TAB_N);   // [SPW * D] keep-words of the token sites, one per column
+    const int SPW_ = TOK ? BM / tw.N : 0;
+    unsigned int* wto = wth + SPW_ * D;                           //   (bf16 mode with dropout only: token_mfma.h)
+    float* par = reinterpret_cast<float*>(wto + SPW_ * D);        // [nblocks][L::PB]
+    float* bias_s = par + tw.nblocks * L::PB;                     // [Cp] hidden bias (padded layout) of the block in flight
+    constexpr int PB = L::PB, O_LN1W = 0, O_LN1B = D, O_LN2W = 2 * D, O_LN2B = 3 * D, O_CHB2 = 4 * D, O_TOKW = 5 * D,
+                  O_TOKB2 = 5 * D + 32 * TW_LD;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
     const int N = tw.N, T = tw.T, Cp = tw.Cp;
@@ -52,9 +78,60 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
     const long row0 = TOK ? (long)s0 * N : (long)wg * BM;           // first global token row of this tile
     const int R = TOK ? ns * N : (int)min((long)BM, (long)B * N - row0);
     const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
+    const int rr = tid / TPR, rj = tid % TPR;                       // this thread's row and slot in the row-wise phases
+    constexpr int EPT = D / TPR;
 
     TIMER_LSTART();
     if (Act<P>::USES_TABLE) gelu_tab_fill(gtab, make_drop(training, tw.p_drop, 0u, 0u, 0u).scale, tid, NTHREADS);
+    constexpr int MAXB = (int)(sizeof(tw.blk) / sizeof(tw.blk[0]));       // blocks the descriptor type can hold
+    // ---- the small parameters of every block -> LDS.  The block index stays wave-uniform (a per-thread index into the
+    //      by-value descriptor would turn every later descriptor read into a vector load); all blocks' loads are issued
+    //      before the first LDS write, so the whole preload costs one memory round trip ----
+    _Pragma("unroll 1") for (int i = tid; i < D; i += NTHREADS) {
+        float v[MAXB][5];
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b)
+            if (b < tw.nblocks) {
+                const m2m_block& bk = tw.blk[b];
+                v[b][0] = TOK ? bk.ln1_w[i] : 0.f; v[b][1] = TOK ? bk.ln1_b[i] : 0.f;
+                v[b][2] = bk.ln2_w[i]; v[b][3] = bk.ln2_b[i]; v[b][4] = bk.ch_b2[i];
+            }
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b)
+            if (b < tw.nblocks) {
+                float* pb = par + b * PB;
+                if (TOK) { pb[O_LN1W + i] = v[b][0]; pb[O_LN1B + i] = v[b][1]; }
+                pb[O_LN2W + i] = v[b][2]; pb[O_LN2B + i] = v[b][3]; pb[O_CHB2 + i] = v[b][4];
+            }
+    }
+    if constexpr (TOK) {
+        // zero-padded token weights (rows t >= T and columns n >= N are zero):
+        //   tokw[t][0..NMAX) = W1[t][n]   tokw[t][NMAX..2NMAX) = W2[n][t]   tokw[t][2NMAX] = b1[t]
+        _Pragma("unroll 1") for (int idx = tid; idx < 32 * TW_LD; idx += NTHREADS) {
+            const int t = idx / TW_LD, j = idx % TW_LD;
+            float v[MAXB];
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b) {
+                v[b] = 0.f;
+                if (b < tw.nblocks && t < T) {
+                    const m2m_block& bk = tw.blk[b];
+                    if (j < NMAX) { if (j < N) v[b] = bk.tok_w1[t * N + j]; }
+                    else if (j < 2 * NMAX) { if (j - NMAX < N) v[b] = bk.tok_w2[(j - NMAX) * T + t]; }
+                    else if (j == 2 * NMAX) v[b] = bk.tok_b1[t];
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b)
+                if (b < tw.nblocks) par[b * PB + O_TOKW + idx] = v[b];
+        }
+        if (tid < 8) {
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b)
+                if (b < tw.nblocks) par[b * PB + O_TOKB2 + tid] = tid < N ? tw.blk[b].tok_b2[tid] : 0.f;
+        }
+    }
+    // hidden bias of block 0 (every later block's is fetched during the previous block's last phase)
+    _Pragma("unroll 1") for (int i = tid; i < Cp; i += NTHREADS) bias_s[i] = tw.blk[0].ch_b1p[i];
     // ---- load the input tile (rows >= R are zero) ----
     _Pragma("unroll 1") for (int idx = tid; idx < BM * (D / 4); idx += NTHREADS) {
         const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
@@ -72,41 +149,48 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
     }
     __syncthreads();
 
+    // Block input of block b, held by its row thread: save it for the backward pass, LayerNorm-1 -> ub, and the keep-words
+    // of the block's token sites.  Runs once from LDS for block 0 and afterwards inside the phase that produces the value.
+    auto block_input = [&](int b, const float (&x)[EPT]) {
+        const m2m_block& bk = tw.blk[b];
+        const float* pb = par + b * PB;
+        if (training && rr < R) st_row<D>(bk.x_in + (row0 + rr) * D, rj, x);
+        float mean, rstd, y[EPT];
+        reg_stats<D>(x, mean, rstd);
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int c = ln_col<D>(e, rj);
+            y[e] = (x[e] - mean) * rstd * pb[O_LN1W + c] + pb[O_LN1B + c];
+        }
+        st_row<D>(ub + rr * XLD, rj, y);
+        if constexpr (P == PREC_BF16) {
+            const unsigned int site = tw.site_base + 4u * b;
+            token_keep_words<D, DM>(wth, wto, make_drop(training, tw.p_drop, seed, step, site + 0),
+                                    make_drop(training, tw.p_drop, seed, step, site + 1), s0, ns, SPW, N, T, tid);
+        }
+    };
+    if constexpr (TOK) {
+        float x[EPT];
+        ld_row<D>(xs + rr * XLD, rj, x);
+        block_input(0, x);
+        __syncthreads();
+    }
+
     for (int b = 0; b < tw.nblocks; ++b) {
         const m2m_block& bk = tw.blk[b];
+        const float* pb = par + b * PB;
         const unsigned int site = tw.site_base + 4u * b;
         const Drop dr_th = make_drop(training, tw.p_drop, seed, step, site + 0);
         const Drop dr_to = make_drop(training, tw.p_drop, seed, step, site + 1);
         const Drop dr_ch = make_drop(training, tw.p_drop, seed, step, site + 2);
         const Drop dr_co = make_drop(training, tw.p_drop, seed, step, site + 3);
+        TIMER_LMARK(0);   // block input: save / LN1 (in the previous block's last phase from block 1 on)
 
         if constexpr (TOK) {
-        // ---- save block input, LN1 -> ub; token-MLP weights -> LDS (zero-padded to NMAX tokens) ----
-        //   tokw[t][0..NMAX) = W1[t][n]   tokw[t][NMAX..2NMAX) = W2[n][t]   tokw[t][2NMAX] = b1[t]
-        if (training) {
-            _Pragma("unroll 1") for (int idx = tid; idx < R * (D / 4); idx += NTHREADS) {
-                const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
-                *reinterpret_cast<float4*>(bk.x_in + (row0 + r) * D + c) = *reinterpret_cast<const float4*>(xs + r * XLD + c);
-            }
-        }
-        _Pragma("unroll 1") for (int idx = tid; idx < 32 * TW_LD; idx += NTHREADS) {      // rows t >= T are zero
-            const int t = idx / TW_LD, j = idx % TW_LD;
-            float v = 0.f;
-            if (t < T) {
-                if (j < NMAX) { if (j < N) v = bk.tok_w1[t * N + j]; }
-                else if (j < 2 * NMAX) { if (j - NMAX < N) v = bk.tok_w2[(j - NMAX) * T + t]; }
-                else if (j == 2 * NMAX) v = bk.tok_b1[t];
-            }
-            tokw[idx] = v;
-        }
-        if (tid < 8) tokb2[tid] = tid < N ? bk.tok_b2[tid] : 0.f;
-        if constexpr (P == PREC_BF16) token_keep_words<D, DM>(wth, wto, dr_th, dr_to, s0, ns, SPW, N, T, tid);
-        ln_to_tile<D>(xs, ub, bk.ln1_w, bk.ln1_b, tid);
-        __syncthreads();
-        TIMER_LMARK(0);   // load / save / LN1
-
         // ---- token mixing (modules/mixer.py:30-35): bf16 mode on the matrix pipe (token_mfma.h), fp32 mode one thread
         //      per (sample, channel) column ----
+        const float* tokw = pb + O_TOKW;
+        const float* tokb2 = pb + O_TOKB2;
         if constexpr (P == PREC_BF16) {
             token_fwd_mfma<D, NMAX, DM>(ub, xs, tokw, tokb2, gtab, wth, wto, N, ns, dr_th.scale, dr_to.scale, wave, lane);
         } else
@@ -120,8 +204,8 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
                 o[n] = tokb2[n];
             }
             // keep-bits of this column's T hidden units / N outputs (all ones when dropout is off): no branches below
-            const unsigned int wth = drop_row_bits<DM>(dr_th, bd, T);
-            const unsigned int wto = drop_row_bits<DM>(dr_to, bd, N);
+            const unsigned int wth1 = drop_row_bits<DM>(dr_th, bd, T);
+            const unsigned int wto1 = drop_row_bits<DM>(dr_to, bd, N);
 #pragma unroll 4
             for (int t = 0; t < T; ++t) {
                 const float* wr = tokw + t * TW_LD;
@@ -129,14 +213,14 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
 #pragma unroll
                 for (int n = 0; n < NMAX; ++n) h = __builtin_fmaf(wr[n], un[n], h);
                 h = Act<P>::gelu_scaled(gtab, h, dr_th.scale);
-                h = DM == DM_NONE ? h : mask_f(h, bit_to_mask(wth, t));
+                h = DM == DM_NONE ? h : mask_f(h, bit_to_mask(wth1, t));
 #pragma unroll
                 for (int n = 0; n < NMAX; ++n) o[n] = __builtin_fmaf(wr[NMAX + n], h, o[n]);
             }
 #pragma unroll
             for (int n = 0; n < NMAX; ++n) {
                 if (n < N) {
-                    xs[(sl * N + n) * XLD + d] += ((wto >> n) & 1u) ? o[n] * dr_to.scale : 0.f;
+                    xs[(sl * N + n) * XLD + d] += ((wto1 >> n) & 1u) ? o[n] * dr_to.scale : 0.f;
                 }
             }
         }
@@ -144,16 +228,20 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
         TIMER_LMARK(1);   // token mixing
         }   // TOK
 
-        // ---- save x_mid, LN2 -> packed operand image (wide path: the input IS the saved x_mid) ----
-        if (training && TOK) {
-            _Pragma("unroll 1") for (int idx = tid; idx < R * (D / 4); idx += NTHREADS) {
-                const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
-                *reinterpret_cast<float4*>(bk.x_mid + (row0 + r) * D + c) = *reinterpret_cast<const float4*>(xs + r * XLD + c);
+        // ---- save x_mid, LN2 -> packed operand image, all on the row thread's registers (wide path: the input IS the
+        //      saved x_mid) ----
+        {
+            float x[EPT], y[EPT], mean, rstd;
+            ld_row<D>(xs + rr * XLD, rj, x);
+            if (training && TOK && rr < R) st_row<D>(bk.x_mid + (row0 + rr) * D, rj, x);
+            reg_stats<D>(x, mean, rstd);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const int c = ln_col<D>(e, rj);
+                y[e] = (x[e] - mean) * rstd * pb[O_LN2W + c] + pb[O_LN2B + c];
             }
+            pack_row_nat<P, D>(at, rr, rj, y);
         }
-        ln_to_tile<D>(xs, ub, bk.ln2_w, bk.ln2_b, tid);
-        __syncthreads();
-        pack_tile_nat<P, D>(ub, at, tid);
         __syncthreads();
         TIMER_LMARK(2);   // save x_mid, LN2, pack
 
@@ -181,7 +269,7 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
                 for (int dt = 0; dt < DT; ++dt) w2f[f][dt] = ld_frag_global(bk.w2c, (long)(q * NF + f) * DT + dt, lane);
             f32x4_t bias[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) bias[t] = *reinterpret_cast<const f32x4_t*>(bk.ch_b1p + 32 * q + 16 * t + 4 * g);
+            for (int t = 0; t < 2; ++t) bias[t] = *reinterpret_cast<const f32x4_t*>(bias_s + 32 * q + 16 * t + 4 * g);
 
             f32x4_t hacc[MT][2];
 #pragma unroll
@@ -233,19 +321,47 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
         }
         TIMER_LMARK(3);   // hidden-column loop (wave 0)
 
-        // ---- sum the eight waves' partial Y (deterministic order), then + bias, dropout, residual ----
-        __syncthreads();           // every wave is done with `at` / ub before the slabs are overwritten
-        reduce_waves_to_slabs<D>(yacc, slabs, wave, g, il);
-        _Pragma("unroll 1") for (int idx = tid; idx < BM * D; idx += NTHREADS) {
-            const int d = idx / BM, r = idx % BM;
-            if (r < R) {
-                float v = slab_sum<D>(slabs, r, d) + bk.ch_b2[d];
-                v = drop_keep_elem<DM>(dr_co, (unsigned int)(row0 + r) * D + d) ? v * dr_co.scale : 0.f;
-                xs[r * XLD + d] += v;
+        // ---- the waves' partial Y -> row-major slabs (nothing else lives there: no barrier in front) ----
+        if (RowSlabs<D>::N == NWAVES || wave < RowSlabs<D>::N) acc_to_slab<D>(yacc, slabs + (wave % RowSlabs<D>::N) * BM * XLD, g, il);
+        __syncthreads();
+        if (RowSlabs<D>::N < NWAVES) {
+            if (wave >= RowSlabs<D>::N) acc_add_slab<D>(yacc, slabs + (wave % RowSlabs<D>::N) * BM * XLD, g, il);
+            __syncthreads();
+        }
+        TIMER_LMARK(4);   // slabs
+        // ---- sum over the waves (deterministic order) + bias, dropout, residual -> the next block's input, which its row
+        //      thread hands straight to that block's first phase ----
+        {
+            // the next block's hidden bias: requested first, written to LDS at the end of the phase (every wave is out of the
+            // column loop that read this block's)
+            constexpr int BPT = 8;                                  // Cp <= BPT * NTHREADS (checked by the host)
+            float nb[BPT];
+            const bool more = b + 1 < tw.nblocks;
+#pragma unroll
+            for (int k = 0; k < BPT; ++k) {
+                nb[k] = 0.f;
+                if (more && tid + k * NTHREADS < Cp) nb[k] = tw.blk[b + 1].ch_b1p[tid + k * NTHREADS];
             }
+            float v[EPT], x[EPT];
+            slab_row_sum<D>(slabs, rr, rj, v);
+            ld_row<D>(xs + rr * XLD, rj, x);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const int c = ln_col<D>(e, rj);
+                float o = v[e] + pb[O_CHB2 + c];
+                o = drop_keep_elem<DM>(dr_co, (unsigned int)(row0 + rr) * D + c) ? o * dr_co.scale : 0.f;
+                x[e] = rr < R ? x[e] + o : x[e];
+            }
+            st_row<D>(xs + rr * XLD, rj, x);
+            if constexpr (TOK) {
+            if (b + 1 < tw.nblocks) block_input(b + 1, x);
+        }
+#pragma unroll
+            for (int k = 0; k < BPT; ++k)
+                if (more && tid + k * NTHREADS < Cp) bias_s[tid + k * NTHREADS] = nb[k];
         }
         __syncthreads();
-        TIMER_LMARK(4);   // wave reduction + bias/dropout/residual
+        TIMER_LMARK(5);   // wave sum + bias/dropout/residual (+ next block's save / LN1)
     }
 
     // ---- final LayerNorm (modules/mixer.py:131,161,185), output + token mean ----
@@ -257,8 +373,8 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
     }
     const float* res = xs;
     if (tw.has_final_ln) {
-        ln_to_tile<D>(xs, ub, tw.lnf_w, tw.lnf_b, tid);
-        res = ub;
+        ln_to_tile<D>(xs, slabs, tw.lnf_w, tw.lnf_b, tid);     // slab 0 is free after the last block
+        res = slabs;
         __syncthreads();
     }
     _Pragma("unroll 1") for (int idx = tid; idx < R * (D / 4); idx += NTHREADS) {
@@ -276,7 +392,7 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
             pooled[(long)(s0 + sl) * D + d] = s * inv;
         }
     }
-    TIMER_LMARK(5);       // final LN, output, pooled
+    TIMER_LMARK(6);       // final LN, output, pooled
     TIMER_LFLUSH(g_tm_fwd);
 }
 
@@ -319,21 +435,20 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_group_kernel(const FwdGrou
                                                 step_host, step_dev, wg, smem);
 }
 
-template <int P, int D>
-static size_t fwd_lds_bytes() {
-    return (size_t)(BM * TileGeom<D>::XLD + 4 * SlabGeom<D>::FLOATS) * sizeof(float) + (size_t)BM * D * Prec<P>::ESZ + (32 * 20 + 8) * sizeof(float) + GELU_TAB_N * 16 + 2 * (size_t)BM * D * sizeof(unsigned int);
-}
+template <int P, int D, int NMAX>
+static size_t fwd_lds_bytes(int nblocks, int N, int Cp) { return FwdLds<P, D, NMAX>::bytes(nblocks, N, Cp); }
 
 template <int P, int D, int NMAX, int DM>
 static int launch_fwd_dm(const m2m_tower* t, const float* x0, long x0_ss, int B, float* out, long out_ss, float* pooled,
                       int training, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
     const int SPW = NMAX > 0 ? BM / t->N : 1;
     const int grid = NMAX > 0 ? (B + SPW - 1) / SPW : (int)(((long)B * t->N + BM - 1) / BM);
-    const size_t lds = fwd_lds_bytes<P, D>();
+    const size_t lds = fwd_lds_bytes<P, D, NMAX>(t->nblocks, t->N, t->Cp);
+    if (lds > M2M_LDS_MAX || t->Cp > 8 * NTHREADS) { m2m_set_error("tower_forward: blocks x channel_dim exceed the workgroup's LDS", __FILE__, __LINE__); return -1; }
     auto kern = tower_fwd_kernel<P, D, NMAX, DM>;
     static bool attr_done = false;
     if (!attr_done) {
-        M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, M2M_LDS_MAX));
         attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, st, *t, x0, x0_ss, B, out, out_ss, pooled, training, seed, step, step_dev);
@@ -375,11 +490,16 @@ int m2m_chain_forward_rows(const m2m_tower* t, const float* x0, long x0_ss, int 
 template <int P, int D, int NMAX, int DM>
 static int launch_fwd_group_dm(const FwdGroupArgs& a, int B, int training, unsigned int seed, unsigned int step,
                                const unsigned int* step_dev, hipStream_t st) {
-    const size_t lds = fwd_lds_bytes<P, D>();
+    const size_t lds = std::max(fwd_lds_bytes<P, D, NMAX>(a.tw[0].nblocks, a.tw[0].N, a.tw[0].Cp),
+                                fwd_lds_bytes<P, D, NMAX>(a.tw[1].nblocks, a.tw[1].N, a.tw[1].Cp));
+    if (lds > M2M_LDS_MAX || a.tw[0].Cp > 8 * NTHREADS || a.tw[1].Cp > 8 * NTHREADS) {
+        m2m_set_error("towers_forward: blocks x channel_dim exceed the workgroup's LDS", __FILE__, __LINE__);
+        return -1;
+    }
     auto kern = tower_fwd_group_kernel<P, D, NMAX, DM>;
     static bool attr_done = false;
     if (!attr_done) {
-        M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, M2M_LDS_MAX));
         attr_done = true;
     }
     const int mx = a.ntiles[0] > a.ntiles[1] ? a.ntiles[0] : a.ntiles[1];

@@ -17,8 +17,8 @@ import bench                                   # noqa: E402
 
 lib = L.lib()
 NAMES = {
-    "fwd": ["load/save/LN1", "token mix", "save/LN2/pack", "column loop", "reduce+residual", "final LN/out"],
-    "bwd": ["upstream+LNf bwd", "C1+C2 pack", "C3 column loop", "C4+C5 reduce/LN2bwd", "T1 token pair loop", "T2 LN1 bwd + colsums", "T1b shuffles+LDS atomics", "T1c global atomics", "C1a dYd", "C1b b2+packs", "C2a LN2 recompute", "wait other waves", "C4a slabs", "C4b slab sum", "T0 tokw+LN1+operands"],
+    "fwd": ["block input", "token mix", "save/LN2/pack", "column loop", "slabs", "sum+residual(+next LN1)", "final LN/out"],
+    "bwd": ["params+upstream+LNf bwd", "X1 dYd/A/images", "C3 column loop", "C4 slabs(+wait)", "R1 sum/LN2bwd/LN1/operands", "R2 token MLP bwd + LN2 colsums", "R3 token atomics + LN1 bwd"],
     "wgrad": ["wait loads + stage write", "issue refill loads", "barrier", "LDS reads + MFMA", "write-out"],
 }
 
