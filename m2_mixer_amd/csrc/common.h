@@ -98,8 +98,13 @@ static __device__ __forceinline__ unsigned short f2bf(float x) {
     __bf16 b = (__bf16)x;
     return __builtin_bit_cast(unsigned short, b);
 }
+// two floats -> one register of two bf16 (lo in bits 0-15): as a two-element vector conversion this is ONE v_cvt_pk_bf16_f32;
+// written as two scalar casts combined with shift / or, hipcc often converted each value alone (cvt_pk with a dummy second
+// source) and merged them with v_lshlrev + v_or_b32_sdwa: 4 instructions per pair in the hot loops
 static __device__ __forceinline__ unsigned int pack_bf2(float lo, float hi) {
-    return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
 }
 static __device__ __forceinline__ float bf2f(unsigned short b) {
     return __builtin_bit_cast(float, (unsigned int)b << 16);
@@ -168,6 +173,22 @@ static __device__ __forceinline__ void gelu_tab_fill(gtab_t* tab, float scale, i
     for (int k = tid; k < GELU_TAB_N; k += nthreads) tab[k] = pwl_cell(k, scale);
 }
 // gelu(x) * scale and gelu'(x) * scale, `scale` being the value the table was filled with (bf16) / applied here (fp32)
+// Closed form (ActB below): Phi(x) through the Abramowitz-Stegun 7.1.26 erfc polynomial (|err| <
+// 1e-7), one v_exp + one v_rcp + ~13 plain VALU for gelu AND gelu' (they share exp(-x^2/2)); no LDS traffic: the table costs
+// one ds_read_b128 at a random address per element, ~16 LDS cycles per wave-instruction with its bank conflicts.
+static __device__ __forceinline__ void gelu_grad_as(float x, float& g, float& dg) {
+    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);       // exp(-x^2 / 2)
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_fabsf(x), 0.23164189213f, 1.0f));   // 1 / (1 + p |x| / sqrt 2)
+    float p = 0.5f * 1.061405429f;
+    p = __builtin_fmaf(p, t, 0.5f * -1.453152027f);
+    p = __builtin_fmaf(p, t, 0.5f * 1.421413741f);
+    p = __builtin_fmaf(p, t, 0.5f * -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.5f * 0.254829592f);
+    const float q = p * t * e;                                                      // Phi(-|x|)
+    const float cdf = x >= 0.f ? 1.0f - q : q;
+    g = x * cdf;
+    dg = __builtin_fmaf(x * e, 0.3989422804014327f, cdf);
+}
 template <int P> struct Act;
 template <> struct Act<PREC_BF16> {
     static constexpr bool USES_TABLE = true;
@@ -186,6 +207,18 @@ template <> struct Act<PREC_F32> {
     static __device__ __forceinline__ float gelu_scaled(const gtab_t*, float x, float scale) { return gelu_f(x) * scale; }
     static __device__ __forceinline__ void gelu_grad_scaled(const gtab_t*, float x, float scale, float& g, float& dg) {
         gelu_grad_f(x, g, dg);
+        g *= scale;
+        dg *= scale;
+    }
+};
+// The activation as the BACKWARD kernels evaluate it.  bf16 mode: the closed form -- measured against the table in one process
+// (profiles/r02_ab_gelu.txt): the backward chains, whose LDS pipe also carries the parked W1 tiles, ran 3-4 % faster with it,
+// the forward chains 4 % slower (they keep the table).  Both approximate the same function to < 1e-4.
+template <int P> struct ActB : Act<P> {};
+template <> struct ActB<PREC_BF16> {
+    static constexpr bool USES_TABLE = false;
+    static __device__ __forceinline__ void gelu_grad_scaled(const gtab_t*, float x, float scale, float& g, float& dg) {
+        gelu_grad_as(x, g, dg);
         g *= scale;
         dg *= scale;
     }

@@ -196,93 +196,113 @@ static __device__ __forceinline__ void token_bwd_mfma(float* ub, const float* do
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) dw1[tt] = dw2[tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    // PU pairs per pass, stage by stage: one pair alone is a chain of ~10 dependent LDS / MFMA / VALU round trips, and the two
+    // waves of a SIMD do not cover it (measured: 3.2 us per pair against 0.8 us of instruction issue)
+    constexpr int PU = 1;      // (2 was measured: the 64 extra accumulator registers spill around the phase, 165 -> 194 us per two-tower launch)
     const int npair = ns * CP;
-    for (int p = wave; p < npair; p += NWAVES) {
-        const int sl = p / CP, d0 = (p % CP) * 32;
-        f32x4_t H[2][2], dG[2][2];                                           // [column tile][hidden tile]
+    for (int p0 = wave; p0 < npair; p0 += NWAVES * PU) {
+        int sl[PU], d0[PU];
+        bool pv[PU];
+        f32x4_t H[PU][2][2], dG[PU][2][2];                                   // [pair][column tile][hidden tile]
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            float au[KS], ao[KS];                                            // A[i = col][k = n]
+        for (int u = 0; u < PU; ++u) {
+            const int p = p0 + u * NWAVES;
+            pv[u] = p < npair;
+            const int pc = pv[u] ? p : p0;
+            sl[u] = pc / CP;
+            d0[u] = (pc % CP) * 32;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int n = g + 4 * ks;
-                const int off = (sl * N + (n < N ? n : 0)) * XLD + d0 + 16 * ct + il;
-                const float u = ub[off], o = dov[off];
-                au[ks] = n < N ? u : 0.f;
-                ao[ks] = n < N ? o : 0.f;
-            }
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                H[ct][tt] = f32x4_t{b1s[tt], b1s[tt], b1s[tt], b1s[tt]};
-                dG[ct][tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int ct = 0; ct < 2; ++ct) {
+                float au[KS], ao[KS];                                        // A[i = col][k = n]
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    H[ct][tt] = mfma4(au[ks], w1b[tt][ks], H[ct][tt]);
-                    dG[ct][tt] = mfma4(ao[ks], w2b[tt][ks], dG[ct][tt]);
+                    const int n = g + 4 * ks;
+                    const int off = (sl[u] * N + (n < N ? n : 0)) * XLD + d0[u] + 16 * ct + il;
+                    const float uu = ub[off], o = dov[off];
+                    au[ks] = n < N ? uu : 0.f;
+                    ao[ks] = n < N ? o : 0.f;
+                }
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    H[u][ct][tt] = f32x4_t{b1s[tt], b1s[tt], b1s[tt], b1s[tt]};
+                    dG[u][ct][tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        H[u][ct][tt] = mfma4(au[ks], w1b[tt][ks], H[u][ct][tt]);
+                        dG[u][ct][tt] = mfma4(ao[ks], w2b[tt][ks], dG[u][ct][tt]);
+                    }
                 }
             }
         }
         // dH = dG gelu'(H) keep scale, G = gelu(H) keep scale: element (column 16 ct + 4 g + r, hidden unit il + 16 tt)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            u32x4_t w4 = u32x4_t{~0u, ~0u, ~0u, ~0u};
-            if (DM != DM_NONE) w4 = *reinterpret_cast<const u32x4_t*>(wth + sl * D + d0 + 16 * ct + 4 * g);
+        for (int u = 0; u < PU; ++u)
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
+            for (int ct = 0; ct < 2; ++ct) {
+                u32x4_t w4 = u32x4_t{~0u, ~0u, ~0u, ~0u};
+                if (DM != DM_NONE) w4 = *reinterpret_cast<const u32x4_t*>(wth + sl[u] * D + d0[u] + 16 * ct + 4 * g);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float gl, dgl;
-                    Act<PREC_BF16>::gelu_grad_scaled(gtab, H[ct][tt][r], scale_th, gl, dgl);
-                    const float v = dG[ct][tt][r] * dgl;
-                    if (DM == DM_NONE) { dG[ct][tt][r] = v; H[ct][tt][r] = gl; }
-                    else {
-                        const unsigned int mk = (unsigned int)(((int)(w4[r] << (31 - il - 16 * tt))) >> 31);
-                        dG[ct][tt][r] = mask_f(v, mk);
-                        H[ct][tt][r] = mask_f(gl, mk);
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float gl, dgl;
+                        ActB<PREC_BF16>::gelu_grad_scaled(gtab, H[u][ct][tt][r], scale_th, gl, dgl);
+                        const float v = dG[u][ct][tt][r] * dgl;
+                        if (DM == DM_NONE) { dG[u][ct][tt][r] = v; H[u][ct][tt][r] = gl; }
+                        else {
+                            const unsigned int mk = (unsigned int)(((int)(w4[r] << (31 - il - 16 * tt))) >> 31);
+                            dG[u][ct][tt][r] = mask_f(v, mk);
+                            H[u][ct][tt][r] = mask_f(gl, mk);
+                        }
                     }
-                }
-        }
-        Frag hB[2], gB[2];                                                   // k = the pair's 32 columns (chained), j = t
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            hB[tt] = chain_bf16(dG[0][tt], dG[1][tt]);
-            gB[tt] = chain_bf16(H[0][tt], H[1][tt]);
-        }
-        // A operands of the weight gradients: lane (il = n, g) holds columns d0 + chn_k(g, j); row N of U is all ones (db1)
-        Frag ua, oa;
-        {
-            const int row = sl * N + (il < N ? il : 0);
-            const f32x4_t u0 = *reinterpret_cast<const f32x4_t*>(ub + row * XLD + d0 + 4 * g);
-            const f32x4_t u1 = *reinterpret_cast<const f32x4_t*>(ub + row * XLD + d0 + 16 + 4 * g);
-            const f32x4_t o0 = *reinterpret_cast<const f32x4_t*>(dov + row * XLD + d0 + 4 * g);
-            const f32x4_t o1 = *reinterpret_cast<const f32x4_t*>(dov + row * XLD + d0 + 16 + 4 * g);
-            ua = chain_bf16(u0, u1);
-            oa = chain_bf16(o0, o1);
-            if (il >= N) {
-                const unsigned int f = il == N ? 0x3F803F80u : 0u;
-                ua.u = u32x4_t{f, f, f, f};
-                oa.u = u32x4_t{0u, 0u, 0u, 0u};
             }
-        }
+        Frag hB[PU][2];                                                      // k = the pair's 32 columns (chained), j = t
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            dw1[tt] = mfma32(ua, hB[tt], dw1[tt]);
-            dw2[tt] = mfma32(oa, gB[tt], dw2[tt]);
+        for (int u = 0; u < PU; ++u) {
+            Frag gB[2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                hB[u][tt] = chain_bf16(dG[u][0][tt], dG[u][1][tt]);
+                gB[tt] = chain_bf16(H[u][0][tt], H[u][1][tt]);
+            }
+            // A operands of the weight gradients: lane (il = n, g) holds columns d0 + chn_k(g, j); row N of U is all ones (db1)
+            Frag ua, oa;
+            {
+                const int row = sl[u] * N + (il < N ? il : 0);
+                const f32x4_t u0 = *reinterpret_cast<const f32x4_t*>(ub + row * XLD + d0[u] + 4 * g);
+                const f32x4_t u1 = *reinterpret_cast<const f32x4_t*>(ub + row * XLD + d0[u] + 16 + 4 * g);
+                const f32x4_t o0 = *reinterpret_cast<const f32x4_t*>(dov + row * XLD + d0[u] + 4 * g);
+                const f32x4_t o1 = *reinterpret_cast<const f32x4_t*>(dov + row * XLD + d0[u] + 16 + 4 * g);
+                ua = chain_bf16(u0, u1);
+                oa = chain_bf16(o0, o1);
+                if (il >= N || !pv[u]) {
+                    const unsigned int f = (il == N && pv[u]) ? 0x3F803F80u : 0u;
+                    ua.u = u32x4_t{f, f, f, f};
+                    oa.u = u32x4_t{0u, 0u, 0u, 0u};
+                }
+            }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                dw1[tt] = mfma32(ua, hB[u][tt], dw1[tt]);
+                dw2[tt] = mfma32(oa, gB[tt], dw2[tt]);
+            }
+            db2 = mfma32(oa, ones, db2);
         }
-        db2 = mfma32(oa, ones, db2);
         // dU[n][col'] = sum_t W1[t][n] dH[col'][t]: transpose dH (rows t, columns col'), then chain
 #pragma unroll
-        for (int cp = 0; cp < 2; ++cp) {
-            const f32x4_t z = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            const f32x4_t t0 = mfma32(hB[0], idf[cp], z), t1 = mfma32(hB[1], idf[cp], z);
-            const Frag hT = chain_bf16(t0, t1);
-            const f32x4_t du = mfma32(w1t, hT, z);
+        for (int u = 0; u < PU; ++u)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = 4 * g + r;
-                if (n < N) ub[(sl * N + n) * XLD + d0 + 16 * cp + il] = du[r];
+            for (int cp = 0; cp < 2; ++cp) {
+                const f32x4_t z = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                const f32x4_t t0 = mfma32(hB[u][0], idf[cp], z), t1 = mfma32(hB[u][1], idf[cp], z);
+                const Frag hT = chain_bf16(t0, t1);
+                const f32x4_t du = mfma32(w1t, hT, z);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = 4 * g + r;
+                    if (pv[u] && n < N) ub[(sl[u] * N + n) * XLD + d0[u] + 16 * cp + il] = du[r];
+                }
             }
-        }
     }
     float* my = red + wave * TokRed<NMAX>::LD;
 #pragma unroll

@@ -94,7 +94,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
     const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
 
     TIMER_LSTART();
-    if (Act<P>::USES_TABLE) gelu_tab_fill(gtab, make_drop(true, tw.p_drop, 0u, 0u, 0u).scale, tid, NTHREADS);
+    if (ActB<P>::USES_TABLE) gelu_tab_fill(gtab, make_drop(true, tw.p_drop, 0u, 0u, 0u).scale, tid, NTHREADS);
     constexpr int MAXB = (int)(sizeof(tw.blk) / sizeof(tw.blk[0]));       // blocks the descriptor type can hold
     // ---- the small parameters of every block -> LDS.  The block index stays wave-uniform (a per-thread index into the
     //      by-value descriptor would turn every later descriptor read into a vector load); all blocks' loads are issued
@@ -379,7 +379,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float gl, dgl;                                   // both carry the dropout scale
-                        Act<P>::gelu_grad_scaled(gtab, hacc[mt][t][r], dr_ch.scale, gl, dgl);
+                        ActB<P>::gelu_grad_scaled(gtab, hacc[mt][t][r], dr_ch.scale, gl, dgl);
                         const float v = gacc[mt][t][r] * dgl;
                         if (DM == DM_NONE) { gacc[mt][t][r] = v; hacc[mt][t][r] = gl; }
                         else {
@@ -638,7 +638,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                             dh = __builtin_fmaf(w2r[n][tt], dv[n], dh);
                         }
                         float gl, dgl;                                   // both carry the dropout scale
-                        Act<P>::gelu_grad_scaled(gtab, h, dr_th.scale, gl, dgl);
+                        ActB<P>::gelu_grad_scaled(gtab, h, dr_th.scale, gl, dgl);
                         const bool keep = (wth >> (t & 31)) & 1u;
                         const float hact = keep ? gl : 0.f;
                         const float dhp = (keep && pv) ? dh * dgl : 0.f;
