@@ -29,7 +29,7 @@ template <int P, int D, int NMAX, int TG> struct BwdLds {
     // + keep-words of the token-hidden site (one per column of the workgroup's SPW = BM / N samples) + hidden bias of one block
     static size_t bytes(int nblocks, int N, int Cp) {
         return FIXED + (TOK ? (size_t)(BM / N) * D * sizeof(unsigned int) : 0) + (size_t)nblocks * PB * sizeof(float) +
-               (size_t)Cp * sizeof(float);
+               (size_t)Cp * sizeof(float) + 16;
     }
 };
 #ifdef M2M_TIMERS
@@ -79,6 +79,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
     unsigned int* wth = reinterpret_cast<unsigned int*>(red + (TOK ? NWAVES * RED_LD : 0));   // [BM * D] (token path)
     float* par = reinterpret_cast<float*>(wth + (TOK ? (BM / tw.N) * D : 0));                 // [nblocks][PB]
     float* bias_s = par + tw.nblocks * PB;                                                    // [Cp] hidden bias of the block in flight
+    unsigned int* qctr = reinterpret_cast<unsigned int*>(bias_s + tw.Cp);                      // ticket counter of the column loop
 
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, il = lane & 15;
     const int wave = tid >> 6;
@@ -227,6 +228,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
             st_row<D>(ta + r * XLD, j, a);
             pack_row_nat<P, D>(at, r, j, a);
             if (TOK && pend >= 0) colsums(t_prod, ub, tw.blk[pend].g_ln1_w, tw.blk[pend].g_ln1_b, tb1);
+            if (tb1 == 0) *qctr = NWAVES;
 #pragma unroll
             for (int k = 0; k < BPT; ++k)
                 if (tb1 + k * NTHREADS < Cp) bias_s[tb1 + k * NTHREADS] = nb[k];
@@ -275,6 +277,9 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
 #ifndef M2M_W1LDS
 #define M2M_W1LDS 1
 #endif
+#ifndef M2M_TICKETS
+#define M2M_TICKETS 1
+#endif
         constexpr bool W1LDS = M2M_W1LDS && D == 128 && P == PREC_BF16;      // (256-byte rows: hidden_dim 128)
         char* w1slot = reinterpret_cast<char*>(slabs + wave * TILE_F);
         const int swz_w = ((il & 3) << 2) | ((il >> 2) & 3);                       // writer: row 16 t + il, chunk 4 kb + g
@@ -291,7 +296,14 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                     w2f[t][kb] = ld_frag_global_u(p_w2tn, (long)(2 * wave + t) * KD + kb, lane16);
                 }
         }
-        for (int q = wave; q < npairs; q += NWAVES) {
+        // bf16 training: the 32-column steps are handed out by a ticket counter in LDS (the first NWAVES statically).  The loop
+        // is issue-bound and the waves do not run at the same pace (the older ones win the arbitration): with a static split
+        // the fastest wave waited ~4 us per block at the barrier behind the loop.  The next ticket is drawn at the top of a step
+        // and used at its prefetch point.  fp32 (parity) mode keeps the static split: reproducible summation order.
+        constexpr bool TICKETS = P == PREC_BF16 && M2M_TICKETS;
+        for (int q = TICKETS ? __builtin_amdgcn_readfirstlane(wave) : wave; q < npairs;) {
+            unsigned int ticket = 0u;
+            if (TICKETS && lane == 0) ticket = atomicAdd(qctr, 1u);
             f32x4_t bias[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) bias[t] = *reinterpret_cast<const f32x4_t*>(bias_s + 32 * q + 16 * t + 4 * g);
@@ -360,13 +372,14 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) w3f[f][dt] = ld_frag_global_u(p_w1tc, (long)(q * NF + f) * DT + dt, lane16);
             }
-            if (HOLD && q + NWAVES < npairs) {
+            const int qn = TICKETS ? (int)__builtin_amdgcn_readfirstlane(ticket) : q + NWAVES;
+            if (HOLD && qn < npairs) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int kb = 0; kb < KD; ++kb) {
-                        w1f[t][kb] = ld_frag_global_u(p_w1n, (long)(2 * (q + NWAVES) + t) * KD + kb, lane16);
-                        w2f[t][kb] = ld_frag_global_u(p_w2tn, (long)(2 * (q + NWAVES) + t) * KD + kb, lane16);
+                        w1f[t][kb] = ld_frag_global_u(p_w1n, (long)(2 * qn + t) * KD + kb, lane16);
+                        w2f[t][kb] = ld_frag_global_u(p_w2tn, (long)(2 * qn + t) * KD + kb, lane16);
                     }
             }
             Frag hf[MT][NF], af[MT][NF];
@@ -469,6 +482,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) Pr::mma(dacc[mt][dt], hf[mt][f], w3f[f][dt]);
             }
+            q = qn;
         }
         TIMER_LMARK(2);   // C3 hidden-column loop (wave 0)
         int tb2 = tid;
