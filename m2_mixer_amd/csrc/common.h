@@ -211,16 +211,39 @@ template <> struct Act<PREC_F32> {
         dg *= scale;
     }
 };
-// The activation as the BACKWARD kernels evaluate it.  bf16 mode: the closed form -- measured against the table in one process
-// (profiles/r02_ab_gelu.txt): the backward chains, whose LDS pipe also carries the parked W1 tiles, ran 3-4 % faster with it,
-// the forward chains 4 % slower (they keep the table).  Both approximate the same function to < 1e-4.
+// The activation as the BACKWARD kernels evaluate it: the table too (M2M_BWD_FORMULA=1 selects the closed form).  Measured in
+// one process both ways: while the backward column loop still carried ~70 wasted packing instructions per step the closed form
+// won by 3-4 % (less LDS traffic); once those were gone the loop was VALU-issue-bound and the table's fewer instructions win
+// by 2 % on the step (932k vs 915k samples/s).  The forward chains always preferred the table (closed form: +4 % time).
+#ifndef M2M_BWD_FORMULA
+#define M2M_BWD_FORMULA 0
+#endif
 template <int P> struct ActB : Act<P> {};
+#if M2M_BWD_FORMULA
 template <> struct ActB<PREC_BF16> {
     static constexpr bool USES_TABLE = false;
     static __device__ __forceinline__ void gelu_grad_scaled(const gtab_t*, float x, float scale, float& g, float& dg) {
         gelu_grad_as(x, g, dg);
         g *= scale;
         dg *= scale;
+    }
+};
+#endif
+// The activation inside the token-mixing MFMA phases (token_mfma.h): 1 = closed form, 0 = table.  M2M_TOK_FORMULA bit 0: forward,
+// bit 1: backward.
+#ifndef M2M_TOK_FORMULA
+#define M2M_TOK_FORMULA 0
+#endif
+struct ActTokF {
+    static __device__ __forceinline__ float gelu_scaled(const gtab_t* tab, float x, float scale) {
+        if (M2M_TOK_FORMULA & 1) { float g, dg; gelu_grad_as(x, g, dg); return g * scale; }
+        return Act<PREC_BF16>::gelu_scaled(tab, x, scale);
+    }
+};
+struct ActTokB {
+    static __device__ __forceinline__ void gelu_grad_scaled(const gtab_t* tab, float x, float scale, float& g, float& dg) {
+        if (M2M_TOK_FORMULA & 2) { gelu_grad_as(x, g, dg); g *= scale; dg *= scale; }
+        else ActB<PREC_BF16>::gelu_grad_scaled(tab, x, scale, g, dg);
     }
 };
 // 0 / ~0 from bit k of w (v_bfe_i32): keep-masks are applied with one AND

@@ -123,7 +123,7 @@ static __device__ __forceinline__ void token_fwd_mfma(const float* ub, float* xs
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v = Act<PREC_BF16>::gelu_scaled(gtab, hacc[u][tt][r], scale_th);
+                    const float v = ActTokF::gelu_scaled(gtab, hacc[u][tt][r], scale_th);
                     hacc[u][tt][r] = DM == DM_NONE ? v : mask_f(v, bit_to_mask(word[u], 16 * tt + r));
                 }
         f32x4_t o[TU];
@@ -246,7 +246,7 @@ static __device__ __forceinline__ void token_bwd_mfma(float* ub, const float* do
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float gl, dgl;
-                        ActB<PREC_BF16>::gelu_grad_scaled(gtab, H[u][ct][tt][r], scale_th, gl, dgl);
+                        ActTokB::gelu_grad_scaled(gtab, H[u][ct][tt][r], scale_th, gl, dgl);
                         const float v = dG[u][ct][tt][r] * dgl;
                         if (DM == DM_NONE) { dG[u][ct][tt][r] = v; H[u][ct][tt][r] = gl; }
                         else {
