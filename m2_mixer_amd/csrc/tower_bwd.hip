@@ -139,11 +139,18 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
     }
     // x_mid of the last block: its rows are requested now and used by the first phase of the block loop
     float xm[EPT];
+    constexpr int BPT = 8;                                          // Cp <= BPT * NTHREADS (checked by the host)
+    float nb[BPT];                                                  // this thread's share of the next block's hidden bias
     {
         const int r = tid / TPR, j = tid % TPR;
 #pragma unroll
         for (int e = 0; e < EPT; ++e) xm[e] = 0.f;
         if (r < R) ld_row<D>(tw.blk[tw.nblocks - 1].x_mid + (row0 + r) * D, j, xm);
+#pragma unroll
+        for (int k = 0; k < BPT; ++k) {
+            nb[k] = 0.f;
+            if (tid + k * NTHREADS < Cp) nb[k] = tw.blk[tw.nblocks - 1].ch_b1p[tid + k * NTHREADS];
+        }
     }
     // ---- upstream gradient of the tower output ----
     {
@@ -198,16 +205,9 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
         //      transposed operand copy and of the ch_b2 gradient) and straight into its packed NAT image.  The previous
         //      block's LayerNorm-1 parameter gradients are column-summed beside it (other tiles).
         {
-            // this block's hidden bias -> LDS: requested first, written at the end of the phase (the column loop reads it from
-            // there: a global load of it at the top of every step was waited for at once, and with it -- the memory counter is
-            // in order -- everything requested before it)
-            constexpr int BPT = 8;                                  // Cp <= BPT * NTHREADS (checked by the host)
-            float nb[BPT];
-#pragma unroll
-            for (int k = 0; k < BPT; ++k) {
-                nb[k] = 0.f;
-                if (tb1 + k * NTHREADS < Cp) nb[k] = bk.ch_b1p[tb1 + k * NTHREADS];
-            }
+            // this block's hidden bias -> LDS: requested a phase ago (with the x_mid rows), written at the end of this phase
+            // (the column loop reads it from there: a global load of it at the top of every step was waited for at once, and
+            // with it -- the memory counter is in order -- everything requested before it)
             const int r = tb1 / TPR, j = tb1 % TPR;
             float dy[EPT], a[EPT], mean, rstd;
             ld_row<D>(dxs + r * XLD, j, dy);
@@ -753,6 +753,11 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
 #pragma unroll
             for (int e = 0; e < EPT; ++e) xm[e] = 0.f;
             if (r < R) ld_row<D>(tw.blk[b - 1].x_mid + (row0 + r) * D, j, xm);
+#pragma unroll
+            for (int k = 0; k < BPT; ++k) {
+                nb[k] = 0.f;
+                if (tb3 + k * NTHREADS < Cp) nb[k] = tw.blk[b - 1].ch_b1p[tb3 + k * NTHREADS];
+            }
         }
         __syncthreads();
         TIMER_LMARK(6);   // R3: token-gradient atomics, LN1 backward

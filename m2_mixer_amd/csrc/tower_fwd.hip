@@ -26,7 +26,7 @@ template <int P, int D, int NMAX> struct FwdLds {
     // + keep-words of the token sites (two per column of the workgroup's SPW = BM / N samples) + hidden bias of one block
     static size_t bytes(int nblocks, int N, int Cp) {
         return FIXED + (TOK ? 2 * (size_t)(BM / N) * D * sizeof(unsigned int) : 0) + (size_t)nblocks * PB * sizeof(float) +
-               (size_t)Cp * sizeof(float);
+               (size_t)Cp * sizeof(float) + 16;
     }
 };
 #ifdef M2M_TIMERS
@@ -35,6 +35,9 @@ template <int P, int D, int NMAX> struct FwdLds {
 #define M2M_LDS_MAX 163840
 #endif
 
+#ifndef M2M_FWD_TICKETS
+#define M2M_FWD_TICKETS 0     // measured: -0.6 % step time, at the price of run-to-run different forward sums (off)
+#endif
 TIMER_DECL(g_tm_fwd);
 TIMER_READER(m2m_debug_timers_fwd, g_tm_fwd)
 
@@ -67,6 +70,7 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
     unsigned int* wto = wth + SPW_ * D;                           //   (bf16 mode with dropout only: token_mfma.h)
     float* par = reinterpret_cast<float*>(wto + SPW_ * D);        // [nblocks][L::PB]
     float* bias_s = par + tw.nblocks * L::PB;                     // [Cp] hidden bias (padded layout) of the block in flight
+    unsigned int* qctr = reinterpret_cast<unsigned int*>(bias_s + tw.Cp);      // ticket counter of the column loop
     constexpr int PB = L::PB, O_LN1W = 0, O_LN1B = D, O_LN2W = 2 * D, O_LN2B = 3 * D, O_CHB2 = 4 * D, O_TOKW = 5 * D,
                   O_TOKB2 = 5 * D + 32 * TW_LD;
 
@@ -131,7 +135,18 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
         }
     }
     // hidden bias of block 0 (every later block's is fetched during the previous block's last phase)
-    _Pragma("unroll 1") for (int i = tid; i < Cp; i += NTHREADS) bias_s[i] = tw.blk[0].ch_b1p[i];
+    {
+        constexpr int BPT = 8;                                      // Cp <= BPT * NTHREADS (checked by the host)
+        float nb[BPT];
+#pragma unroll
+        for (int k = 0; k < BPT; ++k) {
+            nb[k] = 0.f;
+            if (tid + k * NTHREADS < Cp) nb[k] = tw.blk[0].ch_b1p[tid + k * NTHREADS];
+        }
+#pragma unroll
+        for (int k = 0; k < BPT; ++k)
+            if (tid + k * NTHREADS < Cp) bias_s[tid + k * NTHREADS] = nb[k];
+    }
     // ---- load the input tile (rows >= R are zero) ----
     _Pragma("unroll 1") for (int idx = tid; idx < BM * (D / 4); idx += NTHREADS) {
         const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
@@ -185,6 +200,7 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
         const Drop dr_ch = make_drop(training, tw.p_drop, seed, step, site + 2);
         const Drop dr_co = make_drop(training, tw.p_drop, seed, step, site + 3);
         TIMER_LMARK(0);   // block input: save / LN1 (in the previous block's last phase from block 1 on)
+        if (tid == 0) *qctr = NWAVES;      // tickets of the column loop (barriers lie between here and the loop)
 
         if constexpr (TOK) {
         // ---- token mixing (modules/mixer.py:30-35): bf16 mode on the matrix pipe (token_mfma.h), fp32 mode one thread
@@ -260,7 +276,12 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
 #pragma unroll
                 for (int kb = 0; kb < KD; ++kb) w1f[t][kb] = ld_frag_global(bk.w1n, (long)(2 * wave + t) * KD + kb, lane);
         }
-        for (int q = wave; q < npairs; q += NWAVES) {
+        // bf16 training: steps by ticket, as in tower_bwd.hip (inference and the fp32 parity mode keep the static split:
+        // reproducible sums)
+        const bool tickets = P == PREC_BF16 && M2M_FWD_TICKETS && training;
+        for (int q = __builtin_amdgcn_readfirstlane(wave); q < npairs;) {
+            unsigned int ticket = 0u;
+            if (tickets && lane == 0) ticket = atomicAdd(qctr, 1u);
             // this step's W2 fragments: in flight during GEMM1 + epilogue
             Frag w2f[NF][DT];
 #pragma unroll
@@ -289,12 +310,13 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
             // prefetch the next step's W1 fragments under the epilogue (scheduling barrier: do not hoist the
             // loads above the MFMAs that still read the current fragments)
             __builtin_amdgcn_sched_barrier(0);
-            if (q + NWAVES < npairs) {
+            const int qn = tickets ? (int)__builtin_amdgcn_readfirstlane(ticket) : q + NWAVES;
+            if (qn < npairs) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int kb = 0; kb < KD; ++kb)
-                        w1f[t][kb] = ld_frag_global(bk.w1n, (long)(2 * (q + NWAVES) + t) * KD + kb, lane);
+                        w1f[t][kb] = ld_frag_global(bk.w1n, (long)(2 * qn + t) * KD + kb, lane);
             }
             // bias is already in; GELU + dropout on the accumulators (row c = 32q + 16t + 4g + r, column m = il)
             Frag hf[MT][NF];
@@ -318,6 +340,7 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
                 for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) Pr::mma(yacc[mt][dt], hf[mt][f], w2f[f][dt]);
+            q = qn;
         }
         TIMER_LMARK(3);   // hidden-column loop (wave 0)
 
