@@ -72,8 +72,13 @@ static __device__ __forceinline__ Frag ld_frag_global(const void* base, long blo
 }
 // Global-memory pointer type for values that pass through an opaque asm (which strips the address-space inference: a plain
 // pointer would come back as FLAT, and flat loads also tick lgkmcnt).
-typedef const __attribute__((address_space(1))) char* gptr_t;
-typedef __attribute__((address_space(1))) char* gptr_w_t;
+#if defined(__HIP_DEVICE_COMPILE__)
+#define M2M_AS1 __attribute__((address_space(1)))
+#else
+#define M2M_AS1                                   /* the host pass only parses device code */
+#endif
+typedef const M2M_AS1 char* gptr_t;
+typedef M2M_AS1 char* gptr_w_t;
 // (the value is wave-uniform by construction -- a descriptor field -- and is made so for the compiler too: readfirstlane of
 //  both halves, free when it already sits in SGPRs)
 static __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
@@ -85,8 +90,20 @@ static __device__ __forceinline__ gptr_w_t to_gptr_w(void* p) { return (gptr_w_t
 // fragment load with a wave-uniform block index: scalar base + one 32-bit per-lane offset shared by every load of the loop
 static __device__ __forceinline__ Frag ld_frag_global_u(gptr_t base, long block_uniform, unsigned int lane16) {
     Frag f;
-    f.u = *reinterpret_cast<const __attribute__((address_space(1))) u32x4_t*>(base + block_uniform * 1024 + lane16);
+    f.u = *reinterpret_cast<const M2M_AS1 u32x4_t*>(base + block_uniform * 1024 + lane16);
     return f;
+}
+// One LDS-DMA instruction: 64 lanes x 16 B from per-lane global addresses to the wave-uniform LDS byte address ldst (+ lane x
+// 16).  Inline asm on purpose: outside hipcc's memory-counter bookkeeping, so that completion can be counted by hand (counted
+// s_waitcnt vmcnt(N) + barrier) and several tiles stay in flight.  M0 (the DMA's LDS base) is saved and restored.
+static __device__ __forceinline__ void glds16_g(gptr_t gsrc, unsigned int ldst) {
+    unsigned int keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(ldst) : "memory");
+}
+// LDS byte address of a pointer into the dynamic shared array
+static __device__ __forceinline__ unsigned int lds_addr_of(const void* p) {
+    return (unsigned int)(unsigned long long)(const __attribute__((address_space(3))) void*)p;
 }
 static __device__ __forceinline__ Frag ld_frag_lds(const char* base, int block, int lane) {
     Frag f;

@@ -505,6 +505,7 @@ static WgradPlan wgrad_plan(const m2m_tower* t, int B) {
     while (wgs * groups < 128 && (ntiles + groups - 1) / groups > 64) ++groups;
     if (groups < (32 + wgs - 1) / wgs) groups = (32 + wgs - 1) / wgs;
     if (const char* e = getenv("M2M_WGRAD_GROUPS")) groups = atoi(e);   // diagnostic override (scripts/wgrad_probe.py sweeps it); unset in production
+    if (const char* e = getenv("M2M_WGRAD_LONG_GROUPS")) { if (ntiles > 64) groups = atoi(e); }   // diagnostic: towers with more than 64 steps only
     if (groups < 1) groups = 1;
     int tpg = (ntiles + groups - 1) / groups;
     if (tpg < 4) tpg = 4;
