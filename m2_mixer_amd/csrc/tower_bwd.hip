@@ -444,17 +444,17 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                     const long off = (long)q * m2m_hchn_stride(npair) + (pair * 2 + u) * 1024 + lane * 16;
                     __builtin_nontemporal_store(u32x4_t{pack_bf2(od[0][0], od[0][1]), pack_bf2(od[0][2], od[0][3]),
                                                         pack_bf2(od[1][0], od[1][1]), pack_bf2(od[1][2], od[1][3])},
-                                                reinterpret_cast<__attribute__((address_space(1))) u32x4_t*>(p_dh + off));
+                                                reinterpret_cast<M2M_AS1 u32x4_t*>(p_dh + off));
                     __builtin_nontemporal_store(u32x4_t{pack_bf2(oa[0][0], oa[0][1]), pack_bf2(oa[0][2], oa[0][3]),
                                                         pack_bf2(oa[1][0], oa[1][1]), pack_bf2(oa[1][2], oa[1][3])},
-                                                reinterpret_cast<__attribute__((address_space(1))) u32x4_t*>(p_h + off));
+                                                reinterpret_cast<M2M_AS1 u32x4_t*>(p_h + off));
                 } else {
                     // fp32: a 16-row half is a whole k-block: [column tile][32-row pair][half][lane][16 bytes]
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         const long off = (long)(2 * q + t) * m2m_hchn_stride(npair) + (pair * 2 + u) * 1024 + lane * 16;
-                        __builtin_nontemporal_store(od[t], reinterpret_cast<__attribute__((address_space(1))) f32x4_t*>(p_dh + off));
-                        __builtin_nontemporal_store(oa[t], reinterpret_cast<__attribute__((address_space(1))) f32x4_t*>(p_h + off));
+                        __builtin_nontemporal_store(od[t], reinterpret_cast<M2M_AS1 f32x4_t*>(p_dh + off));
+                        __builtin_nontemporal_store(oa[t], reinterpret_cast<M2M_AS1 f32x4_t*>(p_h + off));
                     }
                 }
             }
