@@ -95,52 +95,31 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
     const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
 
     TIMER_LSTART();
-    if (ActB<P>::USES_TABLE) gelu_tab_fill(gtab, make_drop(true, tw.p_drop, 0u, 0u, 0u).scale, tid, NTHREADS);
     constexpr int MAXB = (int)(sizeof(tw.blk) / sizeof(tw.blk[0]));       // blocks the descriptor type can hold
-    // ---- the small parameters of every block -> LDS.  The block index stays wave-uniform (a per-thread index into the
-    //      by-value descriptor would turn every later descriptor read into a vector load); all blocks' loads are issued
-    //      before the first LDS write, so the whole preload costs one memory round trip ----
-    _Pragma("unroll 1") for (int i = tid; i < D; i += NTHREADS) {
-        float v[MAXB][4];
+    // ---- prologue.  EVERY global load of the launch's start is requested before the first LDS write: the upstream gradient,
+    //      the last block's x_mid rows and hidden bias (used by the first phase of the block loop), the small parameters of
+    //      every block (block index wave-uniform: a per-thread index into the by-value descriptor would turn every later
+    //      descriptor read into a vector load); the GELU table is computed while they fly. ----
+    constexpr int XI = (BM * (D / 4) + NTHREADS - 1) / NTHREADS, BPT = 8, TI = TOK ? (32 * TW_LD + NTHREADS - 1) / NTHREADS : 1;
+    float4 uv[XI];
+    {
+        const float invN = 1.0f / (float)N;
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b)
-            if (b < tw.nblocks) {
-                const m2m_block& bk = tw.blk[b];
-                v[b][0] = TOK ? bk.ln1_w[i] : 0.f; v[b][1] = TOK ? bk.ln1_b[i] : 0.f;
-                v[b][2] = bk.ln2_w[i]; v[b][3] = bk.ln2_b[i];
-            }
-#pragma unroll
-        for (int b = 0; b < MAXB; ++b)
-            if (b < tw.nblocks) {
-                float* pb = par + b * PB;
-                if (TOK) { pb[O_LN1W + i] = v[b][0]; pb[O_LN1B + i] = v[b][1]; }
-                pb[O_LN2W + i] = v[b][2]; pb[O_LN2B + i] = v[b][3];
-            }
-    }
-    if constexpr (TOK) {
-        // zero-padded token weights: tokw[t][0..NMAX) = W1[t][n]  tokw[t][NMAX..2NMAX) = W2[n][t]  tokw[t][2NMAX] = b1[t]  (t < 32)
-        _Pragma("unroll 1") for (int idx = tid; idx < 32 * TW_LD; idx += NTHREADS) {
-            const int t = idx / TW_LD, j = idx % TW_LD;
-            float v[MAXB];
-#pragma unroll
-            for (int b = 0; b < MAXB; ++b) {
-                v[b] = 0.f;
-                if (b < tw.nblocks && t < T) {
-                    const m2m_block& bk = tw.blk[b];
-                    if (j < NMAX) { if (j < N) v[b] = bk.tok_w1[t * N + j]; }
-                    else if (j < 2 * NMAX) { if (j - NMAX < N) v[b] = bk.tok_w2[(j - NMAX) * T + t]; }
-                    else if (j == 2 * NMAX) v[b] = bk.tok_b1[t];
+        for (int k = 0; k < XI; ++k) {
+            const int idx = tid + k * NTHREADS, r = idx / (D / 4), c = (idx % (D / 4)) * 4;
+            uv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < BM * (D / 4) && r < R) {
+                const long gr = row0 + r, gs = gr / N;
+                if (d_out) uv[k] = *reinterpret_cast<const float4*>(d_out + gs * d_out_ss + (gr % N) * D + c);
+                if (d_pooled) {
+                    const float4 p = *reinterpret_cast<const float4*>(d_pooled + gs * D + c);
+                    uv[k].x += p.x * invN; uv[k].y += p.y * invN; uv[k].z += p.z * invN; uv[k].w += p.w * invN;
                 }
             }
-#pragma unroll
-            for (int b = 0; b < MAXB; ++b)
-                if (b < tw.nblocks) par[b * PB + O_TOKW + idx] = v[b];
         }
     }
-    // x_mid of the last block: its rows are requested now and used by the first phase of the block loop
-    float xm[EPT];
-    constexpr int BPT = 8;                                          // Cp <= BPT * NTHREADS (checked by the host)
-    float nb[BPT];                                                  // this thread's share of the next block's hidden bias
+    float xm[EPT];                                                  // x_mid rows of the block about to be processed
+    float nb[BPT];                                                  // this thread's share of that block's hidden bias (Cp <= BPT * NTHREADS)
     {
         const int r = tid / TPR, j = tid % TPR;
 #pragma unroll
@@ -152,21 +131,50 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
             if (tid + k * NTHREADS < Cp) nb[k] = tw.blk[tw.nblocks - 1].ch_b1p[tid + k * NTHREADS];
         }
     }
+    float pv[MAXB][4], tv[TI][MAXB];
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pv[b][q] = 0.f;
+        if (b < tw.nblocks && tid < D) {
+            const m2m_block& bk = tw.blk[b];
+            if (TOK) { pv[b][0] = bk.ln1_w[tid]; pv[b][1] = bk.ln1_b[tid]; }
+            pv[b][2] = bk.ln2_w[tid]; pv[b][3] = bk.ln2_b[tid];
+        }
+#pragma unroll
+        for (int k = 0; k < TI; ++k) {
+            // zero-padded token weights: tokw[t][0..NMAX) = W1[t][n]  tokw[t][NMAX..2NMAX) = W2[n][t]  tokw[t][2NMAX] = b1[t]  (t < 32)
+            tv[k][b] = 0.f;
+            const int idx = tid + k * NTHREADS, t = idx / TW_LD, j = idx % TW_LD;
+            if (TOK && b < tw.nblocks && idx < 32 * TW_LD && t < T) {
+                const m2m_block& bk = tw.blk[b];
+                if (j < NMAX) { if (j < N) tv[k][b] = bk.tok_w1[t * N + j]; }
+                else if (j < 2 * NMAX) { if (j - NMAX < N) tv[k][b] = bk.tok_w2[(j - NMAX) * T + t]; }
+                else if (j == 2 * NMAX) tv[k][b] = bk.tok_b1[t];
+            }
+        }
+    }
+    if (ActB<P>::USES_TABLE) gelu_tab_fill(gtab, make_drop(true, tw.p_drop, 0u, 0u, 0u).scale, tid, NTHREADS);
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b)
+        if (b < tw.nblocks) {
+            float* pb = par + b * PB;
+            if (tid < D) {
+                if (TOK) { pb[O_LN1W + tid] = pv[b][0]; pb[O_LN1B + tid] = pv[b][1]; }
+                pb[O_LN2W + tid] = pv[b][2]; pb[O_LN2B + tid] = pv[b][3];
+            }
+            if constexpr (TOK) {
+#pragma unroll
+                for (int k = 0; k < TI; ++k)
+                    if (tid + k * NTHREADS < 32 * TW_LD) pb[O_TOKW + tid + k * NTHREADS] = tv[k][b];
+            }
+        }
     // ---- upstream gradient of the tower output ----
     {
-        const float invN = 1.0f / (float)N;
-        _Pragma("unroll 1") for (int idx = tid; idx < BM * (D / 4); idx += NTHREADS) {
-            const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < R) {
-                const long gr = row0 + r, gs = gr / N;
-                if (d_out) v = *reinterpret_cast<const float4*>(d_out + gs * d_out_ss + (gr % N) * D + c);
-                if (d_pooled) {
-                    const float4 p = *reinterpret_cast<const float4*>(d_pooled + gs * D + c);
-                    v.x += p.x * invN; v.y += p.y * invN; v.z += p.z * invN; v.w += p.w * invN;
-                }
-            }
-            *reinterpret_cast<float4*>((tw.has_final_ln ? tdy : dxs) + r * XLD + c) = v;
+#pragma unroll
+        for (int k = 0; k < XI; ++k) {
+            const int idx = tid + k * NTHREADS, r = idx / (D / 4), c = (idx % (D / 4)) * 4;
+            if (idx < BM * (D / 4)) *reinterpret_cast<float4*>((tw.has_final_ln ? tdy : dxs) + r * XLD + c) = uv[k];
         }
         __syncthreads();
         if (tw.has_final_ln)

@@ -86,82 +86,86 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
     constexpr int EPT = D / TPR;
 
     TIMER_LSTART();
-    if (Act<P>::USES_TABLE) gelu_tab_fill(gtab, make_drop(training, tw.p_drop, 0u, 0u, 0u).scale, tid, NTHREADS);
     constexpr int MAXB = (int)(sizeof(tw.blk) / sizeof(tw.blk[0]));       // blocks the descriptor type can hold
-    // ---- the small parameters of every block -> LDS.  The block index stays wave-uniform (a per-thread index into the
-    //      by-value descriptor would turn every later descriptor read into a vector load); all blocks' loads are issued
-    //      before the first LDS write, so the whole preload costs one memory round trip ----
-    _Pragma("unroll 1") for (int i = tid; i < D; i += NTHREADS) {
-        float v[MAXB][5];
+    // ---- prologue.  EVERY global load of the launch's start is requested before the first LDS write (input tile, hidden bias
+    //      of block 0, the small parameters of every block); the GELU table is computed while they fly.  Written as four
+    //      load-then-store loops this was four memory round trips at the head of each launch.  The block index of the
+    //      parameter loads stays wave-uniform (a per-thread index into the by-value descriptor would turn every later
+    //      descriptor read into a vector load). ----
+    constexpr int XI = (BM * (D / 4) + NTHREADS - 1) / NTHREADS, BPT = 8, TI = TOK ? (32 * TW_LD + NTHREADS - 1) / NTHREADS : 1;
+    float4 xv[XI];
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b)
-            if (b < tw.nblocks) {
-                const m2m_block& bk = tw.blk[b];
-                v[b][0] = TOK ? bk.ln1_w[i] : 0.f; v[b][1] = TOK ? bk.ln1_b[i] : 0.f;
-                v[b][2] = bk.ln2_w[i]; v[b][3] = bk.ln2_b[i]; v[b][4] = bk.ch_b2[i];
-            }
-#pragma unroll
-        for (int b = 0; b < MAXB; ++b)
-            if (b < tw.nblocks) {
-                float* pb = par + b * PB;
-                if (TOK) { pb[O_LN1W + i] = v[b][0]; pb[O_LN1B + i] = v[b][1]; }
-                pb[O_LN2W + i] = v[b][2]; pb[O_LN2B + i] = v[b][3]; pb[O_CHB2 + i] = v[b][4];
-            }
-    }
-    if constexpr (TOK) {
-        // zero-padded token weights (rows t >= T and columns n >= N are zero):
-        //   tokw[t][0..NMAX) = W1[t][n]   tokw[t][NMAX..2NMAX) = W2[n][t]   tokw[t][2NMAX] = b1[t]
-        _Pragma("unroll 1") for (int idx = tid; idx < 32 * TW_LD; idx += NTHREADS) {
-            const int t = idx / TW_LD, j = idx % TW_LD;
-            float v[MAXB];
-#pragma unroll
-            for (int b = 0; b < MAXB; ++b) {
-                v[b] = 0.f;
-                if (b < tw.nblocks && t < T) {
-                    const m2m_block& bk = tw.blk[b];
-                    if (j < NMAX) { if (j < N) v[b] = bk.tok_w1[t * N + j]; }
-                    else if (j < 2 * NMAX) { if (j - NMAX < N) v[b] = bk.tok_w2[(j - NMAX) * T + t]; }
-                    else if (j == 2 * NMAX) v[b] = bk.tok_b1[t];
-                }
-            }
-#pragma unroll
-            for (int b = 0; b < MAXB; ++b)
-                if (b < tw.nblocks) par[b * PB + O_TOKW + idx] = v[b];
-        }
-        if (tid < 8) {
-#pragma unroll
-            for (int b = 0; b < MAXB; ++b)
-                if (b < tw.nblocks) par[b * PB + O_TOKB2 + tid] = tid < N ? tw.blk[b].tok_b2[tid] : 0.f;
-        }
-    }
-    // hidden bias of block 0 (every later block's is fetched during the previous block's last phase)
-    {
-        constexpr int BPT = 8;                                      // Cp <= BPT * NTHREADS (checked by the host)
-        float nb[BPT];
-#pragma unroll
-        for (int k = 0; k < BPT; ++k) {
-            nb[k] = 0.f;
-            if (tid + k * NTHREADS < Cp) nb[k] = tw.blk[0].ch_b1p[tid + k * NTHREADS];
-        }
-#pragma unroll
-        for (int k = 0; k < BPT; ++k)
-            if (tid + k * NTHREADS < Cp) bias_s[tid + k * NTHREADS] = nb[k];
-    }
-    // ---- load the input tile (rows >= R are zero) ----
-    _Pragma("unroll 1") for (int idx = tid; idx < BM * (D / 4); idx += NTHREADS) {
-        const int r = idx / (D / 4), c = (idx % (D / 4)) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < R) {
+    for (int k = 0; k < XI; ++k) {
+        const int idx = tid + k * NTHREADS, r = idx / (D / 4), c = (idx % (D / 4)) * 4;
+        xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < BM * (D / 4) && r < R) {
             const long gr = row0 + r;
             const float* src = x0 + (gr / N) * x0_ss + (gr % N) * D + c;
-            v = *reinterpret_cast<const float4*>(src);
+            xv[k] = *reinterpret_cast<const float4*>(src);
             for (int p = 1; p < x0_parts; ++p) {             // k-split partial sums of the patch embedding (m2m_embeds_forward)
                 const float4 u = *reinterpret_cast<const float4*>(src + p * x0_pstride);
-                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                xv[k].x += u.x; xv[k].y += u.y; xv[k].z += u.z; xv[k].w += u.w;
             }
         }
-        *reinterpret_cast<float4*>(xs + r * XLD + c) = v;
     }
+    float nb0[BPT];                                                 // Cp <= BPT * NTHREADS (checked by the host)
+#pragma unroll
+    for (int k = 0; k < BPT; ++k) {
+        nb0[k] = 0.f;
+        if (tid + k * NTHREADS < Cp) nb0[k] = tw.blk[0].ch_b1p[tid + k * NTHREADS];
+    }
+    float pv[MAXB][5], tv[TI][MAXB], b2v[MAXB];
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) pv[b][q] = 0.f;
+        b2v[b] = 0.f;
+        if (b < tw.nblocks) {
+            const m2m_block& bk = tw.blk[b];
+            if (tid < D) {
+                if (TOK) { pv[b][0] = bk.ln1_w[tid]; pv[b][1] = bk.ln1_b[tid]; }
+                pv[b][2] = bk.ln2_w[tid]; pv[b][3] = bk.ln2_b[tid]; pv[b][4] = bk.ch_b2[tid];
+            }
+            if (TOK && tid < N) b2v[b] = bk.tok_b2[tid];
+        }
+#pragma unroll
+        for (int k = 0; k < TI; ++k) {
+            // zero-padded token weights (rows t >= T and columns n >= N are zero):
+            //   tokw[t][0..NMAX) = W1[t][n]   tokw[t][NMAX..2NMAX) = W2[n][t]   tokw[t][2NMAX] = b1[t]
+            tv[k][b] = 0.f;
+            const int idx = tid + k * NTHREADS, t = idx / TW_LD, j = idx % TW_LD;
+            if (TOK && b < tw.nblocks && idx < 32 * TW_LD && t < T) {
+                const m2m_block& bk = tw.blk[b];
+                if (j < NMAX) { if (j < N) tv[k][b] = bk.tok_w1[t * N + j]; }
+                else if (j < 2 * NMAX) { if (j - NMAX < N) tv[k][b] = bk.tok_w2[(j - NMAX) * T + t]; }
+                else if (j == 2 * NMAX) tv[k][b] = bk.tok_b1[t];
+            }
+        }
+    }
+    if (Act<P>::USES_TABLE) gelu_tab_fill(gtab, make_drop(training, tw.p_drop, 0u, 0u, 0u).scale, tid, NTHREADS);
+#pragma unroll
+    for (int k = 0; k < XI; ++k) {
+        const int idx = tid + k * NTHREADS, r = idx / (D / 4), c = (idx % (D / 4)) * 4;
+        if (idx < BM * (D / 4)) *reinterpret_cast<float4*>(xs + r * XLD + c) = xv[k];
+    }
+#pragma unroll
+    for (int k = 0; k < BPT; ++k)
+        if (tid + k * NTHREADS < Cp) bias_s[tid + k * NTHREADS] = nb0[k];
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b)
+        if (b < tw.nblocks) {
+            float* pb = par + b * PB;
+            if (tid < D) {
+                if (TOK) { pb[O_LN1W + tid] = pv[b][0]; pb[O_LN1B + tid] = pv[b][1]; }
+                pb[O_LN2W + tid] = pv[b][2]; pb[O_LN2B + tid] = pv[b][3]; pb[O_CHB2 + tid] = pv[b][4];
+            }
+            if constexpr (TOK) {
+#pragma unroll
+                for (int k = 0; k < TI; ++k)
+                    if (tid + k * NTHREADS < 32 * TW_LD) pb[O_TOKW + tid + k * NTHREADS] = tv[k][b];
+                if (tid < 8) pb[O_TOKB2 + tid] = b2v[b];
+            }
+        }
     __syncthreads();
 
     // Block input of block b, held by its row thread: save it for the backward pass, LayerNorm-1 -> ub, and the keep-words
