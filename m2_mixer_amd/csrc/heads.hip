@@ -8,7 +8,9 @@
 // reduction over all B*K elements per head, preds = sigmoid(logits) > 0.5 per label.
 #include "tile.h"
 
+#ifndef HEAD_S
 #define HEAD_S 16       // samples per workgroup (small: the launch sits between forward and backward on the critical path)
+#endif
 #define HEAD_MAXK 32
 #define HEAD_MAXH 4
 
