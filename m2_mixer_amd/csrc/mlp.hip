@@ -223,6 +223,208 @@ __global__ __launch_bounds__(MLP_T) void mlp_bwd_kernel(const m2m_mlp m, const f
     }
 }
 
+// ---- small batches: the same arithmetic on the matrix pipe ------------------------------------------------------------
+// At the cfg batch (128) the VALU kernels above are a chain of dependent LDS reads on 4-16 workgroups: 50 us forward and
+// 67 us backward, ON the critical path of the MIMIC step (the time tower runs beside them and finishes first).  Here a
+// workgroup owns ONE 16-sample tile and every product is v_mfma_f32_16x16x4_f32: exact fp32, and the same k-ordered fmaf chain
+// as the loops above (bitwise the same forward values).  4 waves; a wave takes the 16-column output tiles jt = wave, wave + 4, ...
+#define MLPM_T 256
+#define MLPM_S 16
+static __device__ __forceinline__ f32x4_t mlp_mfma4(float a, float b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__global__ __launch_bounds__(MLPM_T) void mlp_fwd_mfma_kernel(const m2m_mlp m, const float* __restrict__ x, int B, float* __restrict__ out,
+                                                              long out_ss, float* __restrict__ out2, int training, unsigned int seed,
+                                                              unsigned int step_host, const unsigned int* __restrict__ step_dev) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int LD = MLP_MAXW + 1;
+    float* a0 = sm;                                   // [16][LD] activations of the current layer (columns k >= din up to the next multiple of 4: zero)
+    float* a1 = a0 + MLPM_S * LD;
+    float* wt = a1 + MLPM_S * LD;                     // [din4][LD] transposed weights wt[k][j] = W[j][k]; rows k >= din: zero
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
+    const int s0 = blockIdx.x * MLPM_S;
+    const int ns = min(MLPM_S, B - s0);
+    const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
+    {
+        const int din = m.dims[0], din4 = (din + 3) & ~3;
+        for (int i = tid; i < MLPM_S * din4; i += MLPM_T) {
+            const int s = i / din4, k = i % din4;
+            a0[s * LD + k] = (s < ns && k < din) ? x[(long)(s0 + s) * din + k] : 0.f;
+        }
+    }
+    float* cur = a0;
+    float* nxt = a1;
+    for (int l = 0; l < m.nlayers; ++l) {
+        const int din = m.dims[l], dout = m.dims[l + 1], din4 = (din + 3) & ~3, dout4 = (dout + 3) & ~3;
+        const bool hidden = l < m.nlayers - m.has_out;
+        const Drop dr = mlp_drop(m, l, training && hidden, seed, step);
+        __syncthreads();                              // the previous layer is done with wt; cur is complete
+        {
+            const float* __restrict__ w = m.w[l];
+            for (int i0 = tid; i0 < din4 * dout; i0 += MLP_SU * MLPM_T) {
+                float v[MLP_SU];
+#pragma unroll
+                for (int u = 0; u < MLP_SU; ++u) {
+                    const int i = i0 + u * MLPM_T, j = i / din4, k = i % din4;
+                    v[u] = (i < din4 * dout && k < din) ? w[j * din + k] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < MLP_SU; ++u) {
+                    const int i = i0 + u * MLPM_T;
+                    if (i < din4 * dout) wt[(i % din4) * LD + i / din4] = v[u];
+                }
+            }
+        }
+        __syncthreads();
+        for (int jt = wave; jt * 16 < dout; jt += MLPM_T / 64) {
+            const int j = jt * 16 + il;
+            const bool jv = j < dout;
+            const float bj = jv ? m.b[l][j] : 0.f;
+            f32x4_t acc = f32x4_t{bj, bj, bj, bj};
+            for (int k0 = 0; k0 < din4; k0 += 4) {
+                const float a = cur[il * LD + k0 + g];                        // A[i = sample il][k]
+                const float b = jv ? wt[(k0 + g) * LD + j] : 0.f;             // B[k][j = output]
+                acc = mlp_mfma4(a, b, acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int s = 4 * g + r;
+                if (jv) {
+                    float a = acc[r];
+                    if (hidden) {
+                        a = a > 0.f ? a : 0.f;
+                        a = drop_keep(dr, (unsigned int)(s0 + s) * dout + j) ? a * dr.scale : 0.f;
+                        if (training && s < ns) m.act[l][(long)(s0 + s) * dout + j] = a;
+                    }
+                    nxt[s * LD + j] = a;
+                }
+            }
+        }
+        for (int i = tid; i < MLPM_S * (dout4 - dout); i += MLPM_T)          // zero padding of the next layer's k
+            nxt[(i / (dout4 - dout)) * LD + dout + i % (dout4 - dout)] = 0.f;
+        float* t = cur; cur = nxt; nxt = t;
+    }
+    __syncthreads();
+    const int dl = m.dims[m.nlayers];
+    for (int i = tid; i < ns * dl; i += MLPM_T) {
+        const int s = i / dl, j = i % dl;
+        const float v = cur[s * LD + j];
+        out[(long)(s0 + s) * out_ss + j] = v;
+        if (out2) out2[(long)(s0 + s) * dl + j] = v;
+    }
+}
+
+__global__ __launch_bounds__(MLPM_T) void mlp_bwd_mfma_kernel(const m2m_mlp m, const float* __restrict__ x, int B,
+                                                              const float* __restrict__ d_out, long d_out_ss,
+                                                              const float* __restrict__ d_out2) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int LD = MLP_MAXW + 1;
+    float* g0 = sm;                                   // dz: gradient wrt the current layer's pre-dropout output [16][LD]
+    float* g1 = g0 + MLPM_S * LD;                     // gradient wrt its input
+    float* ain = g1 + MLPM_S * LD;                    // the layer's input activations [16][LD]
+    float* wl = ain + MLPM_S * LD;                    // weights [dout4][LD], rows j >= dout: zero
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
+    const int s0 = blockIdx.x * MLPM_S;
+    const int ns = min(MLPM_S, B - s0);
+    const float scale = 65536.0f / (float)m2m_drop_thr(m.p_drop);
+    const int dl = m.dims[m.nlayers];
+    for (int i = tid; i < MLPM_S * dl; i += MLPM_T) {
+        const int s = i / dl, j = i % dl;
+        float v = 0.f;
+        if (s < ns) {
+            if (d_out) v = d_out[(long)(s0 + s) * d_out_ss + j];
+            if (d_out2) v += d_out2[(long)(s0 + s) * dl + j];
+        }
+        g0[s * LD + j] = v;
+    }
+    float* gc = g0;
+    float* gn = g1;
+    for (int l = m.nlayers - 1; l >= 0; --l) {
+        const int din = m.dims[l], dout = m.dims[l + 1], dout4 = (dout + 3) & ~3;
+        const bool hidden = l < m.nlayers - m.has_out;
+        const float* inp = l == 0 ? x : m.act[l - 1];
+        __syncthreads();                              // gc complete; the previous layer is done with wl / ain
+        {
+            const float* __restrict__ w = m.w[l];
+            for (int i0 = tid; i0 < dout4 * din; i0 += MLP_SU * MLPM_T) {
+                float v[MLP_SU];
+#pragma unroll
+                for (int u = 0; u < MLP_SU; ++u) { const int i = i0 + u * MLPM_T; v[u] = i < dout * din ? w[i] : 0.f; }
+#pragma unroll
+                for (int u = 0; u < MLP_SU; ++u) { const int i = i0 + u * MLPM_T; if (i < dout4 * din) wl[(i / din) * LD + i % din] = v[u]; }
+            }
+            for (int i0 = tid; i0 < MLPM_S * din; i0 += MLP_SU * MLPM_T) {
+                float v[MLP_SU];
+#pragma unroll
+                for (int u = 0; u < MLP_SU; ++u) {
+                    const int i = i0 + u * MLPM_T, sI = i / din;
+                    v[u] = (i < MLPM_S * din && sI < ns) ? inp[(long)(s0 + sI) * din + i % din] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < MLP_SU; ++u) { const int i = i0 + u * MLPM_T; if (i < MLPM_S * din) ain[(i / din) * LD + i % din] = v[u]; }
+            }
+        }
+        {                                             // through Dropout and ReLU; columns j in [dout, dout4): zero (k padding of d_in)
+            const float* __restrict__ actl = hidden ? m.act[l] : nullptr;
+            for (int i0 = tid; i0 < MLPM_S * dout4; i0 += MLP_SU * MLPM_T) {
+                float o[MLP_SU];
+#pragma unroll
+                for (int u = 0; u < MLP_SU; ++u) {
+                    const int i = i0 + u * MLPM_T, sI = i / dout4, j = i % dout4;
+                    o[u] = (hidden && i < MLPM_S * dout4 && sI < ns && j < dout) ? actl[(long)(s0 + sI) * dout + j] : 1.f;
+                }
+#pragma unroll
+                for (int u = 0; u < MLP_SU; ++u) {
+                    const int i = i0 + u * MLPM_T;
+                    if (i < MLPM_S * dout4) {
+                        const int j = i % dout4;
+                        float* gp = gc + (i / dout4) * LD + j;
+                        if (j >= dout) *gp = 0.f;
+                        else if (hidden) *gp = o[u] != 0.f ? *gp * scale : 0.f;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // dW[j][k] += sum_s dz[s][j] in[s][k]: tiles (jt, kt) of 16 x 16, the 16 samples are the contraction
+        const int njt = (dout + 15) >> 4, nkt = (din + 15) >> 4;
+        for (int t = wave; t < njt * nkt; t += MLPM_T / 64) {
+            const int jt = t / nkt, kt = t % nkt;
+            const int ja = min(jt * 16 + il, dout - 1), kb = min(kt * 16 + il, din - 1);
+            f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s4 = 0; s4 < MLPM_S; s4 += 4) acc = mlp_mfma4(gc[(s4 + g) * LD + ja], ain[(s4 + g) * LD + kb], acc);
+            const int k = kt * 16 + il;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = jt * 16 + 4 * g + r;
+                if (j < dout && k < din) atomicAdd(m.g_w[l] + j * din + k, acc[r]);
+            }
+        }
+        for (int j = tid; j < dout; j += MLPM_T) {
+            float a = 0.f;
+            for (int s = 0; s < MLPM_S; ++s) a += gc[s * LD + j];
+            atomicAdd(m.g_b[l] + j, a);
+        }
+        if (l > 0) {                                  // d_in[s][k] = sum_j dz[s][j] W[j][k]
+            for (int kt = wave; kt * 16 < din; kt += MLPM_T / 64) {
+                const int k = kt * 16 + il;
+                const bool kv = k < din;
+                f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                for (int j0 = 0; j0 < dout4; j0 += 4) {
+                    const float a = gc[il * LD + j0 + g];                     // A[i = sample il][j]
+                    const float b = kv ? wl[(j0 + g) * LD + k] : 0.f;         // B[j][k]
+                    acc = mlp_mfma4(a, b, acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kv) gn[(4 * g + r) * LD + k] = acc[r];
+            }
+        }
+        float* t = gc; gc = gn; gn = t;
+    }
+}
+
 static int check_mlp(const m2m_mlp* m, int B) {
     if (!m || B < 1) { m2m_set_error("mlp: bad argument", __FILE__, __LINE__); return -1; }
     if (m->nlayers < 1 || m->nlayers > M2M_MLP_MAX_LAYERS) { m2m_set_error("mlp: nlayers out of range", __FILE__, __LINE__); return -1; }
@@ -253,13 +455,21 @@ static int launch_mlp_bwd(const m2m_mlp* m, const float* x, int B, const float* 
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
 }
-#define MLP_SMALL_BATCH 1024      // up to here 8 samples per workgroup
+#define MLP_SMALL_BATCH 2048      // up to here the MFMA kernels (one 16-sample tile per workgroup)
 
 extern "C" int m2m_mlp_forward(const m2m_mlp* m, const float* x, int B, float* out, int64_t out_sample_stride, float* out_dense,
                                int training, uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream) {
     if (int rc = check_mlp(m, B)) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (B <= MLP_SMALL_BATCH) return launch_mlp_fwd<8, 128>(m, x, B, out, (long)out_sample_stride, out_dense, training, seed, step, step_dev, st);
+    if (B <= MLP_SMALL_BATCH) {
+        const size_t lds = sizeof(float) * ((size_t)2 * MLPM_S + MLP_MAXW) * (MLP_MAXW + 1);
+        static bool done = false;
+        if (!done) { M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+        hipLaunchKernelGGL(mlp_fwd_mfma_kernel, dim3((B + MLPM_S - 1) / MLPM_S), dim3(MLPM_T), lds, st, *m, x, B, out, (long)out_sample_stride,
+                           out_dense, training, seed, step, step_dev);
+        M2M_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     return launch_mlp_fwd<32, 256>(m, x, B, out, (long)out_sample_stride, out_dense, training, seed, step, step_dev, st);
 }
 
@@ -267,6 +477,13 @@ extern "C" int m2m_mlp_backward(const m2m_mlp* m, const float* x, int B, const f
                                 const float* d_out_dense, void* stream) {
     if (int rc = check_mlp(m, B)) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (B <= MLP_SMALL_BATCH) return launch_mlp_bwd<8, 128>(m, x, B, d_out, (long)d_out_sample_stride, d_out_dense, st);
+    if (B <= MLP_SMALL_BATCH) {
+        const size_t lds = sizeof(float) * ((size_t)3 * MLPM_S + MLP_MAXW) * (MLP_MAXW + 1);
+        static bool done = false;
+        if (!done) { M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+        hipLaunchKernelGGL(mlp_bwd_mfma_kernel, dim3((B + MLPM_S - 1) / MLPM_S), dim3(MLPM_T), lds, st, *m, x, B, d_out, (long)d_out_sample_stride, d_out_dense);
+        M2M_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     return launch_mlp_bwd<32, 256>(m, x, B, d_out, (long)d_out_sample_stride, d_out_dense, st);
 }
