@@ -206,9 +206,19 @@ static __device__ __forceinline__ void gelu_grad_as(float x, float& g, float& dg
     g = x * cdf;
     dg = __builtin_fmaf(x * e, 0.3989422804014327f, cdf);
 }
+// Forward-only table: {a, b} per cell (8 bytes).  The forward never needs gelu', and an 8-byte read at a random address
+// conflicts far less than a 16-byte one (two 32-lane groups over 64 banks instead of four 16-lane groups of four banks each).
+typedef __attribute__((ext_vector_type(2))) float gtab2_t;
+static __device__ __forceinline__ void gelu_tab2_fill(gtab2_t* tab, float scale, int tid, int nthreads) {
+    for (int k = tid; k < GELU_TAB_N; k += nthreads) { const gtab_t c = pwl_cell(k, scale); tab[k] = gtab2_t{c[0], c[1]}; }
+}
 template <int P> struct Act;
 template <> struct Act<PREC_BF16> {
     static constexpr bool USES_TABLE = true;
+    static __device__ __forceinline__ float gelu_scaled(const gtab2_t* tab, float x, float) {
+        const gtab2_t e = tab[pwl_index(x)];
+        return __builtin_fmaf(e[1], x, e[0]);
+    }
     static __device__ __forceinline__ float gelu_scaled(const gtab_t* tab, float x, float) {
         const gtab_t e = tab[pwl_index(x)];
         return __builtin_fmaf(e[1], x, e[0]);
@@ -222,6 +232,7 @@ template <> struct Act<PREC_BF16> {
 template <> struct Act<PREC_F32> {
     static constexpr bool USES_TABLE = false;
     static __device__ __forceinline__ float gelu_scaled(const gtab_t*, float x, float scale) { return gelu_f(x) * scale; }
+    static __device__ __forceinline__ float gelu_scaled(const gtab2_t*, float x, float scale) { return gelu_f(x) * scale; }
     static __device__ __forceinline__ void gelu_grad_scaled(const gtab_t*, float x, float scale, float& g, float& dg) {
         gelu_grad_f(x, g, dg);
         g *= scale;
@@ -252,7 +263,7 @@ template <> struct ActB<PREC_BF16> {
 #define M2M_TOK_FORMULA 0
 #endif
 struct ActTokF {
-    static __device__ __forceinline__ float gelu_scaled(const gtab_t* tab, float x, float scale) {
+    static __device__ __forceinline__ float gelu_scaled(const gtab2_t* tab, float x, float scale) {
         if (M2M_TOK_FORMULA & 1) { float g, dg; gelu_grad_as(x, g, dg); return g * scale; }
         return Act<PREC_BF16>::gelu_scaled(tab, x, scale);
     }

@@ -53,7 +53,7 @@ static __device__ __forceinline__ void token_keep_words(unsigned int* wth, unsig
 // MFMA (A = W1, B = U), GELU / dropout on the accumulators, which then are the B operand (k = t) of O[n][col] = W2 G.
 template <int D, int NMAX, int DM>
 static __device__ __forceinline__ void token_fwd_mfma(const float* ub, float* xs, const float* tokw, const float* tokb2,
-                                                      const gtab_t* gtab, const unsigned int* wth, const unsigned int* wto,
+                                                      const gtab2_t* gtab, const unsigned int* wth, const unsigned int* wto,
                                                       int N, int ns, float scale_th, float scale_to, int wave, int lane) {
     constexpr int XLD = TileGeom<D>::XLD, TW_LD = 2 * NMAX + 4, KS = NMAX / 4, CT = D / 16;
     const int g = lane >> 4, il = lane & 15;

@@ -22,7 +22,7 @@ template <int P, int D, int NMAX> struct FwdLds {
     static constexpr int NM = TOK ? NMAX : 1, TW_LD = 2 * NM + 4, XLD = D + 4;
     static constexpr int PB = 5 * D + (TOK ? 32 * TW_LD + 8 : 0);          // floats of one block's small parameters
     static constexpr size_t FIXED = (size_t)BM * XLD * sizeof(float) * (1 + (TOK ? 1 : 0) + RowSlabs<D>::N) +
-                                    (size_t)BM * D * Prec<P>::ESZ + GELU_TAB_N * 16;
+                                    (size_t)BM * D * Prec<P>::ESZ + (GELU_TAB_N + 2) * 8;
     // + keep-words of the token sites (two per column of the workgroup's SPW = BM / N samples) + hidden bias of one block
     static size_t bytes(int nblocks, int N, int Cp) {
         return FIXED + (TOK ? 2 * (size_t)(BM / N) * D * sizeof(unsigned int) : 0) + (size_t)nblocks * PB * sizeof(float) +
@@ -64,8 +64,8 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
     float* ub = xs + BM * XLD;                                    // LN1 output       [BM][XLD] (token path only)
     float* slabs = ub + (TOK ? BM * XLD : 0);                     // [RowSlabs<D>::N][BM][XLD]
     char* at = reinterpret_cast<char*>(slabs + RowSlabs<D>::N * BM * XLD);   // packed A image   BM*D*ESZ bytes
-    gtab_t* gtab = reinterpret_cast<gtab_t*>(at + BM * D * Pr::ESZ);          // [GELU_TAB_N] (bf16 mode only)
-    unsigned int* wth = reinterpret_cast<unsigned int*>(gtab + GELU_TAB_N);   // [SPW * D] keep-words of the token sites, one per column
+    gtab2_t* gtab = reinterpret_cast<gtab2_t*>(at + BM * D * Pr::ESZ);        // [GELU_TAB_N] x {a, b} (bf16 mode only)
+    unsigned int* wth = reinterpret_cast<unsigned int*>(gtab + GELU_TAB_N + 2);   // [SPW * D] keep-words of the token sites, one per column
     const int SPW_ = TOK ? BM / tw.N : 0;
     unsigned int* wto = wth + SPW_ * D;                           //   (bf16 mode with dropout only: token_mfma.h)
     float* par = reinterpret_cast<float*>(wto + SPW_ * D);        // [nblocks][L::PB]
@@ -142,7 +142,7 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
             }
         }
     }
-    if (Act<P>::USES_TABLE) gelu_tab_fill(gtab, make_drop(training, tw.p_drop, 0u, 0u, 0u).scale, tid, NTHREADS);
+    if (Act<P>::USES_TABLE) gelu_tab2_fill(gtab, make_drop(training, tw.p_drop, 0u, 0u, 0u).scale, tid, NTHREADS);
 #pragma unroll
     for (int k = 0; k < XI; ++k) {
         const int idx = tid + k * NTHREADS, r = idx / (D / 4), c = (idx % (D / 4)) * 4;
