@@ -290,10 +290,17 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
 #endif
         constexpr bool W1LDS = M2M_W1LDS && D == 128 && P == PREC_BF16;      // (256-byte rows: hidden_dim 128)
         char* w1slot = reinterpret_cast<char*>(slabs + wave * TILE_F);
-        const int swz_w = ((il & 3) << 2) | ((il >> 2) & 3);                       // writer: row 16 t + il, chunk 4 kb + g
+        // physical chunk = logical chunk ^ swz(row), swz(r) = (r & 7) | ((r & 1) << 3): its low three bits are a bijection of
+        // r & 7 (the 8 lanes one ds_write_b128 cycle serves are 8 consecutive rows at one logical chunk: 8 distinct chunks mod
+        // 128 bytes) and so are its high three bits (the 32 lanes one ds_read_b64_tr_b16 cycle serves are 8 consecutive rows x
+        // both chunks of one 32-byte granule: 16 distinct chunks = all 64 banks).  The first swizzle of this slot
+        // ([il1 il0 il3 il2]) was two-way conflicted on both sides: the parked W1 was half of the kernel's LDS-array cycles,
+        // half of those conflicts (SQ_LDS_BANK_CONFLICT with / without the slot).
+        const int swz_w = (il & 7) | ((il & 1) << 3);                              // writer: row 16 t + il, chunk 4 kb + g
         char* w1_wr = w1slot + 256 * il + 16 * (g ^ (swz_w & 3));
-        const int swz_r = ((il >> 2) << 2) | g;                                    // reader: row 16 t + 4 g + (il >> 2)
-        const char* w1_rd = w1slot + 256 * (4 * g + (il >> 2)) + 8 * (il & 1) + 16 * (((il >> 1) & 1) ^ (swz_r & 1));
+        const int rrow = 4 * g + (il >> 2);                                        // reader: row 16 t + 4 g + (il >> 2)
+        const int swz_r = (rrow & 7) | ((rrow & 1) << 3);
+        const char* w1_rd = w1slot + 256 * rrow + 8 * (il & 1) + 16 * (((il >> 1) & 1) ^ (swz_r & 1));
         Frag w1f[2][HOLD ? KD : 1], w2f[2][HOLD ? KD : 1];
         if (HOLD && wave < npairs) {
 #pragma unroll
@@ -309,6 +316,24 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
         // the fastest wave waited ~4 us per block at the barrier behind the loop.  The next ticket is drawn at the top of a step
         // and used at its prefetch point.  fp32 (parity) mode keeps the static split: reproducible summation order.
         constexpr bool TICKETS = P == PREC_BF16 && M2M_TICKETS;
+        // The two waves of a SIMD (w and w + 4) run the same program and leave the barrier before the loop together: their MFMA
+        // clusters and their VALU epilogues would collide.  M2M_STAGGER delays waves 4-7 by about half a step (s_sleep counts 64
+        // cycles) so that one wave's matrix work lies beside its partner's vector work; with tickets the delayed waves simply
+        // draw fewer steps, the stagger costs nothing at the end.  M2M_PRIO_STATIC: the younger half at priority 1 for the
+        // loop; M2M_PRIO_FLIP: priority 1 around each step's MFMA cluster.
+#ifndef M2M_STAGGER
+#define M2M_STAGGER 0
+#endif
+#ifndef M2M_PRIO_STATIC
+#define M2M_PRIO_STATIC 0
+#endif
+#ifndef M2M_PRIO_FLIP
+#define M2M_PRIO_FLIP 0
+#endif
+        if (TICKETS && (M2M_STAGGER > 0 || M2M_PRIO_STATIC) && __builtin_amdgcn_readfirstlane(wave) >= NWAVES / 2) {
+            if (M2M_PRIO_STATIC) __builtin_amdgcn_s_setprio(1);
+            if (M2M_STAGGER > 0) __builtin_amdgcn_s_sleep(M2M_STAGGER);
+        }
         for (int q = TICKETS ? __builtin_amdgcn_readfirstlane(wave) : wave; q < npairs;) {
             unsigned int ticket = 0u;
             if (TICKETS && lane == 0) ticket = atomicAdd(qctr, 1u);
@@ -324,6 +349,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                 gacc[mt][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             }
             if constexpr (HOLD) {
+            if (M2M_PRIO_FLIP) __builtin_amdgcn_s_setprio(1);
             if constexpr (W1LDS) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
@@ -373,6 +399,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
             // during the epilogue.  The scheduling barrier keeps the compiler from hoisting these loads above
             // the MFMAs that still read the current fragments (which would double the live registers).
             __builtin_amdgcn_sched_barrier(0);
+            if (M2M_PRIO_FLIP) __builtin_amdgcn_s_setprio(0);
             Frag w3f[W1LDS ? 1 : NF][W1LDS ? 1 : DT];
             if constexpr (!W1LDS) {
 #pragma unroll
@@ -492,6 +519,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
             }
             q = qn;
         }
+        if (TICKETS && M2M_PRIO_STATIC) __builtin_amdgcn_s_setprio(0);
         TIMER_LMARK(2);   // C3 hidden-column loop (wave 0)
         int tb2 = tid;
         asm volatile("" : "+v"(tb2));

@@ -283,6 +283,11 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
         // bf16 training: steps by ticket, as in tower_bwd.hip (inference and the fp32 parity mode keep the static split:
         // reproducible sums)
         const bool tickets = P == PREC_BF16 && M2M_FWD_TICKETS && training;
+        // stagger of the younger half (waves 4-7 share their SIMDs with waves 0-3): see tower_bwd.hip
+#ifndef M2M_FWD_STAGGER
+#define M2M_FWD_STAGGER 0
+#endif
+        if (M2M_FWD_STAGGER > 0 && P == PREC_BF16 && __builtin_amdgcn_readfirstlane(wave) >= NWAVES / 2) __builtin_amdgcn_s_sleep(M2M_FWD_STAGGER);
         for (int q = __builtin_amdgcn_readfirstlane(wave); q < npairs;) {
             unsigned int ticket = 0u;
             if (tickets && lane == 0) ticket = atomicAdd(qctr, 1u);
