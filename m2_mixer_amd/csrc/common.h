@@ -212,6 +212,24 @@ typedef __attribute__((ext_vector_type(2))) float gtab2_t;
 static __device__ __forceinline__ void gelu_tab2_fill(gtab2_t* tab, float scale, int tid, int nthreads) {
     for (int k = tid; k < GELU_TAB_N; k += nthreads) { const gtab_t c = pwl_cell(k, scale); tab[k] = gtab2_t{c[0], c[1]}; }
 }
+// Backward table: {a, b, c, d} as four fp16 values in 8 bytes.  The backward needs gelu AND gelu' of every hidden element; the
+// 16-byte fp32 entry costs a ds_read_b128 at a random address (four 16-lane groups of four banks each: ~3 LDS cycles per
+// group with its conflicts), the 8-byte entry a ds_read_b64 (two 32-lane groups of two banks).  fp16 coefficients carry a
+// relative error of 2^-11 = 4.9e-4, an eighth of bf16 resolution -- the values are rounded to bf16 right after (the operand of
+// the next product / of the weight gradients); both fmas take the fp16 operands directly (v_fma_mix_f32).  Coefficients are
+// O(1) x the dropout scale, far inside fp16 range.
+typedef _Float16 gtabh_t __attribute__((ext_vector_type(4)));       // {a, b, c, d}
+static __device__ __forceinline__ void gelu_tabh_fill(gtabh_t* tab, float scale, int tid, int nthreads) {
+    for (int k = tid; k < GELU_TAB_N; k += nthreads) {
+        const gtab_t c = pwl_cell(k, scale);
+        tab[k] = gtabh_t{(_Float16)c[0], (_Float16)c[1], (_Float16)c[2], (_Float16)c[3]};
+    }
+}
+static __device__ __forceinline__ void gelu_grad_tabh(const gtabh_t* tab, float x, float& g, float& dg) {
+    const gtabh_t e = tab[pwl_index(x)];
+    g = __builtin_fmaf((float)e[1], x, (float)e[0]);
+    dg = __builtin_fmaf((float)e[3], x, (float)e[2]);
+}
 template <int P> struct Act;
 template <> struct Act<PREC_BF16> {
     static constexpr bool USES_TABLE = true;
@@ -228,6 +246,7 @@ template <> struct Act<PREC_BF16> {
         g = __builtin_fmaf(e[1], x, e[0]);
         dg = __builtin_fmaf(e[3], x, e[2]);
     }
+    static __device__ __forceinline__ void gelu_grad_scaled(const gtabh_t* tab, float x, float, float& g, float& dg) { gelu_grad_tabh(tab, x, g, dg); }
 };
 template <> struct Act<PREC_F32> {
     static constexpr bool USES_TABLE = false;
@@ -237,6 +256,9 @@ template <> struct Act<PREC_F32> {
         gelu_grad_f(x, g, dg);
         g *= scale;
         dg *= scale;
+    }
+    static __device__ __forceinline__ void gelu_grad_scaled(const gtabh_t*, float x, float scale, float& g, float& dg) {
+        gelu_grad_scaled(static_cast<const gtab_t*>(nullptr), x, scale, g, dg);
     }
 };
 // The activation as the BACKWARD kernels evaluate it: the table too (M2M_BWD_FORMULA=1 selects the closed form).  Measured in
@@ -255,7 +277,21 @@ template <> struct ActB<PREC_BF16> {
         g *= scale;
         dg *= scale;
     }
+    static __device__ __forceinline__ void gelu_grad_scaled(const gtabh_t*, float x, float scale, float& g, float& dg) {
+        gelu_grad_scaled(static_cast<const gtab_t*>(nullptr), x, scale, g, dg);
+    }
 };
+#endif
+// Table type of the backward chain kernel (tower_bwd.hip, token_mfma.h's backward): the packed fp16 table (M2M_BWD_HTAB=0: fp32).
+#ifndef M2M_BWD_HTAB
+#define M2M_BWD_HTAB 1
+#endif
+#if M2M_BWD_HTAB
+typedef gtabh_t gtabB_t;
+static __device__ __forceinline__ void gelu_tabB_fill(gtabB_t* tab, float scale, int tid, int nthreads) { gelu_tabh_fill(tab, scale, tid, nthreads); }
+#else
+typedef gtab_t gtabB_t;
+static __device__ __forceinline__ void gelu_tabB_fill(gtabB_t* tab, float scale, int tid, int nthreads) { gelu_tab_fill(tab, scale, tid, nthreads); }
 #endif
 // The activation inside the token-mixing MFMA phases (token_mfma.h): 1 = closed form, 0 = table.  M2M_TOK_FORMULA bit 0: forward,
 // bit 1: backward.
@@ -269,7 +305,8 @@ struct ActTokF {
     }
 };
 struct ActTokB {
-    static __device__ __forceinline__ void gelu_grad_scaled(const gtab_t* tab, float x, float scale, float& g, float& dg) {
+    template <class TAB>
+    static __device__ __forceinline__ void gelu_grad_scaled(const TAB* tab, float x, float scale, float& g, float& dg) {
         if (M2M_TOK_FORMULA & 2) { gelu_grad_as(x, g, dg); g *= scale; dg *= scale; }
         else ActB<PREC_BF16>::gelu_grad_scaled(tab, x, scale, g, dg);
     }

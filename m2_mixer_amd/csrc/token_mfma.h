@@ -156,7 +156,7 @@ static __device__ __forceinline__ void token_fwd_mfma(const float* ub, float* xs
 template <int NMAX> struct TokRed { static constexpr int LD = 2 * (NMAX + 1) * 32 + NMAX; };
 
 template <int D, int NMAX, int DM>
-static __device__ __forceinline__ void token_bwd_mfma(float* ub, const float* dov, const float* tokw, const gtab_t* gtab,
+static __device__ __forceinline__ void token_bwd_mfma(float* ub, const float* dov, const float* tokw, const gtabB_t* gtab,
                                                       const unsigned int* wth, float* red, int N, int ns, float scale_th,
                                                       int wave, int lane) {
     constexpr int XLD = TileGeom<D>::XLD, TW_LD = 2 * NMAX + 4, KS = NMAX / 4, CP = D / 32;

@@ -25,7 +25,7 @@ template <int P, int D, int NMAX, int TG> struct BwdLds {
     static constexpr int RED_LD = RED_LD0 > TokRed<NM>::LD ? RED_LD0 : TokRed<NM>::LD;
     static constexpr int PB = 4 * D + (TOK ? 32 * TW_LD : 0);                  // floats of one block's small parameters
     static constexpr size_t FIXED = (size_t)BM * XLD * sizeof(float) * (1 + RowSlabs<D>::N + 2) + 2 * (size_t)BM * D * Prec<P>::ESZ +
-                                    GELU_TAB_N * 16 + (TOK ? (size_t)NWAVES * RED_LD * sizeof(float) : 0);
+                                    GELU_TAB_N * sizeof(gtabB_t) + (TOK ? (size_t)NWAVES * RED_LD * sizeof(float) : 0);
     // + keep-words of the token-hidden site (one per column of the workgroup's SPW = BM / N samples) + hidden bias of one block
     static size_t bytes(int nblocks, int N, int Cp) {
         return FIXED + (TOK ? (size_t)(BM / N) * D * sizeof(unsigned int) : 0) + (size_t)nblocks * PB * sizeof(float) +
@@ -74,7 +74,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
     float* ta = tdy + TILE_F;                            // A = LN2(x_mid) (fp32)
     char* at = reinterpret_cast<char*>(ta + TILE_F);
     char* dyp = at + IMG_B;
-    gtab_t* gtab = reinterpret_cast<gtab_t*>(dyp + IMG_B);       // [GELU_TAB_N] (bf16 mode only)
+    gtabB_t* gtab = reinterpret_cast<gtabB_t*>(dyp + IMG_B);     // [GELU_TAB_N] (bf16 mode only)
     float* red = reinterpret_cast<float*>(gtab + GELU_TAB_N);    // [NWAVES][RED_LD] (token path)
     unsigned int* wth = reinterpret_cast<unsigned int*>(red + (TOK ? NWAVES * RED_LD : 0));   // [BM * D] (token path)
     float* par = reinterpret_cast<float*>(wth + (TOK ? (BM / tw.N) * D : 0));                 // [nblocks][PB]
@@ -154,7 +154,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
             }
         }
     }
-    if (ActB<P>::USES_TABLE) gelu_tab_fill(gtab, make_drop(true, tw.p_drop, 0u, 0u, 0u).scale, tid, NTHREADS);
+    if (ActB<P>::USES_TABLE) gelu_tabB_fill(gtab, make_drop(true, tw.p_drop, 0u, 0u, 0u).scale, tid, NTHREADS);
 #pragma unroll
     for (int b = 0; b < MAXB; ++b)
         if (b < tw.nblocks) {
