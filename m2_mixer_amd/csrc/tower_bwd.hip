@@ -125,10 +125,13 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
 #pragma unroll
         for (int e = 0; e < EPT; ++e) xm[e] = 0.f;
         if (r < R) ld_row<D>(tw.blk[tw.nblocks - 1].x_mid + (row0 + r) * D, j, xm);
+        // (the pointer as a scalar, read ONCE: left inside the guarded loads hipcc re-read it from the descriptor in front of
+        // every one of them -- pointer load, vmcnt(0), data load, eight times in series)
+        const M2M_AS1 float* b1p = reinterpret_cast<const M2M_AS1 float*>(to_gptr(tw.blk[tw.nblocks - 1].ch_b1p));
 #pragma unroll
         for (int k = 0; k < BPT; ++k) {
             nb[k] = 0.f;
-            if (tid + k * NTHREADS < Cp) nb[k] = tw.blk[tw.nblocks - 1].ch_b1p[tid + k * NTHREADS];
+            if (tid + k * NTHREADS < Cp) nb[k] = b1p[tid + k * NTHREADS];
         }
     }
     float pv[MAXB][4], tv[TI][MAXB];
@@ -147,10 +150,16 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
             tv[k][b] = 0.f;
             const int idx = tid + k * NTHREADS, t = idx / TW_LD, j = idx % TW_LD;
             if (TOK && b < tw.nblocks && idx < 32 * TW_LD && t < T) {
+                // one load through a per-thread choice among three SCALAR pointers (a per-thread choice of the descriptor field
+                // made hipcc load the pointer itself per thread: pointer load, vmcnt(0), data load, once per block in series)
                 const m2m_block& bk = tw.blk[b];
-                if (j < NMAX) { if (j < N) tv[k][b] = bk.tok_w1[t * N + j]; }
-                else if (j < 2 * NMAX) { if (j - NMAX < N) tv[k][b] = bk.tok_w2[(j - NMAX) * T + t]; }
-                else if (j == 2 * NMAX) tv[k][b] = bk.tok_b1[t];
+                const M2M_AS1 float* w1 = reinterpret_cast<const M2M_AS1 float*>(to_gptr(bk.tok_w1));
+                const M2M_AS1 float* w2 = reinterpret_cast<const M2M_AS1 float*>(to_gptr(bk.tok_w2));
+                const M2M_AS1 float* b1 = reinterpret_cast<const M2M_AS1 float*>(to_gptr(bk.tok_b1));
+                const bool v1 = j < NMAX, v2 = !v1 && j < 2 * NMAX;
+                const M2M_AS1 float* src = v1 ? w1 + (t * N + j) : (v2 ? w2 + ((j - NMAX) * T + t) : b1 + t);
+                const bool ok = v1 ? j < N : (v2 ? j - NMAX < N : j == 2 * NMAX);
+                if (ok) tv[k][b] = *src;
             }
         }
     }
@@ -245,14 +254,21 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
         TIMER_LMARK(1);   // X1: dYd, A, packed images (+ previous block's LN1 column sums)
         // (X2) ch_b2 gradient (column sums of dYd) and the transposed (CHN) operand copies for the weight gradients: global
         //      writes from tiles nothing rewrites before the next block -- no barrier between here and the column loop
+        // Every descriptor pointer of this phase and of the column loop, read in ONE batch into scalars: read where they are
+        // used, each cost its own round trip (pointer load, vmcnt(0), use -- the descriptor is addressed through VGPRs once the
+        // block index is a loop counter), four in series between the barrier above and the loop's first weight loads.
+        gptr_w_t p_gb2 = to_gptr_w(bk.g_ch_b2), p_dyt = to_gptr_w(bk.dyt_chn), p_atc = to_gptr_w(bk.at_chn);
+        gptr_t p_w1n = to_gptr(bk.w1n), p_w2tn = to_gptr(bk.w2tn), p_w1tc = to_gptr(bk.w1tc);
+        gptr_w_t p_dh = to_gptr_w(bk.dh_chn), p_h = to_gptr_w(bk.h_chn);
+        asm volatile("" : "+s"(p_gb2), "+s"(p_dyt), "+s"(p_atc), "+s"(p_w1n), "+s"(p_w2tn), "+s"(p_w1tc), "+s"(p_dh), "+s"(p_h));
         _Pragma("unroll 1") for (int d = tb1; d < D; d += NTHREADS) {
             float s_ = 0.f;
 #pragma unroll 4
             for (int r = 0; r < BM; ++r) s_ += tdy[r * XLD + d];
-            atomicAdd(bk.g_ch_b2 + d, s_);
+            atomicAdd(reinterpret_cast<float*>((char*)p_gb2) + d, s_);
         }
-        pack_tile_chn_t<P, D>(tdy, reinterpret_cast<char*>(bk.dyt_chn) + pair_off, tile_in_pair, tb1);
-        pack_tile_chn_t<P, D>(ta, reinterpret_cast<char*>(bk.at_chn) + pair_off, tile_in_pair, tb1);
+        pack_tile_chn_t<P, D>(tdy, (char*)p_dyt + pair_off, tile_in_pair, tb1);
+        pack_tile_chn_t<P, D>(ta, (char*)p_atc + pair_off, tile_in_pair, tb1);
 
         // (C3) hidden-column loop
         f32x4_t dacc[MT][DT];
@@ -264,8 +280,6 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
         // The loop's six streams as scalar (SGPR) base pointers behind an opaque asm: under register pressure hipcc otherwise
         // re-reads them from the descriptor INSIDE the loop (two global_load_dwordx2 + vmcnt(0) per step, which drains the
         // weight prefetch in flight).
-        gptr_t p_w1n = to_gptr(bk.w1n), p_w2tn = to_gptr(bk.w2tn), p_w1tc = to_gptr(bk.w1tc);
-        gptr_w_t p_dh = to_gptr_w(bk.dh_chn), p_h = to_gptr_w(bk.h_chn);
         asm volatile("" : "+s"(p_w1n), "+s"(p_w2tn), "+s"(p_w1tc), "+s"(p_dh), "+s"(p_h));
         const unsigned int lane16 = (unsigned int)lane * 16u;
         // identity block of the transposing MFMA (bf16): lane (g, il) is non-zero iff g == il >> 2, at element il & 3
@@ -789,10 +803,11 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
 #pragma unroll
             for (int e = 0; e < EPT; ++e) xm[e] = 0.f;
             if (r < R) ld_row<D>(tw.blk[b - 1].x_mid + (row0 + r) * D, j, xm);
+            const M2M_AS1 float* b1p = reinterpret_cast<const M2M_AS1 float*>(to_gptr(tw.blk[b - 1].ch_b1p));   // scalar, read once
 #pragma unroll
             for (int k = 0; k < BPT; ++k) {
                 nb[k] = 0.f;
-                if (tb3 + k * NTHREADS < Cp) nb[k] = tw.blk[b - 1].ch_b1p[tb3 + k * NTHREADS];
+                if (tb3 + k * NTHREADS < Cp) nb[k] = b1p[tb3 + k * NTHREADS];
             }
         }
         __syncthreads();

@@ -109,10 +109,11 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
         }
     }
     float nb0[BPT];                                                 // Cp <= BPT * NTHREADS (checked by the host)
+    const M2M_AS1 float* b1p0 = reinterpret_cast<const M2M_AS1 float*>(to_gptr(tw.blk[0].ch_b1p));   // scalar, read once (see tower_bwd.hip)
 #pragma unroll
     for (int k = 0; k < BPT; ++k) {
         nb0[k] = 0.f;
-        if (tid + k * NTHREADS < Cp) nb0[k] = tw.blk[0].ch_b1p[tid + k * NTHREADS];
+        if (tid + k * NTHREADS < Cp) nb0[k] = b1p0[tid + k * NTHREADS];
     }
     float pv[MAXB][5], tv[TI][MAXB], b2v[MAXB];
 #pragma unroll
@@ -135,10 +136,16 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
             tv[k][b] = 0.f;
             const int idx = tid + k * NTHREADS, t = idx / TW_LD, j = idx % TW_LD;
             if (TOK && b < tw.nblocks && idx < 32 * TW_LD && t < T) {
+                // one load through a per-thread choice among three SCALAR pointers (a per-thread choice of the descriptor field
+                // made hipcc load the pointer itself per thread: pointer load, vmcnt(0), data load, once per block in series)
                 const m2m_block& bk = tw.blk[b];
-                if (j < NMAX) { if (j < N) tv[k][b] = bk.tok_w1[t * N + j]; }
-                else if (j < 2 * NMAX) { if (j - NMAX < N) tv[k][b] = bk.tok_w2[(j - NMAX) * T + t]; }
-                else if (j == 2 * NMAX) tv[k][b] = bk.tok_b1[t];
+                const M2M_AS1 float* w1 = reinterpret_cast<const M2M_AS1 float*>(to_gptr(bk.tok_w1));
+                const M2M_AS1 float* w2 = reinterpret_cast<const M2M_AS1 float*>(to_gptr(bk.tok_w2));
+                const M2M_AS1 float* b1 = reinterpret_cast<const M2M_AS1 float*>(to_gptr(bk.tok_b1));
+                const bool v1 = j < NMAX, v2 = !v1 && j < 2 * NMAX;
+                const M2M_AS1 float* src = v1 ? w1 + (t * N + j) : (v2 ? w2 + ((j - NMAX) * T + t) : b1 + t);
+                const bool ok = v1 ? j < N : (v2 ? j - NMAX < N : j == 2 * NMAX);
+                if (ok) tv[k][b] = *src;
             }
         }
     }
@@ -369,10 +376,11 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
             constexpr int BPT = 8;                                  // Cp <= BPT * NTHREADS (checked by the host)
             float nb[BPT];
             const bool more = b + 1 < tw.nblocks;
+            const M2M_AS1 float* b1pn = reinterpret_cast<const M2M_AS1 float*>(to_gptr(tw.blk[more ? b + 1 : b].ch_b1p));   // scalar, read once
 #pragma unroll
             for (int k = 0; k < BPT; ++k) {
                 nb[k] = 0.f;
-                if (more && tid + k * NTHREADS < Cp) nb[k] = tw.blk[b + 1].ch_b1p[tid + k * NTHREADS];
+                if (more && tid + k * NTHREADS < Cp) nb[k] = b1pn[tid + k * NTHREADS];
             }
             float v[EPT], x[EPT];
             slab_row_sum<D>(slabs, rr, rj, v);
