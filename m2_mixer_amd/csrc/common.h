@@ -172,7 +172,14 @@ static __device__ __forceinline__ void gelu_grad_f(float x, float& g, float& dg)
 typedef __attribute__((ext_vector_type(4))) float gtab_t;     // {a, b, c, d}
 static __device__ __forceinline__ unsigned int pwl_index(float x) {
     const float t = __builtin_fmaf(x, PWL_N / (2.0f * PWL_XMAX), 0.5f * PWL_N + 1.0f);
-    const unsigned int i = (unsigned int)__builtin_fmaxf(t, 0.0f);       // v_cvt_u32_f32 saturates at 0 (NaN -> 0 too)
+#if defined(__HIP_DEVICE_COMPILE__)
+    // v_cvt_u32_f32 saturates (t < 0 and NaN -> 0): written as the instruction, the C cast needs a v_max_f32 in front of it to
+    // be defined for negative t -- one VALU instruction per hidden element in loops that are VALU-issue-bound
+    unsigned int i;
+    asm("v_cvt_u32_f32_e32 %0, %1" : "=v"(i) : "v"(t));
+#else
+    const unsigned int i = (unsigned int)__builtin_fmaxf(t, 0.0f);
+#endif
     return i < (unsigned int)(PWL_N + 1) ? i : (unsigned int)(PWL_N + 1);
 }
 static __device__ __forceinline__ gtab_t pwl_cell(int i, float scale) {
@@ -224,6 +231,13 @@ static __device__ __forceinline__ void gelu_tabh_fill(gtabh_t* tab, float scale,
         const gtab_t c = pwl_cell(k, scale);
         tab[k] = gtabh_t{(_Float16)c[0], (_Float16)c[1], (_Float16)c[2], (_Float16)c[3]};
     }
+}
+// keep-mask folded into the index: a dropped element (mk == 0) reads cell 0 = {0, 0, 0, 0}, so gelu and gelu' both come out as
+// 0 with ONE v_and instead of one per value
+static __device__ __forceinline__ void gelu_grad_tabh_masked(const gtabh_t* tab, float x, unsigned int mk, float& g, float& dg) {
+    const gtabh_t e = tab[pwl_index(x) & mk];
+    g = __builtin_fmaf((float)e[1], x, (float)e[0]);
+    dg = __builtin_fmaf((float)e[3], x, (float)e[2]);
 }
 static __device__ __forceinline__ void gelu_grad_tabh(const gtabh_t* tab, float x, float& g, float& dg) {
     const gtabh_t e = tab[pwl_index(x)];

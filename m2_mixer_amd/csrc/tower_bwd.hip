@@ -261,6 +261,24 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
         gptr_t p_w1n = to_gptr(bk.w1n), p_w2tn = to_gptr(bk.w2tn), p_w1tc = to_gptr(bk.w1tc);
         gptr_w_t p_dh = to_gptr_w(bk.dh_chn), p_h = to_gptr_w(bk.h_chn);
         asm volatile("" : "+s"(p_gb2), "+s"(p_dyt), "+s"(p_atc), "+s"(p_w1n), "+s"(p_w2tn), "+s"(p_w1tc), "+s"(p_dh), "+s"(p_h));
+        // The first step's weight fragments: requested HERE, in front of this phase's atomics and operand stores.  (a) their
+        // latency lies beside the phase instead of at the top of the loop; (b) the loop's waits: memory operations retire in
+        // order, and inside the loop two operand stores follow each step's 16 prefetch loads, so waiting for the last load may
+        // leave 2 operations in flight -- but the waitcnt pass merges the loop's entry edge with its back edge, and with the
+        // first loads issued LAST before the loop it had to wait for vmcnt(0) in every step, i.e. for the previous step's
+        // non-temporal stores to be written back (measured without the stores: -6 us per launch).
+        constexpr bool HOLD0 = D <= 128;
+        const unsigned int lane16_0 = (unsigned int)lane * 16u;
+        Frag w1f[2][HOLD0 ? D / Pr::KB : 1], w2f[2][HOLD0 ? D / Pr::KB : 1];
+        if (HOLD0 && wave < (Cp >> 5)) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int kb = 0; kb < D / Pr::KB; ++kb) {
+                    w1f[t][kb] = ld_frag_global_u(p_w1n, (long)(2 * wave + t) * (D / Pr::KB) + kb, lane16_0);
+                    w2f[t][kb] = ld_frag_global_u(p_w2tn, (long)(2 * wave + t) * (D / Pr::KB) + kb, lane16_0);
+                }
+        }
         _Pragma("unroll 1") for (int d = tb1; d < D; d += NTHREADS) {
             float s_ = 0.f;
 #pragma unroll 4
@@ -315,16 +333,6 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
         const int rrow = 4 * g + (il >> 2);                                        // reader: row 16 t + 4 g + (il >> 2)
         const int swz_r = (rrow & 7) | ((rrow & 1) << 3);
         const char* w1_rd = w1slot + 256 * rrow + 8 * (il & 1) + 16 * (((il >> 1) & 1) ^ (swz_r & 1));
-        Frag w1f[2][HOLD ? KD : 1], w2f[2][HOLD ? KD : 1];
-        if (HOLD && wave < npairs) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int kb = 0; kb < KD; ++kb) {
-                    w1f[t][kb] = ld_frag_global_u(p_w1n, (long)(2 * wave + t) * KD + kb, lane16);
-                    w2f[t][kb] = ld_frag_global_u(p_w2tn, (long)(2 * wave + t) * KD + kb, lane16);
-                }
-        }
         // bf16 training: the 32-column steps are handed out by a ticket counter in LDS (the first NWAVES statically).  The loop
         // is issue-bound and the waves do not run at the same pace (the older ones win the arbitration): with a static split
         // the fastest wave waited ~4 us per block at the barrier behind the loop.  The next ticket is drawn at the top of a step
@@ -422,7 +430,11 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                 for (int dt = 0; dt < DT; ++dt) w3f[f][dt] = ld_frag_global_u(p_w1tc, (long)(q * NF + f) * DT + dt, lane16);
             }
             const int qn = TICKETS ? (int)__builtin_amdgcn_readfirstlane(ticket) : q + NWAVES;
+#ifdef M2M_ABL_NOPF
+            if (false) {
+#else
             if (HOLD && qn < npairs) {
+#endif
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -441,6 +453,15 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float gl, dgl;                                   // both carry the dropout scale
+#ifdef M2M_ABL_NOGELU
+                        gacc[mt][t][r] *= 0.5f; hacc[mt][t][r] = mask_f(hacc[mt][t][r], bit_to_mask(word, 16 * t + r)); continue;
+#endif
+                        if constexpr (DM != DM_NONE && ActB<P>::USES_TABLE && M2M_BWD_HTAB) {
+                            gelu_grad_tabh_masked(gtab, hacc[mt][t][r], bit_to_mask(word, 16 * t + r), gl, dgl);
+                            gacc[mt][t][r] *= dgl;
+                            hacc[mt][t][r] = gl;
+                            continue;
+                        }
                         ActB<P>::gelu_grad_scaled(gtab, hacc[mt][t][r], dr_ch.scale, gl, dgl);
                         const float v = gacc[mt][t][r] * dgl;
                         if (DM == DM_NONE) { gacc[mt][t][r] = v; hacc[mt][t][r] = gl; }
@@ -458,6 +479,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
             // [c in registers][m across lanes]; an MFMA against an identity block turns them ([m][c] as the A operand,
             // chained k order) into [m in registers][c across lanes] = exactly the layout that pass consumes, exact in
             // the operand precision.  The MFMA pipe is mostly idle here, so the transpose is nearly free.
+#ifndef M2M_ABL_NOTR
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int u = BM == 16 ? tile_in_pair : mt;        // 16-row half of the 32-row pair
@@ -486,17 +508,29 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                 }
                 // streamed out once and read once by the weight-gradient pass: non-temporal, so that the 100 MB per
                 // launch do not evict the weights the other workgroups of this XCD keep re-reading from its L2
+#ifdef M2M_ABL_NOSTORE
+                asm volatile("" :: "v"(od[0]), "v"(od[1]), "v"(oa[0]), "v"(oa[1]));
+                continue;
+#endif
                 if (P == PREC_BF16) {
                     // [column-tile pair q][32-row pair][16-row half u][lane][tile 2q: 4 bf16 | tile 2q+1: 4 bf16]: one full
                     // 16-byte-per-lane store per operand and step (1 KiB contiguous), and the weight-gradient wave that owns
                     // both column tiles reads it back with one 16-byte load per half
                     const long off = (long)q * m2m_hchn_stride(npair) + (pair * 2 + u) * 1024 + lane * 16;
-                    __builtin_nontemporal_store(u32x4_t{pack_bf2(od[0][0], od[0][1]), pack_bf2(od[0][2], od[0][3]),
-                                                        pack_bf2(od[1][0], od[1][1]), pack_bf2(od[1][2], od[1][3])},
-                                                reinterpret_cast<M2M_AS1 u32x4_t*>(p_dh + off));
-                    __builtin_nontemporal_store(u32x4_t{pack_bf2(oa[0][0], oa[0][1]), pack_bf2(oa[0][2], oa[0][3]),
-                                                        pack_bf2(oa[1][0], oa[1][1]), pack_bf2(oa[1][2], oa[1][3])},
-                                                reinterpret_cast<M2M_AS1 u32x4_t*>(p_h + off));
+#ifndef M2M_ST_NT
+#define M2M_ST_NT 1
+#endif
+                    const u32x4_t sd = u32x4_t{pack_bf2(od[0][0], od[0][1]), pack_bf2(od[0][2], od[0][3]),
+                                               pack_bf2(od[1][0], od[1][1]), pack_bf2(od[1][2], od[1][3])};
+                    const u32x4_t sa = u32x4_t{pack_bf2(oa[0][0], oa[0][1]), pack_bf2(oa[0][2], oa[0][3]),
+                                               pack_bf2(oa[1][0], oa[1][1]), pack_bf2(oa[1][2], oa[1][3])};
+                    if (M2M_ST_NT) {
+                        __builtin_nontemporal_store(sd, reinterpret_cast<M2M_AS1 u32x4_t*>(p_dh + off));
+                        __builtin_nontemporal_store(sa, reinterpret_cast<M2M_AS1 u32x4_t*>(p_h + off));
+                    } else {
+                        *reinterpret_cast<M2M_AS1 u32x4_t*>(p_dh + off) = sd;
+                        *reinterpret_cast<M2M_AS1 u32x4_t*>(p_h + off) = sa;
+                    }
                 } else {
                     // fp32: a 16-row half is a whole k-block: [column tile][32-row pair][half][lane][16 bytes]
 #pragma unroll
@@ -507,6 +541,12 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                     }
                 }
             }
+#endif   // M2M_ABL_NOTR
+#ifdef M2M_ABL_NOP3
+            asm volatile("" :: "v"(hf[0][0].u));
+            q = qn;
+            continue;
+#endif
             if constexpr (W1LDS) {
                 typedef short s16x4 __attribute__((ext_vector_type(4)));
                 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_p;
