@@ -260,6 +260,11 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, i
     float* const o_w1 = bk.g_ch_w1;
     float* const o_w2 = bk.g_ch_w2;
     float* const o_b1 = bk.g_ch_b1;
+    // the same pointers in the global address space for the plain loads / stores of the "+=" write-out (generic pointers from a
+    // descriptor in memory give FLAT accesses, which wait on vmcnt AND lgkmcnt)
+    typedef M2M_GLOBAL_AS float* gf_t;
+    typedef M2M_GLOBAL_AS f32x4_t* gf4_t;
+    const gf_t g_w1 = (gf_t)o_w1, g_w2 = (gf_t)o_w2;
     if (mode != WG_OUT_ATOMIC) {
         constexpr int TLD = D + 4;                           // padded row (floats): the four g-groups land in different banks
         float* tr = reinterpret_cast<float*>(smem) + wave * 16 * TLD;
@@ -272,19 +277,32 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, i
                 for (int r = 0; r < 4; ++r) tr[(4 * g + r) * TLD + 16 * dt + il] = dw1[j][dt][r];
             if (ct < nct) {
                 constexpr int PER = 16 * D / (64 * 4);       // float4 pieces per lane
-                f32x4_t v[PER];
+                f32x4_t v[PER], old[PER];
+                // the old values: UNCONDITIONAL loads (row clamped into the tensor), all requested before the first is used.
+                // Guarded per piece (`if (c < C) v += load`), each load sat in its own basic block with a vmcnt(0) behind it:
+                // 16 + 16 memory round trips in series at the end of every workgroup (~16 us of the launch's tail).
+                if (mode == WG_OUT_ADD) {
+#pragma unroll
+                    for (int i = 0; i < PER; ++i) {
+                        const int idx = i * 64 + lane, row = idx / (D / 4), c4 = idx % (D / 4);
+                        const int c = min(16 * ct + row, C - 1);
+                        old[i] = *(gf4_t)(g_w1 + (long)c * D + 4 * c4);
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < PER; ++i) {
                     const int idx = i * 64 + lane, row = idx / (D / 4), c4 = idx % (D / 4);
                     v[i] = *reinterpret_cast<const f32x4_t*>(tr + row * TLD + 4 * c4);
-                    const int c = 16 * ct + row;
-                    if (mode == WG_OUT_ADD && c < C) v[i] = v[i] + *reinterpret_cast<const f32x4_t*>(o_w1 + (long)c * D + 4 * c4);
+                }
+                if (mode == WG_OUT_ADD) {
+#pragma unroll
+                    for (int i = 0; i < PER; ++i) v[i] = v[i] + old[i];
                 }
 #pragma unroll
                 for (int i = 0; i < PER; ++i) {
                     const int idx = i * 64 + lane, row = idx / (D / 4), c4 = idx % (D / 4);
                     const int c = 16 * ct + row;
-                    if (c < C) *reinterpret_cast<f32x4_t*>(o_w1 + (long)c * D + 4 * c4) = v[i];
+                    if (c < C) *(gf4_t)(g_w1 + (long)c * D + 4 * c4) = v[i];
                 }
             }
         }
@@ -308,6 +326,14 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, i
             if (ct0 + j >= nct) continue;
             const int c0 = 16 * (ct0 + j) + 4 * g;
             const bool vec = c0 + 3 < C && (C & 3) == 0;
+            if ((C & 3) == 0 && 16 * (ct0 + j) + 16 <= C) {   // wave-uniform: the whole column tile is inside the tensor
+                f32x4_t o2[DT];                               // unconditional, batched (see above)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) o2[dt] = *(gf4_t)(g_w2 + (long)(16 * dt + il) * C + c0);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) dw2[j][dt] = dw2[j][dt] + o2[dt];
+                continue;
+            }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 const int d = 16 * dt + il;
@@ -331,7 +357,7 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, i
                 const int d = 16 * dt + il;
                 float* p2 = o_w2 + (long)d * C + c0;
                 if (vec) {
-                    *reinterpret_cast<f32x4_t*>(p2) = dw2[j][dt];
+                    *(gf4_t)(g_w2 + (long)d * C + c0) = dw2[j][dt];
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
