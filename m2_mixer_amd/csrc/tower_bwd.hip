@@ -15,6 +15,8 @@
 // tile, Hact^T and dHpre^T (the hidden activation and its gradient leave the chip ONCE, in operand precision, here).
 #include "tile.h"
 #include "token_mfma.h"
+#include "split.h"
+int m2m_split_small_grads(const SplitReduceArgs& a, hipStream_t st);     // split_mix.hip: sum of the per-workgroup slots into the gradients
 #include <algorithm>
 
 // LDS budget of the backward chain kernel (bytes): FIXED + nblocks * PB * 4
@@ -29,7 +31,7 @@ template <int P, int D, int NMAX, int TG> struct BwdLds {
     // + keep-words of the token-hidden site (one per column of the workgroup's SPW = BM / N samples) + hidden bias of one block
     static size_t bytes(int nblocks, int N, int Cp) {
         return FIXED + (TOK ? (size_t)(BM / N) * D * sizeof(unsigned int) : 0) + (size_t)nblocks * PB * sizeof(float) +
-               (size_t)Cp * sizeof(float) + 16;
+               (size_t)Cp * sizeof(float) + 16 + 8 * (M2M_MAX_BLOCKS + 1);
     }
 };
 #ifdef M2M_TIMERS
@@ -38,16 +40,23 @@ template <int P, int D, int NMAX, int TG> struct BwdLds {
 #define M2M_LDS_MAX 163840
 #endif
 
+// the small parameter gradients' float atomics (M2M_ABL_NOATOM: timing ablation, drops them)
+#ifdef M2M_ABL_NOATOM
+#define M2M_SMALL_ATOMIC(p, v) asm volatile("" :: "v"(p), "v"(v))
+#else
+#define M2M_SMALL_ATOMIC(p, v) atomicAdd(p, v)
+#endif
 TIMER_DECL(g_tm_bwd);
 TIMER_READER(m2m_debug_timers_bwd, g_tm_bwd)
 
 // One workgroup's share of a tower backward: token tile `wg` of `nwg`.  TW is m2m_tower (single-tower launch) or
 // m2m_tower4 (the by-value descriptors of a two-tower launch).
-template <class TW, int P, int D, int NMAX, int TG, int DM>
+template <class TW, int P, int D, int NMAX, int TG, int DM, bool PART = false>
 static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const float* __restrict__ d_out, long d_out_ss,
                                                       const float* __restrict__ d_pooled, float* __restrict__ d_x0, long d_x0_ss,
                                                       unsigned int seed, unsigned int step_host,
-                                                      const unsigned int* __restrict__ step_dev, int wg, int nwg, char* smem) {
+                                                      const unsigned int* __restrict__ step_dev, int wg, int nwg, char* smem,
+                                                      float* __restrict__ part = nullptr) {
     typedef Prec<P> Pr;
     typedef TileGeom<D> G;
     typedef BwdLds<P, D, NMAX, TG> L;
@@ -80,6 +89,9 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
     float* par = reinterpret_cast<float*>(wth + (TOK ? (BM / tw.N) * D : 0));                 // [nblocks][PB]
     float* bias_s = par + tw.nblocks * PB;                                                    // [Cp] hidden bias of the block in flight
     unsigned int* qctr = reinterpret_cast<unsigned int*>(bias_s + tw.Cp);                      // ticket counter of the column loop
+    // this workgroup's partial-sum slots (one per slot set; 0: atomics) -- kept in LDS, not in registers: nothing of the
+    // small-gradient bookkeeping stays live across the hidden-column loop (as registers it cost the loop 2-10 VGPR spills)
+    unsigned long long* slotp = reinterpret_cast<unsigned long long*>(qctr + 4);
 
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, il = lane & 15;
     const int wave = tid >> 6;
@@ -95,6 +107,8 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
     const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
 
     TIMER_LSTART();
+    if (PART && threadIdx.x <= (unsigned)tw.nblocks)
+        slotp[threadIdx.x] = (unsigned long long)(part + ((long)threadIdx.x * nwg + wg) * SPP_STRIDE);
     constexpr int MAXB = (int)(sizeof(tw.blk) / sizeof(tw.blk[0]));       // blocks the descriptor type can hold
     // ---- prologue.  EVERY global load of the launch's start is requested before the first LDS write: the upstream gradient,
     //      the last block's x_mid rows and hidden bias (used by the first phase of the block loop), the small parameters of
@@ -187,22 +201,34 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
         }
         __syncthreads();
         if (tw.has_final_ln)
+        {
+            if constexpr (PART) {
+                float* sl = reinterpret_cast<float*>(slotp[0]);     // slot set 0: the final LayerNorm (written before the barrier above)
+                ln_backward_tile<D, false>(tw.x_final + row0 * D, R, tdy, tw.lnf_w, dxs, false, ta, sl + SPP_LNF(D), sl + SPP_LNF(D) + D, tid);
+            } else
             ln_backward_tile<D>(tw.x_final + row0 * D, R, tdy, tw.lnf_w, dxs, false, ta, tw.g_lnf_w, tw.g_lnf_b, tid);
+        }
     }
 
     TIMER_LMARK(0);       // parameters, upstream + final LN backward
     int pend = -1;        // block whose LayerNorm-1 parameter gradients are still to be column-summed (from t_prod / ub)
     // column sums of two tiles -> global atomics (gamma gradient from `pw`, beta gradient from `pb_`); rows >= R hold zeros
-    auto colsums = [&](const float* pw, const float* pb_, float* gw, float* gb, int t0) {
+    auto colsums = [&](const float* pw, const float* pb_, float* gw, float* gb, int t0, bool store = false) {
         _Pragma("unroll 1") for (int d = t0; d < 2 * D; d += NTHREADS) {
             const float* src = d < D ? pw : pb_;
             const int c = d < D ? d : d - D;
             float s_ = 0.f;
 #pragma unroll 4
             for (int r = 0; r < BM; ++r) s_ += src[r * XLD + c];
-            atomicAdd((d < D ? gw : gb) + c, s_);
+            if (store) (d < D ? gw : gb)[c] = s_;                 // gw / gb point into this workgroup's slot
+            else M2M_SMALL_ATOMIC((d < D ? gw : gb) + c, s_);
         }
     };
+    // Small parameter gradients without atomics (`part` != NULL): every workgroup STORES its partial sums into its own slot
+    // (split.h's layout; slot set 0 = the final LayerNorm, slot set nblocks - b = block b) and one reduction launch adds the
+    // slots to the gradients in a fixed order.  256 workgroups adding to the same ~3000 addresses ran at the contended-atomic
+    // rate: 16 us of the step's two backward launches (timing ablation M2M_ABL_NOATOM), and order-dependent sums.
+    auto slot_of = [&](int b) -> float* { return PART ? reinterpret_cast<float*>(slotp[tw.nblocks - b]) : nullptr; };
     for (int b = tw.nblocks - 1; b >= 0; --b) {
         const m2m_block& bk = tw.blk[b];
         const float* pb = par + b * PB;
@@ -244,7 +270,11 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
             }
             st_row<D>(ta + r * XLD, j, a);
             pack_row_nat<P, D>(at, r, j, a);
-            if (TOK && pend >= 0) colsums(t_prod, ub, tw.blk[pend].g_ln1_w, tw.blk[pend].g_ln1_b, tb1);
+            if (TOK && pend >= 0) {
+                float* sl = slot_of(pend);
+                if constexpr (PART) colsums(t_prod, ub, sl + SPP_LN1(D), sl + SPP_LN1(D) + D, tb1, true);
+                else colsums(t_prod, ub, tw.blk[pend].g_ln1_w, tw.blk[pend].g_ln1_b, tb1);
+            }
             if (tb1 == 0) *qctr = NWAVES;
 #pragma unroll
             for (int k = 0; k < BPT; ++k)
@@ -279,11 +309,13 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                     w2f[t][kb] = ld_frag_global_u(p_w2tn, (long)(2 * wave + t) * (D / Pr::KB) + kb, lane16_0);
                 }
         }
+        float* const sl_b2 = slot_of(b);
         _Pragma("unroll 1") for (int d = tb1; d < D; d += NTHREADS) {
             float s_ = 0.f;
 #pragma unroll 4
             for (int r = 0; r < BM; ++r) s_ += tdy[r * XLD + d];
-            atomicAdd(reinterpret_cast<float*>((char*)p_gb2) + d, s_);
+            if constexpr (PART) sl_b2[SPP_B2(D) + d] = s_;
+            else M2M_SMALL_ATOMIC(reinterpret_cast<float*>((char*)p_gb2) + d, s_);
         }
         pack_tile_chn_t<P, D>(tdy, (char*)p_dyt + pair_off, tile_in_pair, tb1);
         pack_tile_chn_t<P, D>(ta, (char*)p_atc + pair_off, tile_in_pair, tb1);
@@ -661,13 +693,13 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
         asm volatile("" : "+v"(tb3));
         const int lane3 = tb3 & 63;
         if constexpr (!TOK) {
-            colsums(t_prod, t_up, bk.g_ln2_w, bk.g_ln2_b, tb3);
+            { float* sl = slot_of(b); if constexpr (PART) colsums(t_prod, t_up, sl + SPP_LN2, sl + SPP_LN2 + D, tb3, true); else colsums(t_prod, t_up, bk.g_ln2_w, bk.g_ln2_b, tb3); }
         } else {
         // ================= token mixing backward =================
         const float* tokw = pb + O_TOKW;
         if constexpr (P == PREC_BF16) {
             token_bwd_mfma<D, NM, DM>(ub, dov, tokw, gtab, wth, red, N, ns, dr_th.scale, wave, lane3);
-            colsums(t_prod, t_up, bk.g_ln2_w, bk.g_ln2_b, tb3);
+            { float* sl = slot_of(b); if constexpr (PART) colsums(t_prod, t_up, sl + SPP_LN2, sl + SPP_LN2 + D, tb3, true); else colsums(t_prod, t_up, bk.g_ln2_w, bk.g_ln2_b, tb3); }
             __syncthreads();
             TIMER_LMARK(5);   // R2: token MLP backward (MFMA form) + LN2 column sums
             // sum the waves' partial token-weight gradients (layout: TokRed), ONE global atomic per value per workgroup
@@ -682,10 +714,12 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                 float v = 0.f;
 #pragma unroll
                 for (int w = 0; w < NWAVES; ++w) v += red[w * TokRed<NM>::LD + slot];
-                atomicAdd(dst, v);
+                float* sl = slot_of(b);
+                if constexpr (PART) sl[SPP_TOK(D) + i] = v;
+                else M2M_SMALL_ATOMIC(dst, v);
             }
         } else {
-            colsums(t_prod, t_up, bk.g_ln2_w, bk.g_ln2_b, tb3);
+            { float* sl = slot_of(b); if constexpr (PART) colsums(t_prod, t_up, sl + SPP_LN2, sl + SPP_LN2 + D, tb3, true); else colsums(t_prod, t_up, bk.g_ln2_w, bk.g_ln2_b, tb3); }
             constexpr int TTMAX = 32 / TG;                 // hidden units per lane (T <= 32)
             const int tg = tb3 % TG, pl = tb3 / TG;        // TG lanes share a column and split its T hidden units
             const int TT = T / TG;
@@ -804,7 +838,9 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                 float v = 0.f;
 #pragma unroll
                 for (int w = 0; w < NWAVES; ++w) v += red[w * RED_LD + slot];
-                atomicAdd(dst, v);
+                float* sl = slot_of(b);
+                if constexpr (PART) sl[SPP_TOK(D) + i] = v;
+                else M2M_SMALL_ATOMIC(dst, v);
             }
         }
         // (R3) LayerNorm-1 backward on the row thread's registers: dx_in = dx_mid + LN1'(dU); the sources of the LN1 parameter
@@ -853,7 +889,11 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
         __syncthreads();
         TIMER_LMARK(6);   // R3: token-gradient atomics, LN1 backward
     }
-    if (TOK && pend >= 0) colsums(t_prod, ub, tw.blk[pend].g_ln1_w, tw.blk[pend].g_ln1_b, tid);
+    if (TOK && pend >= 0) {
+        float* sl = slot_of(pend);
+        if constexpr (PART) colsums(t_prod, ub, sl + SPP_LN1(D), sl + SPP_LN1(D) + D, tid, true);
+        else colsums(t_prod, ub, tw.blk[pend].g_ln1_w, tw.blk[pend].g_ln1_b, tid);
+    }
 
     // ---- gradient wrt the tower input ----
     _Pragma("unroll 1") for (int idx = tid; idx < R * (D / 4); idx += NTHREADS) {
@@ -865,14 +905,14 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
     TIMER_LFLUSH(g_tm_bwd);
 }
 
-template <int P, int D, int NMAX, int TG, int DM>
+template <int P, int D, int NMAX, int TG, int DM, bool PART = false>
 __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw, int B, const float* __restrict__ d_out,
                                                              long d_out_ss, const float* __restrict__ d_pooled,
                                                              float* __restrict__ d_x0, long d_x0_ss, unsigned int seed,
                                                              unsigned int step_host, const unsigned int* __restrict__ step_dev) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    tower_bwd_body<m2m_tower, P, D, NMAX, TG, DM>(tw, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step_host, step_dev,
-                                                   blockIdx.x, gridDim.x, smem);
+    tower_bwd_body<m2m_tower, P, D, NMAX, TG, DM, PART>(tw, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step_host, step_dev,
+                                                         blockIdx.x, gridDim.x, smem, PART ? tw.gpart : nullptr);
 }
 
 // Two towers side by side in ONE launch (blockIdx.y = tower), see tower_fwd.hip.
@@ -884,9 +924,35 @@ struct BwdGroupArgs {
     float* d_x0[2];
     long d_x0_ss[2];
     int ntiles[2];
+    float* part[2];               // per-workgroup partial-sum slots of the small gradients (m2m_tower.gpart) or NULL: atomics
 };
 static_assert(sizeof(BwdGroupArgs) <= 3584, "kernel arguments are limited to 4 KiB");
-template <int P, int D, int NMAX, int TG, int DM>
+
+// Small parameter gradients (LayerNorms, token MLP, ch_b2) through per-workgroup slots + one reduction launch instead of float
+// atomics: fused-class towers whose descriptor carries the slot buffer (m2m_tower.gpart: the runtime allocates it for bf16,
+// hidden_dim 128).  Timing ablation without these atomics (M2M_ABL_NOATOM): fusion backward -9 us, two-tower backward -7 us --
+// 256 (128) workgroups add to the same ~3000 addresses.  With slots the single-tower launch (the fusion tower: 256-way
+// contention) nets -3 us including its reduction launch, and its small gradients no longer depend on the order of the atomics.
+// M2M_SMALL_PART=0 keeps the atomics everywhere.
+static bool m2m_small_part(const m2m_tower* t) {
+    static const int off = [] { const char* e = getenv("M2M_SMALL_PART"); return e && e[0] == '0'; }();
+    return !off && t->gpart != nullptr && !m2m_is_wide(t) && t->prec == PREC_BF16 && t->D == 128 && t->nblocks >= 1 &&
+           2 * t->T * t->N + t->T + t->N <= SPP_TOK_MAX;
+}
+static void m2m_small_part_reduce_args(SplitReduceTower& x, const m2m_tower* t, int nwg) {
+    memset(&x, 0, sizeof(x));
+    x.part = t->gpart; x.ntiles = nwg; x.nlaunch = t->nblocks + 1; x.D = t->D; x.N = t->N; x.T = t->T;
+    if (t->has_final_ln) { x.g_lnf_w = t->g_lnf_w; x.g_lnf_b = t->g_lnf_b; }
+    for (int b = 0; b < t->nblocks; ++b) {                   // slot set nblocks - b holds block b (tower_bwd_body::slot_of)
+        const int L = t->nblocks - b;
+        const m2m_block& k = t->blk[b];
+        x.g_ln2_w[L] = k.g_ln2_w; x.g_ln2_b[L] = k.g_ln2_b;
+        x.g_tok_w1[L] = k.g_tok_w1; x.g_tok_w2[L] = k.g_tok_w2; x.g_tok_b1[L] = k.g_tok_b1; x.g_tok_b2[L] = k.g_tok_b2;
+        x.g_ln1_w[L] = k.g_ln1_w; x.g_ln1_b[L] = k.g_ln1_b;
+        x.g_b2[L] = k.g_ch_b2;
+    }
+}
+template <int P, int D, int NMAX, int TG, int DM, bool PART = false>
 __global__ __launch_bounds__(NTHREADS) void tower_bwd_group_kernel(const BwdGroupArgs a, int B, unsigned int seed,
                                                                    unsigned int step_host, const unsigned int* __restrict__ step_dev) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -896,8 +962,8 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_group_kernel(const BwdGrou
     const int id = blockIdx.x, xcd = id & 7, t = xcd >> 2;
     const int wg = (id >> 3) * 4 + (xcd & 3);
     if (wg >= a.ntiles[t]) return;
-    tower_bwd_body<m2m_tower4, P, D, NMAX, TG, DM>(a.tw[t], B, a.d_out[t], a.d_out_ss[t], a.d_pooled[t], a.d_x0[t], a.d_x0_ss[t],
-                                                    seed, step_host, step_dev, wg, a.ntiles[t], smem);
+    tower_bwd_body<m2m_tower4, P, D, NMAX, TG, DM, PART>(a.tw[t], B, a.d_out[t], a.d_out_ss[t], a.d_pooled[t], a.d_x0[t], a.d_x0_ss[t],
+                                                          seed, step_host, step_dev, wg, a.ntiles[t], smem, PART ? a.part[t] : nullptr);
 }
 
 template <int P, int D, int NMAX, int TG>
@@ -912,11 +978,14 @@ static int launch_bwd_group_dm(const BwdGroupArgs& a, int B, unsigned int seed, 
         m2m_set_error("towers_backward: blocks x channel_dim exceed the workgroup's LDS", __FILE__, __LINE__);
         return -1;
     }
-    auto kern = tower_bwd_group_kernel<P, D, NMAX, TG, DM>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    constexpr bool CAN_PART = P == PREC_BF16 && D == 128 && NMAX > 0;      // (the slot form is built where the runtime allocates slots)
+    const bool part = CAN_PART && a.part[0] && a.part[1];
+    auto kern = tower_bwd_group_kernel<P, D, NMAX, TG, DM, false>;
+    if constexpr (CAN_PART) { if (part) kern = tower_bwd_group_kernel<P, D, NMAX, TG, DM, true>; }
+    static bool attr_done[2] = {false, false};
+    if (!attr_done[part]) {
         M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, M2M_LDS_MAX));
-        attr_done = true;
+        attr_done[part] = true;
     }
     const int mx = a.ntiles[0] > a.ntiles[1] ? a.ntiles[0] : a.ntiles[1];
     const int grid = 8 * ((mx + 3) / 4);                     // see the XCD-aware mapping in the kernel
@@ -941,14 +1010,24 @@ static int launch_bwd_dm(const m2m_tower* t, int B, const float* d_out, long d_o
     const int grid = NMAX > 0 ? (B + SPW - 1) / SPW : (int)(((long)B * t->N + BM - 1) / BM);
     const size_t lds = bwd_lds_bytes<P, D, NMAX, TG>(t->nblocks, t->N, t->Cp);
     if (lds > M2M_LDS_MAX || t->Cp > 8 * NTHREADS) { m2m_set_error("tower_backward: blocks x channel_dim exceed the workgroup's LDS", __FILE__, __LINE__); return -1; }
-    auto kern = tower_bwd_kernel<P, D, NMAX, TG, DM>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    constexpr bool CAN_PART = P == PREC_BF16 && D == 128 && NMAX > 0;
+    const bool part = CAN_PART && m2m_small_part(t);
+    auto kern = tower_bwd_kernel<P, D, NMAX, TG, DM, false>;
+    if constexpr (CAN_PART) { if (part) kern = tower_bwd_kernel<P, D, NMAX, TG, DM, true>; }
+    static bool attr_done[2] = {false, false};
+    if (!attr_done[part]) {
         M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, M2M_LDS_MAX));
-        attr_done = true;
+        attr_done[part] = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, st, *t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step, step_dev);
     M2M_CHECK_HIP(hipGetLastError());
+    if (part) {
+        SplitReduceArgs r;
+        memset(&r, 0, sizeof(r));
+        r.ntow = 1;
+        m2m_small_part_reduce_args(r.t[0], t, grid);
+        return m2m_split_small_grads(r, st);
+    }
     return 0;
 }
 
@@ -1005,13 +1084,26 @@ extern "C" int m2m_towers_backward(const m2m_tower* const* towers, const m2m_tow
         const int SPW = BM / towers[i]->N;
         a.ntiles[i] = (B + SPW - 1) / SPW;
     }
+    // (two-tower launch: measured a net LOSS -- the slot form of this instantiation spills 7 registers around the column loop
+    // and its reduction launch costs what the 128-way contended atomics cost -- so it stays opt-in: M2M_SMALL_PART=2)
+    static const bool group_part = [] { const char* e = getenv("M2M_SMALL_PART"); return e && e[0] == '2'; }();
+    const bool part = group_part && m2m_small_part(towers[0]) && m2m_small_part(towers[1]);
+    for (int i = 0; i < 2; ++i) a.part[i] = part ? towers[i]->gpart : nullptr;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const m2m_tower* t = towers[0];
+    auto finish = [&](int rc) -> int {
+        if (rc || !part) return rc;
+        SplitReduceArgs r;
+        memset(&r, 0, sizeof(r));
+        r.ntow = 2;
+        for (int i = 0; i < 2; ++i) m2m_small_part_reduce_args(r.t[i], towers[i], a.ntiles[i]);
+        return m2m_split_small_grads(r, st);
+    };
 #define M2M_BWDG_CASE(PP, DD) \
     if (t->prec == PP && t->D == DD) {                                                                          \
-        if (t->N <= 4) return launch_bwd_group<PP, DD, 4, 8>(a, B, seed, step, step_dev, st);                   \
-        if (t->T % 16 == 0) return launch_bwd_group<PP, DD, 8, 16>(a, B, seed, step, step_dev, st);             \
-        return launch_bwd_group<PP, DD, 8, 8>(a, B, seed, step, step_dev, st);                                  \
+        if (t->N <= 4) return finish(launch_bwd_group<PP, DD, 4, 8>(a, B, seed, step, step_dev, st));           \
+        if (t->T % 16 == 0) return finish(launch_bwd_group<PP, DD, 8, 16>(a, B, seed, step, step_dev, st));     \
+        return finish(launch_bwd_group<PP, DD, 8, 8>(a, B, seed, step, step_dev, st));                          \
     }
     M2M_BWDG_CASE(PREC_BF16, 32) M2M_BWDG_CASE(PREC_BF16, 64) M2M_BWDG_CASE(PREC_BF16, 128)
     M2M_BWDG_CASE(PREC_F32, 32) M2M_BWDG_CASE(PREC_F32, 64) M2M_BWDG_CASE(PREC_F32, 128)
