@@ -551,8 +551,8 @@ __global__ __launch_bounds__(NTHREADS) void split_mix_bwd_kernel(const SplitMixB
 // ---------------------------------------------------------------------------------------------------------------------------
 // sum of the per-workgroup partial sums of one backward pass into the gradient buffers (+=), deterministic order
 // ---------------------------------------------------------------------------------------------------------------------------
-#define SPR_COLS 64        // slot entries per workgroup
-#define SPR_GROUPS 16      // workgroup-tile groups summed in parallel, then through LDS
+#define SPR_COLS 32        // slot entries per workgroup
+#define SPR_GROUPS 32      // workgroup-tile groups summed in parallel, then through LDS (256 slots: 8 loads per thread, one batch)
 __global__ __launch_bounds__(SPR_COLS * SPR_GROUPS) void split_small_grads_kernel(const SplitReduceArgs a) {
     __shared__ float red[SPR_GROUPS][SPR_COLS + 1];
     const SplitReduceTower& tw = a.t[blockIdx.z];
