@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define M2M_ABI_VERSION 13
+#define M2M_ABI_VERSION 14
 #define M2M_MAX_BLOCKS 8      /* MixerBlocks per m2m_tower; longer towers are chained by the caller */
 #define M2M_ROWS_PER_WG 16    /* token rows one workgroup keeps on chip */
 
@@ -63,7 +63,9 @@ typedef struct m2m_block {
     void* at_chn;         /* LN2(x_mid)^T                    [pair][dt][lane]   i = d, k = m           (rows x D elements)  */
     void* dyt_chn;        /* d(channel MLP out)^T            [pair][dt][lane]   i = d, k = m                                */
     void* h_chn;          /* hidden activation^T (after GELU + dropout), i = c, k = m, rows x Cp elements.  bf16:
-                           * [ct / 2][pair][16-row half][lane][tile 2q: 4 elem | tile 2q+1: 4 elem]; fp32: [ct][pair][half][lane] */
+                           * [ct / 2][pair][16-row half][lane][tile 2q: 4 elem | tile 2q+1: 4 elem]; fp32: [ct][pair][half][lane].
+                           * Recompute form (m2m_wgrad_form() == 1): the SAME buffer holds the packed NAT image of LN2(x_mid),
+                           * [16-row tile][k-block][lane] 16 B -- the weight-gradient launch recomputes the hidden activation */
     void* dh_chn;         /* gradient wrt the hidden pre-activation ^T, same layout                                          */
 } m2m_block;
 
@@ -97,14 +99,23 @@ typedef struct m2m_tower {
      * same up to fp32 summation order.  slabs == NULL (or nsplit < 2) keeps the one-launch-per-tower path. */
     float* slabs;          /* nsplit x (B*N, D) fp32: partial results of the column-split launches                       */
     int32_t nsplit;        /* slabs the buffer has room for (the library uses up to 8)                                     */
-    int32_t reserved0;
+    int32_t wgrad_flags;   /* M2M_WGRAD_* (weight-gradient launches)                                                        */
     float* xres;           /* (B*N, D) fp32: residual / gradient stream carried between the launches                       */
     float* gpart;          /* (nblocks + 1) x ceil(B / (16 / N)) x M2M_SPLIT_GPART floats: per-workgroup partial sums of the small
                             * gradients (LayerNorms, token MLP, ch_b2), stored plainly and summed by one reduction launch --
                             * deterministic, and free of the same-address atomics of 256 workgroups                          */
     void* a_nat[M2M_MAX_BLOCKS];   /* per block: LN2(x_mid) as packed NAT blocks [16-row tile][k-block], rows padded to 16 */
     void* dy_nat[M2M_MAX_BLOCKS];  /* per block: d(channel MLP out) after its dropout mask, same layout                    */
+    /* ---- weight-gradient slot (optional) ---------------------------------------------------------------------------------
+     * per block 2 C D + C floats laid out [dW1 (C, D) | db1 (C) | dW2 (D, C)] (NULL: none).  With it -- and g_ch_w1 / g_ch_b1 /
+     * g_ch_w2 of every block lying back to back in that order, as in a flat gradient buffer -- m2m_towers_wgrad may split a
+     * tower with twice the rows of its neighbours into TWO row groups: group 0 writes the gradient, group 1 stores its partial
+     * sums here with plain stores (no atomics, no zero fill).  The caller adds the slot to the gradient: inside the optimizer
+     * (m2m_adam_step_ranges) or with m2m_wgrad_fold; m2m_wgrad_slot_groups says whether a launch will use it. */
+    float* wslot[M2M_MAX_BLOCKS];
 } m2m_tower;
+#define M2M_WGRAD_OVERWRITE 1 /* wgrad_flags: g_ch_w1 / g_ch_b1 / g_ch_w2 are WRITTEN ("="), not accumulated ("+="): the caller
+                               * neither zeroes nor accumulates them (the fused engines: one backward per optimizer step) */
 
 /* Patch embedding = Conv2d(Cin, D, (ph,pw), stride=(ph,pw)) + 'b c h w -> b (h w) c'
  * (reference: modules/mixer.py:143-146) or, with H = N, ph = 1, pw = W = K, the plain
@@ -204,9 +215,13 @@ typedef struct m2m_tower_gio {
 } m2m_tower_gio;
 int m2m_towers_backward(const m2m_tower* const* towers, const m2m_tower_gio* io, int ntowers, int B,
                         uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream);
-/* g_ch_w1, g_ch_b1, g_ch_w2 of every block: two contractions over all token rows, streaming the bf16 (fp32 in parity
- * mode) operands m2m_tower_backward stored.  seed / step are accepted for ABI symmetry (dropout is already applied). */
+/* g_ch_w1, g_ch_b1, g_ch_w2 of every block: two contractions over all token rows (reference arithmetic:
+ * modules/mixer.py:37-40 under autograd).  Two forms, chosen by the library per tower (m2m_wgrad_form):
+ *   0  stored operands: streams the bf16 (fp32 in parity mode) Hact^T / dHpre^T m2m_tower_backward stored;
+ *   1  recompute (bf16, hidden_dim 128, dropout off or p = 0.5): recomputes Hact from the packed image of LN2(x_mid) the
+ *      backward left in h_chn and streams only dHpre^T; needs the dropout stream: seed / step / step_dev as in the forward. */
 int m2m_tower_wgrad(const m2m_tower* t, int B, uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream);
+int m2m_wgrad_form(const m2m_tower* t, int B);
 /* The same for up to 4 towers (same precision and hidden_dim) in ONE launch: the towers of a model finish their backward
  * chains together, and one launch lets the hardware balance all their workgroups over the chip.  `dev_towers[i]` is a
  * device-resident byte copy of *towers[i] (kernel arguments are limited to 4 KiB; the caller refreshes the copy whenever
@@ -215,7 +230,14 @@ int m2m_tower_wgrad(const m2m_tower* t, int B, uint32_t seed, uint32_t step, con
  * as there) in extra workgroups that back-fill the CUs the tower workgroups leave idle; nembeds = 0: towers only. */
 int m2m_towers_wgrad(const m2m_tower* const* towers, const m2m_tower* const* dev_towers, int ntowers,
                      const m2m_embed* const* embeds, const float* const* inputs, const float* const* d_x0s, int nembeds,
-                     int B, void* stream);
+                     int B, uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream);
+/* row groups m2m_tower_wgrad / m2m_towers_wgrad would give this tower at batch B without M2M_WGRAD_OVERWRITE (1: every gradient
+ * element has a single owner; more: the groups add with float atomics -- such a tower must not set M2M_WGRAD_OVERWRITE) */
+int m2m_wgrad_groups(const m2m_tower* t, int B);
+/* bit i set: m2m_towers_wgrad on these towers at batch B leaves the second row group of tower i in its wslot */
+int m2m_wgrad_slot_groups(const m2m_tower* const* towers, int ntowers, int B);
+/* g_ch_w1 / g_ch_b1 / g_ch_w2 of every block += the tower's wslot (complete gradients before a data-parallel exchange) */
+int m2m_wgrad_fold(const m2m_tower* t, void* stream);
 /* g_w += d_x0^T patches(input), g_b += column sums of d_x0. */
 int m2m_embed_wgrad(const m2m_embed* e, const float* input, const float* d_x0, int B, void* stream);
 int m2m_embeds_wgrad(const m2m_embed* const* embeds, const float* const* inputs, const float* const* d_x0s, int nembeds, int B,
@@ -283,6 +305,17 @@ int m2m_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
 int m2m_adam_step_bf16(float* param, float* grad, const void* grad_bf16, float* exp_avg, float* exp_avg_sq, int64_t n,
                        float* state, float beta1, float beta2, float eps, float weight_decay,
                        float grad_scale, int bump_step, void* stream);
+
+/* m2m_adam_step / m2m_adam_step_bf16 with up to M2M_MAX_GRAD_RANGES special index ranges [lo, lo + n) of the flat buffers:
+ *   add  != NULL : the gradient of element i is grad[i] + add[i - lo] (a weight-gradient slot, m2m_tower.wslot; add + (i - lo)
+ *                  must be 16-byte aligned whenever i is a multiple of 4: allocate the slot with lo % 4 floats of lead padding);
+ *   keep != 0    : grad[i] is not cleared (the next backward overwrites it: M2M_WGRAD_OVERWRITE).
+ * `ranges` is a HOST array (copied into the kernel arguments); ranges must not overlap.  grad_bf16 may be NULL. */
+#define M2M_MAX_GRAD_RANGES 16
+typedef struct m2m_grad_range { int64_t lo, n; const float* add; int32_t keep; int32_t reserved; } m2m_grad_range;
+int m2m_adam_step_ranges(float* param, float* grad, const void* grad_bf16, float* exp_avg, float* exp_avg_sq, int64_t n,
+                         float* state, float beta1, float beta2, float eps, float weight_decay, float grad_scale, int bump_step,
+                         const m2m_grad_range* ranges, int nranges, void* stream);
 
 /* Adam + m2m_pack_all in ONE launch: the workgroups that update a channel-mixing weight tile (or an embedding weight) emit its
  * packed operand copies from the values they have just computed, so the re-pack does not re-read the fp32 masters; everything

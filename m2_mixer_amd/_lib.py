@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("M2M_LIB_PATH", os.path.join(_HERE, "libm2mixer.so"))   # override: diagnostic builds
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 MAX_BLOCKS = 8
 ROWS_PER_WG = 16
 HCHN_PAD = 4096          # >= the pad between operand streams the library uses (csrc/tile.h M2M_HCHN_PAD)
@@ -48,8 +48,19 @@ class Tower(C.Structure):
                 ("lnf_w", _fp), ("lnf_b", _fp), ("g_lnf_w", _fp), ("g_lnf_b", _fp), ("x_final", _fp),
                 ("ws_a", _fp), ("ws_b", _fp), ("blk", Block * MAX_BLOCKS),
                 # split path (csrc/split.h): slab buffer of the column-split launches, carry stream, per-block operand images
-                ("slabs", _fp), ("nsplit", C.c_int32), ("reserved0", C.c_int32), ("xres", _fp), ("gpart", _fp),
-                ("a_nat", _fp * MAX_BLOCKS), ("dy_nat", _fp * MAX_BLOCKS)]
+                ("slabs", _fp), ("nsplit", C.c_int32), ("wgrad_flags", C.c_int32), ("xres", _fp), ("gpart", _fp),
+                ("a_nat", _fp * MAX_BLOCKS), ("dy_nat", _fp * MAX_BLOCKS),
+                # weight-gradient slot: second row group of a long tower, folded in by the optimizer
+                ("wslot", _fp * MAX_BLOCKS)]
+
+
+WGRAD_OVERWRITE = 1      # Tower.wgrad_flags (M2M_WGRAD_OVERWRITE)
+MAX_GRAD_RANGES = 16
+
+
+class GradRange(C.Structure):
+    """m2m_grad_range"""
+    _fields_ = [("lo", C.c_int64), ("n", C.c_int64), ("add", _fp), ("keep", C.c_int32), ("reserved", C.c_int32)]
 
 
 class TowerIO(C.Structure):
@@ -112,7 +123,13 @@ SIGNATURES = {
     "m2m_towers_backward": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.POINTER(TowerGIO), C.c_int, C.c_int, C.c_uint32, C.c_uint32,
                                       _fp, _fp]),
     "m2m_towers_wgrad": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.POINTER(_fp), C.c_int, C.POINTER(C.POINTER(Embed)), C.POINTER(_fp),
-                                   C.POINTER(_fp), C.c_int, C.c_int, _fp]),
+                                   C.POINTER(_fp), C.c_int, C.c_int, C.c_uint32, C.c_uint32, _fp, _fp]),
+    "m2m_wgrad_form": (C.c_int, [C.POINTER(Tower), C.c_int]),
+    "m2m_wgrad_groups": (C.c_int, [C.POINTER(Tower), C.c_int]),
+    "m2m_wgrad_slot_groups": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.c_int, C.c_int]),
+    "m2m_wgrad_fold": (C.c_int, [C.POINTER(Tower), _fp]),
+    "m2m_adam_step_ranges": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int64, _fp, C.c_float, C.c_float, C.c_float, C.c_float,
+                                       C.c_float, C.c_int, C.POINTER(GradRange), C.c_int, _fp]),
     "m2m_counter_add": (C.c_int, [_fp, C.c_uint32, _fp]),
     "m2m_embed_wgrad": (C.c_int, [C.POINTER(Embed), _fp, _fp, C.c_int, _fp]),
     "m2m_embeds_wgrad": (C.c_int, [C.POINTER(C.POINTER(Embed)), C.POINTER(_fp), C.POINTER(_fp), C.c_int, C.c_int, _fp]),

@@ -335,58 +335,167 @@ __global__ void adam_bump_kernel(float* state) { state[0] += 1.0f; }
 // zeroed gradients without a separate fill pass (|gscale| is the scale).
 // LOWP: the gradient VALUE comes from a bf16 copy (the all-reduced, compressed gradient of the data-parallel step: no pass
 // to widen it back); the fp32 gradient buffer is only cleared.
+// Ranges (m2m_adam_step_ranges): inside [lo, lo + n) the gradient is grad[i] + add[i - lo] (a weight-gradient slot) and / or is
+// not cleared (keep: the next backward overwrites it).  A workgroup walks 1024-element chunks (256 threads x 16 bytes); the
+// range a chunk lies in is a wave-uniform decision, chunks that straddle a range boundary (a handful) go element by element.
+struct AdamRanges {
+    int n;
+    long lo[M2M_MAX_GRAD_RANGES], hi[M2M_MAX_GRAD_RANGES];
+    const float* add[M2M_MAX_GRAD_RANGES];
+    int keep[M2M_MAX_GRAD_RANGES];
+};
+struct AdamK { float b1, b2, eps, wd, gscale, step_size, inv_sqrt_bc2; };
+static __device__ __forceinline__ void adam_one(const AdamK& k, float g, float& p, float& m, float& v) {
+    g *= k.gscale;
+    if (k.wd != 0.f) g = __builtin_fmaf(k.wd, p, g);
+    m = k.b1 * m + (1.0f - k.b1) * g;
+    v = k.b2 * v + (1.0f - k.b2) * g * g;
+    const float denom = sqrtf(v) * k.inv_sqrt_bc2 + k.eps;
+    p = p - k.step_size * (m / denom);
+}
 template <bool LOWP>
-__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ gr, const unsigned short* __restrict__ gb,
-                            float* __restrict__ m, float* __restrict__ v, long n, const float* __restrict__ state, float b1,
-                            float b2, float eps, float wd, float gscale_in) {
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ gr, const unsigned short* __restrict__ gb,
+                                                   float* __restrict__ m, float* __restrict__ v, long n, const float* __restrict__ state,
+                                                   float b1, float b2, float eps, float wd, float gscale_in, const AdamRanges rg) {
     const bool consume = gscale_in < 0.f;
-    const float gscale = consume ? -gscale_in : gscale_in;
     const float stepf = state[0], lr = state[1];
     const float bc1 = 1.0f - powf(b1, stepf);
     const float bc2 = 1.0f - powf(b2, stepf);
-    const float step_size = lr / bc1;
-    const float inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        float g = (LOWP ? __uint_as_float((unsigned int)gb[i] << 16) : gr[i]) * gscale;
-        if (consume) gr[i] = 0.f;
-        const float pv = p[i];
-        if (wd != 0.f) g = __builtin_fmaf(wd, pv, g);
-        const float mi = b1 * m[i] + (1.0f - b1) * g;
-        const float vi = b2 * v[i] + (1.0f - b2) * g * g;
-        m[i] = mi;
-        v[i] = vi;
-        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
-        p[i] = pv - step_size * (mi / denom);
+    AdamK k;
+    k.b1 = b1; k.b2 = b2; k.eps = eps; k.wd = wd;
+    k.gscale = consume ? -gscale_in : gscale_in;
+    k.step_size = lr / bc1;
+    k.inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+    // (the flat buffers are 16-byte aligned at element 0 or the host takes the scalar entry: adam_launch)
+    const long nchunks = (n + 1023) >> 10;
+    for (long ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        const long c0 = ch << 10, c1 = min(c0 + 1024, n);
+        // classify the chunk: -1 outside every range, r >= 0 wholly inside range r, -2 straddling
+        int cls = -1;
+        for (int r = 0; r < rg.n; ++r) {
+            if (c0 >= rg.lo[r] && c1 <= rg.hi[r]) { cls = r; break; }
+            if (c0 < rg.hi[r] && c1 > rg.lo[r]) { cls = -2; break; }
+        }
+        const long i = c0 + 4 * (long)threadIdx.x;
+        if (cls != -2 && c1 - c0 == 1024) {
+            const float4 pv4 = *reinterpret_cast<const float4*>(p + i);
+            const float4 mv4 = *reinterpret_cast<const float4*>(m + i);
+            const float4 vv4 = *reinterpret_cast<const float4*>(v + i);
+            float g[4];
+            if (LOWP) {
+                const uint2 q = *reinterpret_cast<const uint2*>(gb + i);
+                g[0] = __uint_as_float(q.x << 16); g[1] = __uint_as_float(q.x & 0xFFFF0000u);
+                g[2] = __uint_as_float(q.y << 16); g[3] = __uint_as_float(q.y & 0xFFFF0000u);
+            } else {
+                const float4 q = *reinterpret_cast<const float4*>(gr + i);
+                g[0] = q.x; g[1] = q.y; g[2] = q.z; g[3] = q.w;
+            }
+            bool keep = false;
+            if (cls >= 0) {
+                keep = rg.keep[cls] != 0;
+                if (rg.add[cls]) {
+                    const float4 a = *reinterpret_cast<const float4*>(rg.add[cls] + (i - rg.lo[cls]));
+                    g[0] += a.x; g[1] += a.y; g[2] += a.z; g[3] += a.w;
+                }
+            }
+            float pp[4] = {pv4.x, pv4.y, pv4.z, pv4.w}, mm[4] = {mv4.x, mv4.y, mv4.z, mv4.w}, vv[4] = {vv4.x, vv4.y, vv4.z, vv4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) adam_one(k, g[e], pp[e], mm[e], vv[e]);
+            if (consume && !keep) *reinterpret_cast<float4*>(gr + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(m + i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+            *reinterpret_cast<float4*>(v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            *reinterpret_cast<float4*>(p + i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        } else {
+            for (long e = i; e < min(i + 4, c1); ++e) {
+                float g = LOWP ? __uint_as_float((unsigned int)gb[e] << 16) : gr[e];
+                bool keep = false;
+                for (int r = 0; r < rg.n; ++r)
+                    if (e >= rg.lo[r] && e < rg.hi[r]) {
+                        keep = rg.keep[r] != 0;
+                        if (rg.add[r]) g += rg.add[r][e - rg.lo[r]];
+                    }
+                float pp = p[e], mm = m[e], vv = v[e];
+                adam_one(k, g, pp, mm, vv);
+                if (consume && !keep) gr[e] = 0.f;
+                m[e] = mm; v[e] = vv; p[e] = pp;
+            }
+        }
     }
 }
 
 static int adam_launch(float* param, float* grad, const void* grad_bf16, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
-                       float beta1, float beta2, float eps, float weight_decay, float grad_scale, int bump_step, void* stream) {
+                       float beta1, float beta2, float eps, float weight_decay, float grad_scale, int bump_step,
+                       const m2m_grad_range* ranges, int nranges, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (bump_step) hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, st, state);
     if (n <= 0) return 0;
-    const int threads = 256;
-    long grid = ceil_div(n, threads);
-    if (grid > 2048) grid = 2048;
+    if (nranges < 0 || nranges > M2M_MAX_GRAD_RANGES || (nranges > 0 && !ranges)) { m2m_set_error("adam_step: bad ranges", __FILE__, __LINE__); return -1; }
+    // the 16-byte accesses of the kernel need every buffer aligned at element 0 (segments of the flat buffers that start at an
+    // odd element are walked with a scalar head: shift the range so that the vector body is aligned)
+    const uintptr_t al = (uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq;
+    long head = 0;
+    if (al & 15) {
+        // all four share the misalignment when they are same-offset slices of aligned flat buffers
+        const uintptr_t mis = (uintptr_t)param & 15;
+        if (((uintptr_t)grad & 15) != mis || ((uintptr_t)exp_avg & 15) != mis || ((uintptr_t)exp_avg_sq & 15) != mis || (mis & 3) ||
+            (grad_bf16 && (((uintptr_t)grad_bf16 & 7) != (mis >> 1)))) {
+            m2m_set_error("adam_step: parameter / gradient / moment buffers must share their 16-byte phase", __FILE__, __LINE__);
+            return -1;
+        }
+        head = (long)((16 - mis) >> 2);
+        if (head > n) head = (long)n;
+    } else if (grad_bf16 && ((uintptr_t)grad_bf16 & 7)) {
+        m2m_set_error("adam_step_bf16: the bf16 gradient must be 8-byte aligned where the fp32 buffers are 16-byte aligned", __FILE__, __LINE__);
+        return -1;
+    }
+    AdamRanges rg;
+    memset(&rg, 0, sizeof(rg));
+    rg.n = nranges;
+    for (int r = 0; r < nranges; ++r) {
+        if (ranges[r].lo < 0 || ranges[r].n < 0 || ranges[r].lo + ranges[r].n > n) { m2m_set_error("adam_step_ranges: range outside the buffers", __FILE__, __LINE__); return -1; }
+        rg.lo[r] = (long)ranges[r].lo - head; rg.hi[r] = (long)(ranges[r].lo + ranges[r].n) - head;
+        rg.add[r] = ranges[r].add; rg.keep[r] = ranges[r].keep;
+        // vector loads of add[i - lo] at i % 4 == 0 (relative to the aligned body): add - lo must be 16-byte aligned
+        if (rg.add[r] && (((uintptr_t)rg.add[r] - (uintptr_t)(rg.lo[r] * 4)) & 15)) {
+            m2m_set_error("adam_step_ranges: `add` must have the 16-byte phase of its range (lead-pad the slot by lo % 4 floats)", __FILE__, __LINE__);
+            return -1;
+        }
+    }
     const unsigned short* gb = reinterpret_cast<const unsigned short*>(grad_bf16);
-    if (gb) hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)grid), dim3(threads), 0, st, param, grad, gb, exp_avg, exp_avg_sq,
-                               (long)n, state, beta1, beta2, eps, weight_decay, grad_scale);
-    else hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)grid), dim3(threads), 0, st, param, grad, gb, exp_avg, exp_avg_sq,
-                            (long)n, state, beta1, beta2, eps, weight_decay, grad_scale);
+    auto launch = [&](float* p_, float* g_, const unsigned short* gb_, float* m_, float* v_, long n_, const AdamRanges& r_) {
+        long grid = ceil_div(n_, 1024);
+        if (grid > 2048) grid = 2048;
+        if (gb_) hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, p_, g_, gb_, m_, v_, n_, state, beta1, beta2, eps,
+                                    weight_decay, grad_scale, r_);
+        else hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, p_, g_, gb_, m_, v_, n_, state, beta1, beta2, eps,
+                                weight_decay, grad_scale, r_);
+    };
+    if (head > 0) {
+        // scalar head: a 1-chunk launch whose only chunk is shorter than 1024 elements goes element by element
+        AdamRanges rh = rg;
+        for (int r = 0; r < rh.n; ++r) { rh.lo[r] += head; rh.hi[r] += head; }
+        launch(param, grad, gb, exp_avg, exp_avg_sq, head, rh);
+    }
+    if (n - head > 0)
+        launch(param + head, grad + head, gb ? gb + head : nullptr, exp_avg + head, exp_avg_sq + head, (long)n - head, rg);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
 }
 extern "C" int m2m_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
                              float beta1, float beta2, float eps, float weight_decay, float grad_scale, int bump_step,
                              void* stream) {
-    return adam_launch(param, grad, nullptr, exp_avg, exp_avg_sq, n, state, beta1, beta2, eps, weight_decay, grad_scale, bump_step, stream);
+    return adam_launch(param, grad, nullptr, exp_avg, exp_avg_sq, n, state, beta1, beta2, eps, weight_decay, grad_scale, bump_step, nullptr, 0, stream);
 }
 extern "C" int m2m_adam_step_bf16(float* param, float* grad, const void* grad_bf16, float* exp_avg, float* exp_avg_sq, int64_t n,
                                   float* state, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                                   int bump_step, void* stream) {
     if (!grad_bf16) { m2m_set_error("adam_step_bf16: null bf16 gradient", __FILE__, __LINE__); return -1; }
-    return adam_launch(param, grad, grad_bf16, exp_avg, exp_avg_sq, n, state, beta1, beta2, eps, weight_decay, grad_scale, bump_step, stream);
+    return adam_launch(param, grad, grad_bf16, exp_avg, exp_avg_sq, n, state, beta1, beta2, eps, weight_decay, grad_scale, bump_step, nullptr, 0, stream);
+}
+extern "C" int m2m_adam_step_ranges(float* param, float* grad, const void* grad_bf16, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                    float* state, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                                    int bump_step, const m2m_grad_range* ranges, int nranges, void* stream) {
+    return adam_launch(param, grad, grad_bf16, exp_avg, exp_avg_sq, n, state, beta1, beta2, eps, weight_decay, grad_scale, bump_step, ranges, nranges, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -131,6 +131,10 @@ static inline m2m_tower4 m2m_shrink(const m2m_tower* t) { m2m_tower4 r; memcpy(&
 
 // Which execution path a tower takes (see include/m2mixer.h): fused = whole samples per workgroup.
 static inline bool m2m_is_wide(const m2m_tower* t) { return t->N > 8 || t->D > 128; }
+// Form of the channel-mixing weight gradients of a tower at batch B (tower_wgrad.hip).  true: the weight-gradient launch
+// recomputes the hidden activation from the packed image of A = LN2(x_mid) that the backward chain leaves in
+// m2m_block.h_chn (tower_bwd_body<HREC>), and only dHpre^T is streamed; false: both hidden operands are stored and streamed.
+bool m2m_wgrad_recompute(const m2m_tower* t, int B);
 
 template <int D> struct TileGeom {
     static constexpr int XLD = D + 4;          // padded fp32 row stride (floats)

@@ -51,7 +51,10 @@ TIMER_READER(m2m_debug_timers_bwd, g_tm_bwd)
 
 // One workgroup's share of a tower backward: token tile `wg` of `nwg`.  TW is m2m_tower (single-tower launch) or
 // m2m_tower4 (the by-value descriptors of a two-tower launch).
-template <class TW, int P, int D, int NMAX, int TG, int DM, bool PART = false>
+// HREC: the weight-gradient launch recomputes the hidden activation itself (tower_wgrad_rc.h): this kernel then stores the packed
+// NAT image of A = LN2(x_mid) where Hact^T would have gone (m2m_block.h_chn) and keeps only the dHpre^T stream -- half the
+// operand spill, two of the four transposing MFMAs and one of the two streaming stores per step less.
+template <class TW, int P, int D, int NMAX, int TG, int DM, bool PART = false, bool HREC = false>
 static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const float* __restrict__ d_out, long d_out_ss,
                                                       const float* __restrict__ d_pooled, float* __restrict__ d_x0, long d_x0_ss,
                                                       unsigned int seed, unsigned int step_host,
@@ -319,6 +322,12 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
         }
         pack_tile_chn_t<P, D>(tdy, (char*)p_dyt + pair_off, tile_in_pair, tb1);
         pack_tile_chn_t<P, D>(ta, (char*)p_atc + pair_off, tile_in_pair, tb1);
+        if constexpr (HREC) {
+            // the packed NAT image of A (this workgroup's 16 rows: [kb][lane] 16 B), straight from LDS: the first operand of
+            // the weight-gradient launch's recompute of Hpre = A W1^T
+            if (tb1 < IMG_B / 16)
+                *reinterpret_cast<M2M_AS1 u32x4_t*>(p_h + (long)wg * IMG_B + tb1 * 16) = *reinterpret_cast<const u32x4_t*>(at + tb1 * 16);
+        }
 
         // (C3) hidden-column loop
         f32x4_t dacc[MT][DT];
@@ -505,7 +514,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                     }
                 }
                 Chain<P>::make(gacc[mt][0], gacc[mt][1], hf[mt]);     // dHpre: operand of dA += dHpre W1
-                Chain<P>::make(hacc[mt][0], hacc[mt][1], af[mt]);     // Hact : only stored, for the weight gradients
+                if constexpr (!HREC) Chain<P>::make(hacc[mt][0], hacc[mt][1], af[mt]);     // Hact : only stored, for the weight gradients
             }
             // Operands of the weight-gradient pass: dHpre^T and Hact^T with k = token row.  The accumulators hold
             // [c in registers][m across lanes]; an MFMA against an identity block turns them ([m][c] as the A operand,
@@ -529,12 +538,12 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
                         const s16x4 id16 = __builtin_bit_cast(s16x4, u32x2{id_a, id_b});
                         od[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, u32x2{hf[mt][0].u[2 * t], hf[mt][0].u[2 * t + 1]}), id16, od[t], 0, 0, 0);
-                        oa[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, u32x2{af[mt][0].u[2 * t], af[mt][0].u[2 * t + 1]}), id16, oa[t], 0, 0, 0);
+                        if constexpr (!HREC) oa[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, u32x2{af[mt][0].u[2 * t], af[mt][0].u[2 * t + 1]}), id16, oa[t], 0, 0, 0);
                     } else {
                         Frag id;
                         id.f = f32x4_t{4 * g + 0 == il ? 1.f : 0.f, 4 * g + 1 == il ? 1.f : 0.f, 4 * g + 2 == il ? 1.f : 0.f, 4 * g + 3 == il ? 1.f : 0.f};
                         Pr::mma(od[t], hf[mt][t], id);
-                        Pr::mma(oa[t], af[mt][t], id);
+                        if constexpr (!HREC) Pr::mma(oa[t], af[mt][t], id);
                     }
                     // od[t][r] = dHpre[m = 16u + 4g + r][c = 32q + 16t + il]
                 }
@@ -554,14 +563,13 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
 #endif
                     const u32x4_t sd = u32x4_t{pack_bf2(od[0][0], od[0][1]), pack_bf2(od[0][2], od[0][3]),
                                                pack_bf2(od[1][0], od[1][1]), pack_bf2(od[1][2], od[1][3])};
-                    const u32x4_t sa = u32x4_t{pack_bf2(oa[0][0], oa[0][1]), pack_bf2(oa[0][2], oa[0][3]),
-                                               pack_bf2(oa[1][0], oa[1][1]), pack_bf2(oa[1][2], oa[1][3])};
-                    if (M2M_ST_NT) {
-                        __builtin_nontemporal_store(sd, reinterpret_cast<M2M_AS1 u32x4_t*>(p_dh + off));
-                        __builtin_nontemporal_store(sa, reinterpret_cast<M2M_AS1 u32x4_t*>(p_h + off));
-                    } else {
-                        *reinterpret_cast<M2M_AS1 u32x4_t*>(p_dh + off) = sd;
-                        *reinterpret_cast<M2M_AS1 u32x4_t*>(p_h + off) = sa;
+                    if (M2M_ST_NT) __builtin_nontemporal_store(sd, reinterpret_cast<M2M_AS1 u32x4_t*>(p_dh + off));
+                    else *reinterpret_cast<M2M_AS1 u32x4_t*>(p_dh + off) = sd;
+                    if constexpr (!HREC) {
+                        const u32x4_t sa = u32x4_t{pack_bf2(oa[0][0], oa[0][1]), pack_bf2(oa[0][2], oa[0][3]),
+                                                   pack_bf2(oa[1][0], oa[1][1]), pack_bf2(oa[1][2], oa[1][3])};
+                        if (M2M_ST_NT) __builtin_nontemporal_store(sa, reinterpret_cast<M2M_AS1 u32x4_t*>(p_h + off));
+                        else *reinterpret_cast<M2M_AS1 u32x4_t*>(p_h + off) = sa;
                     }
                 } else {
                     // fp32: a 16-row half is a whole k-block: [column tile][32-row pair][half][lane][16 bytes]
@@ -569,7 +577,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                     for (int t = 0; t < 2; ++t) {
                         const long off = (long)(2 * q + t) * m2m_hchn_stride(npair) + (pair * 2 + u) * 1024 + lane * 16;
                         __builtin_nontemporal_store(od[t], reinterpret_cast<M2M_AS1 f32x4_t*>(p_dh + off));
-                        __builtin_nontemporal_store(oa[t], reinterpret_cast<M2M_AS1 f32x4_t*>(p_h + off));
+                        if constexpr (!HREC) __builtin_nontemporal_store(oa[t], reinterpret_cast<M2M_AS1 f32x4_t*>(p_h + off));
                     }
                 }
             }
@@ -905,14 +913,14 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
     TIMER_LFLUSH(g_tm_bwd);
 }
 
-template <int P, int D, int NMAX, int TG, int DM, bool PART = false>
+template <int P, int D, int NMAX, int TG, int DM, bool PART = false, bool HREC = false>
 __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw, int B, const float* __restrict__ d_out,
                                                              long d_out_ss, const float* __restrict__ d_pooled,
                                                              float* __restrict__ d_x0, long d_x0_ss, unsigned int seed,
                                                              unsigned int step_host, const unsigned int* __restrict__ step_dev) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    tower_bwd_body<m2m_tower, P, D, NMAX, TG, DM, PART>(tw, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step_host, step_dev,
-                                                         blockIdx.x, gridDim.x, smem, PART ? tw.gpart : nullptr);
+    tower_bwd_body<m2m_tower, P, D, NMAX, TG, DM, PART, HREC>(tw, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step_host, step_dev,
+                                                               blockIdx.x, gridDim.x, smem, PART ? tw.gpart : nullptr);
 }
 
 // Two towers side by side in ONE launch (blockIdx.y = tower), see tower_fwd.hip.
@@ -952,7 +960,7 @@ static void m2m_small_part_reduce_args(SplitReduceTower& x, const m2m_tower* t, 
         x.g_b2[L] = k.g_ch_b2;
     }
 }
-template <int P, int D, int NMAX, int TG, int DM, bool PART = false>
+template <int P, int D, int NMAX, int TG, int DM, bool PART = false, bool HREC = false>
 __global__ __launch_bounds__(NTHREADS) void tower_bwd_group_kernel(const BwdGroupArgs a, int B, unsigned int seed,
                                                                    unsigned int step_host, const unsigned int* __restrict__ step_dev) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -962,8 +970,8 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_group_kernel(const BwdGrou
     const int id = blockIdx.x, xcd = id & 7, t = xcd >> 2;
     const int wg = (id >> 3) * 4 + (xcd & 3);
     if (wg >= a.ntiles[t]) return;
-    tower_bwd_body<m2m_tower4, P, D, NMAX, TG, DM, PART>(a.tw[t], B, a.d_out[t], a.d_out_ss[t], a.d_pooled[t], a.d_x0[t], a.d_x0_ss[t],
-                                                          seed, step_host, step_dev, wg, a.ntiles[t], smem, PART ? a.part[t] : nullptr);
+    tower_bwd_body<m2m_tower4, P, D, NMAX, TG, DM, PART, HREC>(a.tw[t], B, a.d_out[t], a.d_out_ss[t], a.d_pooled[t], a.d_x0[t], a.d_x0_ss[t],
+                                                                seed, step_host, step_dev, wg, a.ntiles[t], smem, PART ? a.part[t] : nullptr);
 }
 
 template <int P, int D, int NMAX, int TG>
@@ -971,7 +979,7 @@ static size_t bwd_lds_bytes(int nblocks, int N, int Cp) { return BwdLds<P, D, NM
 
 template <int P, int D, int NMAX, int TG, int DM>
 static int launch_bwd_group_dm(const BwdGroupArgs& a, int B, unsigned int seed, unsigned int step, const unsigned int* step_dev,
-                               hipStream_t st) {
+                               hipStream_t st, bool hrec_req) {
     const size_t lds = std::max(bwd_lds_bytes<P, D, NMAX, TG>(a.tw[0].nblocks, a.tw[0].N, a.tw[0].Cp),
                                 bwd_lds_bytes<P, D, NMAX, TG>(a.tw[1].nblocks, a.tw[1].N, a.tw[1].Cp));
     if (lds > M2M_LDS_MAX || a.tw[0].Cp > 8 * NTHREADS || a.tw[1].Cp > 8 * NTHREADS) {
@@ -980,12 +988,19 @@ static int launch_bwd_group_dm(const BwdGroupArgs& a, int B, unsigned int seed, 
     }
     constexpr bool CAN_PART = P == PREC_BF16 && D == 128 && NMAX > 0;      // (the slot form is built where the runtime allocates slots)
     const bool part = CAN_PART && a.part[0] && a.part[1];
-    auto kern = tower_bwd_group_kernel<P, D, NMAX, TG, DM, false>;
-    if constexpr (CAN_PART) { if (part) kern = tower_bwd_group_kernel<P, D, NMAX, TG, DM, true>; }
-    static bool attr_done[2] = {false, false};
-    if (!attr_done[part]) {
+    constexpr bool CAN_HREC = P == PREC_BF16 && D == 128 && DM != DM_GEN;   // (m2m_wgrad_recompute's instantiations)
+    const bool hrec = CAN_HREC && hrec_req;
+    if (hrec_req && !CAN_HREC) { m2m_set_error("towers_backward: recompute form requested for an instantiation without it", __FILE__, __LINE__); return -1; }
+    auto kern = tower_bwd_group_kernel<P, D, NMAX, TG, DM, false, false>;
+    if constexpr (CAN_PART) { if (part) kern = tower_bwd_group_kernel<P, D, NMAX, TG, DM, true, false>; }
+    if constexpr (CAN_HREC) {
+        if (hrec) kern = tower_bwd_group_kernel<P, D, NMAX, TG, DM, false, true>;
+        if constexpr (CAN_PART) { if (hrec && part) kern = tower_bwd_group_kernel<P, D, NMAX, TG, DM, true, true>; }
+    }
+    static bool attr_done[4] = {false, false, false, false};
+    if (!attr_done[part + 2 * hrec]) {
         M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, M2M_LDS_MAX));
-        attr_done[part] = true;
+        attr_done[part + 2 * hrec] = true;
     }
     const int mx = a.ntiles[0] > a.ntiles[1] ? a.ntiles[0] : a.ntiles[1];
     const int grid = 8 * ((mx + 3) / 4);                     // see the XCD-aware mapping in the kernel
@@ -995,11 +1010,11 @@ static int launch_bwd_group_dm(const BwdGroupArgs& a, int B, unsigned int seed, 
 }
 template <int P, int D, int NMAX, int TG>
 static int launch_bwd_group(const BwdGroupArgs& a, int B, unsigned int seed, unsigned int step, const unsigned int* step_dev,
-                            hipStream_t st) {
+                            hipStream_t st, bool hrec) {
     switch (m2m_drop_mode(1, a.tw[0].p_drop)) {
-        case DM_NONE: return launch_bwd_group_dm<P, D, NMAX, TG, DM_NONE>(a, B, seed, step, step_dev, st);
-        case DM_HALF: return launch_bwd_group_dm<P, D, NMAX, TG, DM_HALF>(a, B, seed, step, step_dev, st);
-        default:      return launch_bwd_group_dm<P, D, NMAX, TG, DM_GEN>(a, B, seed, step, step_dev, st);
+        case DM_NONE: return launch_bwd_group_dm<P, D, NMAX, TG, DM_NONE>(a, B, seed, step, step_dev, st, hrec);
+        case DM_HALF: return launch_bwd_group_dm<P, D, NMAX, TG, DM_HALF>(a, B, seed, step, step_dev, st, hrec);
+        default:      return launch_bwd_group_dm<P, D, NMAX, TG, DM_GEN>(a, B, seed, step, step_dev, st, hrec);
     }
 }
 
@@ -1012,12 +1027,18 @@ static int launch_bwd_dm(const m2m_tower* t, int B, const float* d_out, long d_o
     if (lds > M2M_LDS_MAX || t->Cp > 8 * NTHREADS) { m2m_set_error("tower_backward: blocks x channel_dim exceed the workgroup's LDS", __FILE__, __LINE__); return -1; }
     constexpr bool CAN_PART = P == PREC_BF16 && D == 128 && NMAX > 0;
     const bool part = CAN_PART && m2m_small_part(t);
-    auto kern = tower_bwd_kernel<P, D, NMAX, TG, DM, false>;
-    if constexpr (CAN_PART) { if (part) kern = tower_bwd_kernel<P, D, NMAX, TG, DM, true>; }
-    static bool attr_done[2] = {false, false};
-    if (!attr_done[part]) {
+    constexpr bool CAN_HREC = P == PREC_BF16 && D == 128 && DM != DM_GEN;
+    const bool hrec = CAN_HREC && m2m_wgrad_recompute(t, B);
+    auto kern = tower_bwd_kernel<P, D, NMAX, TG, DM, false, false>;
+    if constexpr (CAN_PART) { if (part) kern = tower_bwd_kernel<P, D, NMAX, TG, DM, true, false>; }
+    if constexpr (CAN_HREC) {
+        if (hrec) kern = tower_bwd_kernel<P, D, NMAX, TG, DM, false, true>;
+        if constexpr (CAN_PART) { if (hrec && part) kern = tower_bwd_kernel<P, D, NMAX, TG, DM, true, true>; }
+    }
+    static bool attr_done[4] = {false, false, false, false};
+    if (!attr_done[part + 2 * hrec]) {
         M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, M2M_LDS_MAX));
-        attr_done[part] = true;
+        attr_done[part + 2 * hrec] = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, st, *t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step, step_dev);
     M2M_CHECK_HIP(hipGetLastError());
@@ -1042,6 +1063,7 @@ static int launch_bwd(const m2m_tower* t, int B, const float* d_out, long d_out_
 }
 
 int m2m_check_tower(const m2m_tower* t, int B);
+bool m2m_wgrad_recompute(const m2m_tower* t, int B);     // tower_wgrad.hip
 int m2m_backward_wide(const m2m_tower* t, int B, const float* d_out, long d_out_ss, const float* d_pooled, float* d_x0,
                       long d_x0_ss, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st);
 
@@ -1091,6 +1113,13 @@ extern "C" int m2m_towers_backward(const m2m_tower* const* towers, const m2m_tow
     for (int i = 0; i < 2; ++i) a.part[i] = part ? towers[i]->gpart : nullptr;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const m2m_tower* t = towers[0];
+    // both towers share precision, hidden_dim and dropout (m2m_can_group): the weight-gradient form follows from those and
+    // from the split-path eligibility, which sent both towers down the split path above or neither
+    const bool hrec = m2m_wgrad_recompute(towers[0], B) && m2m_wgrad_recompute(towers[1], B);
+    if (hrec != (m2m_wgrad_recompute(towers[0], B) || m2m_wgrad_recompute(towers[1], B))) {
+        m2m_set_error("towers_backward: the two towers disagree on the weight-gradient form: launch them separately", __FILE__, __LINE__);
+        return -1;
+    }
     auto finish = [&](int rc) -> int {
         if (rc || !part) return rc;
         SplitReduceArgs r;
@@ -1101,9 +1130,9 @@ extern "C" int m2m_towers_backward(const m2m_tower* const* towers, const m2m_tow
     };
 #define M2M_BWDG_CASE(PP, DD) \
     if (t->prec == PP && t->D == DD) {                                                                          \
-        if (t->N <= 4) return finish(launch_bwd_group<PP, DD, 4, 8>(a, B, seed, step, step_dev, st));           \
-        if (t->T % 16 == 0) return finish(launch_bwd_group<PP, DD, 8, 16>(a, B, seed, step, step_dev, st));     \
-        return finish(launch_bwd_group<PP, DD, 8, 8>(a, B, seed, step, step_dev, st));                          \
+        if (t->N <= 4) return finish(launch_bwd_group<PP, DD, 4, 8>(a, B, seed, step, step_dev, st, hrec));           \
+        if (t->T % 16 == 0) return finish(launch_bwd_group<PP, DD, 8, 16>(a, B, seed, step, step_dev, st, hrec));     \
+        return finish(launch_bwd_group<PP, DD, 8, 8>(a, B, seed, step, step_dev, st, hrec));                          \
     }
     M2M_BWDG_CASE(PREC_BF16, 32) M2M_BWDG_CASE(PREC_BF16, 64) M2M_BWDG_CASE(PREC_BF16, 128)
     M2M_BWDG_CASE(PREC_F32, 32) M2M_BWDG_CASE(PREC_F32, 64) M2M_BWDG_CASE(PREC_F32, 128)

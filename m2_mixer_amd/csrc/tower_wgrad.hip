@@ -17,6 +17,7 @@
 #include "embed_wgrad.h"
 #include <stdlib.h>
 #include <string.h>
+bool m2m_split_eligible(const m2m_tower* t, int B, int training);     // split_api.hip
 
 // address-space qualifier for pointers known to be global memory (device pass only; the host pass just parses)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -37,8 +38,12 @@
 #define WG_MINWAVES 2
 #endif
 #define WG_THREADS (WG_WAVES * 64)
-#define WG_OUT_ATOMIC 0   // how a workgroup hands over its results (wgrad_body)
+#define WG_OUT_ATOMIC 0   // how a workgroup hands over its results (wgrad_write_w)
 #define WG_OUT_ADD 1
+#define WG_OUT_STORE 2    // "=": single owner, the old values are not read (m2m_tower.wgrad_flags & M2M_WGRAD_OVERWRITE, and the
+                          //      second row group of a tower with a partial-gradient slot, m2m_tower.wslot)
+
+#include "tower_wgrad_rc.h"   // WgOut, wgrad_write_w, the recompute form (bf16, hidden_dim 128)
 
 TIMER_DECL(g_tm_wg);
 TIMER_READER(m2m_debug_timers_wgrad, g_tm_wg)
@@ -72,7 +77,7 @@ template <int P, int D> struct WgradGeom {
 
 // One workgroup's share: column slice `slice` of block `bk`, token tiles [group * tiles_per_group, ...).
 template <int P, int D>
-static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, int C, int slice, int group, int mode,
+static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, const WgOut& out, int Cp, int C, int slice, int group,
                                                   int ntiles, int tiles_per_group, char* smem) {
     typedef Prec<P> Pr;
     typedef WgradGeom<P, D> G;
@@ -243,200 +248,100 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, int Cp, i
             if (tile + k < t_end) step(p[k], tile + k, t_end, it++);
     }
 
-    // ---- results: dw1[j][dt][r] = dW1[c = 16 ct + 4g + r][d = 16dt + il]; dw2 likewise = dW2[d][c] ----
-    // WG_OUT_ADD    "+=" onto the caller's gradient by its single owner (one row group): ALL loads of the old values
-    //               first (they overlap each other; one dependent load-add-store at a time cost 40 % of the kernel),
-    //               then the stores.
-    // WG_OUT_ATOMIC "+=" by several row groups: no-return float atomics onto the zeroed gradient (two groups: a + b ==
-    //               b + a, still bit-deterministic).  Device-scope float atomics sustain only ~0.7 TB/s on this part:
-    //               fine for small launches, ruinous for a whole model's gradients.
-    // (Measured and dropped: "=" stores into per-group partial-gradient slots summed by the optimizer -- the loop of a
-    // 2-4 group split is 20-35 us shorter, its 2-4x write-out traffic gives all of it back.)
-    // The accumulators hold one matrix index across lanes and the other in registers, the wrong way round for both
-    // results' row-major layouts (4-byte accesses in 4 to 64 segments per instruction cost 17 us per workgroup), so the
-    // tiles are transposed through the (now free) LDS stage, each wave in its own part (one wave's LDS accesses complete in
-    // order: no barrier beyond the first).
     __syncthreads();                                         // every wave is done reading the stage
-    float* const o_w1 = bk.g_ch_w1;
-    float* const o_w2 = bk.g_ch_w2;
-    float* const o_b1 = bk.g_ch_b1;
-    // the same pointers in the global address space for the plain loads / stores of the "+=" write-out (generic pointers from a
-    // descriptor in memory give FLAT accesses, which wait on vmcnt AND lgkmcnt)
-    typedef M2M_GLOBAL_AS float* gf_t;
-    typedef M2M_GLOBAL_AS f32x4_t* gf4_t;
-    const gf_t g_w1 = (gf_t)o_w1, g_w2 = (gf_t)o_w2;
-    if (mode != WG_OUT_ATOMIC) {
-        constexpr int TLD = D + 4;                           // padded row (floats): the four g-groups land in different banks
-        float* tr = reinterpret_cast<float*>(smem) + wave * 16 * TLD;
+    wgrad_write_w<D, CPW>(dw1, dw2, out, ct0, nct, C, smem, wave, lane);
+    // db1[j][r]: column c = 16 (ct0 + j) + 4g + r, identical in all 16 lanes il: lane il == 0 writes
 #pragma unroll
-        for (int j = 0; j < CPW; ++j) {
-            const int ct = ct0 + j;
+    for (int j = 0; j < CPW; ++j) {
+        if (ct0 + j >= nct || il != 0) continue;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) tr[(4 * g + r) * TLD + 16 * dt + il] = dw1[j][dt][r];
-            if (ct < nct) {
-                constexpr int PER = 16 * D / (64 * 4);       // float4 pieces per lane
-                f32x4_t v[PER], old[PER];
-                // the old values: UNCONDITIONAL loads (row clamped into the tensor), all requested before the first is used.
-                // Guarded per piece (`if (c < C) v += load`), each load sat in its own basic block with a vmcnt(0) behind it:
-                // 16 + 16 memory round trips in series at the end of every workgroup (~16 us of the launch's tail).
-                if (mode == WG_OUT_ADD) {
-#pragma unroll
-                    for (int i = 0; i < PER; ++i) {
-                        const int idx = i * 64 + lane, row = idx / (D / 4), c4 = idx % (D / 4);
-                        const int c = min(16 * ct + row, C - 1);
-                        old[i] = *(gf4_t)(g_w1 + (long)c * D + 4 * c4);
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < PER; ++i) {
-                    const int idx = i * 64 + lane, row = idx / (D / 4), c4 = idx % (D / 4);
-                    v[i] = *reinterpret_cast<const f32x4_t*>(tr + row * TLD + 4 * c4);
-                }
-                if (mode == WG_OUT_ADD) {
-#pragma unroll
-                    for (int i = 0; i < PER; ++i) v[i] = v[i] + old[i];
-                }
-#pragma unroll
-                for (int i = 0; i < PER; ++i) {
-                    const int idx = i * 64 + lane, row = idx / (D / 4), c4 = idx % (D / 4);
-                    const int c = 16 * ct + row;
-                    if (c < C) *(gf4_t)(g_w1 + (long)c * D + 4 * c4) = v[i];
-                }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < CPW; ++j) {
-            if (ct0 + j >= nct) continue;
-            const int c0 = 16 * (ct0 + j) + 4 * g;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const int d = 16 * dt + il;                  // 16 consecutive d of one row in 16 lanes
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (c0 + r < C) atomicAdd(o_w1 + (long)(c0 + r) * D + d, dw1[j][dt][r]);
-            }
-        }
-    }
-    if (mode == WG_OUT_ADD) {
-#pragma unroll
-        for (int j = 0; j < CPW; ++j) {
-            if (ct0 + j >= nct) continue;
-            const int c0 = 16 * (ct0 + j) + 4 * g;
-            const bool vec = c0 + 3 < C && (C & 3) == 0;
-            if ((C & 3) == 0 && 16 * (ct0 + j) + 16 <= C) {   // wave-uniform: the whole column tile is inside the tensor
-                f32x4_t o2[DT];                               // unconditional, batched (see above)
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt) o2[dt] = *(gf4_t)(g_w2 + (long)(16 * dt + il) * C + c0);
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt) dw2[j][dt] = dw2[j][dt] + o2[dt];
-                continue;
-            }
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const int d = 16 * dt + il;
-                const float* p2 = o_w2 + (long)d * C + c0;    // four consecutive c of row d
-                if (vec) {
-                    dw2[j][dt] = dw2[j][dt] + *reinterpret_cast<const f32x4_t*>(p2);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (c0 + r < C) dw2[j][dt][r] += p2[r];
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < CPW; ++j) {
-            if (ct0 + j >= nct) continue;
-            const int c0 = 16 * (ct0 + j) + 4 * g;
-            const bool vec = c0 + 3 < C && (C & 3) == 0;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const int d = 16 * dt + il;
-                float* p2 = o_w2 + (long)d * C + c0;
-                if (vec) {
-                    *(gf4_t)(g_w2 + (long)d * C + c0) = dw2[j][dt];
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (c0 + r < C) p2[r] = dw2[j][dt][r];
-                }
-            }
-            if (il == 0) {                                  // db1[r] is identical in all 16 columns: column 0 writes
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (c0 + r < C) o_b1[c0 + r] += db1[j][r];
-            }
-        }
-    } else {
-        // dW2[d][c]: each wave transposes its (d x 16 CPW) slice, CHT d-tiles at a time, and writes 16 CPW consecutive
-        // columns of a row per 16 CPW lanes.
-        constexpr int W = 16 * CPW, TLD2 = W + 1, RPI = 64 / W;     // columns per wave, padded LDS row, rows per instruction
-        constexpr int CAP = 16 * (D + 4) / (16 * TLD2);             // d-tiles the wave's LDS part holds
-        constexpr int CHT = CAP >= 4 ? 4 : (CAP >= 2 ? 2 : 1);
-        static_assert(DT % CHT == 0 && CAP >= 1, "dW2 transpose chunks");
-        float* tr = reinterpret_cast<float*>(smem) + wave * 16 * (D + 4);
-#pragma unroll
-        for (int j = 0; j < CPW; ++j) {
-            if (ct0 + j >= nct || il != 0) continue;
-            const int c0 = 16 * (ct0 + j) + 4 * g;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (c0 + r >= C) continue;
-                atomicAdd(o_b1 + c0 + r, db1[j][r]);
-            }
-        }
-        const int cw = 16 * ct0 + (lane % W);                // this lane's column in the transposed read
-#pragma unroll
-        for (int ch = 0; ch < DT / CHT; ++ch) {
-#pragma unroll
-            for (int dtl = 0; dtl < CHT; ++dtl)
-#pragma unroll
-                for (int j = 0; j < CPW; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) tr[(16 * dtl + il) * TLD2 + 16 * j + 4 * g + r] = dw2[j][CHT * ch + dtl][r];
-#pragma unroll
-            for (int i = 0; i < 16 * CHT / RPI; ++i) {
-                const int row = RPI * i + lane / W;
-                const float v = tr[row * TLD2 + lane % W];
-                if (cw < C) {
-                    float* q = o_w2 + (long)(16 * CHT * ch + row) * C + cw;
-                    atomicAdd(q, v);
-                }
-            }
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * (ct0 + j) + 4 * g + r;
+            if (c >= C) continue;
+            if (out.mode == WG_OUT_ATOMIC) atomicAdd(out.b1 + c, db1[j][r]);
+            else if (out.mode == WG_OUT_ADD) out.b1[c] += db1[j][r];
+            else out.b1[c] = db1[j][r];
         }
     }
     TIMER_MARK(g_tm_wg, 4);        // result write-out
 }
 
-template <int P, int D>
-__global__ __launch_bounds__(WG_THREADS, (WgradGeom<P, D>::MINWAVES)) void tower_wgrad_kernel(const m2m_tower tw, int ntiles, int tiles_per_group) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    wgrad_body<P, D>(tw.blk[blockIdx.y], tw.Cp, tw.C, blockIdx.x, blockIdx.z, gridDim.z == 1 ? WG_OUT_ADD : WG_OUT_ATOMIC, ntiles,
-                     tiles_per_group, smem);
+// Where workgroup (block b, row group `group` of `ngroups`) of tower tw puts its results.
+//   one group                : the caller's gradient, "+=" (or "=" with M2M_WGRAD_OVERWRITE)
+//   two groups, slot mode    : group 0 as above; group 1 stores its partial sums into the tower's partial-gradient slot
+//                              (m2m_tower.wslot[b], laid out [dW1 | db1 | dW2] like the flat gradient), which the optimizer
+//                              adds (m2m_adam_step_ranges) or m2m_wgrad_fold folds in
+//   otherwise                : float atomics onto the (zeroed) gradient
+template <class TW>
+static __device__ __forceinline__ WgOut wgrad_out(const TW& tw, int b, int group, int ngroups, int slot_mode) {
+    const m2m_block& bk = tw.blk[b];
+    WgOut o;
+    o.w1 = bk.g_ch_w1; o.w2 = bk.g_ch_w2; o.b1 = bk.g_ch_b1;
+    const bool overwrite = (tw.wgrad_flags & M2M_WGRAD_OVERWRITE) != 0;
+    if (ngroups == 1) o.mode = overwrite ? WG_OUT_STORE : WG_OUT_ADD;
+    else if (slot_mode) {
+        if (group == 0) o.mode = overwrite ? WG_OUT_STORE : WG_OUT_ADD;
+        else {
+            const long cd = (long)tw.C * tw.D;
+            float* s = tw.wslot[b];
+            o.w1 = s; o.b1 = s + cd; o.w2 = s + cd + tw.C;
+            o.mode = WG_OUT_STORE;
+        }
+    } else o.mode = WG_OUT_ATOMIC;
+    return o;
 }
 
-// Several towers in ONE launch (blockIdx.y = job = (tower, block)): the three towers of a model finish their backward
-// chains at about the same time, and one launch lets the hardware dispatcher balance their ~480 workgroups over the chip
-// instead of three launches on three queues of a replayed graph racing (and sometimes serialising) each other.
+// RCDM: -1 = stored-operand form; DM_NONE / DM_HALF = recompute form with that dropout mode (bf16, hidden_dim 128 only)
+template <int P, int D, int RCDM> struct WgradKernelGeom {
+    static constexpr bool RC = RCDM >= 0;
+    static constexpr int LDS_B = RC ? RcGeom<D>::LDS_B : WgradGeom<P, D>::LDS_B;
+    static constexpr int COLS = RC ? RcGeom<D>::COLS : WgradGeom<P, D>::COLS;
+    static constexpr int MINWAVES = RC ? 2 : WgradGeom<P, D>::MINWAVES;
+};
+
+template <int P, int D, int RCDM, class TW>
+static __device__ __forceinline__ void wgrad_dispatch(const TW& tw, int b, int slice, int group, int ngroups, int slot_mode, int ntiles,
+                                                      int tpg, int rows_per_t16, unsigned int seed, unsigned int step, char* smem) {
+    const WgOut out = wgrad_out(tw, b, group, ngroups, slot_mode);
+    if constexpr (RCDM >= 0) {
+        const Drop dr = make_drop(true, tw.p_drop, seed, step, tw.site_base + 4u * (unsigned int)b + 2u);
+        wgrad_rc_body<D, RCDM>(tw.blk[b], out, tw.Cp, tw.C, slice, group, ntiles, tpg, rows_per_t16, dr.key, dr.scale, smem);
+    } else {
+        wgrad_body<P, D>(tw.blk[b], out, tw.Cp, tw.C, slice, group, ntiles, tpg, smem);
+    }
+}
+
+template <int P, int D, int RCDM>
+__global__ __launch_bounds__(WG_THREADS, (WgradKernelGeom<P, D, RCDM>::MINWAVES)) void tower_wgrad_kernel(
+    const m2m_tower tw, int ntiles, int tiles_per_group, int slot_mode, int rows_per_t16, unsigned int seed, unsigned int step_host,
+    const unsigned int* __restrict__ step_dev) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
+    wgrad_dispatch<P, D, RCDM>(tw, (int)blockIdx.y, (int)blockIdx.x, (int)blockIdx.z, (int)gridDim.z, slot_mode, ntiles, tiles_per_group,
+                               rows_per_t16, seed, step, smem);
+}
+
+// Several towers in ONE launch (job = (tower, block)): the three towers of a model finish their backward chains at about the
+// same time, and one launch lets the hardware dispatcher balance their ~300 workgroups over the chip instead of three
+// launches on three queues of a replayed graph racing (and sometimes serialising) each other.
 // The descriptors are device-resident copies (kernel arguments are limited to 4 KiB, one m2m_tower is 2.4 KiB).
 #define WG_MAX_TOWERS 4
 #define WG_MAX_JOBS 32
 struct WgradGroupArgs {
     const m2m_tower* tw[WG_MAX_TOWERS];
-    int ntiles[WG_MAX_TOWERS], tpg[WG_MAX_TOWERS], groups[WG_MAX_TOWERS], nsl[WG_MAX_TOWERS];
+    int ntiles[WG_MAX_TOWERS], tpg[WG_MAX_TOWERS], groups[WG_MAX_TOWERS], nsl[WG_MAX_TOWERS], slot[WG_MAX_TOWERS], rpt[WG_MAX_TOWERS];
     unsigned char job_tower[WG_MAX_JOBS], job_block[WG_MAX_JOBS];
     int max_nsl, njobs, n_tower_wgs;
+    unsigned int seed, step_host;
+    const unsigned int* step_dev;
 };
 // The grid is one-dimensional: id -> (slice, job, group) in that order (slice fastest), then -- so that they are dispatched
 // last and back-fill the CUs whose tower workgroup has finished -- the workgroups of the model's two patch-embedding
 // weight gradients (embed_wgrad.h).  A second launch beside this one costs a fork and a join in the replayed graph
 // (~10 us each) and slows this kernel by contending for the same CUs.
-template <int P, int D>
-__global__ __launch_bounds__(WG_THREADS, (WgradGeom<P, D>::MINWAVES)) void tower_wgrad_group_kernel(const WgradGroupArgs a,
-                                                                                                    const EmbedWgradGroupArgs ea) {
+template <int P, int D, int RCDM>
+__global__ __launch_bounds__(WG_THREADS, (WgradKernelGeom<P, D, RCDM>::MINWAVES)) void tower_wgrad_group_kernel(const WgradGroupArgs a,
+                                                                                                          const EmbedWgradGroupArgs ea) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int id = blockIdx.x;
     if (id >= a.n_tower_wgs) {
@@ -447,46 +352,134 @@ __global__ __launch_bounds__(WG_THREADS, (WgradGeom<P, D>::MINWAVES)) void tower
     const int t = a.job_tower[job];
     if (slice >= a.nsl[t] || group >= a.groups[t]) return;
     const m2m_tower& tw = *a.tw[t];
-    wgrad_body<P, D>(tw.blk[a.job_block[job]], tw.Cp, tw.C, slice, group, a.groups[t] == 1 ? WG_OUT_ADD : WG_OUT_ATOMIC,
-                     a.ntiles[t], a.tpg[t], smem);
+    const unsigned int step = a.step_host + (a.step_dev ? *a.step_dev : 0u);
+    wgrad_dispatch<P, D, RCDM>(tw, (int)a.job_block[job], slice, group, a.groups[t], a.slot[t], a.ntiles[t], a.tpg[t], a.rpt[t], a.seed,
+                               step, smem);
 }
 
-struct WgradPlan { int ntiles, nsl, groups, tpg; };
-template <int P, int D>
-static WgradPlan wgrad_plan(const m2m_tower* t, int B);
+// ---- host side ---------------------------------------------------------------------------------------------------------
+static int wgrad_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+// The recompute form: bf16, hidden_dim 128, dropout off or p == 0.5 (the one-bit keep stream), and not a tower the split path
+// takes (its chain launches store both hidden operands).  M2M_WGRAD_RECOMP=0 keeps the stored-operand form everywhere (A/B).
+bool m2m_wgrad_recompute(const m2m_tower* t, int B) {
+    static const int on = wgrad_env("M2M_WGRAD_RECOMP", 1);
+    if (!on || t->prec != PREC_BF16 || t->D != 128 || t->nblocks < 1 || t->Cp < 64) return false;
+    if (m2m_drop_mode(1, t->p_drop) == DM_GEN) return false;
+    if (m2m_split_eligible(t, B, 1)) return false;
+    return true;
+}
+extern "C" int m2m_wgrad_form(const m2m_tower* t, int B) { return t && m2m_wgrad_recompute(t, B) ? 1 : 0; }
 
-template <int P, int D>
-static int launch_wgrad(const m2m_tower* t, int B, hipStream_t st) {
-    const WgradPlan pl = wgrad_plan<P, D>(t, B);
-    const size_t lds = (size_t)WgradGeom<P, D>::LDS_B;
-    auto kern = tower_wgrad_kernel<P, D>;
+// The partial-gradient slot can stand in for a second row group when the three channel-mixing gradients of every block lie
+// back to back ([dW1 | db1 | dW2], the flat engines' layout), because the slot is folded in as ONE range per block.
+static bool wgrad_slot_usable(const m2m_tower* t) {
+    static const int on = wgrad_env("M2M_WGRAD_SLOT", 1);
+    if (!on || t->nblocks < 1) return false;
+    for (int b = 0; b < t->nblocks; ++b) {
+        const m2m_block& k = t->blk[b];
+        if (!t->wslot[b]) return false;
+        if (k.g_ch_b1 != k.g_ch_w1 + (long)t->C * t->D || k.g_ch_w2 != k.g_ch_b1 + t->C) return false;
+    }
+    return true;
+}
+
+struct WgradPlan { int ntiles, nsl, groups, tpg, rpt, slot; };
+static WgradPlan wgrad_plan(const m2m_tower* t, int B, int cols) {
+    const bool wide = m2m_is_wide(t);                           // wide path: chain tiles are any BM consecutive rows
+    const int SPW = wide ? 1 : BM / t->N;                       // samples per chain tile
+    const int nchain = wide ? (int)(((long)B * t->N + BM - 1) / BM) : (B + SPW - 1) / SPW;   // chain tiles (BM rows each)
+    const int ntiles = (nchain * BM + WBM - 1) / WBM;           // streamed tiles (WBM rows each)
+    const int nsl = (t->Cp + cols - 1) / cols;                  // column slices (128 or 64 columns)
+    // A workgroup's time is linear in its number of 32-row steps, so the launch time is set by its longest workgroup: rows
+    // are split into groups until a workgroup has at most 64 steps (2048 rows) or the launch reaches ~128 workgroups.
+    // Groups beyond the first add their partial results with float atomics onto the zeroed gradient (two groups: a + b ==
+    // b + a, bit-deterministic; more -- only tiny launches -- are not), which an overwriting caller (M2M_WGRAD_OVERWRITE:
+    // the gradient is NOT zero on entry) cannot have: one group then, or two through the slot (launch_wgrad_group).
+    int groups = 1;
+    const int wgs = nsl * t->nblocks;
+    while (wgs * groups < 128 && (ntiles + groups - 1) / groups > 64) ++groups;
+    if (groups < (32 + wgs - 1) / wgs) groups = (32 + wgs - 1) / wgs;
+    if (const char* e = getenv("M2M_WGRAD_GROUPS")) groups = atoi(e);   // diagnostic override (scripts/wgrad_probe.py sweeps it); unset in production
+    if (const char* e = getenv("M2M_WGRAD_LONG_GROUPS")) { if (ntiles > 64) groups = atoi(e); }   // diagnostic: towers with more than 64 steps only
+    if (t->wgrad_flags & M2M_WGRAD_OVERWRITE) groups = 1;
+    if (groups < 1) groups = 1;
+    int tpg = (ntiles + groups - 1) / groups;
+    if (tpg < 4) tpg = 4;
+    if (tpg > ntiles) tpg = ntiles;
+    groups = (ntiles + tpg - 1) / tpg;
+    WgradPlan pl;
+    pl.ntiles = ntiles; pl.nsl = nsl; pl.groups = groups; pl.tpg = tpg; pl.slot = 0;
+    pl.rpt = wide ? BM : SPW * t->N;                            // token rows per chain tile (the dropout row index of the recompute form)
+    return pl;
+}
+// two row groups through the slot: the second group's partial sums are plain stores, folded in by the optimizer
+static void wgrad_plan_slot_split(WgradPlan& pl) {
+    pl.groups = 2;
+    pl.tpg = (pl.ntiles + 1) / 2;
+    pl.slot = 1;
+}
+static int wgrad_cols(const m2m_tower* t, int B) {
+    if (m2m_wgrad_recompute(t, B)) return RcGeom<128>::COLS;
+    return t->prec == PREC_BF16 && t->D <= 128 ? WG_WAVES * 32 : WG_WAVES * 16;
+}
+extern "C" int m2m_wgrad_groups(const m2m_tower* t, int B) {
+    if (!t || t->nblocks < 1) return 1;
+    m2m_tower c = *t;
+    c.wgrad_flags &= ~M2M_WGRAD_OVERWRITE;
+    return wgrad_plan(&c, B, wgrad_cols(t, B)).groups;
+}
+
+template <int P, int D, int RCDM>
+static int launch_wgrad(const m2m_tower* t, int B, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
+    typedef WgradKernelGeom<P, D, RCDM> KG;
+    const WgradPlan pl = wgrad_plan(t, B, KG::COLS);
+    const size_t lds = (size_t)KG::LDS_B;
+    auto kern = tower_wgrad_kernel<P, D, RCDM>;
     static bool attr_done = false;
     if (!attr_done) {
         M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(pl.nsl, t->nblocks, pl.groups), dim3(WG_THREADS), lds, st, *t, pl.ntiles, pl.tpg);
+    hipLaunchKernelGGL(kern, dim3(pl.nsl, t->nblocks, pl.groups), dim3(WG_THREADS), lds, st, *t, pl.ntiles, pl.tpg, 0, pl.rpt, seed, step,
+                       step_dev);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
-template <int P, int D>
+// Plans of a multi-tower launch: per tower as above; then a tower whose workgroups would run at least twice as many steps as
+// the shortest tower's (the fusion tower: twice the rows) is split into two row groups IF it has a usable partial-gradient
+// slot -- its workgroups alone on their CUs set the launch time otherwise (128 steps against 64).
+static void wgrad_group_plans(const m2m_tower* const* host, int n, int B, int cols, WgradPlan* pl) {
+    int min_tpg = 1 << 30;
+    for (int i = 0; i < n; ++i) { pl[i] = wgrad_plan(host[i], B, cols); if (pl[i].tpg < min_tpg) min_tpg = pl[i].tpg; }
+    for (int i = 0; i < n; ++i)
+        if (n > 1 && pl[i].groups == 1 && pl[i].tpg >= 2 * min_tpg && pl[i].tpg >= 32 && wgrad_slot_usable(host[i])) wgrad_plan_slot_split(pl[i]);
+}
+
+template <int P, int D, int RCDM>
 static int launch_wgrad_group(const m2m_tower* const* host, const m2m_tower* const* dev, int n, const m2m_embed* const* embeds,
-                              const float* const* inputs, const float* const* d_x0s, int nembeds, int B, hipStream_t st) {
+                              const float* const* inputs, const float* const* d_x0s, int nembeds, int B, unsigned int seed,
+                              unsigned int step, const unsigned int* step_dev, hipStream_t st) {
+    typedef WgradKernelGeom<P, D, RCDM> KG;
     WgradGroupArgs a;
     memset(&a, 0, sizeof(a));
     int njobs = 0, max_nsl = 1, max_groups = 1;
     // longest workgroups first (most token tiles per workgroup): they are dispatched first and the short ones back-fill
     int order[WG_MAX_TOWERS];
     WgradPlan pl[WG_MAX_TOWERS];
-    for (int i = 0; i < n; ++i) { order[i] = i; pl[i] = wgrad_plan<P, D>(host[i], B); }
+    wgrad_group_plans(host, n, B, KG::COLS, pl);
+    for (int i = 0; i < n; ++i) order[i] = i;
     for (int i = 0; i < n; ++i)
         for (int j = i + 1; j < n; ++j)
             if (pl[order[j]].tpg > pl[order[i]].tpg) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
     for (int k = 0; k < n; ++k) {
         const int i = order[k];
         a.tw[i] = dev[i];
-        a.ntiles[i] = pl[i].ntiles; a.tpg[i] = pl[i].tpg; a.groups[i] = pl[i].groups; a.nsl[i] = pl[i].nsl;
+        a.ntiles[i] = pl[i].ntiles; a.tpg[i] = pl[i].tpg; a.groups[i] = pl[i].groups; a.nsl[i] = pl[i].nsl; a.slot[i] = pl[i].slot;
+        a.rpt[i] = pl[i].rpt;
         if (pl[i].nsl > max_nsl) max_nsl = pl[i].nsl;
         if (pl[i].groups > max_groups) max_groups = pl[i].groups;
         for (int b = 0; b < host[i]->nblocks; ++b) {
@@ -498,13 +491,14 @@ static int launch_wgrad_group(const m2m_tower* const* host, const m2m_tower* con
     }
     if (njobs == 0 && nembeds == 0) return 0;
     a.max_nsl = max_nsl; a.njobs = njobs; a.n_tower_wgs = max_nsl * njobs * max_groups;
+    a.seed = seed; a.step_host = step; a.step_dev = step_dev;
     EmbedWgradGroupArgs ea;
     memset(&ea, 0, sizeof(ea));
     // ~2 embedding workgroups per CU: they are short and only fill what the tower workgroups leave idle
     const int n_embed_wgs = nembeds ? embed_wgrad_group_args(ea, embeds, inputs, d_x0s, B, 512) : 0;
-    const size_t lds_t = (size_t)WgradGeom<P, D>::LDS_B, lds_e = nembeds ? embed_wgrad_lds<D, P>() : 0;
+    const size_t lds_t = (size_t)KG::LDS_B, lds_e = nembeds ? embed_wgrad_lds<D, P>() : 0;
     const size_t lds = lds_t > lds_e ? lds_t : lds_e;
-    auto kern = tower_wgrad_group_kernel<P, D>;
+    auto kern = tower_wgrad_group_kernel<P, D, RCDM>;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
         M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -515,40 +509,28 @@ static int launch_wgrad_group(const m2m_tower* const* host, const m2m_tower* con
     return 0;
 }
 
-template <int P, int D>
-static WgradPlan wgrad_plan(const m2m_tower* t, int B) {
-    const bool wide = m2m_is_wide(t);                           // wide path: chain tiles are any BM consecutive rows
-    const int SPW = wide ? 1 : BM / t->N;                       // samples per chain tile
-    const int nchain = wide ? (int)(((long)B * t->N + BM - 1) / BM) : (B + SPW - 1) / SPW;   // chain tiles (BM rows each)
-    const int ntiles = (nchain * BM + WBM - 1) / WBM;           // streamed tiles (WBM rows each)
-    const int nsl = (t->Cp + WgradGeom<P, D>::COLS - 1) / WgradGeom<P, D>::COLS;   // column slices (128 or 64 columns)
-    // A workgroup's time is linear in its number of 32-row steps (~0.85 us each), so the launch time
-    // is set by its longest workgroup: rows are split into groups until a workgroup has at most 64 steps (2048 rows) or the
-    // launch reaches ~128 workgroups.  Two groups add their partial results with float atomics onto the zeroed gradient:
-    // a + b == b + a, so the result stays bit-deterministic; more groups (only tiny launches) are not.
-    int groups = 1;
-    const int wgs = nsl * t->nblocks;
-    while (wgs * groups < 128 && (ntiles + groups - 1) / groups > 64) ++groups;
-    if (groups < (32 + wgs - 1) / wgs) groups = (32 + wgs - 1) / wgs;
-    if (const char* e = getenv("M2M_WGRAD_GROUPS")) groups = atoi(e);   // diagnostic override (scripts/wgrad_probe.py sweeps it); unset in production
-    if (const char* e = getenv("M2M_WGRAD_LONG_GROUPS")) { if (ntiles > 64) groups = atoi(e); }   // diagnostic: towers with more than 64 steps only
-    if (groups < 1) groups = 1;
-    int tpg = (ntiles + groups - 1) / groups;
-    if (tpg < 4) tpg = 4;
-    if (tpg > ntiles) tpg = ntiles;
-    groups = (ntiles + tpg - 1) / tpg;
-    WgradPlan pl;
-    pl.ntiles = ntiles; pl.nsl = nsl; pl.groups = groups; pl.tpg = tpg;
-    return pl;
-}
-
 int m2m_check_tower(const m2m_tower* t, int B);
+
+// 1 if m2m_towers_wgrad on these towers at batch B leaves part of tower i's channel-mixing gradients in its slot (bit i of the
+// result): the caller must then add the slot (m2m_adam_step_ranges / m2m_wgrad_fold) before using the gradient.
+extern "C" int m2m_wgrad_slot_groups(const m2m_tower* const* towers, int ntowers, int B) {
+    if (!towers || ntowers < 1 || ntowers > WG_MAX_TOWERS) return 0;
+    WgradPlan pl[WG_MAX_TOWERS];
+    wgrad_group_plans(towers, ntowers, B, wgrad_cols(towers[0], B), pl);
+    int bits = 0;
+    for (int i = 0; i < ntowers; ++i) bits |= pl[i].slot << i;
+    return bits;
+}
 
 extern "C" int m2m_tower_wgrad(const m2m_tower* t, int B, uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream) {
     if (int rc = m2m_check_tower(t, B)) return rc;
     if (t->nblocks == 0) return 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define M2M_WG_CASE(PP, DD) if (t->prec == PP && t->D == DD) return launch_wgrad<PP, DD>(t, B, st);
+    if (m2m_wgrad_recompute(t, B)) {
+        if (m2m_drop_mode(1, t->p_drop) == DM_HALF) return launch_wgrad<PREC_BF16, 128, DM_HALF>(t, B, seed, step, step_dev, st);
+        return launch_wgrad<PREC_BF16, 128, DM_NONE>(t, B, seed, step, step_dev, st);
+    }
+#define M2M_WG_CASE(PP, DD) if (t->prec == PP && t->D == DD) return launch_wgrad<PP, DD, -1>(t, B, seed, step, step_dev, st);
     M2M_WG_CASE(PREC_BF16, 32) M2M_WG_CASE(PREC_BF16, 64) M2M_WG_CASE(PREC_BF16, 128) M2M_WG_CASE(PREC_BF16, 256)
     M2M_WG_CASE(PREC_F32, 32) M2M_WG_CASE(PREC_F32, 64) M2M_WG_CASE(PREC_F32, 128) M2M_WG_CASE(PREC_F32, 256)
 #undef M2M_WG_CASE
@@ -558,7 +540,7 @@ extern "C" int m2m_tower_wgrad(const m2m_tower* t, int B, uint32_t seed, uint32_
 
 extern "C" int m2m_towers_wgrad(const m2m_tower* const* towers, const m2m_tower* const* dev_towers, int ntowers,
                                 const m2m_embed* const* embeds, const float* const* inputs, const float* const* d_x0s, int nembeds,
-                                int B, void* stream) {
+                                int B, uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream) {
     if (!towers || !dev_towers || ntowers < 1 || ntowers > WG_MAX_TOWERS) { m2m_set_error("towers_wgrad: 1..4 towers", __FILE__, __LINE__); return -1; }
     if (nembeds != 0 && (nembeds != EMB_GROUP || !embeds || !inputs || !d_x0s)) {
         m2m_set_error("towers_wgrad: no patch embeddings or exactly two", __FILE__, __LINE__);
@@ -569,6 +551,11 @@ extern "C" int m2m_towers_wgrad(const m2m_tower* const* towers, const m2m_tower*
         if (!dev_towers[i]) { m2m_set_error("towers_wgrad: missing device-resident descriptor", __FILE__, __LINE__); return -1; }
         if (towers[i]->prec != towers[0]->prec || towers[i]->D != towers[0]->D) {
             m2m_set_error("towers_wgrad: the towers of one launch must share precision and hidden_dim", __FILE__, __LINE__);
+            return -1;
+        }
+        if (m2m_wgrad_recompute(towers[i], B) != m2m_wgrad_recompute(towers[0], B) ||
+            (m2m_wgrad_recompute(towers[0], B) && m2m_drop_mode(1, towers[i]->p_drop) != m2m_drop_mode(1, towers[0]->p_drop))) {
+            m2m_set_error("towers_wgrad: the towers of one launch must share the weight-gradient form and the dropout mode", __FILE__, __LINE__);
             return -1;
         }
     }
@@ -582,10 +569,33 @@ extern "C" int m2m_towers_wgrad(const m2m_tower* const* towers, const m2m_tower*
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const m2m_tower* t = towers[0];
-#define M2M_WGG_CASE(PP, DD) if (t->prec == PP && t->D == DD) return launch_wgrad_group<PP, DD>(towers, dev_towers, ntowers, embeds, inputs, d_x0s, nembeds, B, st);
+    if (m2m_wgrad_recompute(t, B)) {
+        if (m2m_drop_mode(1, t->p_drop) == DM_HALF)
+            return launch_wgrad_group<PREC_BF16, 128, DM_HALF>(towers, dev_towers, ntowers, embeds, inputs, d_x0s, nembeds, B, seed, step, step_dev, st);
+        return launch_wgrad_group<PREC_BF16, 128, DM_NONE>(towers, dev_towers, ntowers, embeds, inputs, d_x0s, nembeds, B, seed, step, step_dev, st);
+    }
+#define M2M_WGG_CASE(PP, DD) if (t->prec == PP && t->D == DD) return launch_wgrad_group<PP, DD, -1>(towers, dev_towers, ntowers, embeds, inputs, d_x0s, nembeds, B, seed, step, step_dev, st);
     M2M_WGG_CASE(PREC_BF16, 32) M2M_WGG_CASE(PREC_BF16, 64) M2M_WGG_CASE(PREC_BF16, 128) M2M_WGG_CASE(PREC_BF16, 256)
     M2M_WGG_CASE(PREC_F32, 32) M2M_WGG_CASE(PREC_F32, 64) M2M_WGG_CASE(PREC_F32, 128) M2M_WGG_CASE(PREC_F32, 256)
 #undef M2M_WGG_CASE
     m2m_set_error("towers_wgrad: unsupported (prec, D)", __FILE__, __LINE__);
     return -1;
+}
+
+// g_ch_w1 / g_ch_b1 / g_ch_w2 += the tower's partial-gradient slot (blocks with contiguous channel gradients; see
+// m2m_tower.wslot).  For callers that need the complete gradient before the optimizer (the data-parallel exchange).
+__global__ void wgrad_fold_kernel(float* __restrict__ g, const float* __restrict__ s, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] += s[i];
+}
+extern "C" int m2m_wgrad_fold(const m2m_tower* t, void* stream) {
+    if (!t) { m2m_set_error("wgrad_fold: null tower", __FILE__, __LINE__); return -1; }
+    if (!wgrad_slot_usable(t)) { m2m_set_error("wgrad_fold: channel gradients are not contiguous", __FILE__, __LINE__); return -1; }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long n = 2L * t->C * t->D + t->C;
+    for (int b = 0; b < t->nblocks; ++b) {
+        hipLaunchKernelGGL(wgrad_fold_kernel, dim3(512), dim3(256), 0, st, t->blk[b].g_ch_w1, t->wslot[b], n);
+        M2M_CHECK_HIP(hipGetLastError());
+    }
+    return 0;
 }

@@ -1,0 +1,412 @@
+// Channel-mixing weight gradients, RECOMPUTE form (bf16, hidden_dim 128): the hidden activation never leaves the chip.
+//
+//   dW1[c][d] = sum_m dHpre[m][c] A[m][d]      dW2[d][c] = sum_m dYd[m][d] Hact[m][c]      db1[c] = sum_m dHpre[m][c]
+//   Hact[m][c] = dropout(gelu(A[m][:] W1[c][:] + b1[c]))                    (reference: modules/mixer.py:13-19, :37-40)
+//
+// The stored-operand form (tower_wgrad.hip) streams Hact^T and dHpre^T from HBM: 2 x rows x C bf16 per block, 300 MB per
+// step of M2-Mixer-B at batch 512, written by the backward chains and read back here -- the launch ran at the HBM rate
+// (559 MB at 4.9 TB/s) and the backward chains paid ~13 us for the transposes and stores.  Here a wave keeps the W1 rows of
+// its 32 hidden columns in registers (the `w1n` fragments: 32 VGPRs), takes the packed NAT image of A = LN2(x_mid) -- 8 KB
+// per 32 token rows, L2-resident, written by tower_bwd_body<HREC> where Hact^T used to go -- and recomputes
+//       Hpre[m][c] = A[m][:] W1[c][:]      (16 MFMAs per 32-row step: A as the FIRST operand, so the accumulators hold
+//                                           [m = 4g + r][c = il], which IS the chained operand layout "c = il, k = m" of the
+//                                           gradient products -- no transpose, no LDS round trip)
+// then bias / GELU (the forward's table) / keep-bit on the accumulators, and the same 32 + 32 gradient MFMAs as before.
+// Only dHpre^T is still streamed (it needs dYd W2 as well: recomputing it too costs 16 more MFMAs and the GELU' epilogue
+// per step, more than the 150 MB it saves are worth once the launch is no longer HBM-bound).
+//
+// Staging: the three shared 8 KB images of a step (A^T and dYd^T in chained k order for the gradient products, A in natural
+// order for the recompute) go global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR staging), double-buffered, ONE
+// barrier per step; the wave's own dHpre^T fragments go through a register ring RC_DEPTH steps deep.  vmcnt bookkeeping: the
+// DMAs are inline asm, invisible to hipcc; per step a wave issues 6 DMAs then 2 ring loads, so at the top of a step "all but
+// the 2 youngest" (s_waitcnt vmcnt(2)) == this step's images have landed and so has its ring entry.
+#pragma once
+#include "tile.h"
+
+#define RC_WAVES 4
+#define RC_THREADS (RC_WAVES * 64)
+#ifndef RC_DEPTH
+#define RC_DEPTH 2        // steps of dHpre^T fragments in flight (8 VGPRs each)
+#endif
+#ifndef RC_DB1_MFMA
+#define RC_DB1_MFMA 0     // 1: db1 through an all-ones MFMA operand (12 VGPRs more), 0: v_dot2c_f32_bf16 on the fragments
+#endif
+
+template <int D> struct RcGeom {
+    static constexpr int KD = D / 32, DT = D / 16;
+    static constexpr int IMG_B = 32 * D * 2;                 // one 32-row bf16 image
+    static constexpr int STAGE_B = 3 * IMG_B;                // A^T (CHN) | dYd^T (CHN) | A (NAT)
+    static constexpr int PPI = IMG_B / 1024;                 // 1 KiB DMA pieces per image
+    static constexpr int PPW = PPI / RC_WAVES;               // pieces per image and wave
+    static constexpr int TAB_B = GELU_TAB_N * (int)sizeof(gtab2_t);
+    static constexpr int TR_B = RC_WAVES * 16 * (D + 4) * 4; // write-out transposes (alias the stage)
+    static constexpr int LDS_B = (2 * STAGE_B > TR_B ? 2 * STAGE_B : TR_B) + TAB_B;
+    static constexpr int COLS = RC_WAVES * 32;
+};
+
+// LDS-DMA with a scalar base and a 32-bit per-lane offset (cf. glds16_g in common.h)
+static __device__ __forceinline__ void glds16_sv(unsigned long long sbase, unsigned int voff, unsigned int ldst) {
+    unsigned int keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(ldst) : "memory");
+}
+
+struct WgOut {            // where a workgroup's results go
+    float* w1; float* w2; float* b1;
+    int mode;             // WG_OUT_*
+};
+
+// Shared by both forms.  The accumulators dw1[j][dt][r] = dW1[c = 16 (ct0 + j) + 4g + r][d = 16 dt + il], dw2 likewise =
+// dW2[d][c]; the caller has passed a barrier since the last read of the LDS stage.
+//   WG_OUT_ADD    "+=" onto the caller's gradient by its single owner (one row group): ALL loads of the old values first (they
+//                 overlap each other; one dependent load-add-store at a time cost 40 % of the kernel), then the stores.
+//   WG_OUT_STORE  "=" by a single owner: no loads at all.
+//   WG_OUT_ATOMIC "+=" by several row groups: no-return float atomics onto the zeroed gradient (two groups: a + b == b + a,
+//                 still bit-deterministic).  Device-scope float atomics sustain ~1 TB/s: fine for small launches, ruinous for a
+//                 whole model's gradients.
+// The accumulators hold one matrix index across lanes and the other in registers, the wrong way round for dW1's row-major
+// layout (4-byte accesses in 4 to 64 segments per instruction cost 17 us per workgroup), so dW1's tiles are transposed through
+// the (now free) LDS stage, each wave in its own part (one wave's LDS accesses complete in order: no further barrier); dW2
+// has four consecutive c per lane already (16-byte accesses).
+template <int D, int CPW>
+static __device__ __forceinline__ void wgrad_write_w(f32x4_t (&dw1)[CPW][D / 16], f32x4_t (&dw2)[CPW][D / 16], const WgOut& out,
+                                                     int ct0, int nct, int C, char* smem, int wave, int lane) {
+    constexpr int DT = D / 16;
+    const int g = lane >> 4, il = lane & 15, mode = out.mode;
+    // the pointers in the global address space for the plain loads / stores (generic pointers from a descriptor in memory
+    // give FLAT accesses, which wait on vmcnt AND lgkmcnt)
+    typedef M2M_AS1 float* gf_t;
+    typedef M2M_AS1 f32x4_t* gf4_t;
+    float* const o_w1 = out.w1;
+    float* const o_w2 = out.w2;
+    const gf_t g_w1 = (gf_t)o_w1, g_w2 = (gf_t)o_w2;
+    if (mode != WG_OUT_ATOMIC) {
+        constexpr int TLD = D + 4;                           // padded row (floats): the four g-groups land in different banks
+        float* tr = reinterpret_cast<float*>(smem) + wave * 16 * TLD;
+#pragma unroll
+        for (int j = 0; j < CPW; ++j) {
+            const int ct = ct0 + j;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tr[(4 * g + r) * TLD + 16 * dt + il] = dw1[j][dt][r];
+            if (ct < nct) {
+                constexpr int PER = 16 * D / (64 * 4);       // float4 pieces per lane
+                f32x4_t v[PER], old[PER];
+                // the old values: UNCONDITIONAL loads (row clamped into the tensor), all requested before the first is used.
+                // Guarded per piece, each load sat in its own basic block with a vmcnt(0) behind it.
+                if (mode == WG_OUT_ADD) {
+#pragma unroll
+                    for (int i = 0; i < PER; ++i) {
+                        const int idx = i * 64 + lane, row = idx / (D / 4), c4 = idx % (D / 4);
+                        const int c = min(16 * ct + row, C - 1);
+                        old[i] = *(gf4_t)(g_w1 + (long)c * D + 4 * c4);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    const int idx = i * 64 + lane, row = idx / (D / 4), c4 = idx % (D / 4);
+                    v[i] = *reinterpret_cast<const f32x4_t*>(tr + row * TLD + 4 * c4);
+                }
+                if (mode == WG_OUT_ADD) {
+#pragma unroll
+                    for (int i = 0; i < PER; ++i) v[i] = v[i] + old[i];
+                }
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    const int idx = i * 64 + lane, row = idx / (D / 4), c4 = idx % (D / 4);
+                    const int c = 16 * ct + row;
+                    if (c < C) *(gf4_t)(g_w1 + (long)c * D + 4 * c4) = v[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CPW; ++j) {
+            if (ct0 + j >= nct) continue;
+            const int c0 = 16 * (ct0 + j) + 4 * g;
+            const bool vec = c0 + 3 < C && (C & 3) == 0;
+            if ((C & 3) == 0 && 16 * (ct0 + j) + 16 <= C) {   // wave-uniform: the whole column tile is inside the tensor
+                if (mode == WG_OUT_ADD) {
+                    f32x4_t o2[DT];                           // unconditional, batched (see above)
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) o2[dt] = *(gf4_t)(g_w2 + (long)(16 * dt + il) * C + c0);
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) dw2[j][dt] = dw2[j][dt] + o2[dt];
+                }
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) *(gf4_t)(g_w2 + (long)(16 * dt + il) * C + c0) = dw2[j][dt];
+                continue;
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = 16 * dt + il;
+                float* p2 = o_w2 + (long)d * C + c0;          // four consecutive c of row d
+                if (vec) {
+                    if (mode == WG_OUT_ADD) dw2[j][dt] = dw2[j][dt] + *reinterpret_cast<const f32x4_t*>(p2);
+                    *(gf4_t)(g_w2 + (long)d * C + c0) = dw2[j][dt];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (c0 + r < C) p2[r] = (mode == WG_OUT_ADD ? p2[r] : 0.f) + dw2[j][dt][r];
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < CPW; ++j) {
+            if (ct0 + j >= nct) continue;
+            const int c0 = 16 * (ct0 + j) + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = 16 * dt + il;                  // 16 consecutive d of one row in 16 lanes
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c0 + r < C) atomicAdd(o_w1 + (long)(c0 + r) * D + d, dw1[j][dt][r]);
+            }
+        }
+        // dW2[d][c]: each wave transposes its (d x 16 CPW) slice, CHT d-tiles at a time, and adds 16 CPW consecutive
+        // columns of a row per 16 CPW lanes.
+        constexpr int W = 16 * CPW, TLD2 = W + 1, RPI = 64 / W;     // columns per wave, padded LDS row, rows per instruction
+        constexpr int CAP = 16 * (D + 4) / (16 * TLD2);             // d-tiles the wave's LDS part holds
+        constexpr int CHT = CAP >= 4 ? 4 : (CAP >= 2 ? 2 : 1);
+        static_assert(DT % CHT == 0 && CAP >= 1, "dW2 transpose chunks");
+        float* tr = reinterpret_cast<float*>(smem) + wave * 16 * (D + 4);
+        const int cw = 16 * ct0 + (lane % W);                // this lane's column in the transposed read
+#pragma unroll
+        for (int ch = 0; ch < DT / CHT; ++ch) {
+#pragma unroll
+            for (int dtl = 0; dtl < CHT; ++dtl)
+#pragma unroll
+                for (int j = 0; j < CPW; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tr[(16 * dtl + il) * TLD2 + 16 * j + 4 * g + r] = dw2[j][CHT * ch + dtl][r];
+#pragma unroll
+            for (int i = 0; i < 16 * CHT / RPI; ++i) {
+                const int row = RPI * i + lane / W;
+                const float v = tr[row * TLD2 + lane % W];
+                if (cw < C) atomicAdd(o_w2 + (long)(16 * CHT * ch + row) * C + cw, v);
+            }
+        }
+    }
+}
+
+template <int D, int DM>
+static __device__ __forceinline__ void wgrad_rc_body(const m2m_block& bk, const WgOut& out, int Cp, int C, int slice, int group,
+                                                     int ntiles, int tiles_per_group, int rows_per_t16, unsigned int drop_key,
+                                                     float drop_scale, char* smem) {
+    typedef Prec<PREC_BF16> Pr;
+    typedef RcGeom<D> G;
+    constexpr int KD = G::KD, DT = G::DT, IMG_B = G::IMG_B, STAGE_B = G::STAGE_B, PPW = G::PPW, CPW = 2;
+    static_assert(DM == DM_NONE || DM == DM_HALF, "general-p dropout keeps the stored-operand form");
+    static_assert(G::PPI % RC_WAVES == 0, "every wave issues the same number of DMAs (vmcnt bookkeeping)");
+
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, il = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nct = Cp >> 4;
+    const int q = slice * RC_WAVES + wave;                  // this wave's 32-column group (the dropout word index)
+    const int ct0 = 2 * q;
+    const int t_begin = group * tiles_per_group;
+    const int t_end = min(ntiles, t_begin + tiles_per_group);
+    if (t_begin >= t_end) return;
+    int ctl[CPW];                                           // column tiles past the end (last slice) shadow the last one
+#pragma unroll
+    for (int j = 0; j < CPW; ++j) ctl[j] = min(ct0 + j, nct - 1);
+
+    gtab2_t* gtab = reinterpret_cast<gtab2_t*>(smem + (2 * STAGE_B > G::TR_B ? 2 * STAGE_B : G::TR_B));
+    gelu_tab2_fill(gtab, drop_scale, tid, RC_THREADS);
+
+    // ---- per-launch constants of the wave: its W1 rows (second operand of the recompute) and hidden bias ----
+    Frag w1f[CPW][KD];
+    float b1v[CPW];
+    {
+        const gptr_t p_w1n = to_gptr(bk.w1n);
+        const M2M_AS1 float* b1p = reinterpret_cast<const M2M_AS1 float*>(to_gptr(bk.ch_b1p));
+#pragma unroll
+        for (int j = 0; j < CPW; ++j) {
+#pragma unroll
+            for (int kb = 0; kb < KD; ++kb) w1f[j][kb] = ld_frag_global_u(p_w1n, (long)ctl[j] * KD + kb, (unsigned int)lane * 16u);
+            b1v[j] = b1p[16 * ctl[j] + il];
+        }
+    }
+
+    // ---- streams ----
+    const unsigned long long s_at = uniform_u64((unsigned long long)bk.at_chn), s_dyt = uniform_u64((unsigned long long)bk.dyt_chn),
+                             s_an = uniform_u64((unsigned long long)bk.h_chn);       // (HREC: h_chn holds the NAT image of A)
+    const unsigned int sbase = lds_addr_of(smem);
+    const unsigned int voff = (unsigned int)(wave * PPW) * 1024u + (unsigned int)lane * 16u;
+    auto stage = [&](int tile, int buf) {                   // this wave's share of a step's three images: 3 x PPW DMAs
+        const unsigned long long o = (unsigned long long)tile * IMG_B;
+#pragma unroll
+        for (int img = 0; img < 3; ++img) {
+            const unsigned long long src = (img == 0 ? s_at : (img == 1 ? s_dyt : s_an)) + o;
+#pragma unroll
+            for (int h = 0; h < PPW; ++h)
+                glds16_sv(src, voff + h * 1024u,
+                          __builtin_amdgcn_readfirstlane(sbase + buf * STAGE_B + img * IMG_B + (wave * PPW + h) * 1024));
+        }
+    };
+    // dHpre^T fragments of the wave's column-tile pair: [pair q][32-row tile][16-row half][lane][tile 2q: 8 B | tile 2q+1: 8 B]
+    typedef const M2M_AS1 u32x4_t* g4_t;
+    const gptr_t src_dh = to_gptr(bk.dh_chn) + (long)(ctl[0] >> 1) * m2m_hchn_stride(ntiles) + lane * 16;
+    struct Ring { u32x4_t d0, d1; };
+    auto ring_load = [&](Ring& r, int tile) {
+        r.d0 = __builtin_nontemporal_load((g4_t)(src_dh + (long)tile * 2048));
+        r.d1 = __builtin_nontemporal_load((g4_t)(src_dh + (long)tile * 2048 + 1024));
+    };
+
+    f32x4_t dw1[CPW][DT], dw2[CPW][DT];
+#pragma unroll
+    for (int j = 0; j < CPW; ++j)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            dw1[j][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            dw2[j][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+#if RC_DB1_MFMA
+    f32x4_t db1[CPW] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+    Frag ones;
+    ones.u = u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+#else
+    float db1[CPW] = {0.f, 0.f};                            // this lane's rows only; summed over the four lane groups at the end
+#endif
+
+    const unsigned int ngroups32 = (unsigned int)(Cp >> 5);
+    // the keep-word of hidden-column group q for token row m is mix32(key ^ (m * ngroups32 + q)) (tile.h: drop_word_half); a
+    // step needs 32 of them (one per row): lane L computes row (L & 31)'s word and the 8 a lane needs come by ds_bpermute
+    const int my_t16 = (lane >> 4) & 1, my_r = lane & 15;
+
+    auto step = [&](const Ring& r, int tile, int buf) {
+        const char* cur = smem + buf * STAGE_B;
+        Frag df[CPW];
+#pragma unroll
+        for (int j = 0; j < CPW; ++j) df[j].u = u32x4_t{r.d0[2 * j], r.d0[2 * j + 1], r.d1[2 * j], r.d1[2 * j + 1]};
+        // ---- recompute Hpre (bias in the accumulators) ----
+        f32x4_t hacc[2][CPW];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int j = 0; j < CPW; ++j) hacc[mt][j] = f32x4_t{b1v[j], b1v[j], b1v[j], b1v[j]};
+#pragma unroll
+        for (int kb = 0; kb < KD; ++kb)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const Frag a = ld_frag_lds(cur + 2 * IMG_B, mt * KD + kb, lane);
+#pragma unroll
+                for (int j = 0; j < CPW; ++j) Pr::mma(hacc[mt][j], a, w1f[j][kb]);
+            }
+        // ---- dW1 += dHpre^T A (independent of the recompute: its MFMAs run beside the epilogue below) ----
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const Frag at = ld_frag_lds(cur, dt, lane);
+#pragma unroll
+            for (int j = 0; j < CPW; ++j) Pr::mma(dw1[j][dt], df[j], at);
+        }
+#if RC_DB1_MFMA
+#pragma unroll
+        for (int j = 0; j < CPW; ++j) Pr::mma(db1[j], df[j], ones);
+#else
+        {
+            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+            const bf16x2_t one2 = __builtin_bit_cast(bf16x2_t, 0x3F803F80u);
+#pragma unroll
+            for (int j = 0; j < CPW; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    db1[j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, df[j].u[e]), one2, db1[j], false);
+        }
+#endif
+        // ---- GELU + dropout on the accumulators: element (m = 32 tile + 16 mt + 4g + r, c = 32 q + 16 j + il) ----
+        unsigned int myword = 0xFFFFFFFFu;
+        if (DM == DM_HALF) {
+            const unsigned int m = (unsigned int)((2 * tile + my_t16) * rows_per_t16 + my_r);
+            myword = mix32(drop_key ^ (m * ngroups32 + (unsigned int)q));
+        }
+        Frag hf[CPW];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                unsigned int w = 0xFFFFFFFFu;
+                if (DM == DM_HALF) w = (unsigned int)__shfl((int)myword, 16 * mt + 4 * g + r, 64) >> il;
+#pragma unroll
+                for (int j = 0; j < CPW; ++j) {
+                    const float x = hacc[mt][j][r];
+                    unsigned int idx = pwl_index(x);
+                    if (DM == DM_HALF) idx &= (unsigned int)(((int)(w << (31 - 16 * j))) >> 31);   // dropped: cell 0 = {0, 0}
+                    const gtab2_t e = gtab[idx];
+                    hacc[mt][j][r] = __builtin_fmaf(e[1], x, e[0]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CPW; ++j) Chain<PREC_BF16>::make(hacc[0][j], hacc[1][j], &hf[j]);
+        // ---- dW2^T += Hact^T dYd ----
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const Frag dyt = ld_frag_lds(cur + IMG_B, dt, lane);
+#pragma unroll
+            for (int j = 0; j < CPW; ++j) Pr::mma(dw2[j][dt], hf[j], dyt);
+        }
+    };
+
+    // ---- pipeline ----
+    // issue order per step i (tile T_i): [wait: images of T_i landed] barrier | DMA(T_{i+1}) x 3 PPW | ring(T_{i+RC_DEPTH}) x 2 |
+    // compute(T_i).  One barrier per step: buffer (i + 1) & 1 was last read in step i - 1, which every wave has left when it
+    // arrives at the barrier of step i.  All loads are unconditional (tile clamped): a fixed number per step keeps the counts.
+    Ring ring[RC_DEPTH];
+    stage(t_begin, 0);
+#pragma unroll
+    for (int k = 0; k < RC_DEPTH; ++k) ring_load(ring[k], min(t_begin + k, t_end - 1));
+    __syncthreads();                                        // GELU table visible (drains the prologue loads once: fine)
+    int tile = t_begin, it = 0;
+    auto one = [&](Ring& r) {
+        // everything but the youngest two memory operations (the ring entry of a later step) has arrived: this step's images
+        // (own share) and its ring entry.  RC_DEPTH == 1: the ring entry IS the youngest pair.
+        if (RC_DEPTH >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        Ring cur = r;
+        asm volatile("" : "+v"(cur.d0), "+v"(cur.d1));      // hipcc's own wait for the ring entry: HERE, not behind the DMAs below
+        __builtin_amdgcn_s_barrier();
+        stage(min(tile + 1, t_end - 1), (it + 1) & 1);
+        ring_load(r, min(tile + RC_DEPTH, t_end - 1));
+        step(cur, tile, it & 1);
+        ++tile; ++it;
+    };
+    for (; tile + RC_DEPTH <= t_end;) {
+#pragma unroll
+        for (int k = 0; k < RC_DEPTH; ++k) one(ring[k]);
+    }
+#pragma unroll
+    for (int k = 0; k + 1 < RC_DEPTH; ++k)
+        if (tile < t_end) one(ring[k]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the redundant tail DMAs must not land in the transposes below
+    __syncthreads();                                        // every wave is done with the stage
+
+    // ---- results ----
+    wgrad_write_w<D, CPW>(dw1, dw2, out, ct0, nct, C, smem, wave, lane);
+#pragma unroll
+    for (int j = 0; j < CPW; ++j) {
+        if (ct0 + j >= nct) continue;
+#if RC_DB1_MFMA
+        // db1[j][r]: column c = 16 (ct0 + j) + 4g + r, identical in all 16 lanes il
+        if (il == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * (ct0 + j) + 4 * g + r;
+                if (c >= C) continue;
+                if (out.mode == WG_OUT_ATOMIC) atomicAdd(out.b1 + c, db1[j][r]);
+                else if (out.mode == WG_OUT_ADD) out.b1[c] += db1[j][r];
+                else out.b1[c] = db1[j][r];
+            }
+        }
+#else
+        const float s = lane_class_sum(db1[j], 16);         // over the four lane groups: column c = 16 (ct0 + j) + il
+        const int c = 16 * (ct0 + j) + il;
+        if (g == 0 && c < C) {
+            if (out.mode == WG_OUT_ATOMIC) atomicAdd(out.b1 + c, s);
+            else if (out.mode == WG_OUT_ADD) out.b1[c] += s;
+            else out.b1[c] = s;
+        }
+#endif
+    }
+}

@@ -26,7 +26,7 @@ from . import _lib as L
 from . import config
 from .runtime import (AdamPackPlan, BLOCK_FIELDS, BLOCK_KEYS, EmbedRuntime, MlpRuntime, TowerRuntime, block_param_shapes, heads_bce,
                       heads_ce, can_group, can_group_embeds, can_pack_all, embeds_forward, pack_all,
-                      towers_backward, towers_forward, towers_wgrad)
+                      towers_backward, towers_forward, towers_wgrad, wgrad_slot_groups)
 
 
 def config_fused_update() -> bool:
@@ -170,6 +170,12 @@ class _FlatEngine:
         self._graph = None
         self._static = None
         self._adam_plans: Dict[tuple, AdamPackPlan] = {}
+        # weight-gradient launch options (_setup_wgrad): towers whose second row group lands in a slot, and the special
+        # index ranges of the flat Adam: (lo, n, slot or None, keep)
+        self._slot_towers: List[TowerRuntime] = []
+        self._ranges_add: list = []
+        self._ranges_keep: list = []
+        self._slots_folded = False
         # side streams for the paths whose towers cannot share a launch (wide towers, mixed shapes, the MIMIC static MLP): the
         # second modality runs beside the first.  The AV-MNIST step needs none of them: nine launches on the main stream.
         self.s_b = torch.cuda.Stream(device=dev)
@@ -192,6 +198,43 @@ class _FlatEngine:
         rt.ensure_buffers(self.B)
         rt.ensure_workspace(self.B)
         return rt
+
+    def _setup_wgrad(self, towers: Sequence[TowerRuntime], grouped: bool):
+        """Options of the channel-mixing weight-gradient launch for a step that runs ONE backward per optimizer step:
+          * overwrite: a tower whose gradient elements have a single owner writes them with "=" (no read of the old values)
+            and the flat Adam leaves those ranges uncleared (-66 MB per step on M2-Mixer-B);
+          * slot: in the grouped launch a tower with twice the rows of its neighbours (the fusion tower) is split into two
+            row groups, the second storing into a slot that the flat Adam adds -- its workgroups no longer run twice as long
+            as everyone else's.
+        M2M_WGRAD_OVERWRITE=0 / M2M_WGRAD_SLOT=0 switch them off (A/B)."""
+        import os
+        self._slot_towers, self._ranges_add, self._ranges_keep = [], [], []
+        if os.environ.get("M2M_WGRAD_OVERWRITE", "1") == "0":
+            return
+        bits = 0
+        if grouped and os.environ.get("M2M_WGRAD_SLOT", "1") != "0":
+            have = [t.alloc_wslot(self.flat_g) for t in towers]
+            bits = wgrad_slot_groups(towers, self.B) if all(have) else 0
+        table = []                                   # all-or-nothing per tower (the kernel's range table holds MAX_GRAD_RANGES)
+        order = sorted(range(len(towers)), key=lambda i: -(bits >> i & 1))       # slot towers first: their ranges are mandatory
+        for i in order:
+            t = towers[i]
+            slot = bool(bits >> i & 1)
+            if not slot:
+                t.clear_wslot()
+            rng = t.channel_grad_ranges(self.flat_g)
+            fits = rng is not None and len(table) + len(rng) <= L.MAX_GRAD_RANGES
+            if slot and not fits:
+                raise RuntimeError("more slot ranges than m2m_adam_step_ranges takes")
+            if not fits or (t.wgrad_groups(self.B) != 1 and not slot):
+                continue
+            t.set_wgrad_overwrite(True)
+            views = t.wslot_views() if slot else [None] * len(rng)
+            if slot:
+                self._slot_towers.append(t)
+            table += [(lo, n, v, 1) for (lo, n), v in zip(rng, views)]
+        self._ranges_add = sorted(table, key=lambda r: r[0])
+        self._ranges_keep = [(lo, n, None, k) for lo, n, _, k in self._ranges_add]
 
     def _head(self, name: str, pooled, d_pooled, weight: float, with_grad: bool) -> dict:
         key = "classifier_fusion.classifer." if name == "fusion" else f"classifier_{name}."
@@ -278,24 +321,40 @@ class _FlatEngine:
         """An engine for another batch size over THIS engine's parameters, gradients, Adam state and step counters
         (constructor argument share=): the step that takes an epoch's ragged last batch, or a validation engine."""
         prec = {v: k for k, v in L.PREC_BY_NAME.items() if k in ("bf16", "fp32")}[self.prec]
-        return type(self)(self.cfg, batch_size, device=self.device, precision=prec, lr=float(self.adam_state[1]),
-                          betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, seed=self.seed, init=False,
-                          share=self, **self._sibling_kwargs())
+        sib = type(self)(self.cfg, batch_size, device=self.device, precision=prec, lr=float(self.adam_state[1]),
+                         betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, seed=self.seed, init=False,
+                         share=self, **self._sibling_kwargs())
+        # Both engines work on ONE gradient buffer: a range one of them leaves uncleared ("keep": its own next backward
+        # overwrites it) must be overwritten by the other one's backward too, or that one would accumulate onto stale values.
+        mine, theirs = {r[0] for r in self._ranges_add}, {r[0] for r in sib._ranges_add}
+        for eng, other in ((self, theirs), (sib, mine)):
+            eng._ranges_add = [(lo, n, v, int(k and lo in other)) for lo, n, v, k in eng._ranges_add]
+            eng._ranges_keep = [(lo, n, None, k) for lo, n, _, k in eng._ranges_add]
+        return sib
 
     # ---- optimizer -------------------------------------------------------------------------------------------
-    def _adam(self, lo: int, hi: int, grad_scale: float, bump: bool, grad_bf16: Optional[torch.Tensor] = None):
+    def _adam(self, lo: int, hi: int, grad_scale: float, bump: bool, grad_bf16: Optional[torch.Tensor] = None, ranges=None):
         """Adam over flat elements [lo, hi); clears the gradients it consumes.  grad_bf16: a bf16 copy of the whole flat
         gradient (the compressed all-reduce result) to take the values from instead of flat_g."""
         n = hi - lo
         off = lo * 4
         tail = (self.adam_state.data_ptr(), self.betas[0], self.betas[1], self.eps, self.weight_decay, -abs(grad_scale), int(bump),
                 L.stream_ptr())
+        if grad_bf16 is not None and (grad_bf16.dtype != torch.bfloat16 or grad_bf16.numel() != self.n_params or not grad_bf16.is_cuda):
+            raise RuntimeError("grad_bf16 must be a bf16 device copy of the whole flat gradient")
+        if ranges:
+            if lo != 0 or hi != self.n_params:
+                raise RuntimeError("gradient ranges are indexed over the whole flat buffer")
+            arr = (L.GradRange * len(ranges))()
+            for i, (rlo, rn, add, keep) in enumerate(ranges):
+                arr[i].lo, arr[i].n, arr[i].add, arr[i].keep = rlo, rn, L.ptr(add), int(keep)
+            L.check(L.lib().m2m_adam_step_ranges(self.flat_p.data_ptr(), self.flat_g.data_ptr(), L.ptr(grad_bf16), self.flat_m.data_ptr(),
+                                                 self.flat_v.data_ptr(), n, *tail[:-1], arr, len(ranges), tail[-1]), "adam_step_ranges")
+            return
         if grad_bf16 is None:
             L.check(L.lib().m2m_adam_step(self.flat_p.data_ptr() + off, self.flat_g.data_ptr() + off, self.flat_m.data_ptr() + off,
                                           self.flat_v.data_ptr() + off, n, *tail), "adam_step")
         else:
-            if grad_bf16.dtype != torch.bfloat16 or grad_bf16.numel() != self.n_params or not grad_bf16.is_cuda:
-                raise RuntimeError("grad_bf16 must be a bf16 device copy of the whole flat gradient")
             L.check(L.lib().m2m_adam_step_bf16(self.flat_p.data_ptr() + off, self.flat_g.data_ptr() + off,
                                                grad_bf16.data_ptr() + lo * 2, self.flat_m.data_ptr() + off,
                                                self.flat_v.data_ptr() + off, n, *tail), "adam_step_bf16")
@@ -308,9 +367,14 @@ class _FlatEngine:
     def forward_backward(self, *batch):
         """forward (dropout on) -> multi-head loss -> backward; gradients are ADDED into flat_g, which must be
         zero on entry: it is cleared at construction and again by every optimizer_step (the Adam kernel clears
-        each element it consumes), so no separate fill pass is needed."""
+        each element it consumes), so no separate fill pass is needed.  (Channel-mixing weight gradients of the
+        overwriting towers -- _setup_wgrad -- are written, not added: those ranges need no clearing.)  On return flat_g
+        holds the complete gradient: a row group the weight-gradient launch left in a slot is folded in here."""
         self._forward(*batch, training=True, with_grad=True, prologue=True)
         self._backward(*batch[:-1])
+        for t in self._slot_towers:
+            t.wgrad_fold()
+        self._slots_folded = True
 
     def fused_step(self, *batch):
         """forward + backward + Adam + re-pack in one go (no gradient exchange: single-GPU training)."""
@@ -327,8 +391,11 @@ class _FlatEngine:
         """Adam over every parameter + operand re-pack.  One launch (m2m_adam_pack_all) where the model allows it: the
         re-pack then takes the updated weights from the workgroup that computed them instead of re-reading the masters."""
         mods = self._adam_pack_modules() if config_fused_update() else None
-        if mods is None:
-            self._adam(0, self.n_params, grad_scale, False, grad_bf16)        # negative scale inside: clears the gradients
+        # the slot of a two-group tower: added inside Adam (fused step) unless forward_backward has folded it in already
+        ranges = self._ranges_keep if (self._slots_folded or grad_bf16 is not None) else self._ranges_add
+        self._slots_folded = False
+        if mods is None or ranges:
+            self._adam(0, self.n_params, grad_scale, False, grad_bf16, ranges)    # negative scale inside: clears the gradients
             self.pack()
             return
         key = (abs(float(grad_scale)), 0 if grad_bf16 is None else grad_bf16.data_ptr())
@@ -483,6 +550,7 @@ class _TwoTowerEngine(_FlatEngine):
         self.d_fused = f(B, self.Nf, D)
         self.dx0_a, self.dx0_b = f(B * self.Na, D), f(B * self.Nb, D)
         self.preds = torch.zeros(self._preds_shape(), dtype=torch.int32, device=dev)
+        self._setup_wgrad([self.t_fus, self.t_a, self.t_b], grouped=True)
 
     def _preds_shape(self):
         return (3, self.B)
@@ -572,13 +640,14 @@ class _TwoTowerEngine(_FlatEngine):
             self.t_b.backward(B, d_b_part, fs, self.dpool_b, self.dx0_b, self.Nb * D, self.seed, 0, sd)
             main.wait_stream(s_a)
         if can_group_embeds(self.e_a, self.e_b) and self.e_a.prec == self.t_a.prec and self.e_a.D == self.t_a.D:
-            towers_wgrad([self.t_fus, self.t_a, self.t_b], B, [self.e_a, self.e_b], [xa, xb], [self.dx0_a, self.dx0_b])
+            towers_wgrad([self.t_fus, self.t_a, self.t_b], B, [self.e_a, self.e_b], [xa, xb], [self.dx0_a, self.dx0_b],
+                         seed=self.seed, step=0, step_dev=sd)
         else:
             s_e.wait_stream(main)
             with torch.cuda.stream(s_e):
                 self.e_b.wgrad(xb, self.dx0_b, B)
                 self.e_a.wgrad(xa, self.dx0_a, B)
-            towers_wgrad([self.t_fus, self.t_a, self.t_b], B)
+            towers_wgrad([self.t_fus, self.t_a, self.t_b], B, seed=self.seed, step=0, step_dev=sd)
             main.wait_stream(s_e)
         if fused_update:
             self._update(1.0)

@@ -270,6 +270,62 @@ class TowerRuntime:
                                            d_x0.data_ptr(), d_x0_ss, seed & 0xFFFFFFFF, step & 0xFFFFFFFF,
                                            L.ptr(step_dev), L.stream_ptr()), "tower_backward")
 
+    # ---- weight-gradient launch options (include/m2mixer.h: wgrad_flags, wslot) ----------------------------------------
+    def wgrad_form(self, B: int) -> int:
+        """1: the library's weight-gradient launch recomputes the hidden activation for this tower at batch B."""
+        return int(L.lib().m2m_wgrad_form(C.byref(self.desc), B))
+
+    def wgrad_groups(self, B: int) -> int:
+        return int(L.lib().m2m_wgrad_groups(C.byref(self.desc), B))
+
+    def channel_grad_ranges(self, flat_g: torch.Tensor):
+        """[(lo, n)] per block: the flat-gradient index range of g_ch_w1 | g_ch_b1 | g_ch_w2 when the three lie back to back
+        inside `flat_g` (the engines' layout), else None."""
+        out = []
+        cd = self.C * self.D
+        base, end = flat_g.data_ptr(), flat_g.data_ptr() + flat_g.numel() * 4
+        for i in range(self.nblocks):
+            b = self.desc.blk[i]
+            w1, b1, w2 = b.g_ch_w1, b.g_ch_b1, b.g_ch_w2
+            if not w1 or b1 != w1 + 4 * cd or w2 != b1 + 4 * self.C or w1 < base or w2 + 4 * cd > end:
+                return None
+            out.append(((w1 - base) // 4, 2 * cd + self.C))
+        return out
+
+    def alloc_wslot(self, flat_g: torch.Tensor) -> bool:
+        """Partial-gradient slot of every block (second row group of the weight-gradient launch), each with the 16-byte
+        phase of its flat-gradient range so that the optimizer can add it with vector loads."""
+        rng = self.channel_grad_ranges(flat_g)
+        if rng is None or self.nblocks == 0:
+            return False
+        n = rng[0][1]
+        buf = torch.zeros(self.nblocks * (n + 8), device=self.device)
+        views = []
+        off = 0
+        for i, (lo, _) in enumerate(rng):
+            while (off - lo) % 4:          # (buf is 256-byte aligned): element `off` gets the phase of flat element `lo`
+                off += 1
+            v = buf[off:off + n]
+            self.desc.wslot[i] = v.data_ptr()
+            views.append(v)
+            off += n
+        self._keep["wslot"] = (buf, views)
+        return True
+
+    def clear_wslot(self):
+        for i in range(L.MAX_BLOCKS):
+            self.desc.wslot[i] = None
+        self._keep.pop("wslot", None)
+
+    def wslot_views(self):
+        return self._keep["wslot"][1] if "wslot" in self._keep else None
+
+    def set_wgrad_overwrite(self, on: bool):
+        self.desc.wgrad_flags = (self.desc.wgrad_flags | L.WGRAD_OVERWRITE) if on else (self.desc.wgrad_flags & ~L.WGRAD_OVERWRITE)
+
+    def wgrad_fold(self):
+        L.check(L.lib().m2m_wgrad_fold(C.byref(self.desc), L.stream_ptr()), "wgrad_fold")
+
     def wgrad(self, B: int, seed: int, step: int, step_dev: Optional[torch.Tensor] = None):
         L.check(L.lib().m2m_tower_wgrad(C.byref(self.desc), B, seed & 0xFFFFFFFF, step & 0xFFFFFFFF, L.ptr(step_dev),
                                         L.stream_ptr()), "tower_wgrad")
@@ -330,17 +386,27 @@ def towers_backward(towers: Sequence[TowerRuntime], ios: Sequence[tuple], B: int
             "towers_backward")
 
 
+def wgrad_slot_groups(towers: Sequence[TowerRuntime], B: int) -> int:
+    """bit i: towers_wgrad(towers, B) leaves tower i's second row group in its slot (TowerRuntime.alloc_wslot)."""
+    n = len(towers)
+    host = (C.POINTER(L.Tower) * n)(*[C.pointer(t.desc) for t in towers])
+    return int(L.lib().m2m_wgrad_slot_groups(host, n, B))
+
+
 def towers_wgrad(towers: Sequence[TowerRuntime], B: int, embeds: Sequence["EmbedRuntime"] = (),
-                 inputs: Sequence[torch.Tensor] = (), d_x0s: Sequence[torch.Tensor] = ()):
+                 inputs: Sequence[torch.Tensor] = (), d_x0s: Sequence[torch.Tensor] = (), seed: int = 0, step: int = 0,
+                 step_dev: Optional[torch.Tensor] = None):
     """Channel-mixing weight gradients of several towers (same precision / hidden_dim) in one launch; with `embeds`
-    (the model's two patch embeddings, their inputs and d_x0) also the embedding gradients, in the same launch."""
+    (the model's two patch embeddings, their inputs and d_x0) also the embedding gradients, in the same launch.
+    seed / step / step_dev: the dropout stream of the forward (the recompute form regenerates the hidden keep-mask)."""
     n, ne = len(towers), len(embeds)
     host = (C.POINTER(L.Tower) * n)(*[C.pointer(t.desc) for t in towers])
     dev = (C.c_void_p * n)(*[t.device_desc() for t in towers])
     ep = (C.POINTER(L.Embed) * max(ne, 1))(*[C.pointer(e.desc) for e in embeds])
     ip = (C.c_void_p * max(ne, 1))(*[t.data_ptr() for t in inputs])
     dp = (C.c_void_p * max(ne, 1))(*[t.data_ptr() for t in d_x0s])
-    L.check(L.lib().m2m_towers_wgrad(host, dev, n, ep, ip, dp, ne, B, L.stream_ptr()), "towers_wgrad")
+    L.check(L.lib().m2m_towers_wgrad(host, dev, n, ep, ip, dp, ne, B, seed & 0xFFFFFFFF, step & 0xFFFFFFFF, L.ptr(step_dev),
+                                     L.stream_ptr()), "towers_wgrad")
 
 
 def can_pack_all(towers: Sequence[TowerRuntime], embeds: Sequence["EmbedRuntime"]) -> bool:

@@ -41,11 +41,46 @@ def test_struct_layouts_match_header(lib):
     import ctypes as C
     # m2m_block: 12 params + 5 packed + 12 grads + 6 saved pointers; m2m_tower header is 40 bytes then 7 pointers
     assert C.sizeof(lib.Block) == 35 * 8
-    assert C.sizeof(lib.Tower) == 40 + 7 * 8 + lib.MAX_BLOCKS * C.sizeof(lib.Block) + 8 + 8 + 8 + 8 + 2 * 8 * lib.MAX_BLOCKS
+    assert C.sizeof(lib.Tower) == 40 + 7 * 8 + lib.MAX_BLOCKS * C.sizeof(lib.Block) + 8 + 8 + 8 + 8 + 3 * 8 * lib.MAX_BLOCKS
     assert lib.Tower.slabs.offset == 96 + lib.MAX_BLOCKS * C.sizeof(lib.Block)
     assert lib.Tower.blk.offset == 96
     assert C.sizeof(lib.Embed) == 40 + 5 * 8
     assert C.sizeof(lib.Head) == 6 * 8 + 8
+
+
+def test_struct_layouts_against_the_c_compiler(lib, tmp_path):
+    """sizeof / offsetof of every struct that crosses the boundary, as gcc sees include/m2mixer.h, against the ctypes mirror."""
+    import ctypes as C
+    import subprocess
+    fields = {"m2m_block": ("Block", ["ln1_w", "w1n", "g_ln1_w", "x_in", "dh_chn"]),
+              "m2m_tower": ("Tower", ["p_drop", "lnf_w", "blk", "slabs", "wgrad_flags", "xres", "gpart", "a_nat", "dy_nat", "wslot"]),
+              "m2m_embed": ("Embed", ["Kp", "w", "g_b"]),
+              "m2m_head": ("Head", ["d_pooled", "weight"]),
+              "m2m_mlp": ("Mlp", ["dims", "p_drop", "w", "act"]),
+              "m2m_grad_range": ("GradRange", ["lo", "n", "add", "keep"]),
+              "m2m_step_head": ("StepHead", ["losses", "nlosses"])}
+    # ctypes names that differ from the C field names
+    alias = {("Tower", "x0_ss"): "x0_sample_stride"}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "m2mixer.h"', 'int main(void) {']
+    for cname, (_, fl) in fields.items():
+        src.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for f in fl:
+            src.append(f'printf("{cname}.{f} %zu\\n", offsetof({cname}, {f}));')
+    src += ['printf("M2M_MAX_GRAD_RANGES %d\\n", M2M_MAX_GRAD_RANGES);', 'printf("M2M_WGRAD_OVERWRITE %d\\n", M2M_WGRAD_OVERWRITE);',
+            'printf("M2M_ABI_VERSION %d\\n", M2M_ABI_VERSION);', 'return 0; }']
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)], check=True)
+    got = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for cname, (pyname, fl) in fields.items():
+        cls = getattr(lib, pyname)
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for f in fl:
+            assert int(got[f"{cname}.{f}"]) == getattr(cls, f).offset, f"{cname}.{f}"
+    assert int(got["M2M_MAX_GRAD_RANGES"]) == lib.MAX_GRAD_RANGES
+    assert int(got["M2M_WGRAD_OVERWRITE"]) == lib.WGRAD_OVERWRITE
+    assert int(got["M2M_ABI_VERSION"]) == lib.ABI_VERSION
 
 
 def test_registry_and_state_dict_keys():
