@@ -26,7 +26,10 @@
 #define RC_WAVES 4
 #define RC_THREADS (RC_WAVES * 64)
 #ifndef RC_DEPTH
-#define RC_DEPTH 2        // steps of dHpre^T fragments in flight (8 VGPRs each)
+#define RC_DEPTH 1        // steps of dHpre^T fragments in flight (8 VGPRs each; 2 spills 6 registers at RC_LA 2, 26 at RC_LA 3)
+#endif
+#ifndef RC_LA
+#define RC_LA 3           // LDS fragments read ahead of their MFMAs
 #endif
 #ifndef RC_DB1_MFMA
 #define RC_DB1_MFMA 0     // 1: db1 through an all-ones MFMA operand (12 VGPRs more), 0: v_dot2c_f32_bf16 on the fragments
@@ -198,6 +201,7 @@ static __device__ __forceinline__ void wgrad_rc_body(const m2m_block& bk, const 
     typedef RcGeom<D> G;
     constexpr int KD = G::KD, DT = G::DT, IMG_B = G::IMG_B, STAGE_B = G::STAGE_B, PPW = G::PPW, CPW = 2;
     static_assert(DM == DM_NONE || DM == DM_HALF, "general-p dropout keeps the stored-operand form");
+    static_assert(RC_DEPTH >= 1, "ring depth");
     static_assert(G::PPI % RC_WAVES == 0, "every wave issues the same number of DMAs (vmcnt bookkeeping)");
 
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, il = lane & 15;
@@ -275,32 +279,36 @@ static __device__ __forceinline__ void wgrad_rc_body(const m2m_block& bk, const 
     // step needs 32 of them (one per row): lane L computes row (L & 31)'s word and the 8 a lane needs come by ds_bpermute
     const int my_t16 = (lane >> 4) & 1, my_r = lane & 15;
 
+    // One 32-row step.  The LDS fragment reads run RC_LA fragments ahead of the MFMAs that consume them (left to hipcc every read
+    // was waited for at once: ds_read, lgkmcnt(0), two MFMAs, ...), and the GELU epilogue of accumulator row (mt, r) is written
+    // between the dW1 MFMAs of d-tile 4 mt + r -- those do not depend on the recompute -- so that a wave alone on its SIMD
+    // overlaps its own vector work with its own matrix work.
     auto step = [&](const Ring& r, int tile, int buf) {
         const char* cur = smem + buf * STAGE_B;
+        constexpr int LA = RC_LA;
         Frag df[CPW];
 #pragma unroll
         for (int j = 0; j < CPW; ++j) df[j].u = u32x4_t{r.d0[2 * j], r.d0[2 * j + 1], r.d1[2 * j], r.d1[2 * j + 1]};
-        // ---- recompute Hpre (bias in the accumulators) ----
+        // ---- recompute Hpre (bias in the accumulators): fragment q = (kb, mt) ----
         f32x4_t hacc[2][CPW];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int j = 0; j < CPW; ++j) hacc[mt][j] = f32x4_t{b1v[j], b1v[j], b1v[j], b1v[j]};
+        {
+            constexpr int NQ = 2 * KD, L = LA < NQ ? LA : NQ;
+            Frag aq[L];
 #pragma unroll
-        for (int kb = 0; kb < KD; ++kb)
+            for (int q = 0; q < L; ++q) aq[q] = ld_frag_lds(cur + 2 * IMG_B, (q & 1) * KD + (q >> 1), lane);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const Frag a = ld_frag_lds(cur + 2 * IMG_B, mt * KD + kb, lane);
+            for (int q = 0; q < NQ; ++q) {
+                const Frag a = aq[q % L];
+                if (q + L < NQ) aq[q % L] = ld_frag_lds(cur + 2 * IMG_B, ((q + L) & 1) * KD + ((q + L) >> 1), lane);
 #pragma unroll
-                for (int j = 0; j < CPW; ++j) Pr::mma(hacc[mt][j], a, w1f[j][kb]);
+                for (int j = 0; j < CPW; ++j) Pr::mma(hacc[q & 1][j], a, w1f[j][q >> 1]);
             }
-        // ---- dW1 += dHpre^T A (independent of the recompute: its MFMAs run beside the epilogue below) ----
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const Frag at = ld_frag_lds(cur, dt, lane);
-#pragma unroll
-            for (int j = 0; j < CPW; ++j) Pr::mma(dw1[j][dt], df[j], at);
         }
+        // ---- db1 (this lane's rows) ----
 #if RC_DB1_MFMA
 #pragma unroll
         for (int j = 0; j < CPW; ++j) Pr::mma(db1[j], df[j], ones);
@@ -308,44 +316,68 @@ static __device__ __forceinline__ void wgrad_rc_body(const m2m_block& bk, const 
         {
             typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
             const bf16x2_t one2 = __builtin_bit_cast(bf16x2_t, 0x3F803F80u);
+            // (pairs taken by shufflevector from the typed view: __builtin_bit_cast of the vector ELEMENT df[j].u[e] was
+            // miscompiled -- all four dot products read element 0)
 #pragma unroll
-            for (int j = 0; j < CPW; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    db1[j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, df[j].u[e]), one2, db1[j], false);
+            for (int j = 0; j < CPW; ++j) {
+                db1[j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(df[j].h, df[j].h, 0, 1), one2, db1[j], false);
+                db1[j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(df[j].h, df[j].h, 2, 3), one2, db1[j], false);
+                db1[j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(df[j].h, df[j].h, 4, 5), one2, db1[j], false);
+                db1[j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(df[j].h, df[j].h, 6, 7), one2, db1[j], false);
+            }
         }
 #endif
-        // ---- GELU + dropout on the accumulators: element (m = 32 tile + 16 mt + 4g + r, c = 32 q + 16 j + il) ----
+        // ---- dW1 += dHpre^T A, with the GELU + dropout of accumulator row (mt, r) = d-tile index between its MFMAs:
+        //      element (m = 32 tile + 16 mt + 4g + r, c = 32 q + 16 j + il) ----
         unsigned int myword = 0xFFFFFFFFu;
         if (DM == DM_HALF) {
             const unsigned int m = (unsigned int)((2 * tile + my_t16) * rows_per_t16 + my_r);
             myword = mix32(drop_key ^ (m * ngroups32 + (unsigned int)q));
         }
-        Frag hf[CPW];
+        {
+            constexpr int L = LA < DT ? LA : DT;
+            Frag tq[L];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+            for (int dt = 0; dt < L; ++dt) tq[dt] = ld_frag_lds(cur, dt, lane);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                unsigned int w = 0xFFFFFFFFu;
-                if (DM == DM_HALF) w = (unsigned int)__shfl((int)myword, 16 * mt + 4 * g + r, 64) >> il;
+            for (int dt = 0; dt < DT; ++dt) {
+                const Frag at = tq[dt % L];
+                if (dt + L < DT) tq[dt % L] = ld_frag_lds(cur, dt + L, lane);
 #pragma unroll
-                for (int j = 0; j < CPW; ++j) {
-                    const float x = hacc[mt][j][r];
-                    unsigned int idx = pwl_index(x);
-                    if (DM == DM_HALF) idx &= (unsigned int)(((int)(w << (31 - 16 * j))) >> 31);   // dropped: cell 0 = {0, 0}
-                    const gtab2_t e = gtab[idx];
-                    hacc[mt][j][r] = __builtin_fmaf(e[1], x, e[0]);
+                for (int j = 0; j < CPW; ++j) Pr::mma(dw1[j][dt], df[j], at);
+                // epilogue rows: DT d-tiles serve the 8 rows (mt, r); DT > 8 would leave the later ones without, DT < 8 doubles up
+#pragma unroll
+                for (int row = dt * 8 / DT; row < (dt + 1) * 8 / DT; ++row) {
+                    const int mt = row >> 2, rr = row & 3;
+                    unsigned int w = 0xFFFFFFFFu;
+                    if (DM == DM_HALF) w = (unsigned int)__shfl((int)myword, 16 * mt + 4 * g + rr, 64) >> il;
+#pragma unroll
+                    for (int j = 0; j < CPW; ++j) {
+                        const float x = hacc[mt][j][rr];
+                        unsigned int idx = pwl_index(x);
+                        if (DM == DM_HALF) idx &= (unsigned int)(((int)(w << (31 - 16 * j))) >> 31);   // dropped: cell 0 = {0, 0}
+                        const gtab2_t e = gtab[idx];
+                        hacc[mt][j][rr] = __builtin_fmaf(e[1], x, e[0]);
+                    }
                 }
             }
         }
+        Frag hf[CPW];
 #pragma unroll
         for (int j = 0; j < CPW; ++j) Chain<PREC_BF16>::make(hacc[0][j], hacc[1][j], &hf[j]);
         // ---- dW2^T += Hact^T dYd ----
+        {
+            constexpr int L = LA < DT ? LA : DT;
+            Frag yq[L];
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const Frag dyt = ld_frag_lds(cur + IMG_B, dt, lane);
+            for (int dt = 0; dt < L; ++dt) yq[dt] = ld_frag_lds(cur + IMG_B, dt, lane);
 #pragma unroll
-            for (int j = 0; j < CPW; ++j) Pr::mma(dw2[j][dt], hf[j], dyt);
+            for (int dt = 0; dt < DT; ++dt) {
+                const Frag dyt = yq[dt % L];
+                if (dt + L < DT) yq[dt % L] = ld_frag_lds(cur + IMG_B, dt + L, lane);
+#pragma unroll
+                for (int j = 0; j < CPW; ++j) Pr::mma(dw2[j][dt], hf[j], dyt);
+            }
         }
     };
 
@@ -353,32 +385,38 @@ static __device__ __forceinline__ void wgrad_rc_body(const m2m_block& bk, const 
     // issue order per step i (tile T_i): [wait: images of T_i landed] barrier | DMA(T_{i+1}) x 3 PPW | ring(T_{i+RC_DEPTH}) x 2 |
     // compute(T_i).  One barrier per step: buffer (i + 1) & 1 was last read in step i - 1, which every wave has left when it
     // arrives at the barrier of step i.  All loads are unconditional (tile clamped): a fixed number per step keeps the counts.
-    Ring ring[RC_DEPTH];
+    // The ring has RC_DEPTH + 1 slots and the loop is unrolled by that: step i consumes slot i % NS and refills slot
+    // (i + RC_DEPTH) % NS = the slot the PREVIOUS step consumed -- never the one in use, so no register copies at the back
+    // edge (with RC_DEPTH slots the refill target was live: hipcc rotated the ring with v_mov behind a vmcnt(0) per trip).
+    constexpr int NS = RC_DEPTH + 1;
+    Ring ring[NS];
     stage(t_begin, 0);
+#pragma unroll
+    for (int k = 0; k < NS; ++k) ring[k].d0 = ring[k].d1 = u32x4_t{0u, 0u, 0u, 0u};
 #pragma unroll
     for (int k = 0; k < RC_DEPTH; ++k) ring_load(ring[k], min(t_begin + k, t_end - 1));
     __syncthreads();                                        // GELU table visible (drains the prologue loads once: fine)
     int tile = t_begin, it = 0;
-    auto one = [&](Ring& r) {
+    auto one = [&](Ring& use, Ring& refill) {
         // everything but the youngest two memory operations (the ring entry of a later step) has arrived: this step's images
-        // (own share) and its ring entry.  RC_DEPTH == 1: the ring entry IS the youngest pair.
+        // (own share) and its ring entry
+        // (RC_DEPTH == 1: the ring entry of THIS step is the youngest pair)
         if (RC_DEPTH >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        Ring cur = r;
-        asm volatile("" : "+v"(cur.d0), "+v"(cur.d1));      // hipcc's own wait for the ring entry: HERE, not behind the DMAs below
+        asm volatile("" : "+v"(use.d0), "+v"(use.d1));      // hipcc's own wait for the ring entry: HERE, not behind the DMAs below
         __builtin_amdgcn_s_barrier();
         stage(min(tile + 1, t_end - 1), (it + 1) & 1);
-        ring_load(r, min(tile + RC_DEPTH, t_end - 1));
-        step(cur, tile, it & 1);
+        ring_load(refill, min(tile + RC_DEPTH, t_end - 1));
+        step(use, tile, it & 1);
         ++tile; ++it;
     };
-    for (; tile + RC_DEPTH <= t_end;) {
+    for (; tile + NS <= t_end;) {
 #pragma unroll
-        for (int k = 0; k < RC_DEPTH; ++k) one(ring[k]);
+        for (int k = 0; k < NS; ++k) one(ring[k], ring[(k + RC_DEPTH) % NS]);
     }
 #pragma unroll
-    for (int k = 0; k + 1 < RC_DEPTH; ++k)
-        if (tile < t_end) one(ring[k]);
+    for (int k = 0; k + 1 < NS; ++k)
+        if (tile < t_end) one(ring[k], ring[(k + RC_DEPTH) % NS]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the redundant tail DMAs must not land in the transposes below
     __syncthreads();                                        // every wave is done with the stage
 

@@ -48,10 +48,13 @@ class ResidentAVMnist:
         return image.to(self.device), audio.to(self.device), labels.to(self.device)
 
     def num_samples(self, split: str) -> int:
-        """Samples of `split` this rank sees: r, r + world, ... (Lightning's DistributedSampler(shuffle=False) pads the last
-        ranks with repeats; here a rank simply gets one sample fewer)."""
+        """Samples of `split` this rank sees.  As torch's DistributedSampler(drop_last=False) -- what Lightning puts in
+        front of the reference's loaders under DDP (datasets/avmnist.py:180-190, run.py:69-70) -- EVERY rank gets
+        ceil(n / world): the index list is padded with its own head until it divides evenly, then rank r takes
+        r, r + world, ...  Equal counts are what keeps the ranks' collectives in step (an epoch is the same number of
+        batches, of the same sizes, on every rank)."""
         n = self.splits[split][2].shape[0]
-        return (n - self.rank + self.world - 1) // self.world
+        return (n + self.world - 1) // self.world
 
     def num_batches(self, split: str, batch_size: int, drop_last: bool = False) -> int:
         """The reference's DataLoaders keep the ragged last batch (`drop_last` is left False, datasets/avmnist.py:180-190)."""
@@ -60,8 +63,9 @@ class ResidentAVMnist:
 
     def batches(self, split: str, batch_size: int, shuffle: bool = False, generator: Optional[torch.Generator] = None,
                 drop_last: bool = False) -> Iterator[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
-        """Rank r takes samples r, r + world, ... (what Lightning's DistributedSampler(shuffle=False) hands a DDP rank).
-        The last batch may be smaller than batch_size (drop_last=False, as the reference)."""
+        """Rank r takes samples r, r + world, ... of the padded index list (see num_samples: DistributedSampler semantics;
+        under `shuffle` every rank must pass a generator in the same state).  The last batch may be smaller than batch_size
+        (drop_last=False, as the reference)."""
         image, audio, labels = self.splits[split]
         n = labels.shape[0]
         if shuffle:
@@ -71,6 +75,9 @@ class ResidentAVMnist:
         else:
             order = None
         if order is not None and self.world > 1:
+            pad = self.num_samples(split) * self.world - n
+            if pad:
+                order = torch.cat([order, order[:pad]])         # (n >= world: one wrap-around suffices)
             order = order[self.rank::self.world]
         mine = self.num_samples(split)
         for b in range(self.num_batches(split, batch_size, drop_last)):
@@ -103,12 +110,16 @@ class PlateauLR:
 
 
 def run_epoch(engine, data: ResidentAVMnist, split: str, batch_size: int, train: bool, log_interval_steps: int = 50,
-              replay=None, log=None, tail_engine=None) -> Dict[str, float]:
+              replay=None, log=None, tail_engine=None, grad_sync=None) -> Dict[str, float]:
     """One pass over EVERY sample of `split` (the reference's loaders keep the ragged last batch,
     datasets/avmnist.py:180-190).  train=True drives the captured step (`replay`, from engine.capture) or
     engine.train_step.  A last batch smaller than batch_size -- the captured graph and the engine's buffers have a static
     batch size -- goes through `tail_engine` (default: engine.sibling(remainder), same parameters / Adam state, built on
     first use and kept on the engine), eagerly; packed operand copies are re-synchronised around it.
+    Data parallel (world > 1): pass the `grad_sync` the replay was captured with -- EVERY training step exchanges gradients,
+    the eager ones (no replay, the ragged last batch) included, as Lightning's DDP does; the ranks see equally many samples
+    (ResidentAVMnist.num_samples), hence the same sequence of collectives.  Returned metrics are this rank's (the reference
+    logs without sync_dist).
 
     Per-step values are summed on the device and read back every `log_interval_steps` steps and at the end (cfg
     `log_interval_steps`, cfg/avmnist/*.yml:3): the four losses (modules/train_test_module.py:72-92: step losses), the three
@@ -122,8 +133,9 @@ def run_epoch(engine, data: ResidentAVMnist, split: str, batch_size: int, train:
     # [loss_a, loss_b, loss_fusion, loss] step sums | the same weighted by the step's batch size | hits a, b, fusion
     acc = torch.zeros(11, device=dev, dtype=torch.float64)
     seen, host = 0, np.zeros(11)
+    if train and grad_sync is None and getattr(data, "world", 1) > 1:
+        raise RuntimeError("run_epoch: world > 1 needs the gradient exchange (grad_sync=parallel.GradSync(...))")
     nb = data.num_batches(split, batch_size)
-    n_tail = data.num_samples(split) % batch_size
     for i, (image, audio, labels) in enumerate(data.batches(split, batch_size, shuffle=(split == "test"))):
         bs = labels.shape[0]
         eng = engine
@@ -140,7 +152,7 @@ def run_epoch(engine, data: ResidentAVMnist, split: str, batch_size: int, train:
             if replay is not None and eng is engine:
                 replay(image, audio, labels)
             else:
-                eng.train_step(image, audio, labels)
+                eng.train_step(image, audio, labels, grad_sync=grad_sync)
         else:
             eng.evaluate(image, audio, labels)
         if eng is not engine and train:
