@@ -43,10 +43,10 @@ bool m2m_split_eligible(const m2m_tower* t, int B, int training);     // split_a
 #define WG_OUT_STORE 2    // "=": single owner, the old values are not read (m2m_tower.wgrad_flags & M2M_WGRAD_OVERWRITE, and the
                           //      second row group of a tower with a partial-gradient slot, m2m_tower.wslot)
 
-#include "tower_wgrad_rc.h"   // WgOut, wgrad_write_w, the recompute form (bf16, hidden_dim 128)
-
 TIMER_DECL(g_tm_wg);
 TIMER_READER(m2m_debug_timers_wgrad, g_tm_wg)
+
+#include "tower_wgrad_rc.h"   // WgOut, wgrad_write_w, the recompute form (bf16, hidden_dim 128)
 
 template <int P, int D> struct WgradGeom {
     static constexpr int NF = Chain<P>::NF;
@@ -331,14 +331,21 @@ struct WgradGroupArgs {
     const m2m_tower* tw[WG_MAX_TOWERS];
     int ntiles[WG_MAX_TOWERS], tpg[WG_MAX_TOWERS], groups[WG_MAX_TOWERS], nsl[WG_MAX_TOWERS], slot[WG_MAX_TOWERS], rpt[WG_MAX_TOWERS];
     unsigned char job_tower[WG_MAX_JOBS], job_block[WG_MAX_JOBS];
-    int max_nsl, njobs, n_tower_wgs;
+    short job_start[WG_MAX_JOBS + 1];                 // first linear workgroup index of job j (its workgroups: group-major, slice fastest)
+    short xcd_start[8], xcd_len[8];                   // XCD x runs linear indices [xcd_start[x], xcd_start[x] + xcd_len[x])
+    int njobs, n_tower_wgs;                           // n_tower_wgs = 8 x the longest XCD chunk (ids beyond a chunk return at once)
     unsigned int seed, step_host;
     const unsigned int* step_dev;
 };
-// The grid is one-dimensional: id -> (slice, job, group) in that order (slice fastest), then -- so that they are dispatched
-// last and back-fill the CUs whose tower workgroup has finished -- the workgroups of the model's two patch-embedding
-// weight gradients (embed_wgrad.h).  A second launch beside this one costs a fork and a join in the replayed graph
-// (~10 us each) and slows this kernel by contending for the same CUs.
+// The grid is one-dimensional.  Tower workgroups first, XCD-aware: the hardware deals consecutive workgroup ids to the 8 XCDs
+// round-robin (id % 8), each XCD has its own 4 MB L2, and what a workgroup re-reads -- the 32-row operand images of ITS
+// (tower, block) job, 1.5 MB per job and row group on M2-Mixer-B, shared by the job's 24 column slices -- should come from
+// that L2.  With slices dealt out in id order every XCD touched every job (18 MB of images through each 4 MB L2: the images
+// came from the Infinity Cache at ~33 GB/s per CU and paced the loop at ~2 us per step).  So the jobs' workgroups are laid
+// out in ONE linear list, job-major, and XCD x takes a contiguous eighth of it: an L2 serves two or three jobs.
+// Then -- dispatched last, back-filling the CUs whose tower workgroup has finished -- the workgroups of the model's two
+// patch-embedding weight gradients (embed_wgrad.h); a second launch beside this one costs a fork and a join in the replayed
+// graph (~10 us each) and slows this kernel by contending for the same CUs.
 template <int P, int D, int RCDM>
 __global__ __launch_bounds__(WG_THREADS, (WgradKernelGeom<P, D, RCDM>::MINWAVES)) void tower_wgrad_group_kernel(const WgradGroupArgs a,
                                                                                                           const EmbedWgradGroupArgs ea) {
@@ -348,9 +355,13 @@ __global__ __launch_bounds__(WG_THREADS, (WgradKernelGeom<P, D, RCDM>::MINWAVES)
         embed_wgrad_group_body<P, D, WG_THREADS>(ea, id - a.n_tower_wgs, smem);
         return;
     }
-    const int slice = id % a.max_nsl, job = (id / a.max_nsl) % a.njobs, group = id / (a.max_nsl * a.njobs);
-    const int t = a.job_tower[job];
-    if (slice >= a.nsl[t] || group >= a.groups[t]) return;
+    const int xcd = id & 7, idx = id >> 3;
+    if (idx >= a.xcd_len[xcd]) return;
+    const int lin = a.xcd_start[xcd] + idx;
+    int job = 0;
+    while (job + 1 < a.njobs && lin >= a.job_start[job + 1]) ++job;
+    const int t = a.job_tower[job], rel = lin - a.job_start[job];
+    const int slice = rel % a.nsl[t], group = rel / a.nsl[t];
     const m2m_tower& tw = *a.tw[t];
     const unsigned int step = a.step_host + (a.step_dev ? *a.step_dev : 0u);
     wgrad_dispatch<P, D, RCDM>(tw, (int)a.job_block[job], slice, group, a.groups[t], a.slot[t], a.ntiles[t], a.tpg[t], a.rpt[t], a.seed,
@@ -363,9 +374,14 @@ static int wgrad_env(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 // The recompute form: bf16, hidden_dim 128, dropout off or p == 0.5 (the one-bit keep stream), and not a tower the split path
-// takes (its chain launches store both hidden operands).  M2M_WGRAD_RECOMP=0 keeps the stored-operand form everywhere (A/B).
+// takes (its chain launches store both hidden operands).  OFF by default (M2M_WGRAD_RECOMP=1 enables it): measured on
+// M2-Mixer-B, batch 512, the merged launch takes 134-142 us against 111-115 us for the stored-operand form -- the launch
+// leaves the HBM bound (150 MB instead of 300 MB of hidden operands) but a wave's step grows from 36 MFMAs + two loads to 48
+// MFMAs + ~150 VALU + 40 LDS reads + 8 LDS-DMA pieces (~75 cycles of issue EACH), and with 292 workgroups on 256 CUs most
+// SIMDs hold ONE wave, so nothing overlaps that issue stream (in-kernel timers, scripts/rc_timers.py: 1.05 us of compute,
+// 0.29 us of DMA issue, 0.25 us of DMA wait per 32-row step).  DESIGN.md section 4e.
 bool m2m_wgrad_recompute(const m2m_tower* t, int B) {
-    static const int on = wgrad_env("M2M_WGRAD_RECOMP", 1);
+    static const int on = wgrad_env("M2M_WGRAD_RECOMP", 0);
     if (!on || t->prec != PREC_BF16 || t->D != 128 || t->nblocks < 1 || t->Cp < 64) return false;
     if (m2m_drop_mode(1, t->p_drop) == DM_GEN) return false;
     if (m2m_split_eligible(t, B, 1)) return false;
@@ -387,7 +403,8 @@ static bool wgrad_slot_usable(const m2m_tower* t) {
 }
 
 struct WgradPlan { int ntiles, nsl, groups, tpg, rpt, slot; };
-static WgradPlan wgrad_plan(const m2m_tower* t, int B, int cols) {
+// honour_overwrite == false: the plan the tower would get if its gradient were zeroed and accumulated (m2m_wgrad_groups)
+static WgradPlan wgrad_plan(const m2m_tower* t, int B, int cols, bool honour_overwrite = true) {
     const bool wide = m2m_is_wide(t);                           // wide path: chain tiles are any BM consecutive rows
     const int SPW = wide ? 1 : BM / t->N;                       // samples per chain tile
     const int nchain = wide ? (int)(((long)B * t->N + BM - 1) / BM) : (B + SPW - 1) / SPW;   // chain tiles (BM rows each)
@@ -397,14 +414,14 @@ static WgradPlan wgrad_plan(const m2m_tower* t, int B, int cols) {
     // are split into groups until a workgroup has at most 64 steps (2048 rows) or the launch reaches ~128 workgroups.
     // Groups beyond the first add their partial results with float atomics onto the zeroed gradient (two groups: a + b ==
     // b + a, bit-deterministic; more -- only tiny launches -- are not), which an overwriting caller (M2M_WGRAD_OVERWRITE:
-    // the gradient is NOT zero on entry) cannot have: one group then, or two through the slot (launch_wgrad_group).
+    // the gradient is NOT zero on entry) cannot have: one group then, or two through the slot (wgrad_group_plans).
     int groups = 1;
     const int wgs = nsl * t->nblocks;
     while (wgs * groups < 128 && (ntiles + groups - 1) / groups > 64) ++groups;
     if (groups < (32 + wgs - 1) / wgs) groups = (32 + wgs - 1) / wgs;
     if (const char* e = getenv("M2M_WGRAD_GROUPS")) groups = atoi(e);   // diagnostic override (scripts/wgrad_probe.py sweeps it); unset in production
     if (const char* e = getenv("M2M_WGRAD_LONG_GROUPS")) { if (ntiles > 64) groups = atoi(e); }   // diagnostic: towers with more than 64 steps only
-    if (t->wgrad_flags & M2M_WGRAD_OVERWRITE) groups = 1;
+    if (honour_overwrite && (t->wgrad_flags & M2M_WGRAD_OVERWRITE)) groups = 1;
     if (groups < 1) groups = 1;
     int tpg = (ntiles + groups - 1) / groups;
     if (tpg < 4) tpg = 4;
@@ -415,21 +432,13 @@ static WgradPlan wgrad_plan(const m2m_tower* t, int B, int cols) {
     pl.rpt = wide ? BM : SPW * t->N;                            // token rows per chain tile (the dropout row index of the recompute form)
     return pl;
 }
-// two row groups through the slot: the second group's partial sums are plain stores, folded in by the optimizer
-static void wgrad_plan_slot_split(WgradPlan& pl) {
-    pl.groups = 2;
-    pl.tpg = (pl.ntiles + 1) / 2;
-    pl.slot = 1;
-}
 static int wgrad_cols(const m2m_tower* t, int B) {
     if (m2m_wgrad_recompute(t, B)) return RcGeom<128>::COLS;
     return t->prec == PREC_BF16 && t->D <= 128 ? WG_WAVES * 32 : WG_WAVES * 16;
 }
 extern "C" int m2m_wgrad_groups(const m2m_tower* t, int B) {
     if (!t || t->nblocks < 1) return 1;
-    m2m_tower c = *t;
-    c.wgrad_flags &= ~M2M_WGRAD_OVERWRITE;
-    return wgrad_plan(&c, B, wgrad_cols(t, B)).groups;
+    return wgrad_plan(t, B, wgrad_cols(t, B), false).groups;
 }
 
 template <int P, int D, int RCDM>
@@ -449,14 +458,24 @@ static int launch_wgrad(const m2m_tower* t, int B, unsigned int seed, unsigned i
     return 0;
 }
 
-// Plans of a multi-tower launch: per tower as above; then a tower whose workgroups would run at least twice as many steps as
-// the shortest tower's (the fusion tower: twice the rows) is split into two row groups IF it has a usable partial-gradient
-// slot -- its workgroups alone on their CUs set the launch time otherwise (128 steps against 64).
+// Plans of a multi-tower launch: per tower as above; then, for a tower with a usable partial-gradient slot (m2m_tower.wslot),
+//   * two row groups that would add with atomics become two groups through the slot (plain stores; the fusion tower of
+//     M2-Mixer-B: 12.6 MB of float atomics at ~1 TB/s sat at the end of the launch);
+//   * one group whose workgroups would run at least twice as many steps as the shortest tower's is split in two the same way
+//     (its workgroups alone on their CUs would set the launch time).
 static void wgrad_group_plans(const m2m_tower* const* host, int n, int B, int cols, WgradPlan* pl) {
     int min_tpg = 1 << 30;
-    for (int i = 0; i < n; ++i) { pl[i] = wgrad_plan(host[i], B, cols); if (pl[i].tpg < min_tpg) min_tpg = pl[i].tpg; }
-    for (int i = 0; i < n; ++i)
-        if (n > 1 && pl[i].groups == 1 && pl[i].tpg >= 2 * min_tpg && pl[i].tpg >= 32 && wgrad_slot_usable(host[i])) wgrad_plan_slot_split(pl[i]);
+    WgradPlan nat[WG_MAX_TOWERS];
+    for (int i = 0; i < n; ++i) {
+        pl[i] = wgrad_plan(host[i], B, cols);
+        nat[i] = wgrad_plan(host[i], B, cols, false);
+        if (nat[i].tpg < min_tpg) min_tpg = nat[i].tpg;
+    }
+    for (int i = 0; i < n; ++i) {
+        if (n < 2 || !wgrad_slot_usable(host[i])) continue;
+        if (nat[i].groups == 2) { pl[i] = nat[i]; pl[i].slot = 1; }
+        else if (nat[i].groups == 1 && nat[i].tpg >= 2 * min_tpg && nat[i].tpg >= 32) { pl[i] = nat[i]; pl[i].groups = 2; pl[i].tpg = (pl[i].ntiles + 1) / 2; pl[i].slot = 1; }
+    }
 }
 
 template <int P, int D, int RCDM>
@@ -466,7 +485,7 @@ static int launch_wgrad_group(const m2m_tower* const* host, const m2m_tower* con
     typedef WgradKernelGeom<P, D, RCDM> KG;
     WgradGroupArgs a;
     memset(&a, 0, sizeof(a));
-    int njobs = 0, max_nsl = 1, max_groups = 1;
+    int njobs = 0, total = 0;
     // longest workgroups first (most token tiles per workgroup): they are dispatched first and the short ones back-fill
     int order[WG_MAX_TOWERS];
     WgradPlan pl[WG_MAX_TOWERS];
@@ -480,17 +499,26 @@ static int launch_wgrad_group(const m2m_tower* const* host, const m2m_tower* con
         a.tw[i] = dev[i];
         a.ntiles[i] = pl[i].ntiles; a.tpg[i] = pl[i].tpg; a.groups[i] = pl[i].groups; a.nsl[i] = pl[i].nsl; a.slot[i] = pl[i].slot;
         a.rpt[i] = pl[i].rpt;
-        if (pl[i].nsl > max_nsl) max_nsl = pl[i].nsl;
-        if (pl[i].groups > max_groups) max_groups = pl[i].groups;
         for (int b = 0; b < host[i]->nblocks; ++b) {
             if (njobs >= WG_MAX_JOBS) { m2m_set_error("towers_wgrad: more than 32 (tower, block) jobs", __FILE__, __LINE__); return -1; }
             a.job_tower[njobs] = (unsigned char)i;
             a.job_block[njobs] = (unsigned char)b;
+            a.job_start[njobs] = (short)total;
+            total += pl[i].nsl * pl[i].groups;
             ++njobs;
         }
     }
     if (njobs == 0 && nembeds == 0) return 0;
-    a.max_nsl = max_nsl; a.njobs = njobs; a.n_tower_wgs = max_nsl * njobs * max_groups;
+    if (total > 32000) { m2m_set_error("towers_wgrad: too many workgroups for one launch", __FILE__, __LINE__); return -1; }
+    a.job_start[njobs] = (short)total;
+    int max_len = 0;
+    for (int x = 0, at = 0; x < 8; ++x) {
+        const int len = total / 8 + (x < total % 8 ? 1 : 0);
+        a.xcd_start[x] = (short)at; a.xcd_len[x] = (short)len;
+        at += len;
+        if (len > max_len) max_len = len;
+    }
+    a.njobs = njobs; a.n_tower_wgs = 8 * max_len;
     a.seed = seed; a.step_host = step; a.step_dev = step_dev;
     EmbedWgradGroupArgs ea;
     memset(&ea, 0, sizeof(ea));

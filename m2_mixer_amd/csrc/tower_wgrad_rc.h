@@ -17,16 +17,18 @@
 //
 // Staging: the three shared 8 KB images of a step (A^T and dYd^T in chained k order for the gradient products, A in natural
 // order for the recompute) go global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR staging), double-buffered, ONE
-// barrier per step; the wave's own dHpre^T fragments go through a register ring RC_DEPTH steps deep.  vmcnt bookkeeping: the
-// DMAs are inline asm, invisible to hipcc; per step a wave issues 6 DMAs then 2 ring loads, so at the top of a step "all but
-// the 2 youngest" (s_waitcnt vmcnt(2)) == this step's images have landed and so has its ring entry.
+// barrier per step; the wave's own dHpre^T fragments (2 KB per step, an HBM stream) go by LDS-DMA too, into a private ring of
+// RC_NR slots, RC_NR - 1 steps ahead.  vmcnt bookkeeping: every memory operation of the loop is an inline-asm DMA, invisible to
+// hipcc; per step a wave issues 6 image DMAs then 2 ring DMAs, so at the top of a step "all but the 2 youngest" (s_waitcnt
+// vmcnt(2)) == this step's images have landed (own share; the barrier covers the other waves') and so has its ring slot,
+// requested RC_NR - 1 steps ago.
 #pragma once
 #include "tile.h"
 
 #define RC_WAVES 4
 #define RC_THREADS (RC_WAVES * 64)
-#ifndef RC_DEPTH
-#define RC_DEPTH 1        // steps of dHpre^T fragments in flight (8 VGPRs each; 2 spills 6 registers at RC_LA 2, 26 at RC_LA 3)
+#ifndef RC_NR
+#define RC_NR 3           // LDS ring slots of a wave's dHpre^T stream: RC_NR - 1 steps in flight (3: 76 KB per workgroup, two per CU)
 #endif
 #ifndef RC_LA
 #define RC_LA 3           // LDS fragments read ahead of their MFMAs
@@ -43,7 +45,9 @@ template <int D> struct RcGeom {
     static constexpr int PPW = PPI / RC_WAVES;               // pieces per image and wave
     static constexpr int TAB_B = GELU_TAB_N * (int)sizeof(gtab2_t);
     static constexpr int TR_B = RC_WAVES * 16 * (D + 4) * 4; // write-out transposes (alias the stage)
-    static constexpr int LDS_B = (2 * STAGE_B > TR_B ? 2 * STAGE_B : TR_B) + TAB_B;
+    static constexpr int BODY_B = 2 * STAGE_B > TR_B ? 2 * STAGE_B : TR_B;
+    static constexpr int RING_B = RC_WAVES * RC_NR * 2048;   // per wave RC_NR slots of its own dHpre^T fragments (2 KiB per step)
+    static constexpr int LDS_B = BODY_B + TAB_B + RING_B;
     static constexpr int COLS = RC_WAVES * 32;
 };
 
@@ -51,6 +55,12 @@ template <int D> struct RcGeom {
 static __device__ __forceinline__ void glds16_sv(unsigned long long sbase, unsigned int voff, unsigned int ldst) {
     unsigned int keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(ldst) : "memory");
+}
+// the same, non-temporal: a stream that is read exactly once must not evict the images the other column slices re-read from L2
+static __device__ __forceinline__ void glds16_sv_nt(unsigned long long sbase, unsigned int voff, unsigned int ldst) {
+    unsigned int keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(ldst) : "memory");
 }
 
@@ -201,7 +211,6 @@ static __device__ __forceinline__ void wgrad_rc_body(const m2m_block& bk, const 
     typedef RcGeom<D> G;
     constexpr int KD = G::KD, DT = G::DT, IMG_B = G::IMG_B, STAGE_B = G::STAGE_B, PPW = G::PPW, CPW = 2;
     static_assert(DM == DM_NONE || DM == DM_HALF, "general-p dropout keeps the stored-operand form");
-    static_assert(RC_DEPTH >= 1, "ring depth");
     static_assert(G::PPI % RC_WAVES == 0, "every wave issues the same number of DMAs (vmcnt bookkeeping)");
 
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, il = lane & 15;
@@ -212,6 +221,8 @@ static __device__ __forceinline__ void wgrad_rc_body(const m2m_block& bk, const 
     const int t_begin = group * tiles_per_group;
     const int t_end = min(ntiles, t_begin + tiles_per_group);
     if (t_begin >= t_end) return;
+    TIMER_WG_BEGIN();
+    TIMER_LSTART();
     int ctl[CPW];                                           // column tiles past the end (last slice) shadow the last one
 #pragma unroll
     for (int j = 0; j < CPW; ++j) ctl[j] = min(ct0 + j, nct - 1);
@@ -250,12 +261,14 @@ static __device__ __forceinline__ void wgrad_rc_body(const m2m_block& bk, const 
         }
     };
     // dHpre^T fragments of the wave's column-tile pair: [pair q][32-row tile][16-row half][lane][tile 2q: 8 B | tile 2q+1: 8 B]
-    typedef const M2M_AS1 u32x4_t* g4_t;
-    const gptr_t src_dh = to_gptr(bk.dh_chn) + (long)(ctl[0] >> 1) * m2m_hchn_stride(ntiles) + lane * 16;
-    struct Ring { u32x4_t d0, d1; };
-    auto ring_load = [&](Ring& r, int tile) {
-        r.d0 = __builtin_nontemporal_load((g4_t)(src_dh + (long)tile * 2048));
-        r.d1 = __builtin_nontemporal_load((g4_t)(src_dh + (long)tile * 2048 + 1024));
+    const unsigned long long s_dh = uniform_u64((unsigned long long)bk.dh_chn + (unsigned long long)(ctl[0] >> 1) * m2m_hchn_stride(ntiles));
+    const unsigned int lane16 = (unsigned int)lane * 16u;
+    const unsigned int ring_lds = sbase + G::BODY_B + G::TAB_B + (unsigned int)wave * (RC_NR * 2048);
+    const char* ring_ptr = smem + G::BODY_B + G::TAB_B + wave * (RC_NR * 2048);
+    auto ring_load = [&](int tile, int slot) {               // 2 DMAs: the two 16-row halves
+        const unsigned long long src = s_dh + (unsigned long long)tile * 2048;
+        glds16_sv_nt(src, lane16, __builtin_amdgcn_readfirstlane(ring_lds + slot * 2048));
+        glds16_sv_nt(src, lane16 + 1024u, __builtin_amdgcn_readfirstlane(ring_lds + slot * 2048 + 1024));
     };
 
     f32x4_t dw1[CPW][DT], dw2[CPW][DT];
@@ -275,20 +288,22 @@ static __device__ __forceinline__ void wgrad_rc_body(const m2m_block& bk, const 
 #endif
 
     const unsigned int ngroups32 = (unsigned int)(Cp >> 5);
-    // the keep-word of hidden-column group q for token row m is mix32(key ^ (m * ngroups32 + q)) (tile.h: drop_word_half); a
-    // step needs 32 of them (one per row): lane L computes row (L & 31)'s word and the 8 a lane needs come by ds_bpermute
-    const int my_t16 = (lane >> 4) & 1, my_r = lane & 15;
+    // (the keep-word of hidden-column group q for token row m is mix32(key ^ (m * ngroups32 + q)): tile.h, drop_word_half)
 
     // One 32-row step.  The LDS fragment reads run RC_LA fragments ahead of the MFMAs that consume them (left to hipcc every read
     // was waited for at once: ds_read, lgkmcnt(0), two MFMAs, ...), and the GELU epilogue of accumulator row (mt, r) is written
     // between the dW1 MFMAs of d-tile 4 mt + r -- those do not depend on the recompute -- so that a wave alone on its SIMD
     // overlaps its own vector work with its own matrix work.
-    auto step = [&](const Ring& r, int tile, int buf) {
+    auto step = [&](int slot, int tile, int buf) {
         const char* cur = smem + buf * STAGE_B;
         constexpr int LA = RC_LA;
         Frag df[CPW];
+        {
+            const u32x4_t d0 = *reinterpret_cast<const u32x4_t*>(ring_ptr + slot * 2048 + lane * 16);
+            const u32x4_t d1 = *reinterpret_cast<const u32x4_t*>(ring_ptr + slot * 2048 + 1024 + lane * 16);
 #pragma unroll
-        for (int j = 0; j < CPW; ++j) df[j].u = u32x4_t{r.d0[2 * j], r.d0[2 * j + 1], r.d1[2 * j], r.d1[2 * j + 1]};
+            for (int j = 0; j < CPW; ++j) df[j].u = u32x4_t{d0[2 * j], d0[2 * j + 1], d1[2 * j], d1[2 * j + 1]};
+        }
         // ---- recompute Hpre (bias in the accumulators): fragment q = (kb, mt) ----
         f32x4_t hacc[2][CPW];
 #pragma unroll
@@ -314,53 +329,62 @@ static __device__ __forceinline__ void wgrad_rc_body(const m2m_block& bk, const 
         for (int j = 0; j < CPW; ++j) Pr::mma(db1[j], df[j], ones);
 #else
         {
-            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-            const bf16x2_t one2 = __builtin_bit_cast(bf16x2_t, 0x3F803F80u);
-            // (pairs taken by shufflevector from the typed view: __builtin_bit_cast of the vector ELEMENT df[j].u[e] was
-            // miscompiled -- all four dot products read element 0)
+            // plain unpack + add
 #pragma unroll
-            for (int j = 0; j < CPW; ++j) {
-                db1[j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(df[j].h, df[j].h, 0, 1), one2, db1[j], false);
-                db1[j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(df[j].h, df[j].h, 2, 3), one2, db1[j], false);
-                db1[j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(df[j].h, df[j].h, 4, 5), one2, db1[j], false);
-                db1[j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(df[j].h, df[j].h, 6, 7), one2, db1[j], false);
-            }
+            for (int j = 0; j < CPW; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned int u = df[j].u[e];
+                    db1[j] += __builtin_bit_cast(float, u << 16) + __builtin_bit_cast(float, u & 0xFFFF0000u);
+                }
         }
 #endif
-        // ---- dW1 += dHpre^T A, with the GELU + dropout of accumulator row (mt, r) = d-tile index between its MFMAs:
-        //      element (m = 32 tile + 16 mt + 4g + r, c = 32 q + 16 j + il) ----
-        unsigned int myword = 0xFFFFFFFFu;
+        // ---- dW1 += dHpre^T A, with the GELU + dropout epilogue of the recompute between its MFMAs (they do not depend on it).
+        //      Element (m = 32 tile + 16 mt + 4g + r, c = 32 q + 16 j + il).  Every LDS round trip of the epilogue is issued as a
+        //      BATCH and consumed one MFMA group later: written row by row (keep-word -> index -> table read -> fma, each step
+        //      waiting for the previous one) the 8 rows cost 16 exposed LDS latencies per step -- 1.1 us of a 1.5 us step.
+        //      Keep-words without LDS: lane (g, n) computes the word of row (mt = n >> 2, r = n & 3) of ITS lane group g (n < 8),
+        //      and a DPP row broadcast (row_newbcast:n, VALU) hands it to the group's 16 lanes, shifted to the lane's bit. ----
+        unsigned int wsh[8];
         if (DM == DM_HALF) {
-            const unsigned int m = (unsigned int)((2 * tile + my_t16) * rows_per_t16 + my_r);
-            myword = mix32(drop_key ^ (m * ngroups32 + (unsigned int)q));
+            const unsigned int m = (unsigned int)((2 * tile + ((il >> 2) & 1)) * rows_per_t16 + 4 * g + (il & 3));
+            const unsigned int myword = mix32(drop_key ^ (m * ngroups32 + (unsigned int)q));
+#define RC_BCAST(n) wsh[n] = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)myword, 0x150 + n, 0xF, 0xF, false) >> il;
+            RC_BCAST(0) RC_BCAST(1) RC_BCAST(2) RC_BCAST(3) RC_BCAST(4) RC_BCAST(5) RC_BCAST(6) RC_BCAST(7)
+#undef RC_BCAST
         }
         {
             constexpr int L = LA < DT ? LA : DT;
             Frag tq[L];
 #pragma unroll
             for (int dt = 0; dt < L; ++dt) tq[dt] = ld_frag_lds(cur, dt, lane);
+            gtab2_t te[4][CPW];                              // table entries of one 16-row tile in flight
+            auto lookup = [&](int mt) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int j = 0; j < CPW; ++j) {
+                        unsigned int idx = pwl_index(hacc[mt][j][rr]);
+                        if (DM == DM_HALF) idx &= (unsigned int)(((int)(wsh[4 * mt + rr] << (31 - 16 * j))) >> 31);   // dropped: cell 0 = {0, 0}
+                        te[rr][j] = gtab[idx];
+                    }
+            };
+            auto apply = [&](int mt) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int j = 0; j < CPW; ++j) hacc[mt][j][rr] = __builtin_fmaf(te[rr][j][1], hacc[mt][j][rr], te[rr][j][0]);
+            };
+            lookup(0);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 const Frag at = tq[dt % L];
                 if (dt + L < DT) tq[dt % L] = ld_frag_lds(cur, dt + L, lane);
 #pragma unroll
                 for (int j = 0; j < CPW; ++j) Pr::mma(dw1[j][dt], df[j], at);
-                // epilogue rows: DT d-tiles serve the 8 rows (mt, r); DT > 8 would leave the later ones without, DT < 8 doubles up
-#pragma unroll
-                for (int row = dt * 8 / DT; row < (dt + 1) * 8 / DT; ++row) {
-                    const int mt = row >> 2, rr = row & 3;
-                    unsigned int w = 0xFFFFFFFFu;
-                    if (DM == DM_HALF) w = (unsigned int)__shfl((int)myword, 16 * mt + 4 * g + rr, 64) >> il;
-#pragma unroll
-                    for (int j = 0; j < CPW; ++j) {
-                        const float x = hacc[mt][j][rr];
-                        unsigned int idx = pwl_index(x);
-                        if (DM == DM_HALF) idx &= (unsigned int)(((int)(w << (31 - 16 * j))) >> 31);   // dropped: cell 0 = {0, 0}
-                        const gtab2_t e = gtab[idx];
-                        hacc[mt][j][rr] = __builtin_fmaf(e[1], x, e[0]);
-                    }
-                }
+                if (dt == DT / 2 - 1) { apply(0); lookup(1); }
             }
+            apply(1);
         }
         Frag hf[CPW];
 #pragma unroll
@@ -382,45 +406,43 @@ static __device__ __forceinline__ void wgrad_rc_body(const m2m_block& bk, const 
     };
 
     // ---- pipeline ----
-    // issue order per step i (tile T_i): [wait: images of T_i landed] barrier | DMA(T_{i+1}) x 3 PPW | ring(T_{i+RC_DEPTH}) x 2 |
-    // compute(T_i).  One barrier per step: buffer (i + 1) & 1 was last read in step i - 1, which every wave has left when it
-    // arrives at the barrier of step i.  All loads are unconditional (tile clamped): a fixed number per step keeps the counts.
-    // The ring has RC_DEPTH + 1 slots and the loop is unrolled by that: step i consumes slot i % NS and refills slot
-    // (i + RC_DEPTH) % NS = the slot the PREVIOUS step consumed -- never the one in use, so no register copies at the back
-    // edge (with RC_DEPTH slots the refill target was live: hipcc rotated the ring with v_mov behind a vmcnt(0) per trip).
-    constexpr int NS = RC_DEPTH + 1;
-    Ring ring[NS];
+    // issue order per step i (tile T_i): [wait: images of T_i + ring slot of T_i landed] barrier | image DMAs of T_{i+1} (3 PPW) |
+    // ring DMAs of T_{i+RC_NR-1} (2) | compute(T_i).  One barrier per step: stage buffer (i + 1) & 1 was last read in step i - 1,
+    // which every wave has left when it arrives at the barrier of step i; the ring is private to the wave, and the slot refilled
+    // in step i is the one step i - 1 consumed.  All DMAs are unconditional (tile clamped): a fixed number per step keeps the
+    // counts.
+    static_assert(RC_NR >= 2, "ring slots");
     stage(t_begin, 0);
 #pragma unroll
-    for (int k = 0; k < NS; ++k) ring[k].d0 = ring[k].d1 = u32x4_t{0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int k = 0; k < RC_DEPTH; ++k) ring_load(ring[k], min(t_begin + k, t_end - 1));
-    __syncthreads();                                        // GELU table visible (drains the prologue loads once: fine)
-    int tile = t_begin, it = 0;
-    auto one = [&](Ring& use, Ring& refill) {
-        // everything but the youngest two memory operations (the ring entry of a later step) has arrived: this step's images
-        // (own share) and its ring entry
-        // (RC_DEPTH == 1: the ring entry of THIS step is the youngest pair)
-        if (RC_DEPTH >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    for (int k = 0; k < RC_NR - 1; ++k) ring_load(min(t_begin + k, t_end - 1), k);
+    __syncthreads();                                        // GELU table visible (drains the prologue DMAs once: fine)
+    TIMER_LMARK(0);       // prologue: W1 fragments, table, first DMAs
+    int it = 0;
+    for (int tile = t_begin; tile < t_end; ++tile, ++it) {
+        // everything but the youngest two DMAs (the ring slot of a later step) has arrived
+        if (RC_NR >= 3) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("" : "+v"(use.d0), "+v"(use.d1));      // hipcc's own wait for the ring entry: HERE, not behind the DMAs below
+        TIMER_LMARK(1);   // wait for this step's DMAs
         __builtin_amdgcn_s_barrier();
+        TIMER_LMARK(2);   // barrier
         stage(min(tile + 1, t_end - 1), (it + 1) & 1);
-        ring_load(refill, min(tile + RC_DEPTH, t_end - 1));
-        step(use, tile, it & 1);
-        ++tile; ++it;
-    };
-    for (; tile + NS <= t_end;) {
-#pragma unroll
-        for (int k = 0; k < NS; ++k) one(ring[k], ring[(k + RC_DEPTH) % NS]);
+        ring_load(min(tile + RC_NR - 1, t_end - 1), (it + RC_NR - 1) % RC_NR);
+        TIMER_LMARK(3);   // DMA issue
+        step(it % RC_NR, tile, it & 1);
+        TIMER_LMARK(4);   // compute
     }
-#pragma unroll
-    for (int k = 0; k + 1 < NS; ++k)
-        if (tile < t_end) one(ring[k], ring[(k + RC_DEPTH) % NS]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the redundant tail DMAs must not land in the transposes below
     __syncthreads();                                        // every wave is done with the stage
 
     // ---- results ----
+#if !RC_DB1_MFMA
+    // db1: the four lane groups' partial sums of column c = 16 (ct0 + j) + il, added in straight-line code right behind the loop
+#pragma unroll
+    for (int j = 0; j < CPW; ++j) {
+        db1[j] += __shfl_xor(db1[j], 16, 64);
+        db1[j] += __shfl_xor(db1[j], 32, 64);
+    }
+#endif
     wgrad_write_w<D, CPW>(dw1, dw2, out, ct0, nct, C, smem, wave, lane);
 #pragma unroll
     for (int j = 0; j < CPW; ++j) {
@@ -438,8 +460,8 @@ static __device__ __forceinline__ void wgrad_rc_body(const m2m_block& bk, const 
             }
         }
 #else
-        const float s = lane_class_sum(db1[j], 16);         // over the four lane groups: column c = 16 (ct0 + j) + il
         const int c = 16 * (ct0 + j) + il;
+        const float s = db1[j];
         if (g == 0 && c < C) {
             if (out.mode == WG_OUT_ATOMIC) atomicAdd(out.b1 + c, s);
             else if (out.mode == WG_OUT_ADD) out.b1[c] += s;
@@ -447,4 +469,7 @@ static __device__ __forceinline__ void wgrad_rc_body(const m2m_block& bk, const 
         }
 #endif
     }
+    TIMER_LMARK(5);       // write-out
+    TIMER_LFLUSH(g_tm_wg);
+    TIMER_WG_END(g_tm_wg);
 }

@@ -36,6 +36,16 @@ def relerr(a, b):
     return float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12)
 
 
+def grads_cleared(eng):
+    """After an optimizer step every gradient element Adam is responsible for clearing is zero: everything outside the ranges
+    the engine leaves to the next backward's overwriting weight-gradient launch (engine._setup_wgrad)."""
+    g = eng.flat_g.detach().clone()
+    for lo, n, _, keep in eng._ranges_add:
+        if keep:
+            g[lo:lo + n] = 0
+    return float(g.abs().max()) == 0.0
+
+
 def abserr(a, b):
     return float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max())
 
@@ -170,7 +180,7 @@ def test_adam_moments_and_parameters_vs_oracle(size, B, seed, fused_update, dev,
         ref = O.avmnist_train_step(image, audio, labels, params, cfg, state, lr=1e-2)      # updates params / state in place
         eng.train_step(*gb)
         torch.cuda.synchronize()
-        assert float(eng.adam_state[0]) == step and float(eng.flat_g.abs().max()) == 0.0
+        assert float(eng.adam_state[0]) == step and grads_cleared(eng)
         for k in shapes:
             if k.endswith("token_mix.2.net.3.bias"):
                 continue

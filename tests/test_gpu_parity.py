@@ -36,6 +36,16 @@ def relerr(a, b):
     return float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12)
 
 
+def grads_cleared(eng):
+    """After an optimizer step every gradient element Adam is responsible for clearing is zero: everything outside the ranges
+    the engine leaves to the next backward's overwriting weight-gradient launch (engine._setup_wgrad)."""
+    g = eng.flat_g.detach().clone()
+    for lo, n, _, keep in eng._ranges_add:
+        if keep:
+            g[lo:lo + n] = 0
+    return float(g.abs().max()) == 0.0
+
+
 def abserr(a, b):
     return float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max())
 
@@ -177,7 +187,7 @@ def test_avmnist_step_fp32_vs_reference_golden(size, B, seed, dev):
     for k in shapes:
         check(gold, f"grad//{k}", eng.grads[k], 1e-4, 1e-3, what="grad ")
     eng.optimizer_step()
-    assert float(eng.flat_g.abs().max()) == 0.0, "Adam must leave the gradient buffer cleared"
+    assert grads_cleared(eng), "Adam must leave the gradient buffer cleared"
     # second step goes through the Adam update
     eng.train_step(image, audio, labels)
     torch.cuda.synchronize()
@@ -300,7 +310,7 @@ def test_full_size_properties(dev):
     # so compare the update direction statistically rather than bit for bit
     agree = float(((b.flat_p - eng.flat_p).sign() == (pa - eng.flat_p).sign()).float().mean())
     assert agree > 0.999, agree
-    assert float(b.flat_g.abs().max()) == 0.0
+    assert grads_cleared(b)
     # losses are sane for random init: each head near ln(10)
     assert all(abs(float(v) - np.log(10)) < 0.5 for v in la[:3])
 
@@ -442,7 +452,7 @@ def test_mimic_step_fp32_vs_reference_golden(dev):
     before = eng.flat_p.clone()
     eng.optimizer_step()
     torch.cuda.synchronize()
-    assert float(eng.flat_g.abs().max()) == 0.0
+    assert grads_cleared(eng)
     assert float((eng.flat_p - before).abs().max()) <= 1e-2 * 1.001
 
 
@@ -616,7 +626,7 @@ def test_data_parallel_step_path_matches_fused_step(dev):
     torch.cuda.synchronize()
     assert calls and all(n == a.n_params for n in calls)
     assert torch.allclose(a.losses, b.losses, rtol=0, atol=2e-3), (a.losses, b.losses)     # float-atomic order in the small gradients
-    assert float(b.flat_g.abs().max()) == 0.0 and float(a.flat_g.abs().max()) == 0.0
+    assert grads_cleared(b) and grads_cleared(a)
     da, db = a.flat_p - p0, b.flat_p - p0
     assert float((da - db).abs().max()) <= 2e-3 * 3 * 0.51      # a few sign flips of ~0 gradients at most (lr = 1e-3, 3 steps)
     assert float((da.sign() == db.sign()).float().mean()) > 0.995
@@ -640,7 +650,7 @@ def test_adam_from_bf16_gradient_equals_adam_from_widened_gradient(dev):
     b.optimizer_step(0.5, gb)
     torch.cuda.synchronize()
     assert torch.equal(a.flat_p, b.flat_p) and torch.equal(a.flat_m, b.flat_m) and torch.equal(a.flat_v, b.flat_v)
-    assert float(b.flat_g.abs().max()) == 0.0
+    assert grads_cleared(b)
 
 
 # ---------------------------------------------------------------------------------------------------------------
