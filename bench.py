@@ -185,7 +185,7 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def launch_ranks(n: int, argv) -> int:
+def launch_ranks(n: int, argv, script=None) -> int:
     """`python bench.py --gpus N` without a torchrun environment: start N fresh rank processes (one per GPU) through
     torch.distributed.run, BEFORE this process has made any GPU call, relay rank 0's JSON line and the ranks' stderr, and
     return non-zero if any rank failed.  (The driver may equally start the ranks itself; then WORLD_SIZE is set and this
@@ -197,7 +197,7 @@ def launch_ranks(n: int, argv) -> int:
         port = sk.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+           "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
     log(f"--gpus {n} without WORLD_SIZE: launching {n} ranks: {' '.join(cmd[1:8])} ...")
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     lines = []
@@ -229,9 +229,10 @@ def main():
     ap.add_argument("--steps-per-graph", type=int, default=10,
                     help="N = 1: training steps captured per hipGraph (each with its own input slot); the replay gap between "
                          "graphs is ~17 us.  Remainder steps run through a single-step graph")
-    ap.add_argument("--grad-compress", default="bf16", choices=["none", "bf16"],
-                    help="N > 1: dtype of the gradient all-reduce.  bf16 (default: the step computes in bf16 anyway; the "
-                         "equivalent of DDP's bf16_compress_hook) halves the bytes on xGMI; none = fp32, exact DDP semantics")
+    ap.add_argument("--grad-compress", default="none", choices=["none", "bf16"],
+                    help="N > 1: dtype of the gradient all-reduce.  none (default) = fp32: what the reference's DDP exchanges "
+                         "(run.py:69-70).  bf16 = the equivalent of DDP's bf16_compress_hook, half the bytes on xGMI; its error is "
+                         "bounded in tests/test_host_cpu.py::test_bf16_compressed_exchange_error_bound")
     ap.add_argument("--preheat-ms", type=float, default=300.0,
                     help="~this many ms of untimed steps (preheat_ms / 0.75 of them) before the W warm-up steps, so a fresh box's "
                          "clocks have ramped up when the warm-up starts (reported in config.preheat_ms; 0 disables)")
@@ -410,7 +411,8 @@ def profile_launches(eng, image, audio, labels, nsteps):
             eng._backward(image, audio)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            eng._update(1.0)                  # Adam + operand re-pack: one launch (m2m_adam_pack_all)
+            eng._update(1.0)                  # the flat Adam launch + the operand re-pack launch (m2m_pack_all); with
+                                              # M2M_FUSED_UPDATE=1 one launch (m2m_adam_pack_all)
             e1.record()
             spans.setdefault("adam+pack", {"events": [], "flops": 0})["events"].append((e0, e1))
         torch.cuda.synchronize()

@@ -299,17 +299,29 @@ class _FlatEngine:
         return {"state": state, "param_groups": [group]}
 
     def load_optimizer_state_dict(self, osd: dict):
+        """torch.optim.Adam.state_dict() as the reference writes it (Lightning: `optimizer_states[0]`).  Parameters without an
+        entry -- a state dict saved before the first step, or with modalities frozen (`requires_grad=False` parameters never get
+        Adam state: models/avmnist.py:314-324) -- start from zero moments; the ONE step count the fused Adam keeps is taken
+        from the entries that are present (they must agree)."""
         keys = list(self.shapes)
-        if sorted(osd["state"].keys()) != list(range(len(keys))):
-            raise KeyError("optimizer state: expected one entry per parameter, indexed in parameters() order")
-        steps = {float(st["step"]) for st in osd["state"].values()}
-        if len(steps) != 1:
+        state = osd.get("state", {})
+        bad = [i for i in state if not isinstance(i, int) or i < 0 or i >= len(keys)]
+        if bad:
+            raise KeyError(f"optimizer state: entries {bad[:4]} do not index this model's {len(keys)} parameters")
+        steps = {float(st["step"]) for st in state.values() if "step" in st}
+        if len(steps) > 1:
             raise RuntimeError("optimizer state: the fused Adam keeps ONE step count for all parameters")
         for i, k in enumerate(keys):
-            self.exp_avg[k].copy_(osd["state"][i]["exp_avg"].to(self.device, torch.float32).reshape(self.shapes[k]))
-            self.exp_avg_sq[k].copy_(osd["state"][i]["exp_avg_sq"].to(self.device, torch.float32).reshape(self.shapes[k]))
-        self.adam_state[0] = steps.pop()
-        self.set_lr(float(osd["param_groups"][0]["lr"]))
+            st = state.get(i)
+            if st is None or "exp_avg" not in st:
+                self.exp_avg[k].zero_()
+                self.exp_avg_sq[k].zero_()
+                continue
+            self.exp_avg[k].copy_(st["exp_avg"].to(self.device, torch.float32).reshape(self.shapes[k]))
+            self.exp_avg_sq[k].copy_(st["exp_avg_sq"].to(self.device, torch.float32).reshape(self.shapes[k]))
+        self.adam_state[0] = steps.pop() if steps else 0.0
+        if osd.get("param_groups"):
+            self.set_lr(float(osd["param_groups"][0]["lr"]))
 
     def set_lr(self, lr: float):
         self.adam_state[1] = lr
@@ -324,6 +336,8 @@ class _FlatEngine:
         sib = type(self)(self.cfg, batch_size, device=self.device, precision=prec, lr=float(self.adam_state[1]),
                          betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, seed=self.seed, init=False,
                          share=self, **self._sibling_kwargs())
+        if hasattr(self, "pos_weight"):                      # MM-IMDb: the LOADED criterion buffer, not cfg's
+            sib.pos_weight.copy_(self.pos_weight)
         # Both engines work on ONE gradient buffer: a range one of them leaves uncleared ("keep": its own next backward
         # overwrites it) must be overwritten by the other one's backward too, or that one would accumulate onto stale values.
         mine, theirs = {r[0] for r in self._ranges_add}, {r[0] for r in sib._ranges_add}

@@ -68,7 +68,10 @@ class _TowerFunction(torch.autograd.Function):
             rt.ensure_workspace(B)
             saved.append(rt.fresh_saved(B) if need_grad else None)
             if dropping and not need_grad:
-                rt.ensure_buffers(B)        # dropout without autograd (train() under no_grad): the kernels still save
+                # dropout without autograd (train() under no_grad, e.g. MC-dropout passes): the kernels still save their
+                # activations -- into a scratch set, NOT into the set a pending differentiated forward left bound in the
+                # descriptor (its backward re-binds its own set: use_saved)
+                rt.fresh_saved(B)
             rt.forward(cur, N * D, B, out, N * D, None, need_grad or dropping, seed, step)
             cur = out
         ctx.saved = saved if need_grad else None

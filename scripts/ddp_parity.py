@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Two-rank data-parallel step parity.
+
+N ranks x batch B followed by the gradient exchange must equal ONE rank on the concatenated N*B batch -- DDP's defining
+property (the reference gets it from Lightning: run.py:69-70).  Started as `python scripts/ddp_parity.py` this launches two
+ranks through torch.distributed.run BEFORE any GPU call (as bench.py::launch_ranks does); the ranks share ONE GPU and
+exchange over gloo (M2M_DIST_BACKEND=gloo: RCCL needs a device per rank), which exercises everything but the transport:
+GradSync, the 1/world scale folded into Adam, the slot fold before the exchange, the two-graph captured step.
+AV-MNIST M2-Mixer-S, fp32, dropout 0 (a rank's dropout stream is indexed by its LOCAL sample number), exchange in fp32.
+Checks, after 2 steps: parameters of the two ranks identical; equal to the one-rank engine on the concatenated batch and
+to the CPU oracle's two Adam steps (<= 1e-3; the reference's exactly-zero-gradient tensor excluded).
+Prints one JSON line (rank 0)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+
+def launch(n):
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, M2M_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    if "WORLD_SIZE" not in os.environ:
+        sys.exit(launch(2))
+    import torch
+    import gen_util as G
+    from m2_mixer_amd import parallel
+    from m2_mixer_amd.engine import AVMnistEngine
+    from oracle import m2mixer_oracle as O
+
+    rank, _, world = parallel.init_from_env()
+    dev = torch.device("cuda:0")                       # every rank on the one GPU of the box
+    torch.cuda.set_device(dev)
+    prec = sys.argv[1] if len(sys.argv) > 1 else "fp32"
+    size = sys.argv[2] if len(sys.argv) > 2 else "S"
+    cfg = dict(G.AVMNIST[size], dropout=0.0)
+    B, steps, lr = 8, 2, 1e-2
+    shapes = G.avmnist_shapes(cfg)
+    params0 = dict(G.make_params(shapes, 31))
+    batches = [G.avmnist_batch(B, 40 + r, cfg) for r in range(world)]          # rank r trains on batches[r]
+    skip = lambda k: k.endswith("token_mix.2.net.3.bias")
+
+    def run(captured):
+        eng = AVMnistEngine(cfg, B, device=dev, precision=prec, lr=lr, init=False)
+        eng.load_state_dict(params0 if rank == 0 else {k: torch.zeros_like(v) for k, v in params0.items()})
+        parallel.broadcast_parameters(eng.flat_p)       # DDP's initial broadcast: rank 1 starts from zeros on purpose
+        eng.pack()
+        sync = parallel.GradSync()
+        mine = tuple(t.to(dev) for t in batches[rank])
+        if captured:
+            replay = eng.capture(*mine, grad_sync=sync)
+            for _ in range(steps):
+                replay(*mine)
+        else:
+            for _ in range(steps):
+                eng.train_step(*mine, grad_sync=sync)
+        torch.cuda.synchronize()
+        return eng
+
+    out = {"world": world, "precision": prec, "model": size, "per_rank_batch": B, "steps": steps}
+    for captured in (False, True):
+        eng = run(captured)
+        tag = "captured" if captured else "eager"
+        # (a) both ranks hold the same parameters
+        gathered = [torch.empty_like(eng.flat_p) for _ in range(world)]
+        torch.distributed.all_gather(gathered, eng.flat_p)
+        out[f"{tag}_ranks_max_diff"] = float((gathered[0] - gathered[1]).abs().max())
+        if rank == 0:
+            # (b) one rank, concatenated batch
+            cat = tuple(torch.cat([b[i] for b in batches]).to(dev) for i in range(3))
+            one = AVMnistEngine(cfg, B * world, device=dev, precision=prec, lr=lr, init=False)
+            one.load_state_dict(params0)
+            for _ in range(steps):
+                one.train_step(*cat)
+            torch.cuda.synchronize()
+            out[f"{tag}_vs_one_rank"] = max(float((eng.params[k] - one.params[k]).abs().max()) for k in shapes if not skip(k))
+            # (c) the CPU oracle: two Adam steps on the concatenated batch
+            p, st = dict(params0), {}
+            for _ in range(steps):
+                O.avmnist_train_step(*(torch.cat([b[i] for b in batches]) for i in range(3)), p, cfg, st, lr=lr)
+            out[f"{tag}_vs_oracle"] = max(float((eng.params[k].cpu() - p[k]).abs().max()) for k in shapes if not skip(k))
+        torch.distributed.barrier()
+    tol = 1e-3 if prec == "fp32" else 3e-2
+    if rank == 0:
+        out["tolerance"] = tol
+        out["ok"] = all(v <= tol for k, v in out.items() if k.endswith(("_vs_one_rank", "_vs_oracle"))) and \
+            all(v == 0.0 for k, v in out.items() if k.endswith("_ranks_max_diff"))
+        print(json.dumps(out), flush=True)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+    if rank == 0 and not out["ok"]:
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()

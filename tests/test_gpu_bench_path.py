@@ -410,6 +410,11 @@ def test_module_path_is_reentrant(dev):
         ya = blk(a)
         with torch.no_grad():
             blk(x2.to(dev))                                              # validation-style forward in between
+            # ... and an MC-dropout pass (train mode, dropout ON, no autograd) at the SAME batch size as the pending
+            # forward: the kernels save activations then too -- into a scratch set, not into `ya`'s
+            blk.dropout_p = 0.5
+            blk(x1.to(dev) * 3.0)
+            blk.dropout_p = 0.0
         yb = blk(b)
         (yb * dy2.to(dev)).sum().backward()                              # backwards in the opposite order
         (ya * dy1.to(dev)).sum().backward()
