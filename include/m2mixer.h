@@ -113,6 +113,11 @@ typedef struct m2m_tower {
      * sums here with plain stores (no atomics, no zero fill).  The caller adds the slot to the gradient: inside the optimizer
      * (m2m_adam_step_ranges) or with m2m_wgrad_fold; m2m_wgrad_slot_groups says whether a launch will use it. */
     float* wslot[M2M_MAX_BLOCKS];
+    /* ---- packed image of the gradient wrt the tower input (optional) ------------------------------------------------------
+     * With it m2m_tower_backward / m2m_towers_backward also leave d_x0^T as packed operand blocks, laid out like at_chn
+     * ([32-row pair][d tile][lane] 16 B, k = token row in chained order): the first operand of the patch-embedding weight
+     * gradient, which then needs neither LDS staging nor atomics (m2m_towers_wgrad, `embed_towers`). */
+    void* dx0_chn;
 } m2m_tower;
 #define M2M_WGRAD_OVERWRITE 1 /* wgrad_flags: g_ch_w1 / g_ch_b1 / g_ch_w2 are WRITTEN ("="), not accumulated ("+="): the caller
                                * neither zeroes nor accumulates them (the fused engines: one backward per optimizer step) */
@@ -229,8 +234,12 @@ int m2m_wgrad_form(const m2m_tower* t, int B);
  * nembeds = 2: the same launch also computes m2m_embed_wgrad for the model's two patch embeddings (inputs[i], d_x0s[i]
  * as there) in extra workgroups that back-fill the CUs the tower workgroups leave idle; nembeds = 0: towers only. */
 int m2m_towers_wgrad(const m2m_tower* const* towers, const m2m_tower* const* dev_towers, int ntowers,
-                     const m2m_embed* const* embeds, const float* const* inputs, const float* const* d_x0s, int nembeds,
+                     const m2m_embed* const* embeds, const float* const* inputs, const float* const* d_x0s,
+                     const m2m_tower* const* embed_towers, int nembeds,
                      int B, uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream);
+                     /* embed_towers (NULL or one per embedding): the tower embedding i feeds.  When its dx0_chn image is
+                      * present (bf16) the embedding gradients take the single-owner form: a workgroup owns 16 pixel columns
+                      * over ALL token rows, operands straight from the image, plain "+=" -- no atomics. */
 /* row groups m2m_tower_wgrad / m2m_towers_wgrad would give this tower at batch B without M2M_WGRAD_OVERWRITE (1: every gradient
  * element has a single owner; more: the groups add with float atomics -- such a tower must not set M2M_WGRAD_OVERWRITE) */
 int m2m_wgrad_groups(const m2m_tower* t, int B);

@@ -51,7 +51,9 @@ class Tower(C.Structure):
                 ("slabs", _fp), ("nsplit", C.c_int32), ("wgrad_flags", C.c_int32), ("xres", _fp), ("gpart", _fp),
                 ("a_nat", _fp * MAX_BLOCKS), ("dy_nat", _fp * MAX_BLOCKS),
                 # weight-gradient slot: second row group of a long tower, folded in by the optimizer
-                ("wslot", _fp * MAX_BLOCKS)]
+                ("wslot", _fp * MAX_BLOCKS),
+                # packed image of d_x0^T for the patch-embedding weight gradient
+                ("dx0_chn", _fp)]
 
 
 WGRAD_OVERWRITE = 1      # Tower.wgrad_flags (M2M_WGRAD_OVERWRITE)
@@ -123,7 +125,7 @@ SIGNATURES = {
     "m2m_towers_backward": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.POINTER(TowerGIO), C.c_int, C.c_int, C.c_uint32, C.c_uint32,
                                       _fp, _fp]),
     "m2m_towers_wgrad": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.POINTER(_fp), C.c_int, C.POINTER(C.POINTER(Embed)), C.POINTER(_fp),
-                                   C.POINTER(_fp), C.c_int, C.c_int, C.c_uint32, C.c_uint32, _fp, _fp]),
+                                   C.POINTER(_fp), C.POINTER(C.POINTER(Tower)), C.c_int, C.c_int, C.c_uint32, C.c_uint32, _fp, _fp]),
     "m2m_wgrad_form": (C.c_int, [C.POINTER(Tower), C.c_int]),
     "m2m_wgrad_groups": (C.c_int, [C.POINTER(Tower), C.c_int]),
     "m2m_wgrad_slot_groups": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.c_int, C.c_int]),

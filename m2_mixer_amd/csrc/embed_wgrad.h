@@ -141,6 +141,106 @@ static __device__ __forceinline__ void embed_wgrad_body(const m2m_embed& em, con
     if (chunk == 0 && tid < D) { if (single) em.g_b[tid] += bsum; else atomicAdd(em.g_b + tid, bsum); }
 }
 
+// ---- fast form (bf16) ---------------------------------------------------------------------------------------------------
+// g_w[d][k] += sum_m dx0[m][d] patch[m][k] with a SINGLE OWNER per output: a workgroup owns EFK = 16 pixel columns k over ALL
+// token rows; its waves split the 32-row pairs among themselves, each accumulating a full [D x 16] partial in MFMA
+// accumulators, ONE reduction through LDS at the end, plain "+=".  No atomics (the row-group form above adds 9.6 MB of partial
+// sums with float atomics on M2-Mixer-B: 28-30 us as a launch of its own against < 10 us for 26 MB of input and 1.7 GFLOP),
+// no LDS staging: the first operand comes as the packed image of d_x0^T the tower backward leaves (m2m_tower.dx0_chn,
+// [32-row pair][d tile][lane] 16 B, chained k order), the second one is gathered straight from the input -- lane (g, il)
+// needs pixel k0 + il of the 8 token rows its chained k positions name: 8 four-byte loads, 16 consecutive pixels per lane
+// group and row.  Reference: the weight gradient of MLPMixer.to_patch_embedding (modules/mixer.py:143-146) under autograd.
+#define EFK 16
+template <int D, int NT>
+static __device__ __forceinline__ void embed_wgrad_fast_body(const m2m_embed& em, const float* __restrict__ in,
+                                                             const char* __restrict__ dx0_chn, long M, int N, int npairs, int rpt,
+                                                             int chunk, char* smem) {
+    typedef Prec<PREC_BF16> Pr;
+    constexpr int DT = D / 16, NW = NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, il = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    PatchGeom pg{em.Cin, em.H, em.W, em.ph, em.pw, em.W / em.pw, N, em.K};
+    const int k0 = chunk * EFK;
+    const int ko = patch_koff(pg, k0 + il);                      // this lane's pixel; -1 beyond K
+    const bool bias = chunk == 0;
+
+    f32x4_t acc[DT], accb[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { acc[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; accb[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    Frag ones;
+    ones.u = u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+
+    struct Tile { Frag a[DT]; float v[8]; };
+    auto load = [&](Tile& t, int p) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) t.a[dt] = ld_frag_global(dx0_chn, (long)p * DT + dt, lane);
+        // element e of the lane's second-operand fragment: token slot 16 (e >> 2) + 4 g + (e & 3) of the pair (chained k order)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int r = 4 * g + (e & 3);
+            const long row = (long)(2 * p + (e >> 2)) * rpt + r;
+            const long rb = r < rpt ? patch_rowbase(pg, row, M) : -1;
+            t.v[e] = (rb >= 0 && ko >= 0) ? in[rb + ko] : 0.f;
+        }
+    };
+    auto mac = [&](const Tile& t) {
+        Frag b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b.u[e] = pack_bf2(t.v[2 * e], t.v[2 * e + 1]);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            Pr::mma(acc[dt], t.a[dt], b);
+            if (bias) Pr::mma(accb[dt], t.a[dt], ones);
+        }
+    };
+    // two pairs in flight per wave (register double buffer)
+    Tile t0, t1;
+    int p = wave;
+    if (p < npairs) load(t0, p);
+    for (; p < npairs; p += 2 * NW) {
+        if (p + NW < npairs) load(t1, p + NW);
+        mac(t0);
+        if (p + NW < npairs) {
+            if (p + 2 * NW < npairs) load(t0, p + 2 * NW);
+            mac(t1);
+        }
+    }
+    // ---- reduction over the waves: [wave][dt][lane] 16 B, then wave w finishes d-tiles w, w + NW, ... ----
+    f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) red[(wave * DT + dt) * 64 + lane] = acc[dt];
+    __syncthreads();
+    for (int dt = wave; dt < DT; dt += NW) {
+        f32x4_t s = red[dt * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) s = s + red[(w * DT + dt) * 64 + lane];
+        const int k = k0 + il;
+        if (k < em.K) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float* q = em.g_w + (long)(16 * dt + 4 * g + r) * em.K + k;       // element (d = 16 dt + 4 g + r, k): 16 lanes = 64 B
+                *q += s[r];
+            }
+        }
+    }
+    if (bias) {                                                   // (workgroup-uniform) the same once more for the row sums
+        __syncthreads();
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) red[(wave * DT + dt) * 64 + lane] = accb[dt];
+        __syncthreads();
+        for (int dt = wave; dt < DT; dt += NW) {
+            f32x4_t sb = red[dt * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) sb = sb + red[(w * DT + dt) * 64 + lane];
+            if (il == 0) {                                        // every column of accb holds the row sums: column 0 writes
+#pragma unroll
+                for (int r = 0; r < 4; ++r) em.g_b[16 * dt + 4 * g + r] += sb[r];
+            }
+        }
+    }
+}
+template <int D, int NT> static constexpr size_t embed_wgrad_fast_lds() { return (size_t)(NT / 64) * (D / 16) * 64 * 16; }
+
 // Both patch embeddings of a two-tower model behind one launch: workgroups [0, nwg(0)) serve embedding 0, the rest 1.
 #define EMB_GROUP 2
 struct EmbedWgradGroupArgs {
@@ -149,14 +249,24 @@ struct EmbedWgradGroupArgs {
     const float* dx0[EMB_GROUP];
     long M[EMB_GROUP];
     int N[EMB_GROUP], tpg[EMB_GROUP], nchunks[EMB_GROUP], groups[EMB_GROUP];
+    // fast form (fast != 0): nchunks = ceil(K / EFK), groups = 1
+    const char* dx0_chn[EMB_GROUP];
+    int npairs[EMB_GROUP], rpt[EMB_GROUP], fast;
 };
 template <int P, int D, int NT>
 static __device__ __forceinline__ void embed_wgrad_group_body(const EmbedWgradGroupArgs& a, int id, char* smem) {
     const int n0 = a.nchunks[0] * a.groups[0];
     const int e = id < n0 ? 0 : 1;
     if (e) id -= n0;
-    embed_wgrad_body<P, D, NT>(a.em[e], a.in[e], a.dx0[e], a.M[e], a.N[e], a.tpg[e], id % a.nchunks[e], id / a.nchunks[e],
-                               a.groups[e] == 1, smem);
+    if constexpr (P == PREC_BF16) {
+        if (a.fast) {
+            embed_wgrad_fast_body<D, NT>(a.em[e], a.in[e], a.dx0_chn[e], a.M[e], a.N[e], a.npairs[e], a.rpt[e], id, smem);
+            return;
+        }
+    }
+    if constexpr (NT % 64 == 0 && EBM % (NT / 64) == 0)           // (the row-group form's tile mapping: 256 or 512 threads)
+        embed_wgrad_body<P, D, NT>(a.em[e], a.in[e], a.dx0[e], a.M[e], a.N[e], a.tpg[e], id % a.nchunks[e], id / a.nchunks[e],
+                                   a.groups[e] == 1, smem);
 }
 
 struct EmbedWgradPlan { long M; int N, nchunks, groups, tpg; };
@@ -177,6 +287,27 @@ template <int D, int P> static constexpr size_t embed_wgrad_lds() {   // indepen
     return (size_t)EBM * TileGeom<D>::XLD * 4 + (size_t)EBM * 68 * 4 + (size_t)EBM * D * Prec<P>::ESZ + (size_t)EBM * 64 * Prec<P>::ESZ;
 }
 
+
+// The fast form's arguments: embedding i takes its d_x0^T image from tower tw[i] (geometry of the image = the tower's chain
+// tiles at batch B).  Returns the number of workgroups, 0 if the fast form does not apply (missing image, fp32, wide tower).
+static inline int embed_wgrad_group_args_fast(EmbedWgradGroupArgs& a, const m2m_embed* const* es, const float* const* ins,
+                                              const m2m_tower* const* tw, int B) {
+    memset(&a, 0, sizeof(a));
+    int total = 0;
+    for (int i = 0; i < EMB_GROUP; ++i) {
+        const m2m_embed* e = es[i];
+        const m2m_tower* t = tw ? tw[i] : nullptr;
+        const int N = (e->H / e->ph) * (e->W / e->pw);
+        if (!t || !t->dx0_chn || e->prec != PREC_BF16 || t->prec != PREC_BF16 || m2m_is_wide(t) || t->N != N || t->D != e->D) return 0;
+        const int SPW = BM / t->N, nchain = (B + SPW - 1) / SPW;
+        a.em[i] = *e; a.in[i] = ins[i]; a.dx0_chn[i] = (const char*)t->dx0_chn;
+        a.M[i] = (long)B * N; a.N[i] = N; a.npairs[i] = (nchain * BM + WPAIR - 1) / WPAIR; a.rpt[i] = SPW * t->N;
+        a.nchunks[i] = (e->K + EFK - 1) / EFK; a.groups[i] = 1; a.tpg[i] = 0;
+        total += a.nchunks[i];
+    }
+    a.fast = 1;
+    return total;
+}
 
 // Fills the group arguments (embedding with more row tiles per workgroup first); returns the number of workgroups.
 static inline int embed_wgrad_group_args(EmbedWgradGroupArgs& a, const m2m_embed* const* es, const float* const* ins,

@@ -518,6 +518,7 @@ static m2m_tower block_view(const m2m_tower* t, int b) {
     v.blk[0] = t->blk[b];
     v.site_base = t->site_base + 4u * (unsigned int)b;
     v.has_final_ln = (b == t->nblocks - 1) ? t->has_final_ln : 0;
+    v.dx0_chn = nullptr;        // (the chain launch of a view does not produce the tower-input gradient: token mixing follows)
     return v;
 }
 

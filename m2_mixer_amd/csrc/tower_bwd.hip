@@ -59,7 +59,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                                                       const float* __restrict__ d_pooled, float* __restrict__ d_x0, long d_x0_ss,
                                                       unsigned int seed, unsigned int step_host,
                                                       const unsigned int* __restrict__ step_dev, int wg, int nwg, char* smem,
-                                                      float* __restrict__ part = nullptr) {
+                                                      float* __restrict__ part = nullptr, char* dx0_chn = nullptr) {
     typedef Prec<P> Pr;
     typedef TileGeom<D> G;
     typedef BwdLds<P, D, NMAX, TG> L;
@@ -910,6 +910,9 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
         *reinterpret_cast<float4*>(d_x0 + (gr / N) * d_x0_ss + (gr % N) * D + c) =
             *reinterpret_cast<const float4*>(dxs + r * XLD + c);
     }
+    // ... and, on request, as packed operand blocks (d_x0^T, k = token row): the first operand of the patch-embedding weight
+    // gradient (embed_wgrad.h, fast form); rows >= R of the tile are zero
+    if (dx0_chn) pack_tile_chn_t<P, D>(dxs, dx0_chn + pair_off, tile_in_pair, tid);
     TIMER_LFLUSH(g_tm_bwd);
 }
 
@@ -920,7 +923,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
                                                              unsigned int step_host, const unsigned int* __restrict__ step_dev) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     tower_bwd_body<m2m_tower, P, D, NMAX, TG, DM, PART, HREC>(tw, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step_host, step_dev,
-                                                               blockIdx.x, gridDim.x, smem, PART ? tw.gpart : nullptr);
+                                                               blockIdx.x, gridDim.x, smem, PART ? tw.gpart : nullptr, (char*)tw.dx0_chn);
 }
 
 // Two towers side by side in ONE launch (blockIdx.y = tower), see tower_fwd.hip.
@@ -933,6 +936,7 @@ struct BwdGroupArgs {
     long d_x0_ss[2];
     int ntiles[2];
     float* part[2];               // per-workgroup partial-sum slots of the small gradients (m2m_tower.gpart) or NULL: atomics
+    char* dx0_chn[2];             // packed image of d_x0^T (m2m_tower.dx0_chn) or NULL
 };
 static_assert(sizeof(BwdGroupArgs) <= 3584, "kernel arguments are limited to 4 KiB");
 
@@ -971,7 +975,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_group_kernel(const BwdGrou
     const int wg = (id >> 3) * 4 + (xcd & 3);
     if (wg >= a.ntiles[t]) return;
     tower_bwd_body<m2m_tower4, P, D, NMAX, TG, DM, PART, HREC>(a.tw[t], B, a.d_out[t], a.d_out_ss[t], a.d_pooled[t], a.d_x0[t], a.d_x0_ss[t],
-                                                                seed, step_host, step_dev, wg, a.ntiles[t], smem, PART ? a.part[t] : nullptr);
+                                                                seed, step_host, step_dev, wg, a.ntiles[t], smem, PART ? a.part[t] : nullptr, a.dx0_chn[t]);
 }
 
 template <int P, int D, int NMAX, int TG>
@@ -1103,6 +1107,7 @@ extern "C" int m2m_towers_backward(const m2m_tower* const* towers, const m2m_tow
         a.d_out[i] = io[i].d_out; a.d_out_ss[i] = (long)io[i].d_out_sample_stride;
         a.d_pooled[i] = io[i].d_pooled;
         a.d_x0[i] = io[i].d_x0; a.d_x0_ss[i] = (long)io[i].d_x0_sample_stride;
+        a.dx0_chn[i] = (char*)towers[i]->dx0_chn;
         const int SPW = BM / towers[i]->N;
         a.ntiles[i] = (B + SPW - 1) / SPW;
     }

@@ -30,14 +30,16 @@ bool m2m_split_eligible(const m2m_tower* t, int B, int training);     // split_a
 #ifndef WG_RING_MAX
 #define WG_RING_MAX 24    // VGPR budget of one tile in flight that still allows a second one (register ring depth 2)
 #endif
-#define WG_WAVES 4
+#define WG_WAVES 4        // waves of a tower workgroup, except:
+#ifndef WG_WAVES_WIDE
+#define WG_WAVES_WIDE 5   // bf16, hidden_dim 128 (the stored-operand form of M2-Mixer-B): 160 hidden columns per workgroup -> 240
+#endif                    // workgroups for the model, ONE per CU, all of the same length (towers alone: 102 -> 80 us)
 #ifndef WG_LA
 #define WG_LA 4           // LDS fragments read ahead of their MFMAs
 #endif
 #ifndef WG_MINWAVES
 #define WG_MINWAVES 2
 #endif
-#define WG_THREADS (WG_WAVES * 64)
 #define WG_OUT_ATOMIC 0   // how a workgroup hands over its results (wgrad_write_w)
 #define WG_OUT_ADD 1
 #define WG_OUT_STORE 2    // "=": single owner, the old values are not read (m2m_tower.wgrad_flags & M2M_WGRAD_OVERWRITE, and the
@@ -50,6 +52,8 @@ TIMER_READER(m2m_debug_timers_wgrad, g_tm_wg)
 
 template <int P, int D> struct WgradGeom {
     static constexpr int NF = Chain<P>::NF;
+    static constexpr int WAVES = (P == PREC_BF16 && D == 128) ? WG_WAVES_WIDE : WG_WAVES;
+    static constexpr int THREADS = WAVES * 64;
 #ifdef WG_CPW_FORCE
     static constexpr int CPW = WG_CPW_FORCE;
 #else
@@ -57,7 +61,7 @@ template <int P, int D> struct WgradGeom {
 #endif
     static constexpr int IMG_B = WBM * D * Prec<P>::ESZ;
     static constexpr int STAGE_B = 2 * IMG_B;                                          // A^T | dYd^T of one tile
-    static constexpr int NLD = (STAGE_B + WG_THREADS * 16 - 1) / (WG_THREADS * 16);   // 16-byte pieces per thread per tile
+    static constexpr int NLD = (STAGE_B + THREADS * 16 - 1) / (THREADS * 16);   // 16-byte pieces per thread per tile
     // token tiles per step (= per barrier).  Measured on M2-Mixer-B: 4 tiles per step with one workgroup per CU (the next
     // step's 128 KiB of loads in flight in up to 512 VGPRs) was SLOWER (230 vs 160 us for the three towers) than one
     // tile per step with two workgroups per CU, so 1 is the default; the knob stays for other shapes.
@@ -68,8 +72,8 @@ template <int P, int D> struct WgradGeom {
 #endif
     static constexpr int RING_REGS = NLD * 4 + CPW * 2 * NF * 4;                      // VGPRs of one tile in flight
     static constexpr int DEPTH = (TPS == 1 && RING_REGS <= WG_RING_MAX) ? 2 : 1;      // steps of loads in flight
-    static constexpr int COLS = WG_WAVES * CPW * 16;                                   // hidden columns per workgroup
-    static constexpr int TR_B = WG_WAVES * 16 * (D + 4) * 4;                          // dW1 write-out transpose: 16 x (D + 4) floats per wave
+    static constexpr int COLS = WAVES * CPW * 16;                                   // hidden columns per workgroup
+    static constexpr int TR_B = WAVES * 16 * (D + 4) * 4;                          // dW1 write-out transpose: 16 x (D + 4) floats per wave
     static constexpr int LDS_B = 2 * TPS * STAGE_B > TR_B ? 2 * TPS * STAGE_B : TR_B;  // dynamic LDS of the kernel
     static constexpr int MINWAVES = TPS > 2 ? 1 : 2;                                   // waves per SIMD the kernel is built for
     static_assert(TPS == 1 || DEPTH == 1, "multi-tile steps use a ring of one step");
@@ -86,7 +90,7 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, const WgO
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, il = lane & 15;
     const int nct = Cp >> 4;
-    const int ct0 = (slice * WG_WAVES + wave) * CPW;        // this wave's first 16-column tile
+    const int ct0 = (slice * G::WAVES + wave) * CPW;        // this wave's first 16-column tile
 
     f32x4_t dw1[CPW][DT], dw2[CPW][DT], db1[CPW];
 #pragma unroll
@@ -126,7 +130,7 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, const WgO
             const int tile = min(tile0 + u, t_end - 1);
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
-                const int o = min((i * WG_THREADS + tid) * 16, STAGE_B - 16);
+                const int o = min((i * G::THREADS + tid) * 16, STAGE_B - 16);
                 const gptr_t sp = o < IMG_B ? src_at : src_dyt;
                 p.st[u][i] = *(const M2M_GLOBAL_AS u32x4_t*)(sp + (long)tile * IMG_B + (o < IMG_B ? o : o - IMG_B));
             }
@@ -176,7 +180,7 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, const WgO
             char* cur = buf + u * STAGE_B;
 #pragma unroll
             for (int k = 0; k < NLD; ++k) {
-                const int o = (k * WG_THREADS + tid) * 16;
+                const int o = (k * G::THREADS + tid) * 16;
                 if (o < STAGE_B) *reinterpret_cast<u32x4_t*>(cur + o) = p.st[u][k];
             }
         }
@@ -297,6 +301,7 @@ template <int P, int D, int RCDM> struct WgradKernelGeom {
     static constexpr int LDS_B = RC ? RcGeom<D>::LDS_B : WgradGeom<P, D>::LDS_B;
     static constexpr int COLS = RC ? RcGeom<D>::COLS : WgradGeom<P, D>::COLS;
     static constexpr int MINWAVES = RC ? 2 : WgradGeom<P, D>::MINWAVES;
+    static constexpr int THREADS = RC ? RC_THREADS : WgradGeom<P, D>::THREADS;
 };
 
 template <int P, int D, int RCDM, class TW>
@@ -312,7 +317,7 @@ static __device__ __forceinline__ void wgrad_dispatch(const TW& tw, int b, int s
 }
 
 template <int P, int D, int RCDM>
-__global__ __launch_bounds__(WG_THREADS, (WgradKernelGeom<P, D, RCDM>::MINWAVES)) void tower_wgrad_kernel(
+__global__ __launch_bounds__((WgradKernelGeom<P, D, RCDM>::THREADS), (WgradKernelGeom<P, D, RCDM>::MINWAVES)) void tower_wgrad_kernel(
     const m2m_tower tw, int ntiles, int tiles_per_group, int slot_mode, int rows_per_t16, unsigned int seed, unsigned int step_host,
     const unsigned int* __restrict__ step_dev) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -347,12 +352,12 @@ struct WgradGroupArgs {
 // patch-embedding weight gradients (embed_wgrad.h); a second launch beside this one costs a fork and a join in the replayed
 // graph (~10 us each) and slows this kernel by contending for the same CUs.
 template <int P, int D, int RCDM>
-__global__ __launch_bounds__(WG_THREADS, (WgradKernelGeom<P, D, RCDM>::MINWAVES)) void tower_wgrad_group_kernel(const WgradGroupArgs a,
+__global__ __launch_bounds__((WgradKernelGeom<P, D, RCDM>::THREADS), (WgradKernelGeom<P, D, RCDM>::MINWAVES)) void tower_wgrad_group_kernel(const WgradGroupArgs a,
                                                                                                           const EmbedWgradGroupArgs ea) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int id = blockIdx.x;
     if (id >= a.n_tower_wgs) {
-        embed_wgrad_group_body<P, D, WG_THREADS>(ea, id - a.n_tower_wgs, smem);
+        embed_wgrad_group_body<P, D, WgradKernelGeom<P, D, RCDM>::THREADS>(ea, id - a.n_tower_wgs, smem);
         return;
     }
     const int xcd = id & 7, idx = id >> 3;
@@ -434,7 +439,8 @@ static WgradPlan wgrad_plan(const m2m_tower* t, int B, int cols, bool honour_ove
 }
 static int wgrad_cols(const m2m_tower* t, int B) {
     if (m2m_wgrad_recompute(t, B)) return RcGeom<128>::COLS;
-    return t->prec == PREC_BF16 && t->D <= 128 ? WG_WAVES * 32 : WG_WAVES * 16;
+    if (t->prec == PREC_BF16 && t->D == 128) return WG_WAVES_WIDE * 32;
+    return t->prec == PREC_BF16 && t->D < 128 ? WG_WAVES * 32 : WG_WAVES * 16;
 }
 extern "C" int m2m_wgrad_groups(const m2m_tower* t, int B) {
     if (!t || t->nblocks < 1) return 1;
@@ -452,7 +458,7 @@ static int launch_wgrad(const m2m_tower* t, int B, unsigned int seed, unsigned i
         M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(pl.nsl, t->nblocks, pl.groups), dim3(WG_THREADS), lds, st, *t, pl.ntiles, pl.tpg, 0, pl.rpt, seed, step,
+    hipLaunchKernelGGL(kern, dim3(pl.nsl, t->nblocks, pl.groups), dim3(KG::THREADS), lds, st, *t, pl.ntiles, pl.tpg, 0, pl.rpt, seed, step,
                        step_dev);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
@@ -480,8 +486,8 @@ static void wgrad_group_plans(const m2m_tower* const* host, int n, int B, int co
 
 template <int P, int D, int RCDM>
 static int launch_wgrad_group(const m2m_tower* const* host, const m2m_tower* const* dev, int n, const m2m_embed* const* embeds,
-                              const float* const* inputs, const float* const* d_x0s, int nembeds, int B, unsigned int seed,
-                              unsigned int step, const unsigned int* step_dev, hipStream_t st) {
+                              const float* const* inputs, const float* const* d_x0s, const m2m_tower* const* embed_towers,
+                              int nembeds, int B, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
     typedef WgradKernelGeom<P, D, RCDM> KG;
     WgradGroupArgs a;
     memset(&a, 0, sizeof(a));
@@ -522,9 +528,22 @@ static int launch_wgrad_group(const m2m_tower* const* host, const m2m_tower* con
     a.seed = seed; a.step_host = step; a.step_dev = step_dev;
     EmbedWgradGroupArgs ea;
     memset(&ea, 0, sizeof(ea));
-    // ~2 embedding workgroups per CU: they are short and only fill what the tower workgroups leave idle
-    const int n_embed_wgs = nembeds ? embed_wgrad_group_args(ea, embeds, inputs, d_x0s, B, 512) : 0;
-    const size_t lds_t = (size_t)KG::LDS_B, lds_e = nembeds ? embed_wgrad_lds<D, P>() : 0;
+    // The patch-embedding gradients ride in the same launch, dispatched last.  Fast form (single owner, bf16, needs the d_x0^T
+    // images of the towers the embeddings feed): ~200 short workgroups.  Otherwise the row-group form (~2 workgroups per CU,
+    // float atomics) -- which needs 256-thread workgroups: an instantiation with wider tower workgroups launches it separately.
+    int n_embed_wgs = 0;
+    size_t lds_e = 0;
+    bool embeds_separately = false;
+    if (nembeds) {
+        n_embed_wgs = P == PREC_BF16 ? embed_wgrad_group_args_fast(ea, embeds, inputs, embed_towers, B) : 0;
+        if (n_embed_wgs) lds_e = embed_wgrad_fast_lds<D, KG::THREADS>();
+        else if (KG::THREADS == 256) { n_embed_wgs = embed_wgrad_group_args(ea, embeds, inputs, d_x0s, B, 512); lds_e = embed_wgrad_lds<D, P>(); }
+        else embeds_separately = true;
+    }
+    if (embeds_separately) {
+        if (int rc = m2m_embeds_wgrad(embeds, inputs, d_x0s, nembeds, B, (void*)st)) return rc;
+    }
+    const size_t lds_t = (size_t)KG::LDS_B;
     const size_t lds = lds_t > lds_e ? lds_t : lds_e;
     auto kern = tower_wgrad_group_kernel<P, D, RCDM>;
     static size_t attr_lds = 0;
@@ -532,7 +551,7 @@ static int launch_wgrad_group(const m2m_tower* const* host, const m2m_tower* con
         M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(a.n_tower_wgs + n_embed_wgs)), dim3(WG_THREADS), lds, st, a, ea);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.n_tower_wgs + n_embed_wgs)), dim3(KG::THREADS), lds, st, a, ea);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -567,7 +586,8 @@ extern "C" int m2m_tower_wgrad(const m2m_tower* t, int B, uint32_t seed, uint32_
 }
 
 extern "C" int m2m_towers_wgrad(const m2m_tower* const* towers, const m2m_tower* const* dev_towers, int ntowers,
-                                const m2m_embed* const* embeds, const float* const* inputs, const float* const* d_x0s, int nembeds,
+                                const m2m_embed* const* embeds, const float* const* inputs, const float* const* d_x0s,
+                                const m2m_tower* const* embed_towers, int nembeds,
                                 int B, uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream) {
     if (!towers || !dev_towers || ntowers < 1 || ntowers > WG_MAX_TOWERS) { m2m_set_error("towers_wgrad: 1..4 towers", __FILE__, __LINE__); return -1; }
     if (nembeds != 0 && (nembeds != EMB_GROUP || !embeds || !inputs || !d_x0s)) {
@@ -599,10 +619,10 @@ extern "C" int m2m_towers_wgrad(const m2m_tower* const* towers, const m2m_tower*
     const m2m_tower* t = towers[0];
     if (m2m_wgrad_recompute(t, B)) {
         if (m2m_drop_mode(1, t->p_drop) == DM_HALF)
-            return launch_wgrad_group<PREC_BF16, 128, DM_HALF>(towers, dev_towers, ntowers, embeds, inputs, d_x0s, nembeds, B, seed, step, step_dev, st);
-        return launch_wgrad_group<PREC_BF16, 128, DM_NONE>(towers, dev_towers, ntowers, embeds, inputs, d_x0s, nembeds, B, seed, step, step_dev, st);
+            return launch_wgrad_group<PREC_BF16, 128, DM_HALF>(towers, dev_towers, ntowers, embeds, inputs, d_x0s, embed_towers, nembeds, B, seed, step, step_dev, st);
+        return launch_wgrad_group<PREC_BF16, 128, DM_NONE>(towers, dev_towers, ntowers, embeds, inputs, d_x0s, embed_towers, nembeds, B, seed, step, step_dev, st);
     }
-#define M2M_WGG_CASE(PP, DD) if (t->prec == PP && t->D == DD) return launch_wgrad_group<PP, DD, -1>(towers, dev_towers, ntowers, embeds, inputs, d_x0s, nembeds, B, seed, step, step_dev, st);
+#define M2M_WGG_CASE(PP, DD) if (t->prec == PP && t->D == DD) return launch_wgrad_group<PP, DD, -1>(towers, dev_towers, ntowers, embeds, inputs, d_x0s, embed_towers, nembeds, B, seed, step, step_dev, st);
     M2M_WGG_CASE(PREC_BF16, 32) M2M_WGG_CASE(PREC_BF16, 64) M2M_WGG_CASE(PREC_BF16, 128) M2M_WGG_CASE(PREC_BF16, 256)
     M2M_WGG_CASE(PREC_F32, 32) M2M_WGG_CASE(PREC_F32, 64) M2M_WGG_CASE(PREC_F32, 128) M2M_WGG_CASE(PREC_F32, 256)
 #undef M2M_WGG_CASE

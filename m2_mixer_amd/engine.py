@@ -565,6 +565,11 @@ class _TwoTowerEngine(_FlatEngine):
         self.dx0_a, self.dx0_b = f(B * self.Na, D), f(B * self.Nb, D)
         self.preds = torch.zeros(self._preds_shape(), dtype=torch.int32, device=dev)
         self._setup_wgrad([self.t_fus, self.t_a, self.t_b], grouped=True)
+        # the embeddings' weight gradients in their single-owner form: the tower backward leaves d_x0^T as packed blocks
+        import os
+        self._embed_towers = []
+        if os.environ.get("M2M_EMBED_FAST", "1") != "0" and self.t_a.enable_dx0_image(B) and self.t_b.enable_dx0_image(B):
+            self._embed_towers = [self.t_a, self.t_b]
 
     def _preds_shape(self):
         return (3, self.B)
@@ -655,7 +660,7 @@ class _TwoTowerEngine(_FlatEngine):
             main.wait_stream(s_a)
         if can_group_embeds(self.e_a, self.e_b) and self.e_a.prec == self.t_a.prec and self.e_a.D == self.t_a.D:
             towers_wgrad([self.t_fus, self.t_a, self.t_b], B, [self.e_a, self.e_b], [xa, xb], [self.dx0_a, self.dx0_b],
-                         seed=self.seed, step=0, step_dev=sd)
+                         seed=self.seed, step=0, step_dev=sd, embed_towers=self._embed_towers)
         else:
             s_e.wait_stream(main)
             with torch.cuda.stream(s_e):

@@ -158,6 +158,10 @@ class TowerRuntime:
         xf = torch.empty(M, self.D, device=self.device)
         self.desc.x_final = xf.data_ptr()
         self._keep["x_final"] = xf
+        if self._keep.get("want_dx0_image"):
+            img0 = torch.zeros(img, dtype=torch.uint8, device=self.device)
+            self.desc.dx0_chn = img0.data_ptr()
+            self._keep["dx0_chn"] = img0
         self._bufB = B
 
     # ---- re-entrancy of the module path (torch autograd): one set of forward-saved activations per forward --------------
@@ -269,6 +273,17 @@ class TowerRuntime:
         L.check(L.lib().m2m_tower_backward(C.byref(self.desc), B, L.ptr(d_out), d_out_ss, L.ptr(d_pooled),
                                            d_x0.data_ptr(), d_x0_ss, seed & 0xFFFFFFFF, step & 0xFFFFFFFF,
                                            L.ptr(step_dev), L.stream_ptr()), "tower_backward")
+
+    def enable_dx0_image(self, B: int) -> bool:
+        """Let the backward also leave d_x0^T as packed operand blocks (m2m_tower.dx0_chn): the patch-embedding weight
+        gradient of the tower's embedding then takes the single-owner form (towers_wgrad(..., embed_towers=...)).  Fused-path
+        bf16 towers only."""
+        if self.wide or self.prec != L.PREC_BF16 or self.nblocks == 0:
+            return False
+        self._keep["want_dx0_image"] = True
+        self._bufB = 0                       # (re)allocate with the image
+        self.ensure_buffers(B)
+        return True
 
     # ---- weight-gradient launch options (include/m2mixer.h: wgrad_flags, wslot) ----------------------------------------
     def wgrad_form(self, B: int) -> int:
@@ -395,17 +410,20 @@ def wgrad_slot_groups(towers: Sequence[TowerRuntime], B: int) -> int:
 
 def towers_wgrad(towers: Sequence[TowerRuntime], B: int, embeds: Sequence["EmbedRuntime"] = (),
                  inputs: Sequence[torch.Tensor] = (), d_x0s: Sequence[torch.Tensor] = (), seed: int = 0, step: int = 0,
-                 step_dev: Optional[torch.Tensor] = None):
+                 step_dev: Optional[torch.Tensor] = None, embed_towers: Sequence[TowerRuntime] = ()):
     """Channel-mixing weight gradients of several towers (same precision / hidden_dim) in one launch; with `embeds`
     (the model's two patch embeddings, their inputs and d_x0) also the embedding gradients, in the same launch.
-    seed / step / step_dev: the dropout stream of the forward (the recompute form regenerates the hidden keep-mask)."""
+    seed / step / step_dev: the dropout stream of the forward (the recompute form regenerates the hidden keep-mask).
+    embed_towers[i]: the tower embedding i feeds; with its d_x0^T image (enable_dx0_image) the embedding gradients take the
+    single-owner form (no atomics)."""
     n, ne = len(towers), len(embeds)
     host = (C.POINTER(L.Tower) * n)(*[C.pointer(t.desc) for t in towers])
     dev = (C.c_void_p * n)(*[t.device_desc() for t in towers])
     ep = (C.POINTER(L.Embed) * max(ne, 1))(*[C.pointer(e.desc) for e in embeds])
     ip = (C.c_void_p * max(ne, 1))(*[t.data_ptr() for t in inputs])
     dp = (C.c_void_p * max(ne, 1))(*[t.data_ptr() for t in d_x0s])
-    L.check(L.lib().m2m_towers_wgrad(host, dev, n, ep, ip, dp, ne, B, seed & 0xFFFFFFFF, step & 0xFFFFFFFF, L.ptr(step_dev),
+    et = (C.POINTER(L.Tower) * max(ne, 1))(*[C.pointer(t.desc) for t in embed_towers]) if len(embed_towers) == ne and ne else None
+    L.check(L.lib().m2m_towers_wgrad(host, dev, n, ep, ip, dp, et, ne, B, seed & 0xFFFFFFFF, step & 0xFFFFFFFF, L.ptr(step_dev),
                                      L.stream_ptr()), "towers_wgrad")
 
 

@@ -86,16 +86,20 @@ def main():
                 one.train_step(*cat)
             torch.cuda.synchronize()
             out[f"{tag}_vs_one_rank"] = max(float((eng.params[k] - one.params[k]).abs().max()) for k in shapes if not skip(k))
+            out[f"{tag}_vs_one_rank_mean"] = float(torch.cat([(eng.params[k] - one.params[k]).abs().flatten() for k in shapes if not skip(k)]).mean())
             # (c) the CPU oracle: two Adam steps on the concatenated batch
             p, st = dict(params0), {}
             for _ in range(steps):
                 O.avmnist_train_step(*(torch.cat([b[i] for b in batches]) for i in range(3)), p, cfg, st, lr=lr)
             out[f"{tag}_vs_oracle"] = max(float((eng.params[k].cpu() - p[k]).abs().max()) for k in shapes if not skip(k))
         torch.distributed.barrier()
-    tol = 1e-3 if prec == "fp32" else 3e-2
+    # fp32: the north star's 1e-3.  bf16: Adam normalises the gradient, so ONE sign flip of a rounding-level gradient moves a
+    # parameter by 2 lr per step -- the maximum is bounded by that, the MEAN deviation must stay at rounding level
+    tol = 1e-3 if prec == "fp32" else 2 * steps * lr * 1.05
     if rank == 0:
         out["tolerance"] = tol
         out["ok"] = all(v <= tol for k, v in out.items() if k.endswith(("_vs_one_rank", "_vs_oracle"))) and \
+            all(v <= 1e-3 for k, v in out.items() if k.endswith("_vs_one_rank_mean")) and \
             all(v == 0.0 for k, v in out.items() if k.endswith("_ranks_max_diff"))
         print(json.dumps(out), flush=True)
     torch.distributed.barrier()

@@ -20,6 +20,8 @@ for t, n in ((eng.t_fus, "fusion"), (eng.t_a, "image"), (eng.t_b, "audio")):
     print(" ", n, "alone %.1f us" % timeit(lambda: towers_wgrad([t], B)))
 if dx is not None:
     print("embeds alone %.1f us" % timeit(lambda: embeds_wgrad(em, inp, dx, B)))
-    print("merged %.1f us" % timeit(lambda: towers_wgrad(tw, B, em, inp, dx)))
+    print("merged (row-group embeds / separate launch) %.1f us" % timeit(lambda: towers_wgrad(tw, B, em, inp, dx)))
+    if getattr(eng, "_embed_towers", None):
+        print("merged (fast embeds) %.1f us" % timeit(lambda: towers_wgrad(tw, B, em, inp, dx, embed_towers=eng._embed_towers)))
 else:
     print([k for k in vars(eng) if "dx" in k or "d_x" in k])
