@@ -136,6 +136,8 @@ typedef struct m2m_embed {
     void* wn;                    /* packed NAT [i=d][k] */
     float* g_w;
     float* g_b;
+    int32_t wgrad_flags;         /* M2M_WGRAD_OVERWRITE: the single-owner weight-gradient form (m2m_towers_wgrad, embed_towers) WRITES */
+    int32_t reserved;            /* g_w ("="; g_b stays "+="): the caller neither zeroes nor accumulates it                          */
 } m2m_embed;
 
 /* ---- library ------------------------------------------------------------------------------------ */
@@ -243,6 +245,9 @@ int m2m_towers_wgrad(const m2m_tower* const* towers, const m2m_tower* const* dev
 /* row groups m2m_tower_wgrad / m2m_towers_wgrad would give this tower at batch B without M2M_WGRAD_OVERWRITE (1: every gradient
  * element has a single owner; more: the groups add with float atomics -- such a tower must not set M2M_WGRAD_OVERWRITE) */
 int m2m_wgrad_groups(const m2m_tower* t, int B);
+/* 1: m2m_towers_wgrad with these embeddings / embed_towers at batch B uses the single-owner embedding form (which honours
+ * m2m_embed.wgrad_flags); 0: the row-group form, "+=" with atomics onto a zeroed gradient */
+int m2m_embeds_wgrad_form(const m2m_embed* const* embeds, const m2m_tower* const* embed_towers, int nembeds, int B);
 /* bit i set: m2m_towers_wgrad on these towers at batch B leaves the second row group of tower i in its wslot */
 int m2m_wgrad_slot_groups(const m2m_tower* const* towers, int ntowers, int B);
 /* g_ch_w1 / g_ch_b1 / g_ch_w2 of every block += the tower's wslot (complete gradients before a data-parallel exchange) */

@@ -85,7 +85,7 @@ class Embed(C.Structure):
     """m2m_embed"""
     _fields_ = [("prec", C.c_int32), ("Cin", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("ph", C.c_int32),
                 ("pw", C.c_int32), ("D", C.c_int32), ("K", C.c_int32), ("Kp", C.c_int32),
-                ("w", _fp), ("b", _fp), ("wn", _fp), ("g_w", _fp), ("g_b", _fp)]
+                ("w", _fp), ("b", _fp), ("wn", _fp), ("g_w", _fp), ("g_b", _fp), ("wgrad_flags", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Head(C.Structure):
@@ -127,6 +127,7 @@ SIGNATURES = {
     "m2m_towers_wgrad": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.POINTER(_fp), C.c_int, C.POINTER(C.POINTER(Embed)), C.POINTER(_fp),
                                    C.POINTER(_fp), C.POINTER(C.POINTER(Tower)), C.c_int, C.c_int, C.c_uint32, C.c_uint32, _fp, _fp]),
     "m2m_wgrad_form": (C.c_int, [C.POINTER(Tower), C.c_int]),
+    "m2m_embeds_wgrad_form": (C.c_int, [C.POINTER(C.POINTER(Embed)), C.POINTER(C.POINTER(Tower)), C.c_int, C.c_int]),
     "m2m_wgrad_groups": (C.c_int, [C.POINTER(Tower), C.c_int]),
     "m2m_wgrad_slot_groups": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.c_int, C.c_int]),
     "m2m_wgrad_fold": (C.c_int, [C.POINTER(Tower), _fp]),

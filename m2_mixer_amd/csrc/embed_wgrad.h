@@ -2,6 +2,7 @@
 // tower_wgrad.hip (as extra workgroups of the merged weight-gradient launch, 256 threads).
 #pragma once
 #include "tile.h"
+#include <stdlib.h>
 
 #define EBM 32             // token rows per tile
 
@@ -150,80 +151,144 @@ static __device__ __forceinline__ void embed_wgrad_body(const m2m_embed& em, con
 // [32-row pair][d tile][lane] 16 B, chained k order), the second one is gathered straight from the input -- lane (g, il)
 // needs pixel k0 + il of the 8 token rows its chained k positions name: 8 four-byte loads, 16 consecutive pixels per lane
 // group and row.  Reference: the weight gradient of MLPMixer.to_patch_embedding (modules/mixer.py:143-146) under autograd.
-#define EFK 16
+#define EFK 32
+template <int D, int NT> static constexpr size_t embed_wgrad_fast_red_bytes() { return (size_t)(NT / 64) * (EFK / 16) * (D / 16) * 64 * 16; }
+bool m2m_split_eligible(const m2m_tower* t, int B, int training);    // split_api.hip (its backward does not write the image)
 template <int D, int NT>
 static __device__ __forceinline__ void embed_wgrad_fast_body(const m2m_embed& em, const float* __restrict__ in,
                                                              const char* __restrict__ dx0_chn, long M, int N, int npairs, int rpt,
-                                                             int chunk, char* smem) {
+                                                             int chunk, bool vec2, char* smem) {
     typedef Prec<PREC_BF16> Pr;
-    constexpr int DT = D / 16, NW = NT / 64;
+    constexpr int DT = D / 16, NW = NT / 64, NB = EFK / 16;
+    static_assert(NB == 2, "two 16-column fragments per workgroup (the 8-byte gather pairs them)");
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, il = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     PatchGeom pg{em.Cin, em.H, em.W, em.ph, em.pw, em.W / em.pw, N, em.K};
     const int k0 = chunk * EFK;
-    const int ko = patch_koff(pg, k0 + il);                      // this lane's pixel; -1 beyond K
-    const bool bias = chunk == 0;
-
-    f32x4_t acc[DT], accb[DT];
+    int ko[NB];                                                  // this lane's pixels (one per 16-column fragment); -1 beyond K
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) { acc[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; accb[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
-    Frag ones;
-    ones.u = u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    for (int jb = 0; jb < NB; ++jb) ko[jb] = patch_koff(pg, vec2 ? k0 + 2 * il + jb : k0 + 16 * jb + il);
+    // vec2 (workgroup-uniform; every patch row, token origin and sample stride even, input 8-byte aligned): lane il owns the
+    // pixel PAIR (2 il, 2 il + 1) -- column il of fragment jb is pixel k0 + 2 il + jb -- and fetches it with ONE 8-byte load
+    // origin of token n's patch inside a sample, by table (LDS): the per-row address is sample * stride + tokoff[n] + ko
+    int* tokoff = reinterpret_cast<int*>(smem + embed_wgrad_fast_red_bytes<D, NT>());
+    for (int n = tid; n < N; n += NT) tokoff[n] = (n / pg.GW) * pg.ph * pg.W + (n % pg.GW) * pg.pw;
+    __syncthreads();
+    const unsigned int sstride = (unsigned int)(em.Cin * em.H * em.W), uN = (unsigned int)N, uM = (unsigned int)M;
+    const unsigned int magic = 0xFFFFFFFFu / uN;                 // floor: the quotient below is exact or one too small
 
-    struct Tile { Frag a[DT]; float v[8]; };
+    f32x4_t acc[NB][DT];
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) acc[jb][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    struct Tile { Frag a[DT]; float v[NB][8]; unsigned int okbits; };
     auto load = [&](Tile& t, int p) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) t.a[dt] = ld_frag_global(dx0_chn, (long)p * DT + dt, lane);
-        // element e of the lane's second-operand fragment: token slot 16 (e >> 2) + 4 g + (e & 3) of the pair (chained k order)
+        // element e of the lane's second-operand fragment: token slot 16 (e >> 2) + 4 g + (e & 3) of the pair (chained k order).
+        // ALL addresses first (branch-free: invalid rows read row 0 and are zeroed afterwards), then ALL loads: written as
+        // `ok ? in[..] : 0` hipcc put every load into its own basic block -- division, LDS lookup, two loads, vmcnt(0), eight
+        // times in series per pair (50 us for the launch).  The empty asm keeps the loads from being sunk back under the test.
+        unsigned int rb[8];
+        bool okr[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int r = 4 * g + (e & 3);
-            const long row = (long)(2 * p + (e >> 2)) * rpt + r;
-            const long rb = r < rpt ? patch_rowbase(pg, row, M) : -1;
-            t.v[e] = (rb >= 0 && ko >= 0) ? in[rb + ko] : 0.f;
+            const unsigned int row = (unsigned int)((2 * p + (e >> 2)) * rpt + r);
+            okr[e] = r < rpt && row < uM;
+            const unsigned int rowc = okr[e] ? row : 0u;
+            unsigned int q = __umulhi(rowc, magic);              // rowc / N by multiplication + one fix-up
+            unsigned int n = rowc - q * uN;
+            if (n >= uN) { n -= uN; q += 1u; }
+            rb[e] = q * sstride + (unsigned int)tokoff[n];
         }
+        if (vec2) {
+            const unsigned int k2 = (unsigned int)max(ko[0], 0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float2 x = *reinterpret_cast<const float2*>(in + rb[e] + k2);
+                t.v[0][e] = x.x; t.v[1][e] = x.y;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int jb = 0; jb < NB; ++jb) t.v[jb][e] = in[rb[e] + (unsigned int)max(ko[jb], 0)];
+        }
+        t.okbits = 0u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t.okbits |= (okr[e] ? 1u : 0u) << e;
     };
     auto mac = [&](const Tile& t) {
-        Frag b;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) b.u[e] = pack_bf2(t.v[2 * e], t.v[2 * e + 1]);
+        for (int jb = 0; jb < NB; ++jb) {
+            Frag b;                                              // (invalid rows / pixels beyond K: zeroed HERE, at the use)
+            float z[8];
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            Pr::mma(acc[dt], t.a[dt], b);
-            if (bias) Pr::mma(accb[dt], t.a[dt], ones);
+            for (int e = 0; e < 8; ++e) z[e] = ((t.okbits >> e) & 1u) && ko[jb] >= 0 ? t.v[jb][e] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b.u[e] = pack_bf2(z[2 * e], z[2 * e + 1]);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) Pr::mma(acc[jb][dt], t.a[dt], b);
         }
     };
-    // two pairs in flight per wave (register double buffer)
-    Tile t0, t1;
-    int p = wave;
-    if (p < npairs) load(t0, p);
-    for (; p < npairs; p += 2 * NW) {
-        if (p + NW < npairs) load(t1, p + NW);
+    // three pairs in flight per wave (register ring, unrolled by three so that no slot is copied)
+    Tile t0, t1, t2;
+    const int p0 = wave;
+    if (p0 < npairs) load(t0, p0);
+    if (p0 + NW < npairs) load(t1, p0 + NW);
+    for (int p = p0; p < npairs; p += 3 * NW) {
+        if (p + 2 * NW < npairs) load(t2, p + 2 * NW);
         mac(t0);
         if (p + NW < npairs) {
-            if (p + 2 * NW < npairs) load(t0, p + 2 * NW);
+            if (p + 3 * NW < npairs) load(t0, p + 3 * NW);
             mac(t1);
-        }
-    }
-    // ---- reduction over the waves: [wave][dt][lane] 16 B, then wave w finishes d-tiles w, w + NW, ... ----
-    f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) red[(wave * DT + dt) * 64 + lane] = acc[dt];
-    __syncthreads();
-    for (int dt = wave; dt < DT; dt += NW) {
-        f32x4_t s = red[dt * 64 + lane];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) s = s + red[(w * DT + dt) * 64 + lane];
-        const int k = k0 + il;
-        if (k < em.K) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float* q = em.g_w + (long)(16 * dt + 4 * g + r) * em.K + k;       // element (d = 16 dt + 4 g + r, k): 16 lanes = 64 B
-                *q += s[r];
+            if (p + 2 * NW < npairs) {
+                if (p + 4 * NW < npairs) load(t1, p + 4 * NW);
+                mac(t2);
             }
         }
     }
-    if (bias) {                                                   // (workgroup-uniform) the same once more for the row sums
+    // ---- reduction over the waves: [wave][jb][dt][lane] 16 B, then wave w finishes (jb, dt) tiles w, w + NW, ... ----
+    f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) red[((wave * NB + jb) * DT + dt) * 64 + lane] = acc[jb][dt];
+    __syncthreads();
+    for (int q = wave; q < NB * DT; q += NW) {
+        const int jb = q / DT, dt = q % DT;
+        f32x4_t s = red[q * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) s = s + red[(w * NB * DT + q) * 64 + lane];
+        const int k = vec2 ? k0 + 2 * il + jb : k0 + 16 * jb + il;
+        if (k < em.K) {
+            const bool store = (em.wgrad_flags & M2M_WGRAD_OVERWRITE) != 0;      // "=": no read of the old values
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float* qd = em.g_w + (long)(16 * dt + 4 * g + r) * em.K + k;      // element (d = 16 dt + 4 g + r, k)
+                *qd = store ? s[r] : *qd + s[r];
+            }
+        }
+    }
+    if (chunk == 0) {
+        // (workgroup-uniform) the bias gradient = row sums of d_x0^T: a second walk over the image with an all-ones second
+        // operand -- one workgroup's extra ~3 us beside ~100 others.  (The image is bf16: the sums carry its rounding, like the
+        // weight gradient; the row-group form summed the fp32 d_x0.)
+        Frag ones;
+        ones.u = u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+        f32x4_t accb[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) accb[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int p = wave; p < npairs; p += NW) {
+            Frag a[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) a[dt] = ld_frag_global(dx0_chn, (long)p * DT + dt, lane);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) Pr::mma(accb[dt], a[dt], ones);
+        }
         __syncthreads();
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) red[(wave * DT + dt) * 64 + lane] = accb[dt];
@@ -239,7 +304,7 @@ static __device__ __forceinline__ void embed_wgrad_fast_body(const m2m_embed& em
         }
     }
 }
-template <int D, int NT> static constexpr size_t embed_wgrad_fast_lds() { return (size_t)(NT / 64) * (D / 16) * 64 * 16; }
+template <int D, int NT> static constexpr size_t embed_wgrad_fast_lds() { return embed_wgrad_fast_red_bytes<D, NT>() + 128 * sizeof(int); }
 
 // Both patch embeddings of a two-tower model behind one launch: workgroups [0, nwg(0)) serve embedding 0, the rest 1.
 #define EMB_GROUP 2
@@ -251,7 +316,7 @@ struct EmbedWgradGroupArgs {
     int N[EMB_GROUP], tpg[EMB_GROUP], nchunks[EMB_GROUP], groups[EMB_GROUP];
     // fast form (fast != 0): nchunks = ceil(K / EFK), groups = 1
     const char* dx0_chn[EMB_GROUP];
-    int npairs[EMB_GROUP], rpt[EMB_GROUP], fast;
+    int npairs[EMB_GROUP], rpt[EMB_GROUP], vec2[EMB_GROUP], fast;
 };
 template <int P, int D, int NT>
 static __device__ __forceinline__ void embed_wgrad_group_body(const EmbedWgradGroupArgs& a, int id, char* smem) {
@@ -260,7 +325,7 @@ static __device__ __forceinline__ void embed_wgrad_group_body(const EmbedWgradGr
     if (e) id -= n0;
     if constexpr (P == PREC_BF16) {
         if (a.fast) {
-            embed_wgrad_fast_body<D, NT>(a.em[e], a.in[e], a.dx0_chn[e], a.M[e], a.N[e], a.npairs[e], a.rpt[e], id, smem);
+            embed_wgrad_fast_body<D, NT>(a.em[e], a.in[e], a.dx0_chn[e], a.M[e], a.N[e], a.npairs[e], a.rpt[e], id, a.vec2[e] != 0, smem);
             return;
         }
     }
@@ -299,10 +364,15 @@ static inline int embed_wgrad_group_args_fast(EmbedWgradGroupArgs& a, const m2m_
         const m2m_tower* t = tw ? tw[i] : nullptr;
         const int N = (e->H / e->ph) * (e->W / e->pw);
         if (!t || !t->dx0_chn || e->prec != PREC_BF16 || t->prec != PREC_BF16 || m2m_is_wide(t) || t->N != N || t->D != e->D) return 0;
+        if (m2m_split_eligible(t, B, 1)) return 0;               // (the split path's backward does not write the image)
+        if (N > 128 || e->D > 128 || (long)B * e->Cin * e->H * e->W >= (1L << 31)) return 0;   // (hidden_dim 256: the ring spills)
         const int SPW = BM / t->N, nchain = (B + SPW - 1) / SPW;
         a.em[i] = *e; a.in[i] = ins[i]; a.dx0_chn[i] = (const char*)t->dx0_chn;
         a.M[i] = (long)B * N; a.N[i] = N; a.npairs[i] = (nchain * BM + WPAIR - 1) / WPAIR; a.rpt[i] = SPW * t->N;
         a.nchunks[i] = (e->K + EFK - 1) / EFK; a.groups[i] = 1; a.tpg[i] = 0;
+        // 8-byte gathers: every address the kernel forms is even (patch rows, token origins, channel / sample strides, K)
+        static const int vec2_on = [] { const char* v = getenv("M2M_EMBED_VEC2"); return v ? atoi(v) : 1; }();
+        a.vec2[i] = (vec2_on && e->pw % 2 == 0 && e->W % 2 == 0 && ((long)e->H * e->W) % 2 == 0 && e->K % 2 == 0 && ((uintptr_t)ins[i] & 7) == 0) ? 1 : 0;
         total += a.nchunks[i];
     }
     a.fast = 1;

@@ -339,6 +339,8 @@ struct WgradGroupArgs {
     short job_start[WG_MAX_JOBS + 1];                 // first linear workgroup index of job j (its workgroups: group-major, slice fastest)
     short xcd_start[8], xcd_len[8];                   // XCD x runs linear indices [xcd_start[x], xcd_start[x] + xcd_len[x])
     int njobs, n_tower_wgs;                           // n_tower_wgs = 8 x the longest XCD chunk (ids beyond a chunk return at once)
+    int n_embed_first, n_embed_pad;                   // embedding workgroups dispatched FIRST: ids [0, n_embed_first), padded to a
+                                                      // multiple of 8 (n_embed_pad) so that tower ids keep their XCD (id % 8)
     unsigned int seed, step_host;
     const unsigned int* step_dev;
 };
@@ -355,7 +357,12 @@ template <int P, int D, int RCDM>
 __global__ __launch_bounds__((WgradKernelGeom<P, D, RCDM>::THREADS), (WgradKernelGeom<P, D, RCDM>::MINWAVES)) void tower_wgrad_group_kernel(const WgradGroupArgs a,
                                                                                                           const EmbedWgradGroupArgs ea) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int id = blockIdx.x;
+    int id = blockIdx.x;
+    if (id < a.n_embed_pad) {
+        if (id < a.n_embed_first) embed_wgrad_group_body<P, D, WgradKernelGeom<P, D, RCDM>::THREADS>(ea, id, smem);
+        return;
+    }
+    id -= a.n_embed_pad;
     if (id >= a.n_tower_wgs) {
         embed_wgrad_group_body<P, D, WgradKernelGeom<P, D, RCDM>::THREADS>(ea, id - a.n_tower_wgs, smem);
         return;
@@ -371,6 +378,15 @@ __global__ __launch_bounds__((WgradKernelGeom<P, D, RCDM>::THREADS), (WgradKerne
     const unsigned int step = a.step_host + (a.step_dev ? *a.step_dev : 0u);
     wgrad_dispatch<P, D, RCDM>(tw, (int)a.job_block[job], slice, group, a.groups[t], a.slot[t], a.ntiles[t], a.tpg[t], a.rpt[t], a.seed,
                                step, smem);
+}
+
+// The single-owner embedding gradients as a launch of their own (256 threads, in front of the tower launch on the same stream):
+// beside five-wave tower workgroups (one per CU, SIMD 0 full) an embedding workgroup finds room only on the 16 CUs the 240 tower
+// workgroups leave free, and ~100 latency-bound workgroups queued on 16 CUs outlast the towers by ~20 us.
+template <int D>
+__global__ __launch_bounds__(256, 2) void embed_wgrad_fast_group_kernel(const EmbedWgradGroupArgs ea) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    embed_wgrad_group_body<PREC_BF16, D, 256>(ea, blockIdx.x, smem);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
@@ -543,6 +559,18 @@ static int launch_wgrad_group(const m2m_tower* const* host, const m2m_tower* con
     if (embeds_separately) {
         if (int rc = m2m_embeds_wgrad(embeds, inputs, d_x0s, nembeds, B, (void*)st)) return rc;
     }
+    if constexpr (P == PREC_BF16) {
+        static const int merged = wgrad_env("M2M_EMBED_MERGED", 1);
+        if (n_embed_wgs && ea.fast && !merged && KG::THREADS != 256) {
+            const size_t le = embed_wgrad_fast_lds<D, 256>();
+            auto ek = embed_wgrad_fast_group_kernel<D>;
+            static bool eattr = false;
+            if (!eattr) { M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ek), hipFuncAttributeMaxDynamicSharedMemorySize, (int)le)); eattr = true; }
+            hipLaunchKernelGGL(ek, dim3((unsigned)n_embed_wgs), dim3(256), le, st, ea);
+            M2M_CHECK_HIP(hipGetLastError());
+            n_embed_wgs = 0; lds_e = 0;
+        }
+    }
     const size_t lds_t = (size_t)KG::LDS_B;
     const size_t lds = lds_t > lds_e ? lds_t : lds_e;
     auto kern = tower_wgrad_group_kernel<P, D, RCDM>;
@@ -551,7 +579,12 @@ static int launch_wgrad_group(const m2m_tower* const* host, const m2m_tower* con
         M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(a.n_tower_wgs + n_embed_wgs)), dim3(KG::THREADS), lds, st, a, ea);
+    // Fast-form embedding workgroups go FIRST (every CU is free then: ~100 of them run beside the first tower workgroups and
+    // are gone after ~15 us; dispatched last they queue on the 16 CUs that 240 one-per-CU tower workgroups leave free and the
+    // launch's end depends on where those land: 101-121 us measured from box to box, against a steady ~95 us).
+    static const int embed_first = wgrad_env("M2M_EMBED_FIRST", 1);
+    if (ea.fast && n_embed_wgs && embed_first) { a.n_embed_first = n_embed_wgs; a.n_embed_pad = (n_embed_wgs + 7) & ~7; n_embed_wgs = 0; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.n_embed_pad + a.n_tower_wgs + n_embed_wgs)), dim3(KG::THREADS), lds, st, a, ea);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -628,6 +661,15 @@ extern "C" int m2m_towers_wgrad(const m2m_tower* const* towers, const m2m_tower*
 #undef M2M_WGG_CASE
     m2m_set_error("towers_wgrad: unsupported (prec, D)", __FILE__, __LINE__);
     return -1;
+}
+
+// 1: m2m_towers_wgrad(..., embeds, ..., embed_towers, ...) at batch B computes the embedding gradients in the single-owner form
+// (and honours m2m_embed.wgrad_flags); 0: the row-group form ("+=" with atomics onto a zeroed gradient).
+extern "C" int m2m_embeds_wgrad_form(const m2m_embed* const* embeds, const m2m_tower* const* embed_towers, int nembeds, int B) {
+    if (!embeds || !embed_towers || nembeds != EMB_GROUP) return 0;
+    EmbedWgradGroupArgs ea;
+    const float* ins[EMB_GROUP] = {nullptr, nullptr};
+    return embed_wgrad_group_args_fast(ea, embeds, ins, embed_towers, B) > 0 ? 1 : 0;
 }
 
 // g_ch_w1 / g_ch_b1 / g_ch_w2 += the tower's partial-gradient slot (blocks with contiguous channel gradients; see

@@ -570,6 +570,18 @@ class _TwoTowerEngine(_FlatEngine):
         self._embed_towers = []
         if os.environ.get("M2M_EMBED_FAST", "1") != "0" and self.t_a.enable_dx0_image(B) and self.t_b.enable_dx0_image(B):
             self._embed_towers = [self.t_a, self.t_b]
+            # their weight gradients are then written ("="), and Adam leaves those ranges uncleared -- if the range table has room
+            import ctypes as C
+            ep = (C.POINTER(L.Embed) * 2)(C.pointer(self.e_a.desc), C.pointer(self.e_b.desc))
+            tp = (C.POINTER(L.Tower) * 2)(C.pointer(self.t_a.desc), C.pointer(self.t_b.desc))
+            fast = bool(L.lib().m2m_embeds_wgrad_form(ep, tp, 2, B))
+            if fast and os.environ.get("M2M_WGRAD_OVERWRITE", "1") != "0" and len(self._ranges_add) + 2 <= L.MAX_GRAD_RANGES:
+                for e, pre in ((self.e_a, f"{a}_mixer."), (self.e_b, f"{b}_mixer.")):
+                    gw = self.grads[pre + "to_patch_embedding.0.weight"]
+                    e.set_wgrad_overwrite(True)
+                    self._ranges_add.append(((gw.data_ptr() - self.flat_g.data_ptr()) // 4, gw.numel(), None, 1))
+                self._ranges_add.sort(key=lambda r: r[0])
+                self._ranges_keep = [(lo, n, None, k) for lo, n, _, k in self._ranges_add]
 
     def _preds_shape(self):
         return (3, self.B)

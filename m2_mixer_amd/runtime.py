@@ -513,6 +513,10 @@ class EmbedRuntime:
         self.desc.g_w, self.desc.g_b = g_w.data_ptr(), g_b.data_ptr()
         self._keep["g"] = (g_w, g_b)
 
+    def set_wgrad_overwrite(self, on: bool):
+        """g_w is WRITTEN by the single-owner weight-gradient form (towers_wgrad with embed_towers), not accumulated."""
+        self.desc.wgrad_flags = L.WGRAD_OVERWRITE if on else 0
+
     def fwd_splits(self) -> int:
         """k-splits embeds_forward should use for this embedding (1: none)."""
         return int(L.lib().m2m_embed_fwd_splits(C.byref(self.desc)))

@@ -362,7 +362,10 @@ def test_grouped_launches_match_single_launches(prec, dev):
     for k in keys:
         g = eng.grads[k]
         o = (g.data_ptr() - eng.flat_g.data_ptr()) // 4
-        assert relerr(g_merged[o:o + g.numel()].view_as(g), g) < 1e-4, k
+        # (the single-owner embedding gradients of the merged launch sum the bf16 image of d_x0^T for the bias too; the
+        # separate launch sums the fp32 d_x0: bf16 rounding of the summands, 2^-9 each)
+        tol = 3e-3 if (prec == "bf16" and k.endswith("to_patch_embedding.0.bias")) else 1e-4
+        assert relerr(g_merged[o:o + g.numel()].view_as(g), g) < tol, k
     # ---- operand packing: the whole model in one launch vs per tower / per embedding, bit for bit
     towers, embeds = [eng.t_a, eng.t_b, eng.t_fus], [eng.e_a, eng.e_b]
     pack_all(towers, embeds)

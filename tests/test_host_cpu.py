@@ -44,7 +44,7 @@ def test_struct_layouts_match_header(lib):
     assert C.sizeof(lib.Tower) == 40 + 7 * 8 + lib.MAX_BLOCKS * C.sizeof(lib.Block) + 8 + 8 + 8 + 8 + 3 * 8 * lib.MAX_BLOCKS + 8
     assert lib.Tower.slabs.offset == 96 + lib.MAX_BLOCKS * C.sizeof(lib.Block)
     assert lib.Tower.blk.offset == 96
-    assert C.sizeof(lib.Embed) == 40 + 5 * 8
+    assert C.sizeof(lib.Embed) == 40 + 5 * 8 + 8
     assert C.sizeof(lib.Head) == 6 * 8 + 8
 
 
@@ -54,7 +54,7 @@ def test_struct_layouts_against_the_c_compiler(lib, tmp_path):
     import subprocess
     fields = {"m2m_block": ("Block", ["ln1_w", "w1n", "g_ln1_w", "x_in", "dh_chn"]),
               "m2m_tower": ("Tower", ["p_drop", "lnf_w", "blk", "slabs", "wgrad_flags", "xres", "gpart", "a_nat", "dy_nat", "wslot", "dx0_chn"]),
-              "m2m_embed": ("Embed", ["Kp", "w", "g_b"]),
+              "m2m_embed": ("Embed", ["Kp", "w", "g_b", "wgrad_flags"]),
               "m2m_head": ("Head", ["d_pooled", "weight"]),
               "m2m_mlp": ("Mlp", ["dims", "p_drop", "w", "act"]),
               "m2m_grad_range": ("GradRange", ["lo", "n", "add", "keep"]),
