@@ -10,6 +10,6 @@ for spec in "$@"; do
 import json
 d=json.loads(open("gpurun_out/${tag}_${name}_${rep}.json").read().strip().split("\n")[-1])
 k=d["kernels_us"]
-print("${name} rep${rep}: %d samples/s %.4f ms | wgrad %.1f adam+pack %.1f bwd %.1f+%.1f fwd %.1f+%.1f" % (d["value"], d["ms_per_step"], k["towers_wgrad[all+embeds]"], k["adam+pack"], k["tower_bwd[fusion]"], k["towers_bwd[image+audio]"], k["towers_fwd[image+audio]"], k["tower_fwd[fusion]"]))
+print("${name} rep${rep}: %d samples/s %.4f ms | wgrad %.1f adam+pack %.1f bwd %.1f+%.1f fwd %.1f+%.1f heads %.1f embeds %.1f" % (d["value"], d["ms_per_step"], k["towers_wgrad[all+embeds]"], k["adam+pack"], k["tower_bwd[fusion]"], k["towers_bwd[image+audio]"], k["towers_fwd[image+audio]"], k["tower_fwd[fusion]"], k["heads_ce"], k["embeds_fwd[image+audio]"]))
 PY
 done; done

@@ -26,3 +26,23 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+# ---- observed maxima of the bf16 parity errors (printed at the end of a run: tolerances follow what is observed) -------------
+OBSERVED = {}
+
+
+def observe(kind: str, value: float, tol: float) -> float:
+    """Record the largest error of a kind seen in this session (and the tolerance it is held to); returns the value."""
+    cur = OBSERVED.get(kind)
+    if cur is None or value > cur[0]:
+        OBSERVED[kind] = (float(value), float(tol))
+    return value
+
+
+def pytest_terminal_summary(terminalreporter):
+    if OBSERVED:
+        terminalreporter.write_line("observed parity errors (max over the session | tolerance):")
+        for k in sorted(OBSERVED):
+            v, t = OBSERVED[k]
+            terminalreporter.write_line(f"  {k:46s} {v:.3e} | {t:.1e}")

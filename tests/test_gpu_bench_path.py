@@ -14,13 +14,14 @@ import pytest
 import torch
 
 import gen_util as G
+from conftest import observe
 from oracle import m2mixer_oracle as O
 
 pytestmark = pytest.mark.gpu
 
 FP32_ATOL = 1e-3       # BASELINE.json north_star: logits within 1e-3 in fp32
-BF16_LOGITS = 3e-2     # bf16 operands, fp32 accumulate: absolute on O(1) logits
-BF16_GRAD_REL = 6e-2   # relative to the gradient tensor's max
+BF16_LOGITS = 2e-2     # bf16 operands, fp32 accumulate: absolute on O(1) logits (<~ 2e-2; observed maxima: test summary)
+BF16_GRAD_REL = 4e-2   # relative to the gradient tensor's max (observed maxima are printed in the test summary)
 
 
 @pytest.fixture(scope="module")
@@ -99,14 +100,14 @@ def test_bench_instantiation_with_dropout_vs_oracle(p_drop, B, dev):
     assert abs(keep - (1 - p_drop)) < 0.02, keep
     ref = O.avmnist_train_step(image, audio, labels, dict(params), cfg, {}, lr=1e-2, drop_p=p_effective(p_drop), masks=masks)
     for i, k in enumerate(("image_logits", "audio_logits", "logits")):
-        assert abserr(eng.logits[i], ref[k]) < BF16_LOGITS, k
+        assert observe("bf16 logits (abs)", abserr(eng.logits[i], ref[k]), BF16_LOGITS) < BF16_LOGITS, k
         assert_preds_match(eng.preds[i], eng.logits[i], ref[k], BF16_LOGITS)
     for i, k in enumerate(("loss_image", "loss_audio", "loss_fusion", "loss")):
         assert abs(float(eng.losses[i]) - float(ref[k])) < 2e-2, k
     for k, g in ref["grads"].items():
         if k.endswith("token_mix.2.net.3.bias"):       # exactly-zero true gradient
             continue
-        assert relerr(eng.grads[k], g) < BF16_GRAD_REL, k
+        assert observe("bf16 gradients (rel to max)", relerr(eng.grads[k], g), BF16_GRAD_REL) < BF16_GRAD_REL, k
 
 
 @pytest.mark.parametrize("p_drop,B", [(0.5, 200), (0.1, 77), (0.0, 130)])
@@ -136,7 +137,7 @@ def test_split_path_ragged_batches_vs_oracle(p_drop, B, dev, monkeypatch):
     ref = O.avmnist_train_step(image, audio, labels, dict(params), cfg, {}, lr=1e-2, drop_p=p_effective(p_drop), masks=masks)
     logits, losses, flat_g = got["1"]
     for i, k in enumerate(("image_logits", "audio_logits", "logits")):
-        assert abserr(logits[i], ref[k]) < BF16_LOGITS, k
+        assert observe("bf16 logits (abs)", abserr(logits[i], ref[k]), BF16_LOGITS) < BF16_LOGITS, k
     for i, k in enumerate(("loss_image", "loss_audio", "loss_fusion", "loss")):
         assert abs(float(losses[i]) - float(ref[k])) < 2e-2, k
     for k, g in ref["grads"].items():
@@ -144,7 +145,7 @@ def test_split_path_ragged_batches_vs_oracle(p_drop, B, dev, monkeypatch):
             continue
         gv = eng.grads[k]
         o = (gv.data_ptr() - eng.flat_g.data_ptr()) // 4
-        assert relerr(flat_g[o:o + gv.numel()].view_as(gv), g) < BF16_GRAD_REL, k
+        assert observe("bf16 gradients (rel to max)", relerr(flat_g[o:o + gv.numel()].view_as(gv), g), BF16_GRAD_REL) < BF16_GRAD_REL, k
     # split vs fused: same masks, same bf16 rounding points; they differ by the GELU table form and fp32 summation order
     assert abserr(got["1"][0], got["0"][0]) < 1e-2 and abserr(got["1"][1], got["0"][1]) < 1e-3
     # evaluation (dropout off, no saved activations: the carry stream is rewritten in place)
@@ -153,7 +154,7 @@ def test_split_path_ragged_batches_vs_oracle(p_drop, B, dev, monkeypatch):
     torch.cuda.synchronize()
     ev = O.avmnist_forward(image, audio, labels, params, cfg)
     for k in ("logits", "image_logits", "audio_logits"):
-        assert abserr(out[k], ev[k]) < BF16_LOGITS, k
+        assert observe("bf16 logits (abs)", abserr(out[k], ev[k]), BF16_LOGITS) < BF16_LOGITS, k
 
 
 @pytest.mark.parametrize("fused_update", ["0", "1"])
@@ -221,12 +222,12 @@ def test_wide_models_bf16_at_config_batches_vs_oracle(task, B, dev):
     ref = fwd(leaves)
     ref["loss"].backward()
     for i, k in enumerate(names):
-        assert abserr(eng.logits[i], ref[k]) < BF16_LOGITS * max(1.0, float(ref[k].detach().abs().max())), k
+        assert observe("bf16 logits (abs)", abserr(eng.logits[i], ref[k]), BF16_LOGITS) < BF16_LOGITS * max(1.0, float(ref[k].detach().abs().max())), k
     assert abs(float(eng.losses[3]) - float(ref["loss"].detach())) < 2e-2 * max(1.0, abs(float(ref["loss"].detach())))
     for k, leaf in leaves.items():
         if k.endswith("token_mix.2.net.3.bias"):
             continue
-        assert relerr(eng.grads[k], leaf.grad) < BF16_GRAD_REL, k
+        assert observe("bf16 gradients (rel to max)", relerr(eng.grads[k], leaf.grad), BF16_GRAD_REL) < BF16_GRAD_REL, k
 
 
 def test_capture_leaves_the_model_untouched_and_graphs_keep_their_own_outputs(dev):
@@ -352,7 +353,7 @@ def test_checkpoint_to_predictions_round_trip_vs_oracle(dev, tmp_path):
     net.eval()
     with torch.no_grad():
         mo = net.shared_step({"image": image[:B].to(dev), "audio": audio[:B].to(dev), "label": labels[:B].to(dev)}, mode="val")
-    assert abserr(mo["logits"], full["logits"][:B]) < BF16_LOGITS        # module default precision is bf16
+    assert observe("bf16 logits (abs)", abserr(mo["logits"], full["logits"][:B]), BF16_LOGITS) < BF16_LOGITS        # module default precision is bf16
     # ---- an engine's training state through save_checkpoint(engine=...) and back
     eng.train_step(image[:B].to(dev), audio[:B].to(dev), labels[:B].to(dev))
     torch.cuda.synchronize()

@@ -14,13 +14,14 @@ import pytest
 import torch
 
 import gen_util as G
+from conftest import observe
 from golden_util import check, load
 from oracle import m2mixer_oracle as O
 
 pytestmark = pytest.mark.gpu
 
 FP32_ATOL = 1e-3
-BF16_REL = 3e-2
+BF16_REL = 2e-2        # (observed maxima are printed in the test summary)
 
 
 @pytest.fixture(scope="module")
@@ -116,10 +117,10 @@ def test_block_bf16_vs_oracle(ci, case, dev):
     xr = x.clone().requires_grad_(True)
     yo = O.mixer_block(xr, leaves)
     (yo * dy).sum().backward()
-    assert relerr(y, yo) < BF16_REL
-    assert relerr(xg.grad, xr.grad) < BF16_REL
+    assert observe("bf16 block out / grads (rel to max)", relerr(y, yo), BF16_REL) < BF16_REL
+    assert observe("bf16 block out / grads (rel to max)", relerr(xg.grad, xr.grad), BF16_REL) < BF16_REL
     for k, prm in blk.named_parameters():
-        assert relerr(prm.grad, leaves[k].grad) < BF16_REL, k
+        assert observe("bf16 block out / grads (rel to max)", relerr(prm.grad, leaves[k].grad), BF16_REL) < BF16_REL, k
 
 
 @pytest.mark.parametrize("p_drop", [0.5, 0.1])
@@ -207,9 +208,9 @@ def test_avmnist_step_bf16_vs_oracle(size, B, dev):
     eng.forward_backward(image.to(dev), audio.to(dev), labels.to(dev))
     torch.cuda.synchronize()
     ref = O.avmnist_train_step(image, audio, labels, params, cfg, {}, lr=1e-2)
-    assert abserr(eng.logits[2], ref["logits"]) < BF16_REL
-    assert abserr(eng.logits[0], ref["image_logits"]) < BF16_REL
-    assert abserr(eng.logits[1], ref["audio_logits"]) < BF16_REL
+    assert observe("bf16 logits (abs)", abserr(eng.logits[2], ref["logits"]), BF16_REL) < BF16_REL
+    assert observe("bf16 logits (abs)", abserr(eng.logits[0], ref["image_logits"]), BF16_REL) < BF16_REL
+    assert observe("bf16 logits (abs)", abserr(eng.logits[1], ref["audio_logits"]), BF16_REL) < BF16_REL
     assert abs(float(eng.losses[3]) - float(ref["loss"])) < 1e-2
     assert_preds_bf16(eng.preds[2], eng.logits[2], ref["logits"])
     assert_preds_bf16(eng.preds[0], eng.logits[0], ref["image_logits"])
@@ -510,7 +511,7 @@ def test_wide_models_bf16_vs_oracle_and_training(task, dev):
     ref = fwd(leaves)
     ref["loss"].backward()
     for i, k in enumerate(names):
-        assert abserr(eng.logits[i], ref[k]) < BF16_REL * max(1.0, float(ref[k].detach().abs().max())), k
+        assert observe("bf16 logits (abs)", abserr(eng.logits[i], ref[k]), BF16_REL) < BF16_REL * max(1.0, float(ref[k].detach().abs().max())), k
     assert abs(float(eng.losses[3]) - float(ref["loss"].detach())) < 2e-2 * max(1.0, abs(float(ref["loss"].detach())))
     for k, leaf in leaves.items():
         if k.endswith("token_mix.2.net.3.bias"):      # exactly-zero true gradient
@@ -546,7 +547,7 @@ def test_mimic_large_batch_token_gradients_vs_oracle(prec, dev):
     leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     ref = O.mimic_forward(*batch, leaves, cfg)
     ref["loss"].backward()
-    tol_l, tol_g = (FP32_ATOL, 2e-3) if prec == "fp32" else (BF16_REL, 6e-2)
+    tol_l, tol_g = (FP32_ATOL, 2e-3) if prec == "fp32" else (BF16_REL, 4e-2)
     assert abserr(eng.logits[2], ref["logits"]) < tol_l * max(1.0, float(ref["logits"].detach().abs().max()))
     assert abs(float(eng.losses[3]) - float(ref["loss"].detach())) < (1e-3 if prec == "fp32" else 2e-2)
     for k, leaf in leaves.items():
