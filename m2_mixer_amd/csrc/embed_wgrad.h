@@ -234,21 +234,16 @@ static __device__ __forceinline__ void embed_wgrad_fast_body(const m2m_embed& em
             for (int dt = 0; dt < DT; ++dt) Pr::mma(acc[jb][dt], t.a[dt], b);
         }
     };
-    // three pairs in flight per wave (register ring, unrolled by three so that no slot is copied)
-    Tile t0, t1, t2;
+    // two pairs in flight per wave (register double buffer, unrolled by two so that no slot is copied; three spilled ~20 registers)
+    Tile t0, t1;
     const int p0 = wave;
     if (p0 < npairs) load(t0, p0);
-    if (p0 + NW < npairs) load(t1, p0 + NW);
-    for (int p = p0; p < npairs; p += 3 * NW) {
-        if (p + 2 * NW < npairs) load(t2, p + 2 * NW);
+    for (int p = p0; p < npairs; p += 2 * NW) {
+        if (p + NW < npairs) load(t1, p + NW);
         mac(t0);
         if (p + NW < npairs) {
-            if (p + 3 * NW < npairs) load(t0, p + 3 * NW);
+            if (p + 2 * NW < npairs) load(t0, p + 2 * NW);
             mac(t1);
-            if (p + 2 * NW < npairs) {
-                if (p + 4 * NW < npairs) load(t1, p + 4 * NW);
-                mac(t2);
-            }
         }
     }
     // ---- reduction over the waves: [wave][jb][dt][lane] 16 B, then wave w finishes (jb, dt) tiles w, w + NW, ... ----

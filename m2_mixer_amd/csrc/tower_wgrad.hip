@@ -295,10 +295,24 @@ static __device__ __forceinline__ WgOut wgrad_out(const TW& tw, int b, int group
     return o;
 }
 
+// the stored-operand form with every stream on LDS-DMA (tower_wgrad_rc.h: wgrad_dma_body) exists for these instantiations
+// Compile-time choice (both loops in one kernel spilled 60 registers); OFF by default (-DM2M_WGRAD_DMA=1 builds it).  Measured on
+// M2-Mixer-B, batch 512, A/B in one process: merged launch 108.3 / 107.2 us with the DMA loop against 107.3 / 106.3 us with the
+// register-staged one; the three towers alone 90 against 82 us.  Three steps of prefetch instead of one change nothing: the loop is
+// not waiting for its operand streams any more (in-kernel timers, scripts/rc_timers.py: per 32-row step 0.46 us LDS reads + MFMAs,
+// 0.24 us DMA issue -- 8 pieces per wave at ~75 cycles each --, 0.18 us barrier, 0.14 us DMA wait; write-out 13 us), and with five
+// waves per workgroup SIMD 0 carries two of them: 2 x 36 MFMAs x 16 cycles = 0.55 us per step is the floor of this tiling.
+#ifndef M2M_WGRAD_DMA
+#define M2M_WGRAD_DMA 0
+#endif
+template <int P, int D, int RCDM> struct WgradHasDma { static constexpr bool value = M2M_WGRAD_DMA && RCDM < 0 && P == PREC_BF16 && D == 128; };
+
 // RCDM: -1 = stored-operand form; DM_NONE / DM_HALF = recompute form with that dropout mode (bf16, hidden_dim 128 only)
 template <int P, int D, int RCDM> struct WgradKernelGeom {
     static constexpr bool RC = RCDM >= 0;
-    static constexpr int LDS_B = RC ? RcGeom<D>::LDS_B : WgradGeom<P, D>::LDS_B;
+    static constexpr int LDS_PLAIN = RC ? RcGeom<D>::LDS_B : WgradGeom<P, D>::LDS_B;
+    static constexpr int LDS_DMA = DrGeom<D, WgradGeom<P, D>::WAVES>::LDS_B;
+    static constexpr int LDS_B = WgradHasDma<P, D, RCDM>::value ? LDS_DMA : LDS_PLAIN;
     static constexpr int COLS = RC ? RcGeom<D>::COLS : WgradGeom<P, D>::COLS;
     static constexpr int MINWAVES = RC ? 2 : WgradGeom<P, D>::MINWAVES;
     static constexpr int THREADS = RC ? RC_THREADS : WgradGeom<P, D>::THREADS;
@@ -306,24 +320,27 @@ template <int P, int D, int RCDM> struct WgradKernelGeom {
 
 template <int P, int D, int RCDM, class TW>
 static __device__ __forceinline__ void wgrad_dispatch(const TW& tw, int b, int slice, int group, int ngroups, int slot_mode, int ntiles,
-                                                      int tpg, int rows_per_t16, unsigned int seed, unsigned int step, char* smem) {
+                                                      int tpg, int rows_per_t16, unsigned int seed, unsigned int step, int dma, char* smem) {
     const WgOut out = wgrad_out(tw, b, group, ngroups, slot_mode);
     if constexpr (RCDM >= 0) {
         const Drop dr = make_drop(true, tw.p_drop, seed, step, tw.site_base + 4u * (unsigned int)b + 2u);
         wgrad_rc_body<D, RCDM>(tw.blk[b], out, tw.Cp, tw.C, slice, group, ntiles, tpg, rows_per_t16, dr.key, dr.scale, smem);
     } else {
-        wgrad_body<P, D>(tw.blk[b], out, tw.Cp, tw.C, slice, group, ntiles, tpg, smem);
+        if constexpr (WgradHasDma<P, D, RCDM>::value)
+            wgrad_dma_body<D, WgradGeom<P, D>::WAVES>(tw.blk[b], out, tw.Cp, tw.C, slice, group, ntiles, tpg, smem);
+        else
+            wgrad_body<P, D>(tw.blk[b], out, tw.Cp, tw.C, slice, group, ntiles, tpg, smem);
     }
 }
 
 template <int P, int D, int RCDM>
 __global__ __launch_bounds__((WgradKernelGeom<P, D, RCDM>::THREADS), (WgradKernelGeom<P, D, RCDM>::MINWAVES)) void tower_wgrad_kernel(
     const m2m_tower tw, int ntiles, int tiles_per_group, int slot_mode, int rows_per_t16, unsigned int seed, unsigned int step_host,
-    const unsigned int* __restrict__ step_dev) {
+    const unsigned int* __restrict__ step_dev, int dma) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
     wgrad_dispatch<P, D, RCDM>(tw, (int)blockIdx.y, (int)blockIdx.x, (int)blockIdx.z, (int)gridDim.z, slot_mode, ntiles, tiles_per_group,
-                               rows_per_t16, seed, step, smem);
+                               rows_per_t16, seed, step, dma, smem);
 }
 
 // Several towers in ONE launch (job = (tower, block)): the three towers of a model finish their backward chains at about the
@@ -339,6 +356,7 @@ struct WgradGroupArgs {
     short job_start[WG_MAX_JOBS + 1];                 // first linear workgroup index of job j (its workgroups: group-major, slice fastest)
     short xcd_start[8], xcd_len[8];                   // XCD x runs linear indices [xcd_start[x], xcd_start[x] + xcd_len[x])
     int njobs, n_tower_wgs;                           // n_tower_wgs = 8 x the longest XCD chunk (ids beyond a chunk return at once)
+    int dma;                                          // stored-operand form: every stream on LDS-DMA (wgrad_dma_body)
     int n_embed_first, n_embed_pad;                   // embedding workgroups dispatched FIRST: ids [0, n_embed_first), padded to a
                                                       // multiple of 8 (n_embed_pad) so that tower ids keep their XCD (id % 8)
     unsigned int seed, step_host;
@@ -377,7 +395,7 @@ __global__ __launch_bounds__((WgradKernelGeom<P, D, RCDM>::THREADS), (WgradKerne
     const m2m_tower& tw = *a.tw[t];
     const unsigned int step = a.step_host + (a.step_dev ? *a.step_dev : 0u);
     wgrad_dispatch<P, D, RCDM>(tw, (int)a.job_block[job], slice, group, a.groups[t], a.slot[t], a.ntiles[t], a.tpg[t], a.rpt[t], a.seed,
-                               step, smem);
+                               step, a.dma, smem);
 }
 
 // The single-owner embedding gradients as a launch of their own (256 threads, in front of the tower launch on the same stream):
@@ -422,6 +440,9 @@ static bool wgrad_slot_usable(const m2m_tower* t) {
     }
     return true;
 }
+
+// M2M_WGRAD_DMA=0: the register-staged stored-operand loop (A/B)
+static int wgrad_use_dma() { static const int on = wgrad_env("M2M_WGRAD_DMA", 1); return on; }
 
 struct WgradPlan { int ntiles, nsl, groups, tpg, rpt, slot; };
 // honour_overwrite == false: the plan the tower would get if its gradient were zeroed and accumulated (m2m_wgrad_groups)
@@ -475,7 +496,7 @@ static int launch_wgrad(const m2m_tower* t, int B, unsigned int seed, unsigned i
         attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(pl.nsl, t->nblocks, pl.groups), dim3(KG::THREADS), lds, st, *t, pl.ntiles, pl.tpg, 0, pl.rpt, seed, step,
-                       step_dev);
+                       step_dev, wgrad_use_dma());
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -542,6 +563,7 @@ static int launch_wgrad_group(const m2m_tower* const* host, const m2m_tower* con
     }
     a.njobs = njobs; a.n_tower_wgs = 8 * max_len;
     a.seed = seed; a.step_host = step; a.step_dev = step_dev;
+    a.dma = wgrad_use_dma();
     EmbedWgradGroupArgs ea;
     memset(&ea, 0, sizeof(ea));
     // The patch-embedding gradients ride in the same launch, dispatched last.  Fast form (single owner, bf16, needs the d_x0^T

@@ -473,3 +473,159 @@ static __device__ __forceinline__ void wgrad_rc_body(const m2m_block& bk, const 
     TIMER_LFLUSH(g_tm_wg);
     TIMER_WG_END(g_tm_wg);
 }
+
+
+// ---- stored-operand form with every stream on LDS-DMA (bf16, hidden_dim 128) ------------------------------------------------
+// The same contraction as wgrad_body (tower_wgrad.hip: both hidden operands stored by the backward chain and streamed here), but
+// NOTHING of a step goes through VGPRs on its way in: the two shared images (A^T, dYd^T: 16 KB per 32 token rows) are staged
+// global -> LDS by LDS-DMA, double-buffered, one barrier per step, and each wave's own Hact^T / dHpre^T fragments (4 KB per step:
+// an HBM stream, read once) go by LDS-DMA into a private ring of DR_NR slots, DR_NR - 1 steps ahead.  The register-staged form
+// holds ONE step of loads in flight per wave (32 VGPRs: there is no room for a second) -- ~40 KB per CU, which at the ~2 us an
+// HBM access takes under load caps the CU near 20 GB/s: the phase timers showed 27 us of LDS + MFMA work per workgroup inside
+// ~110 us of waiting for loads and barriers.  Here three steps (12 KB per wave, 60 KB per CU) are in flight and cost no
+// registers; the price is the DMA issue (~75 cycles per 1 KB piece, 8 pieces per wave and step).
+// vmcnt bookkeeping (every memory operation of the loop is an inline-asm DMA, invisible to hipcc): per step a wave issues 4 image
+// DMAs then 4 ring DMAs; at the top of a step "all but the 4 youngest" have landed = this step's images (own share; the barrier
+// covers the other waves') and its ring slot.
+#ifndef DR_NR
+#define DR_NR 4
+#endif
+template <int D, int NW> struct DrGeom {
+    static constexpr int DT = D / 16;
+    static constexpr int IMG_B = 32 * D * 2;                 // one 32-row bf16 image
+    static constexpr int STAGE_B = 2 * IMG_B;                // A^T | dYd^T
+    static constexpr int NPIECE = STAGE_B / 1024;            // 1 KiB DMA pieces per step
+    static constexpr int PPW = (NPIECE + NW - 1) / NW;       // pieces per wave (the last wave repeats the final piece)
+    static constexpr int TR_B = NW * 16 * (D + 4) * 4;       // write-out transposes (alias the stage)
+    static constexpr int BODY_B = 2 * STAGE_B > TR_B ? 2 * STAGE_B : TR_B;
+    static constexpr int RING_B = NW * DR_NR * 4096;
+    static constexpr int LDS_B = BODY_B + RING_B;
+    static constexpr int COLS = NW * 32;
+};
+
+template <int D, int NW>
+static __device__ __forceinline__ void wgrad_dma_body(const m2m_block& bk, const WgOut& out, int Cp, int C, int slice, int group,
+                                                      int ntiles, int tiles_per_group, char* smem) {
+    typedef Prec<PREC_BF16> Pr;
+    typedef DrGeom<D, NW> G;
+    constexpr int DT = G::DT, IMG_B = G::IMG_B, STAGE_B = G::STAGE_B, PPW = G::PPW, CPW = 2;
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, il = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nct = Cp >> 4;
+    const int q = slice * NW + wave;                        // this wave's 32-column group
+    const int ct0 = 2 * q;
+    const int t_begin = group * tiles_per_group;
+    const int t_end = min(ntiles, t_begin + tiles_per_group);
+    if (t_begin >= t_end) return;
+    TIMER_WG_BEGIN();
+    TIMER_LSTART();
+    const int qc = min(q, (nct >> 1) - 1);                  // column groups past the end (last slice) shadow the last one
+
+    const unsigned long long s_at = uniform_u64((unsigned long long)bk.at_chn), s_dyt = uniform_u64((unsigned long long)bk.dyt_chn);
+    const unsigned long long hoff = (unsigned long long)qc * m2m_hchn_stride(ntiles);
+    const unsigned long long s_h = uniform_u64((unsigned long long)bk.h_chn + hoff), s_dh = uniform_u64((unsigned long long)bk.dh_chn + hoff);
+    const unsigned int sbase = lds_addr_of(smem);
+    const unsigned int lane16 = (unsigned int)lane * 16u;
+    auto stage = [&](int tile, int buf) {                   // this wave's PPW pieces of the step's two images
+        const unsigned long long o = (unsigned long long)tile * IMG_B;
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int piece = min(wave * PPW + k, G::NPIECE - 1);             // wave-uniform; [A^T: 0 .. IMG_B/1024) | dYd^T
+            const int img = piece >= IMG_B / 1024 ? 1 : 0, off = (piece - img * (IMG_B / 1024)) * 1024;
+            glds16_sv((img ? s_dyt : s_at) + o, lane16 + (unsigned int)off,
+                      __builtin_amdgcn_readfirstlane(sbase + buf * STAGE_B + piece * 1024));
+        }
+    };
+    // the wave's own fragments: [pair q][32-row tile][16-row half][lane][tile 2q: 8 B | tile 2q+1: 8 B], Hact^T and dHpre^T
+    const unsigned int ring_lds = sbase + G::BODY_B + (unsigned int)wave * (DR_NR * 4096);
+    const char* ring_ptr = smem + G::BODY_B + wave * (DR_NR * 4096);
+    auto ring_load = [&](int tile, int slot) {              // 4 DMAs: h half 0, h half 1, dh half 0, dh half 1
+        const unsigned long long o = (unsigned long long)tile * 2048;
+        const unsigned int dst = ring_lds + slot * 4096;
+        glds16_sv_nt(s_h + o, lane16, __builtin_amdgcn_readfirstlane(dst));
+        glds16_sv_nt(s_h + o, lane16 + 1024u, __builtin_amdgcn_readfirstlane(dst + 1024));
+        glds16_sv_nt(s_dh + o, lane16, __builtin_amdgcn_readfirstlane(dst + 2048));
+        glds16_sv_nt(s_dh + o, lane16 + 1024u, __builtin_amdgcn_readfirstlane(dst + 3072));
+    };
+
+    f32x4_t dw1[CPW][DT], dw2[CPW][DT], db1[CPW];
+#pragma unroll
+    for (int j = 0; j < CPW; ++j) {
+        db1[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            dw1[j][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            dw2[j][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    Frag ones;
+    ones.u = u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+
+    auto step = [&](int slot, int buf) {
+        const char* cur = smem + buf * STAGE_B;
+        const char* rs = ring_ptr + slot * 4096 + lane * 16;
+        Frag hf[CPW], df[CPW];
+        {
+            const u32x4_t h0 = *reinterpret_cast<const u32x4_t*>(rs), h1 = *reinterpret_cast<const u32x4_t*>(rs + 1024);
+            const u32x4_t d0 = *reinterpret_cast<const u32x4_t*>(rs + 2048), d1 = *reinterpret_cast<const u32x4_t*>(rs + 3072);
+#pragma unroll
+            for (int j = 0; j < CPW; ++j) {
+                hf[j].u = u32x4_t{h0[2 * j], h0[2 * j + 1], h1[2 * j], h1[2 * j + 1]};
+                df[j].u = u32x4_t{d0[2 * j], d0[2 * j + 1], d1[2 * j], d1[2 * j + 1]};
+            }
+        }
+        constexpr int LA = RC_LA < DT ? RC_LA : DT;
+        Frag aq[LA], yq[LA];
+#pragma unroll
+        for (int dt = 0; dt < LA; ++dt) { aq[dt] = ld_frag_lds(cur, dt, lane); yq[dt] = ld_frag_lds(cur + IMG_B, dt, lane); }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const Frag at = aq[dt % LA], dyt = yq[dt % LA];
+            if (dt + LA < DT) { aq[dt % LA] = ld_frag_lds(cur, dt + LA, lane); yq[dt % LA] = ld_frag_lds(cur + IMG_B, dt + LA, lane); }
+#pragma unroll
+            for (int j = 0; j < CPW; ++j) {
+                Pr::mma(dw1[j][dt], df[j], at);
+                Pr::mma(dw2[j][dt], hf[j], dyt);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CPW; ++j) Pr::mma(db1[j], df[j], ones);      // every column = sum over the tile's rows of dHpre[.][c]
+    };
+
+    static_assert(DR_NR >= 3, "ring slots: the vmcnt(4) below assumes the slot of a step was requested at least two steps ago");
+    stage(t_begin, 0);
+#pragma unroll
+    for (int k = 0; k < DR_NR - 1; ++k) ring_load(min(t_begin + k, t_end - 1), k);
+    int it = 0;
+    TIMER_LMARK(0);       // prologue
+    for (int tile = t_begin; tile < t_end; ++tile, ++it) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // (first step: the prologue's ring DMAs of the later slots stay in flight)
+        TIMER_LMARK(1);   // wait for this step's DMAs
+        __builtin_amdgcn_s_barrier();
+        TIMER_LMARK(2);   // barrier
+        stage(min(tile + 1, t_end - 1), (it + 1) & 1);
+        ring_load(min(tile + DR_NR - 1, t_end - 1), (it + DR_NR - 1) % DR_NR);
+        TIMER_LMARK(3);   // DMA issue
+        step(it % DR_NR, it & 1);
+        TIMER_LMARK(4);   // LDS reads + MFMAs
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the redundant tail DMAs must not land in the transposes below
+    __syncthreads();
+    wgrad_write_w<D, CPW>(dw1, dw2, out, ct0, nct, C, smem, wave, lane);
+    // db1[j][r]: column c = 16 (ct0 + j) + 4g + r, identical in all 16 lanes il: lane il == 0 writes
+#pragma unroll
+    for (int j = 0; j < CPW; ++j) {
+        if (ct0 + j >= nct || il != 0) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * (ct0 + j) + 4 * g + r;
+            if (c >= C) continue;
+            if (out.mode == WG_OUT_ATOMIC) atomicAdd(out.b1 + c, db1[j][r]);
+            else if (out.mode == WG_OUT_ADD) out.b1[c] += db1[j][r];
+            else out.b1[c] = db1[j][r];
+        }
+    }
+    TIMER_LMARK(5);       // write-out
+    TIMER_LFLUSH(g_tm_wg);
+    TIMER_WG_END(g_tm_wg);
+}
