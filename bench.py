@@ -32,6 +32,7 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense peaks, MI355X_MICRO
 # summary scripts/collect_profiles.sh writes, keyed by kernel name and by the hash of the kernel sources it was taken on.
 PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc.json")
 LAUNCH_KERNEL = {"towers_bwd[image+audio]": "tower_bwd_group_kernel", "tower_bwd[fusion]": "tower_bwd_kernel",
+                 "tower_bwd[fusion]+heads": "tower_bwd_heads_kernel",
                  "towers_fwd[image+audio]": "tower_fwd_group_kernel", "tower_fwd[fusion]": "tower_fwd_kernel",
                  "towers_wgrad[all+embeds]": "tower_wgrad_group_kernel", "adam+pack": "adam_pack_all_kernel",
                  "embeds_fwd[image+audio]": "embed_fwd_group_kernel", "heads_ce": "heads_kernel"}
@@ -399,6 +400,7 @@ def profile_launches(eng, image, audio, labels, nsteps):
         (eng.t_fus, "forward", "tower_fwd[fusion]", f_tow("fusion")),
         (E, "heads_ce", "heads_ce", alg["heads"] * 3),
         (eng.t_fus, "backward", "tower_bwd[fusion]", b_tow("fusion")),
+        (eng.t_fus, "backward_heads", "tower_bwd[fusion]+heads", b_tow("fusion") + alg["heads"] * 3),
         (E, "towers_backward", "towers_bwd[image+audio]", sum(b_tow(t) for t in two)),
         (E, "towers_wgrad", "towers_wgrad[all+embeds]", sum(alg[t]["channel"] for t in ("image", "audio", "fusion")) + emb),
     ]

@@ -101,7 +101,7 @@ typedef struct m2m_tower {
     int32_t nsplit;        /* slabs the buffer has room for (the library uses up to 8)                                     */
     int32_t wgrad_flags;   /* M2M_WGRAD_* (weight-gradient launches)                                                        */
     float* xres;           /* (B*N, D) fp32: residual / gradient stream carried between the launches                       */
-    float* gpart;          /* (nblocks + 1) x ceil(B / (16 / N)) x M2M_SPLIT_GPART floats: per-workgroup partial sums of the small
+    float* gpart;          /* (nblocks + 1 [+ 3: m2m_tower_backward_heads]) x ceil(B / (16 / N)) x M2M_SPLIT_GPART floats: per-workgroup partial sums of the small
                             * gradients (LayerNorms, token MLP, ch_b2), stored plainly and summed by one reduction launch --
                             * deterministic, and free of the same-address atomics of 256 workgroups                          */
     void* a_nat[M2M_MAX_BLOCKS];   /* per block: LN2(x_mid) as packed NAT blocks [16-row tile][k-block], rows padded to 16 */
@@ -280,6 +280,19 @@ int m2m_heads_ce(const m2m_head* heads, int nheads, const int64_t* labels, int B
  * pos_weight (K); per-head loss = mean over all B*K elements; preds (nheads, B, K) int32 = sigmoid(logits) > 0.5. */
 int m2m_heads_bce(const m2m_head* heads, int nheads, const float* targets, const float* pos_weight, int B, int D, int K,
                   float* logits, float* losses, int32_t* preds, int zero_losses, void* stream);
+
+/* m2m_tower_backward of the tower whose token mean carries head `own`, with the model's classification heads + multi-head
+ * cross-entropy (m2m_heads_ce: models/avmnist.py:271-298) computed in the launch's prologue instead of a launch of their own:
+ * a workgroup owns whole samples and a sample's heads need only its own token means.  heads[h]: pooled / w / b / g_w / g_b /
+ * weight as for m2m_heads_ce; d_pooled of the heads other than `own` is WRITTEN (input of those towers' backward), the one of
+ * `own` stays on chip.  logits (nheads, B, K), preds (nheads, B); losses (nheads + 1) must be zero on entry (m2m_step_prologue)
+ * and, like the head weight gradients, are complete after the call (they go through the tower's gpart slots: the tower needs
+ * room for nblocks + 1 + nheads slot sets).  m2m_tower_backward_heads_ok: 1 if this tower / these heads are taken (bf16,
+ * hidden_dim 128, fused path with gpart, K * D + K + 2 <= M2M_SPLIT_GPART); otherwise use m2m_heads_ce + m2m_tower_backward. */
+int m2m_tower_backward_heads_ok(const m2m_tower* t, int B, int nheads, int K);
+int m2m_tower_backward_heads(const m2m_tower* t, int B, const m2m_head* heads, int nheads, int own, const int64_t* labels,
+                             int K, float* logits, float* losses, int32_t* preds, float* d_x0, int64_t d_x0_sample_stride,
+                             uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream);
 
 /* ---- plain MLP tower (modules/mlp.py:4-27; the MIMIC `static` modality, models/mimic.py:98) ------- */
 #define M2M_MLP_MAX_LAYERS 4

@@ -113,5 +113,9 @@ struct SplitReduceTower {
     float* g_ln1_w[M2M_MAX_BLOCKS + 1]; float* g_ln1_b[M2M_MAX_BLOCKS + 1];
     float* g_b2[M2M_MAX_BLOCKS + 1];
     float* g_lnf_w; float* g_lnf_b;               // launch 0
+    // slot sets head_set0 + h (h < nheads): classification head h of tower_bwd.hip's BwdHeads -- [dW (K, D) | db (K) | loss | weighted loss]
+    int head_set0, nheads, K;
+    float* g_hw[3]; float* g_hb[3];
+    float* losses;                                // [nheads + 1]: per head, then the total
 };
 struct SplitReduceArgs { SplitReduceTower t[2]; int ntow; };

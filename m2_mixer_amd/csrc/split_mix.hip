@@ -563,7 +563,14 @@ __global__ __launch_bounds__(SPR_COLS * SPR_GROUPS) void split_small_grads_kerne
     const int e = blockIdx.x * SPR_COLS + col;
     // slot entry -> destination
     float* dst = nullptr;
-    if (e < SPP_STRIDE) {
+    bool shared_dst = false;
+    if (tw.nheads > 0 && L >= tw.head_set0) {                    // a classification head's slot set
+        const int h = L - tw.head_set0, KD = tw.K * D;
+        if (e < KD) dst = tw.g_hw[h] + e;
+        else if (e < KD + tw.K) dst = tw.g_hb[h] + (e - KD);
+        else if (e == KD + tw.K) dst = tw.losses + h;
+        else if (e == KD + tw.K + 1) { dst = tw.losses + tw.nheads; shared_dst = true; }   // the total: every head's set adds to it
+    } else if (e < SPP_STRIDE) {
         const int ntok = 2 * T * N + T + N;
         if (e < D) dst = tw.g_ln2_w[L] ? tw.g_ln2_w[L] + e : nullptr;
         else if (e < 2 * D) dst = tw.g_ln2_b[L] ? tw.g_ln2_b[L] + (e - D) : nullptr;
@@ -595,7 +602,8 @@ __global__ __launch_bounds__(SPR_COLS * SPR_GROUPS) void split_small_grads_kerne
         float v = 0.f;
 #pragma unroll
         for (int g2 = 0; g2 < SPR_GROUPS; ++g2) v += red[g2][col];
-        *dst += v;
+        if (shared_dst) atomicAdd(dst, v);
+        else *dst += v;
     }
 }
 

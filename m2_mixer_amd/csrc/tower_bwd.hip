@@ -19,6 +19,24 @@
 int m2m_split_small_grads(const SplitReduceArgs& a, hipStream_t st);     // split_mix.hip: sum of the per-workgroup slots into the gradients
 #include <algorithm>
 
+// The classification heads + multi-head cross-entropy computed in the PROLOGUE of the fusion tower's backward launch (template
+// flag HEADS) instead of a launch of their own between forward and backward (heads.hip: 13.5 us of pure latency per step for
+// ~4 MFLOP).  A workgroup owns whole samples, and a sample's three heads need nothing but its own token means (reference:
+// models/avmnist.py:271-298 -- classifier_image / classifier_audio on tokens.mean(1), StandardClassifier on the fused tokens,
+// three CrossEntropyLoss(mean), loss = sum_h weight_h L_h): logits, predictions, loss terms and the gradients wrt the token means
+// come out per workgroup; the head weight gradients and the loss sums go to the workgroup's partial-sum slots (one slot set per
+// head behind the blocks' sets: K D + K + 2 <= M2M_SPLIT_GPART floats) and are added up by the reduction launch that follows
+// this one anyway (m2m_split_small_grads) -- no atomics.  The gradient wrt THIS tower's token mean stays in LDS; the other
+// towers' go to global memory for their backward launch.
+#define BH_MAXH 3
+struct BwdHeads {
+    m2m_head h[BH_MAXH];
+    const int64_t* labels;
+    float* logits;                 // (nheads, B, K)
+    int32_t* preds;                // (nheads, B)
+    int nheads, K, own;            // own: index of the head that sits on this tower's token mean
+};
+
 // LDS budget of the backward chain kernel (bytes): FIXED + nblocks * PB * 4
 template <int P, int D, int NMAX, int TG> struct BwdLds {
     static constexpr bool TOK = NMAX > 0;
@@ -31,7 +49,7 @@ template <int P, int D, int NMAX, int TG> struct BwdLds {
     // + keep-words of the token-hidden site (one per column of the workgroup's SPW = BM / N samples) + hidden bias of one block
     static size_t bytes(int nblocks, int N, int Cp) {
         return FIXED + (TOK ? (size_t)(BM / N) * D * sizeof(unsigned int) : 0) + (size_t)nblocks * PB * sizeof(float) +
-               (size_t)Cp * sizeof(float) + 16 + 8 * (M2M_MAX_BLOCKS + 1);
+               (size_t)Cp * sizeof(float) + 16 + 8 * (M2M_MAX_BLOCKS + 1 + BH_MAXH);
     }
 };
 #ifdef M2M_TIMERS
@@ -54,12 +72,13 @@ TIMER_READER(m2m_debug_timers_bwd, g_tm_bwd)
 // HREC: the weight-gradient launch recomputes the hidden activation itself (tower_wgrad_rc.h): this kernel then stores the packed
 // NAT image of A = LN2(x_mid) where Hact^T would have gone (m2m_block.h_chn) and keeps only the dHpre^T stream -- half the
 // operand spill, two of the four transposing MFMAs and one of the two streaming stores per step less.
-template <class TW, int P, int D, int NMAX, int TG, int DM, bool PART = false, bool HREC = false>
+template <class TW, int P, int D, int NMAX, int TG, int DM, bool PART = false, bool HREC = false, bool HEADS = false>
 static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const float* __restrict__ d_out, long d_out_ss,
                                                       const float* __restrict__ d_pooled, float* __restrict__ d_x0, long d_x0_ss,
                                                       unsigned int seed, unsigned int step_host,
                                                       const unsigned int* __restrict__ step_dev, int wg, int nwg, char* smem,
-                                                      float* __restrict__ part = nullptr, char* dx0_chn = nullptr) {
+                                                      float* __restrict__ part = nullptr, char* dx0_chn = nullptr,
+                                                      const BwdHeads* hd = nullptr) {
     typedef Prec<P> Pr;
     typedef TileGeom<D> G;
     typedef BwdLds<P, D, NMAX, TG> L;
@@ -110,8 +129,83 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
     const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
 
     TIMER_LSTART();
-    if (PART && threadIdx.x <= (unsigned)tw.nblocks)
+    if (PART && threadIdx.x <= (unsigned)tw.nblocks + (HEADS ? BH_MAXH : 0))
         slotp[threadIdx.x] = (unsigned long long)(part + ((long)threadIdx.x * nwg + wg) * SPP_STRIDE);
+    // ---- classification heads of this workgroup's samples (HEADS): see BwdHeads ----
+    float* hdp = slabs + 3 * 4 * D + BH_MAXH * 32 * (D + 1) + BH_MAXH * 4 * 32;     // [SPW][D] d(loss) / d(this tower's token mean)
+    if constexpr (HEADS && PART && TOK) {
+        const int nh = hd->nheads, K = hd->K, DL = D + 1;
+        float* hpool = slabs;                                   // [nh][4][D]
+        float* hwt = hpool + 3 * 4 * D;                         // [nh][K][D + 1]
+        float* hlog = hwt + BH_MAXH * 32 * DL;                  // [nh][4][32] logits, then dlogits
+        for (int i = tid; i < nh * SPW * D; i += NTHREADS) {
+            const int h = i / (SPW * D), sl = (i / D) % SPW, d = i % D;
+            hpool[(h * 4 + sl) * D + d] = sl < ns ? hd->h[h].pooled[(long)(s0 + sl) * D + d] : 0.f;
+        }
+        for (int i = tid; i < nh * K * D; i += NTHREADS) {
+            const int h = i / (K * D), k = (i / D) % K, d = i % D;
+            hwt[(h * 32 + k) * DL + d] = hd->h[h].w[k * D + d];
+        }
+        __syncthreads();
+        // logits: 8 adjacent lanes split each D-long dot product
+        for (int i = tid >> 3; i < nh * SPW * K; i += NTHREADS / 8) {
+            const int h = i / (SPW * K), sl = (i / K) % SPW, k = i % K, part8 = tid & 7;
+            float a = 0.f;
+            for (int d = part8; d < D; d += 8) a = __builtin_fmaf(hpool[(h * 4 + sl) * D + d], hwt[(h * 32 + k) * DL + d], a);
+            a = wave_sum_xor(a, 8) + hd->h[h].b[k];
+            if (part8 == 0) {
+                hlog[(h * 4 + sl) * 32 + k] = a;
+                if (sl < ns) hd->logits[((long)h * B + s0 + sl) * K + k] = a;
+            }
+        }
+        __syncthreads();
+        // softmax cross-entropy per (head, sample): loss term, prediction, dlogits in place
+        float term = 0.f;
+        if (tid < nh * SPW) {
+            const int h = tid / SPW, sl = tid % SPW;
+            float* lg = hlog + (h * 4 + sl) * 32;
+            if (sl < ns) {
+                const int y = (int)hd->labels[s0 + sl];
+                float mx = lg[0];
+                int am = 0;
+                for (int k = 1; k < K; ++k) { const float v = lg[k]; if (v > mx) { mx = v; am = k; } }
+                float se = 0.f;
+                for (int k = 0; k < K; ++k) se += __expf(lg[k] - mx);
+                term = (__logf(se) + mx - lg[y]) / (float)B;
+                const float scale = hd->h[h].weight / (float)B, inv = 1.0f / se;
+                for (int k = 0; k < K; ++k) lg[k] = scale * (__expf(lg[k] - mx) * inv - (k == y ? 1.f : 0.f));
+                hd->preds[(long)h * B + s0 + sl] = am;
+            } else {
+                for (int k = 0; k < K; ++k) lg[k] = 0.f;
+            }
+            hlog[BH_MAXH * 4 * 32 - 16 + tid] = term;          // (rows [2][3][20..31] of the last head's tile are never logits: K <= 11)
+        }
+        __syncthreads();
+        // gradients wrt the token means; head weight / bias gradients and loss sums -> this workgroup's slots
+        for (int i = tid; i < nh * ns * D; i += NTHREADS) {
+            const int h = i / (ns * D), sl = (i / D) % ns, d = i % D;
+            float a = 0.f;
+            for (int k = 0; k < K; ++k) a = __builtin_fmaf(hlog[(h * 4 + sl) * 32 + k], hwt[(h * 32 + k) * DL + d], a);
+            if (h == hd->own) hdp[sl * D + d] = a;
+            else hd->h[h].d_pooled[(long)(s0 + sl) * D + d] = a;
+        }
+        for (int i = tid; i < nh * (K * D + K + 2); i += NTHREADS) {
+            const int h = i / (K * D + K + 2), e = i % (K * D + K + 2);
+            float* sl_h = reinterpret_cast<float*>(slotp[tw.nblocks + 1 + h]);
+            float a = 0.f;
+            if (e < K * D) {
+                const int k = e / D, d = e % D;
+                for (int sl = 0; sl < SPW; ++sl) a = __builtin_fmaf(hlog[(h * 4 + sl) * 32 + k], hpool[(h * 4 + sl) * D + d], a);
+            } else if (e < K * D + K) {
+                for (int sl = 0; sl < SPW; ++sl) a += hlog[(h * 4 + sl) * 32 + (e - K * D)];
+            } else {
+                for (int sl = 0; sl < SPW; ++sl) a += hlog[BH_MAXH * 4 * 32 - 16 + h * SPW + sl];
+                if (e == K * D + K + 1) a *= hd->h[h].weight;                 // this head's share of the total loss
+            }
+            sl_h[e] = a;
+        }
+        __syncthreads();
+    }
     constexpr int MAXB = (int)(sizeof(tw.blk) / sizeof(tw.blk[0]));       // blocks the descriptor type can hold
     // ---- prologue.  EVERY global load of the launch's start is requested before the first LDS write: the upstream gradient,
     //      the last block's x_mid rows and hidden bias (used by the first phase of the block loop), the small parameters of
@@ -128,7 +222,10 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
             if (idx < BM * (D / 4) && r < R) {
                 const long gr = row0 + r, gs = gr / N;
                 if (d_out) uv[k] = *reinterpret_cast<const float4*>(d_out + gs * d_out_ss + (gr % N) * D + c);
-                if (d_pooled) {
+                if constexpr (HEADS && PART && TOK) {
+                    const float4 p = *reinterpret_cast<const float4*>(hdp + (gs - s0) * D + c);
+                    uv[k].x += p.x * invN; uv[k].y += p.y * invN; uv[k].z += p.z * invN; uv[k].w += p.w * invN;
+                } else if (d_pooled) {
                     const float4 p = *reinterpret_cast<const float4*>(d_pooled + gs * D + c);
                     uv[k].x += p.x * invN; uv[k].y += p.y * invN; uv[k].z += p.z * invN; uv[k].w += p.w * invN;
                 }
@@ -925,6 +1022,15 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
     tower_bwd_body<m2m_tower, P, D, NMAX, TG, DM, PART, HREC>(tw, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step_host, step_dev,
                                                                blockIdx.x, gridDim.x, smem, PART ? tw.gpart : nullptr, (char*)tw.dx0_chn);
 }
+// the same with the classification heads in its prologue (BwdHeads); slot form only
+template <int P, int D, int NMAX, int TG, int DM, bool HREC>
+__global__ __launch_bounds__(NTHREADS) void tower_bwd_heads_kernel(const m2m_tower tw, const BwdHeads hd, int B, float* __restrict__ d_x0,
+                                                                   long d_x0_ss, unsigned int seed, unsigned int step_host,
+                                                                   const unsigned int* __restrict__ step_dev) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    tower_bwd_body<m2m_tower, P, D, NMAX, TG, DM, true, HREC, true>(tw, B, nullptr, 0, nullptr, d_x0, d_x0_ss, seed, step_host, step_dev,
+                                                                     blockIdx.x, gridDim.x, smem, tw.gpart, (char*)tw.dx0_chn, &hd);
+}
 
 // Two towers side by side in ONE launch (blockIdx.y = tower), see tower_fwd.hip.
 struct BwdGroupArgs {
@@ -951,9 +1057,14 @@ static bool m2m_small_part(const m2m_tower* t) {
     return !off && t->gpart != nullptr && !m2m_is_wide(t) && t->prec == PREC_BF16 && t->D == 128 && t->nblocks >= 1 &&
            2 * t->T * t->N + t->T + t->N <= SPP_TOK_MAX;
 }
-static void m2m_small_part_reduce_args(SplitReduceTower& x, const m2m_tower* t, int nwg) {
+static void m2m_small_part_reduce_args(SplitReduceTower& x, const m2m_tower* t, int nwg, const BwdHeads* hd = nullptr, float* losses = nullptr) {
     memset(&x, 0, sizeof(x));
     x.part = t->gpart; x.ntiles = nwg; x.nlaunch = t->nblocks + 1; x.D = t->D; x.N = t->N; x.T = t->T;
+    if (hd) {                                                // slot sets nblocks + 1 + h: head h (BwdHeads)
+        x.head_set0 = t->nblocks + 1; x.nheads = hd->nheads; x.K = hd->K; x.losses = losses;
+        for (int h = 0; h < hd->nheads; ++h) { x.g_hw[h] = hd->h[h].g_w; x.g_hb[h] = hd->h[h].g_b; }
+        x.nlaunch += hd->nheads;
+    }
     if (t->has_final_ln) { x.g_lnf_w = t->g_lnf_w; x.g_lnf_b = t->g_lnf_b; }
     for (int b = 0; b < t->nblocks; ++b) {                   // slot set nblocks - b holds block b (tower_bwd_body::slot_of)
         const int L = t->nblocks - b;
@@ -1056,6 +1167,31 @@ static int launch_bwd_dm(const m2m_tower* t, int B, const float* d_out, long d_o
     return 0;
 }
 
+template <int P, int D, int NMAX, int TG, int DM>
+static int launch_bwd_heads_dm(const m2m_tower* t, int B, const BwdHeads& hd, float* losses, float* d_x0, long d_x0_ss, unsigned int seed,
+                               unsigned int step, const unsigned int* step_dev, hipStream_t st) {
+    const int SPW = BM / t->N;
+    const int grid = (B + SPW - 1) / SPW;
+    const size_t lds = bwd_lds_bytes<P, D, NMAX, TG>(t->nblocks, t->N, t->Cp);
+    if (lds > M2M_LDS_MAX || t->Cp > 8 * NTHREADS) { m2m_set_error("tower_backward_heads: blocks x channel_dim exceed the workgroup's LDS", __FILE__, __LINE__); return -1; }
+    constexpr bool CAN_HREC = DM != DM_GEN;
+    const bool hrec = CAN_HREC && m2m_wgrad_recompute(t, B);
+    auto kern = tower_bwd_heads_kernel<P, D, NMAX, TG, DM, false>;
+    if constexpr (CAN_HREC) { if (hrec) kern = tower_bwd_heads_kernel<P, D, NMAX, TG, DM, true>; }
+    static bool attr_done[2] = {false, false};
+    if (!attr_done[hrec]) {
+        M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, M2M_LDS_MAX));
+        attr_done[hrec] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, st, *t, hd, B, d_x0, d_x0_ss, seed, step, step_dev);
+    M2M_CHECK_HIP(hipGetLastError());
+    SplitReduceArgs r;
+    memset(&r, 0, sizeof(r));
+    r.ntow = 1;
+    m2m_small_part_reduce_args(r.t[0], t, grid, &hd, losses);
+    return m2m_split_small_grads(r, st);
+}
+
 template <int P, int D, int NMAX, int TG>
 static int launch_bwd(const m2m_tower* t, int B, const float* d_out, long d_out_ss, const float* d_pooled, float* d_x0,
                       long d_x0_ss, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
@@ -1144,6 +1280,46 @@ extern "C" int m2m_towers_backward(const m2m_tower* const* towers, const m2m_tow
 #undef M2M_BWDG_CASE
     m2m_set_error("towers_backward: unsupported (prec, D)", __FILE__, __LINE__);
     return -1;
+}
+
+// ---- backward of a tower whose launch also computes the model's classification heads (BwdHeads) ----
+// 1 if m2m_tower_backward_heads takes this tower / these heads; 0: use m2m_heads_ce + m2m_tower_backward.
+extern "C" int m2m_tower_backward_heads_ok(const m2m_tower* t, int B, int nheads, int K) {
+    if (!t || m2m_check_tower(t, B) != 0) return 0;
+    // OFF by default (M2M_FUSED_HEADS=1 enables it).  Measured on M2-Mixer-B, batch 512, three interleaved repetitions in one
+    // process: fusion backward + heads in one launch 80.3-80.9 us against 68.2-69.3 + 13.6-14.1 us as two launches -- the heads'
+    // latency chain (token means and head weights from L2 -> logits -> softmax -> gradients -> 15 KB of slot stores per
+    // workgroup) costs ~12 us in front of the backward's own prologue, what the separate launch cost; step time unchanged.
+    static const int on = [] { const char* e = getenv("M2M_FUSED_HEADS"); return e && e[0] == '1'; }();
+    if (!on || !m2m_small_part(t) || m2m_split_eligible(t, B, 1)) return 0;
+    if (nheads < 1 || nheads > BH_MAXH || K < 2 || K * t->D + K + 2 > SPP_STRIDE || K > 16) return 0;
+    return 1;
+}
+extern "C" int m2m_tower_backward_heads(const m2m_tower* t, int B, const m2m_head* heads, int nheads, int own, const int64_t* labels,
+                                        int K, float* logits, float* losses, int32_t* preds, float* d_x0, int64_t d_x0_ss,
+                                        uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream) {
+    if (!m2m_tower_backward_heads_ok(t, B, nheads, K)) { m2m_set_error("tower_backward_heads: unsupported tower / heads (see m2m_tower_backward_heads_ok)", __FILE__, __LINE__); return -1; }
+    if (!heads || !labels || !logits || !losses || !preds || !d_x0 || own < 0 || own >= nheads) { m2m_set_error("tower_backward_heads: null argument", __FILE__, __LINE__); return -1; }
+    BwdHeads hd;
+    memset(&hd, 0, sizeof(hd));
+    for (int h = 0; h < nheads; ++h) {
+        hd.h[h] = heads[h];
+        if (!heads[h].pooled || !heads[h].w || !heads[h].b || !heads[h].g_w || !heads[h].g_b || (h != own && !heads[h].d_pooled)) {
+            m2m_set_error("tower_backward_heads: incomplete head", __FILE__, __LINE__);
+            return -1;
+        }
+    }
+    hd.labels = labels; hd.logits = logits; hd.preds = preds; hd.nheads = nheads; hd.K = K; hd.own = own;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int dm = m2m_drop_mode(1, t->p_drop);
+#define M2M_BWDH_CASE(NM, TGG) \
+    { if (dm == DM_NONE) return launch_bwd_heads_dm<PREC_BF16, 128, NM, TGG, DM_NONE>(t, B, hd, losses, d_x0, d_x0_ss, seed, step, step_dev, st); \
+      if (dm == DM_HALF) return launch_bwd_heads_dm<PREC_BF16, 128, NM, TGG, DM_HALF>(t, B, hd, losses, d_x0, d_x0_ss, seed, step, step_dev, st); \
+      return launch_bwd_heads_dm<PREC_BF16, 128, NM, TGG, DM_GEN>(t, B, hd, losses, d_x0, d_x0_ss, seed, step, step_dev, st); }
+    if (t->N <= 4) M2M_BWDH_CASE(4, 8)
+    if (t->T % 16 == 0) M2M_BWDH_CASE(8, 16)
+    M2M_BWDH_CASE(8, 8)
+#undef M2M_BWDH_CASE
 }
 
 extern "C" int m2m_tower_backward(const m2m_tower* t, int B, const float* d_out, int64_t d_out_ss, const float* d_pooled,

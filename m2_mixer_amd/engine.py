@@ -565,6 +565,7 @@ class _TwoTowerEngine(_FlatEngine):
         self.dx0_a, self.dx0_b = f(B * self.Na, D), f(B * self.Nb, D)
         self.preds = torch.zeros(self._preds_shape(), dtype=torch.int32, device=dev)
         self._setup_wgrad([self.t_fus, self.t_a, self.t_b], grouped=True)
+        self._fused_heads = self._heads_are_ce() and self.t_fus.backward_heads_ok(B, 3, self.K)
         # the embeddings' weight gradients in their single-owner form: the tower backward leaves d_x0^T as packed blocks
         import os
         self._embed_towers = []
@@ -599,6 +600,10 @@ class _TwoTowerEngine(_FlatEngine):
 
     def _loss_heads(self, heads, labels, zero_losses):
         raise NotImplementedError
+
+    def _heads_are_ce(self) -> bool:
+        """True: three cross-entropy heads (the form m2m_tower_backward_heads computes)."""
+        return False
 
     # ---- one training step (enqueue only; no host synchronisation) ----------------------------------------
     def _forward(self, xa, xb, labels, training: bool, with_grad: bool, prologue: bool = False):
@@ -641,6 +646,10 @@ class _TwoTowerEngine(_FlatEngine):
         heads = [self._head(a, self.pool_a, self.dpool_a, hw[a], with_grad),
                  self._head(b, self.pool_b, self.dpool_b, hw[b], with_grad),
                  self._head("fusion", self.pool_fus, self.dpool_fus, hw["fusion"], with_grad)]
+        self._heads = heads
+        self._labels = labels
+        if training and with_grad and self._fused_heads:
+            return                                         # heads + losses ride in the fusion tower's backward launch (_backward)
         self._loss_heads(heads, labels, not training)      # a training step's _prologue already cleared the losses
 
     def _backward(self, xa, xb, fused_update: bool = False):
@@ -650,7 +659,12 @@ class _TwoTowerEngine(_FlatEngine):
         fs = self.Nf * D
         sd = self.drop_step
         a, b = self.MODS
-        self.t_fus.backward(B, None, 0, self.dpool_fus, self.d_fused, fs, self.seed, 0, sd)
+        if self._fused_heads:
+            # the three heads + multi-head CE in the prologue of this launch (m2m_tower_backward_heads): one launch less
+            self.t_fus.backward_heads(B, self._heads, 2, self._labels, self.K, (self.logits, self.losses, self.preds),
+                                      self.d_fused, fs, self.seed, 0, sd)
+        else:
+            self.t_fus.backward(B, None, 0, self.dpool_fus, self.d_fused, fs, self.seed, 0, sd)
         d_b_part = self.d_fused.view(-1)[self.Na * D:]
         main, s_a, _ = self._streams()
         s_e = self.s_emb if self.concurrent else main
@@ -715,6 +729,9 @@ class AVMnistEngine(_TwoTowerEngine):
 
     def _loss_heads(self, heads, labels, zero_losses):
         heads_ce(heads, labels, self.B, self.D, self.K, out=(self.logits, self.losses, self.preds), zero_losses=zero_losses)
+
+    def _heads_are_ce(self) -> bool:
+        return True
 
     # names kept from the first engine revision (bench.py, tests)
     t_img = property(lambda self: self.t_a)

@@ -202,7 +202,8 @@ class TowerRuntime:
         img = ntile16 * (self.D // 32) * 1024
         ntiles = (B + (16 // self.N) - 1) // (16 // self.N)
         bufs = {"slabs": torch.empty(L.SPLIT_MAX, M, self.D, device=self.device), "xres": torch.empty(M, self.D, device=self.device),
-                "gpart": torch.zeros((self.nblocks + 1) * ntiles * L.SPLIT_GPART, device=self.device),
+                # (+ 3 slot sets: the classification heads of m2m_tower_backward_heads)
+                "gpart": torch.zeros((self.nblocks + 4) * ntiles * L.SPLIT_GPART, device=self.device),
                 "a_nat": [torch.zeros(img, dtype=torch.uint8, device=self.device) for _ in range(self.nblocks)],
                 "dy_nat": [torch.zeros(img, dtype=torch.uint8, device=self.device) for _ in range(self.nblocks)]}
         self.desc.slabs, self.desc.nsplit, self.desc.xres = bufs["slabs"].data_ptr(), L.SPLIT_MAX, bufs["xres"].data_ptr()
@@ -340,6 +341,19 @@ class TowerRuntime:
 
     def wgrad_fold(self):
         L.check(L.lib().m2m_wgrad_fold(C.byref(self.desc), L.stream_ptr()), "wgrad_fold")
+
+    def backward_heads_ok(self, B: int, nheads: int, K: int) -> bool:
+        return bool(L.lib().m2m_tower_backward_heads_ok(C.byref(self.desc), B, nheads, K))
+
+    def backward_heads(self, B: int, heads: Sequence[dict], own: int, labels: torch.Tensor, K: int, out, d_x0: torch.Tensor,
+                       d_x0_ss: int, seed: int, step: int, step_dev: Optional[torch.Tensor] = None):
+        """Backward of this tower with the classification heads + multi-head CE in the launch's prologue (include/m2mixer.h:
+        m2m_tower_backward_heads).  heads: dicts as for heads_ce; out = (logits, losses, preds)."""
+        arr = _head_array(heads)
+        logits, losses, preds = out
+        L.check(L.lib().m2m_tower_backward_heads(C.byref(self.desc), B, arr, len(heads), own, labels.data_ptr(), K, logits.data_ptr(),
+                                                 losses.data_ptr(), preds.data_ptr(), d_x0.data_ptr(), d_x0_ss, seed & 0xFFFFFFFF,
+                                                 step & 0xFFFFFFFF, L.ptr(step_dev), L.stream_ptr()), "tower_backward_heads")
 
     def wgrad(self, B: int, seed: int, step: int, step_dev: Optional[torch.Tensor] = None):
         L.check(L.lib().m2m_tower_wgrad(C.byref(self.desc), B, seed & 0xFFFFFFFF, step & 0xFFFFFFFF, L.ptr(step_dev),
