@@ -30,16 +30,16 @@ sys.path.insert(0, ROOT)
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense peaks, MI355X_MICROARCH.md "Chip-level parameters"
 # HBM bytes per launch come from the rocprofv3 PMC passes (counters cannot be collected from inside this process): the
 # summary scripts/collect_profiles.sh writes, keyed by kernel name and by the hash of the kernel sources it was taken on.
-PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r03_pmc.json")
 LAUNCH_KERNEL = {"towers_bwd[image+audio]": "tower_bwd_group_kernel", "tower_bwd[fusion]": "tower_bwd_kernel",
                  "tower_bwd[fusion]+heads": "tower_bwd_heads_kernel",
                  "towers_fwd[image+audio]": "tower_fwd_group_kernel", "tower_fwd[fusion]": "tower_fwd_kernel",
-                 "towers_wgrad[all+embeds]": "tower_wgrad_group_kernel", "adam+pack": "adam_pack_all_kernel",
+                 "towers_wgrad[all+embeds]": "tower_wgrad_group_kernel", "adam+pack": ("adam_kernel", "pack_all_kernel"),
                  "embeds_fwd[image+audio]": "embed_fwd_group_kernel", "heads_ce": "heads_kernel"}
 
 
 def pmc_traffic(launch, model, B, precision):
-    """HBM bytes (2 x FETCH_SIZE + WRITE_SIZE) of one launch of `launch` from profiles/r02_pmc.json -- None, with a
+    """HBM bytes (2 x FETCH_SIZE + WRITE_SIZE) of one launch of `launch` from profiles/r03_pmc.json -- None, with a
     warning, when the file is missing, was taken on other kernel sources, or covers another configuration."""
     if not (model == "B" and B == 512 and precision == "bf16"):
         return None
@@ -51,11 +51,13 @@ def pmc_traffic(launch, model, B, precision):
         return None
     from m2_mixer_amd import _lib
     if rec.get("csrc_sha256") != _lib.csrc_hash():
-        log("roofline.traffic: profiles/r02_pmc.json was collected on different kernel sources (stale) -> null; "
+        log("roofline.traffic: profiles/r03_pmc.json was collected on different kernel sources (stale) -> null; "
             "re-run scripts/collect_profiles.sh")
         return None
-    k = rec["kernels"].get(LAUNCH_KERNEL.get(launch, ""), None)
-    return None if k is None else k["traffic_bytes"]
+    names = LAUNCH_KERNEL.get(launch, "")
+    names = names if isinstance(names, tuple) else (names,)       # a span of several launches (Adam, then the re-pack): their sum
+    ks = [rec["kernels"].get(n) for n in names]
+    return None if any(k is None for k in ks) else sum(k["traffic_bytes"] for k in ks)
 
 
 # AV-MNIST M2-Mixer-B  (reference cfg/avmnist/avmnist_m2-mixer_B.yml:24-56)

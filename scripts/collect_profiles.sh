@@ -27,4 +27,9 @@ cd $R
 python scripts/timeline.py $O/stats/s_kernel_trace.csv 25 > $O/step_timeline.txt
 python scripts/pmc_summary.py $O/pmc $O/pmc.json > $O/pmc_summary_table.md
 python scripts/bench_configs.py > $O/secondary_configs.jsonl 2> $O/secondary.err
+echo "secondary done"
+# two ranks on this one GPU over gloo: N ranks x batch B + exchange == one rank on N x B == the oracle (scripts/ddp_parity.py)
+timeout -k 10 300 python scripts/ddp_parity.py fp32 S 2> $O/ddp2_fp32.err | grep '^{' > $O/ddp2_parity_fp32.json || echo "ddp parity fp32 FAILED"
+timeout -k 10 300 python scripts/ddp_parity.py bf16 B 2> $O/ddp2_bf16.err | grep '^{' > $O/ddp2_parity_bf16.json || echo "ddp parity bf16 FAILED"
+M2M_DIST_BACKEND=gloo M2M_FORCE_DEVICE=0 timeout -k 10 300 python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_ddp2_gloo_rehearsal.json 2> $O/bench_ddp2.err || echo "ddp bench rehearsal FAILED"
 echo "all done"
