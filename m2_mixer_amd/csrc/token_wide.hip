@@ -16,10 +16,13 @@
 #define TW_TMAX 32                 // token_dim upper bound; the kernels are instantiated for TM = 16 and 32 hidden units (h[] registers,
                                    // LDS weight rows): token_dim <= 16 (MIMIC, MM-IMDb) does half the work in half the LDS
 #define TW_LDW (TW_COLS + 1)       // padded row stride of the per-column LDS tiles
-#define TW_NC 16                   // tokens per chunk of the parameter-gradient reduction (backward)
 #define TW_UB 8                    // tokens whose global loads are issued together
-#define TW_WAVES 4                 // waves per workgroup: all own the same 64 columns, each a quarter of the tokens
-#define TW_THREADS (TW_WAVES * 64)
+// Waves per workgroup (template parameter NW: 4, 8 or 16): all own the same 64 columns, each a share of the tokens.  A launch is
+// (samples x D / 64) workgroups of dependent latency chains (row statistics, strided column walks, LDS sums): at the cfg batches
+// (MM-IMDb 32, MIMIC-H 128: 128 workgroups) four waves leave half of the chip's SIMDs empty and every chain four times as long
+// as it need be -- small launches take 16 waves (8 when token_dim > 16), large ones 4 (more workgroups per CU instead).
+// NC: tokens per chunk of the parameter-gradient reduction (backward): 16 at 4 waves, 8 above (more chunks than waves otherwise)
+template <int NW> struct TokNC { static constexpr int value = NW > 4 ? 8 : 16; };
 
 int m2m_chain_forward_rows(const m2m_tower* t, const float* x0, long x0_ss, int B, float* out, long out_ss, int training,
                            unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st);
@@ -92,8 +95,8 @@ static __device__ __forceinline__ void tok_row_stats(const float* __restrict__ s
 }
 
 // ---- forward: x_mid = x + Dropout(W2 Dropout(GELU(W1 LN1(x)^T + b1)) + b2)^T  (modules/mixer.py:30-35, :43) ------
-template <int P, int DM, int TM>
-__global__ __launch_bounds__(TW_THREADS) void token_fwd_kernel(const m2m_tower tw, int b, const float* __restrict__ src, long src_ss,
+template <int P, int DM, int TM, int NW>
+__global__ __launch_bounds__(NW * 64) void token_fwd_kernel(const m2m_tower tw, int b, const float* __restrict__ src, long src_ss,
                                                                int B, float* __restrict__ x_mid, float* __restrict__ save_x_in,
                                                                int training, unsigned int seed, unsigned int step_host,
                                                                const unsigned int* __restrict__ step_dev) {
@@ -105,8 +108,8 @@ __global__ __launch_bounds__(TW_THREADS) void token_fwd_kernel(const m2m_tower t
     float* b1s = w2s + N * TM;
     float* b2s = b1s + TM;
     float* stats = b2s + N;
-    float* hp = smf + ((tok_lds_floats(N, tg.spw, TM) + 3) & ~(size_t)3);   // [TW_WAVES][TM][64] partial hidden pre-activations
-    float* ha = hp + TW_WAVES * TM * TW_COLS;                               // [TM][64]           hidden activations
+    float* hp = smf + ((tok_lds_floats(N, tg.spw, TM) + 3) & ~(size_t)3);   // [NW][TM][64] partial hidden pre-activations
+    float* ha = hp + NW * TM * TW_COLS;                               // [TM][64]           hidden activations
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const m2m_block& bk = tw.blk[b];
@@ -118,8 +121,8 @@ __global__ __launch_bounds__(TW_THREADS) void token_fwd_kernel(const m2m_tower t
     const int s_first = (blockIdx.x / tg.chunks) * tg.spw;
     const int chunk = blockIdx.x % tg.chunks;
     const int ns = min(tg.spw, B - s_first);
-    tok_stage_weights(bk, N, T, TM, w1s, w2s, b1s, b2s, tid, TW_THREADS);
-    tok_row_stats(src, src_ss, s_first, ns * N, N, D, stats, lane, wave, TW_WAVES);
+    tok_stage_weights(bk, N, T, TM, w1s, w2s, b1s, b2s, tid, (NW * 64));
+    tok_row_stats(src, src_ss, s_first, ns * N, N, D, stats, lane, wave, NW);
     __syncthreads();
 
     const int sl = D >= TW_COLS ? 0 : lane / D;
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(TW_THREADS) void token_fwd_kernel(const m2m_tower t
     const float* col = src + (long)s * src_ss + d;
     const float* st = stats + 2 * (pv ? sl : 0) * N;
     // this wave's tokens: a quarter of the N tokens of the column (the four waves work on the same 64 columns)
-    const int NQ = (N + TW_WAVES - 1) / TW_WAVES;
+    const int NQ = (N + NW - 1) / NW;
     const int nb = wave * NQ, ne = min(N, nb + NQ);
 
     float h[TM];
@@ -165,11 +168,11 @@ __global__ __launch_bounds__(TW_THREADS) void token_fwd_kernel(const m2m_tower t
     for (int t = 0; t < TM; ++t) hp[(wave * TM + t) * TW_COLS + lane] = h[t];
     __syncthreads();
 #pragma unroll
-    for (int tq = 0; tq < TM / TW_WAVES; ++tq) {
-        const int t = wave * (TM / TW_WAVES) + tq;
+    for (int tq = 0; tq < TM / NW; ++tq) {
+        const int t = wave * (TM / NW) + tq;
         float a = 0.f;
 #pragma unroll
-        for (int w = 0; w < TW_WAVES; ++w) a += hp[(w * TM + t) * TW_COLS + lane];
+        for (int w = 0; w < NW; ++w) a += hp[(w * TM + t) * TW_COLS + lane];
         float v = 0.f;
         if (t < T) {
             v = gelu_f(a) * dr_th.scale;
@@ -209,8 +212,8 @@ __global__ __launch_bounds__(TW_THREADS) void token_fwd_kernel(const m2m_tower t
 
 // ---- backward, column part: dU (gradient wrt LN1 output) + token-MLP parameter gradients --------------------------
 //   g_mid : gradient wrt x_mid (dense rows);  x_in : saved block input (dense rows);  du_out : receives dU (dense rows)
-template <int P, int DM, int TM>
-__global__ __launch_bounds__(TW_THREADS) void token_bwd_cols_kernel(const m2m_tower tw, int b, const float* __restrict__ g_mid, int B,
+template <int P, int DM, int TM, int NW>
+__global__ __launch_bounds__(NW * 64) void token_bwd_cols_kernel(const m2m_tower tw, int b, const float* __restrict__ g_mid, int B,
                                                                     float* __restrict__ du_out, unsigned int seed,
                                                                     unsigned int step_host, const unsigned int* __restrict__ step_dev, int iters) {
     extern __shared__ __attribute__((aligned(16))) float smf[];
@@ -223,13 +226,14 @@ __global__ __launch_bounds__(TW_THREADS) void token_bwd_cols_kernel(const m2m_to
     float* stats = b2s + N;
     float* hs = smf + ((tok_lds_floats(N, tg.spw, TM) + 3) & ~(size_t)3);   // [TM][TW_LDW] hidden activation (after dropout)
     float* dhs = hs + TM * TW_LDW;                              // [TM][TW_LDW] gradient wrt the hidden pre-activation
+    constexpr int NC = TokNC<NW>::value;
     float* part = dhs + TM * TW_LDW;                            // per wave: [2][TM][64] partial h | dh, later its
-                                                                //           [2][TW_NC][TW_LDW] chunk of U | dV  (whichever is larger)
-    constexpr int PART_F = 2 * TM * TW_COLS > 2 * TW_NC * TW_LDW ? 2 * TM * TW_COLS : 2 * TW_NC * TW_LDW;
+                                                                //           [2][NC][TW_LDW] chunk of U | dV  (whichever is larger)
+    constexpr int PART_F = 2 * TM * TW_COLS > 2 * NC * TW_LDW ? 2 * TM * TW_COLS : 2 * NC * TW_LDW;
     // parameter-gradient accumulators over the `iters` column blocks this workgroup walks: every value has one owner (a lane
     // of a wave), so they are plain LDS read-modify-writes; the float atomics -- the same few hundred addresses for every
     // workgroup of the launch -- happen once per workgroup at the end
-    float* gw1s = part + TW_WAVES * PART_F;                      // [T][N]
+    float* gw1s = part + NW * PART_F;                      // [T][N]
     float* gw2s = gw1s + N * TM;                                // [N][T]
     float* gb1s = gw2s + N * TM;                                // [TM]
     float* gb2s = gb1s + TM;                                    // [N]
@@ -241,8 +245,8 @@ __global__ __launch_bounds__(TW_THREADS) void token_bwd_cols_kernel(const m2m_to
     const Drop dr_th = make_drop(true, tw.p_drop, seed, step, site + 0);
     const Drop dr_to = make_drop(true, tw.p_drop, seed, step, site + 1);
 
-    tok_stage_weights(bk, N, T, TM, w1s, w2s, b1s, b2s, tid, TW_THREADS);
-    for (int i = tid; i < 2 * N * TM + TM + N; i += TW_THREADS) gw1s[i] = 0.f;
+    tok_stage_weights(bk, N, T, TM, w1s, w2s, b1s, b2s, tid, (NW * 64));
+    for (int i = tid; i < 2 * N * TM + TM + N; i += (NW * 64)) gw1s[i] = 0.f;
     const int nblk = ((B + tg.spw - 1) / tg.spw) * tg.chunks;   // column blocks of the launch
     for (int it = 0; it < iters; ++it) {
     const int blk = blockIdx.x * iters + it;
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(TW_THREADS) void token_bwd_cols_kernel(const m2m_to
     const int s_first = (blk / tg.chunks) * tg.spw;
     const int chunk = blk % tg.chunks;
     const int ns = min(tg.spw, B - s_first);
-    tok_row_stats(bk.x_in, (long)N * D, s_first, ns * N, N, D, stats, lane, wave, TW_WAVES);
+    tok_row_stats(bk.x_in, (long)N * D, s_first, ns * N, N, D, stats, lane, wave, NW);
     __syncthreads();
 
     const int sl = D >= TW_COLS ? 0 : lane / D;
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(TW_THREADS) void token_bwd_cols_kernel(const m2m_to
     const long col0 = (long)s * N * D + d;
     const float* st = stats + 2 * (pv ? sl : 0) * N;
     // this wave's tokens: a quarter of the N tokens of the column (the four waves work on the same 64 columns)
-    const int NQ = (N + TW_WAVES - 1) / TW_WAVES;
+    const int NQ = (N + NW - 1) / NW;
     const int nb = wave * NQ, ne = min(N, nb + NQ);
 
     // LN1 output and masked upstream gradient of tokens n0 .. n0 + TW_UB - 1 (clamped to < nmax) of this lane's column:
@@ -322,11 +326,11 @@ __global__ __launch_bounds__(TW_THREADS) void token_bwd_cols_kernel(const m2m_to
     }
     __syncthreads();
 #pragma unroll
-    for (int tq = 0; tq < TM / TW_WAVES; ++tq) {
-        const int t = wave * (TM / TW_WAVES) + tq;
+    for (int tq = 0; tq < TM / NW; ++tq) {
+        const int t = wave * (TM / NW) + tq;
         float hsum = 0.f, dsum = 0.f;
 #pragma unroll
-        for (int w = 0; w < TW_WAVES; ++w) {
+        for (int w = 0; w < NW; ++w) {
             hsum += part[w * PART_F + t * TW_COLS + lane];
             dsum += part[w * PART_F + (TM + t) * TW_COLS + lane];
         }
@@ -361,8 +365,8 @@ __global__ __launch_bounds__(TW_THREADS) void token_bwd_cols_kernel(const m2m_to
         }
     }
     // parameter gradients: sums over the workgroup's 64 columns (fixed order), then one float atomic per value per
-    // workgroup.  U and dV go through LDS one chunk of TW_NC tokens at a time (recomputed from x_in / g_mid, which are
-    // L2-resident by now), chunk c by wave c % TW_WAVES in its own part of LDS -- the partial sums above are dead: every wave
+    // workgroup.  U and dV go through LDS one chunk of NC tokens at a time (recomputed from x_in / g_mid, which are
+    // L2-resident by now), chunk c by wave c % NW in its own part of LDS -- the partial sums above are dead: every wave
     // passed the second barrier only after all had read them -- so the loop needs no further workgroup barrier.
     // (Measured and dropped: the two column sums as fp32 16x16x4 MFMAs fed from the LDS tiles -- 30 % slower at MIMIC's batch
     // 8192, where 8192 workgroups then reach their atomics on the same ~800 addresses together.)
@@ -372,11 +376,11 @@ __global__ __launch_bounds__(TW_THREADS) void token_bwd_cols_kernel(const m2m_to
         for (int k = 0; k < TW_COLS; ++k) a += gr[k];
         gb1s[lane] += a;
     }
-    float* us = part + wave * PART_F;                           // [TW_NC][TW_LDW]  LN1 output of each column, one chunk of tokens
-    float* dvs = us + TW_NC * TW_LDW;                           // [TW_NC][TW_LDW]  masked upstream gradient, same chunk
-    static_assert(TW_NC % TW_UB == 0, "a chunk is a whole number of load batches");
-    for (int n0 = wave * TW_NC; n0 < N; n0 += TW_WAVES * TW_NC) {
-        const int nc = min(TW_NC, N - n0);
+    float* us = part + wave * PART_F;                           // [NC][TW_LDW]  LN1 output of each column, one chunk of tokens
+    float* dvs = us + NC * TW_LDW;                           // [NC][TW_LDW]  masked upstream gradient, same chunk
+    static_assert(NC % TW_UB == 0, "a chunk is a whole number of load batches");
+    for (int n0 = wave * NC; n0 < N; n0 += NW * NC) {
+        const int nc = min(NC, N - n0);
         for (int j0 = 0; j0 < nc; j0 += TW_UB) {
             float u8[TW_UB], dv8[TW_UB];
             u_dv8(n0 + j0, N, u8, dv8);
@@ -417,12 +421,12 @@ __global__ __launch_bounds__(TW_THREADS) void token_bwd_cols_kernel(const m2m_to
     __syncthreads();                                             // the next column block overwrites stats / hs / dhs
     }
     __syncthreads();
-    for (int i = tid; i < T * N; i += TW_THREADS) {
+    for (int i = tid; i < T * N; i += (NW * 64)) {
         atomicAdd(bk.g_tok_w1 + i, gw1s[i]);
         atomicAdd(bk.g_tok_w2 + i, gw2s[i]);
     }
     if (tid < T) atomicAdd(bk.g_tok_b1 + tid, gb1s[tid]);
-    for (int n = tid; n < N; n += TW_THREADS) atomicAdd(bk.g_tok_b2 + n, gb2s[n]);
+    for (int n = tid; n < N; n += (NW * 64)) atomicAdd(bk.g_tok_b2 + n, gb2s[n]);
 }
 
 // ---- backward, row part: dx_in = g_mid + LN1'(dU); gamma / beta gradients ------------------------------------------
@@ -522,20 +526,43 @@ static m2m_tower block_view(const m2m_tower* t, int b) {
     return v;
 }
 
-template <int P, int DM, int TM>
-static int launch_token_fwd(const m2m_tower* t, int b, const float* src, long src_ss, int B, float* x_mid, float* save_x_in,
+// waves per workgroup of a token launch with `nblk` column blocks (see TokNC above)
+static int tok_waves(int nblk, int TM) {
+    static const int forced = [] { const char* e = getenv("M2M_TOKEN_WAVES"); return e ? atoi(e) : 0; }();   // diagnostic (A/B): 4, 8 or 16
+    int nw = nblk <= 256 ? 16 : (nblk <= 512 ? 8 : 4);
+    if (forced == 4 || forced == 8 || forced == 16) nw = forced;
+    if (TM > 16 && nw > 8) nw = 8;                               // 32 hidden units per lane: registers and LDS of 16 waves do not fit
+    return nw;
+}
+
+template <int P, int DM, int TM, int NW>
+static int launch_token_fwd_nw(const m2m_tower* t, int b, const float* src, long src_ss, int B, float* x_mid, float* save_x_in,
                             int training, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
     const TokGeom g = tok_geom(t->D);
     const int grid = ((B + g.spw - 1) / g.spw) * g.chunks;
     const size_t lds = ((tok_lds_floats(t->N, g.spw, TM) + 3) & ~(size_t)3) * sizeof(float) +
-                       (size_t)(TW_WAVES + 1) * TM * TW_COLS * sizeof(float);
-    hipLaunchKernelGGL((token_fwd_kernel<P, DM, TM>), dim3(grid), dim3(TW_THREADS), lds, st, *t, b, src, src_ss, B, x_mid, save_x_in,
-                       training, seed, step, step_dev);
+                       (size_t)(NW + 1) * TM * TW_COLS * sizeof(float);
+    auto kern = token_fwd_kernel<P, DM, TM, NW>;
+    static size_t attr_lds = 48 * 1024;
+    if (lds > attr_lds) {
+        M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, *t, b, src, src_ss, B, x_mid, save_x_in, training, seed, step, step_dev);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
 }
 template <int P, int DM, int TM>
-static int launch_token_bwd(const m2m_tower* t, int b, const float* g_mid, int B, float* du, unsigned int seed, unsigned int step,
+static int launch_token_fwd(const m2m_tower* t, int b, const float* src, long src_ss, int B, float* x_mid, float* save_x_in,
+                            int training, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
+    const TokGeom g = tok_geom(t->D);
+    const int nw = tok_waves(((B + g.spw - 1) / g.spw) * g.chunks, TM);
+    if constexpr (TM <= 16) { if (nw == 16) return launch_token_fwd_nw<P, DM, TM, 16>(t, b, src, src_ss, B, x_mid, save_x_in, training, seed, step, step_dev, st); }
+    if (nw >= 8) return launch_token_fwd_nw<P, DM, TM, 8>(t, b, src, src_ss, B, x_mid, save_x_in, training, seed, step, step_dev, st);
+    return launch_token_fwd_nw<P, DM, TM, 4>(t, b, src, src_ss, B, x_mid, save_x_in, training, seed, step, step_dev, st);
+}
+template <int P, int DM, int TM, int NW>
+static int launch_token_bwd_nw(const m2m_tower* t, int b, const float* g_mid, int B, float* du, unsigned int seed, unsigned int step,
                             const unsigned int* step_dev, hipStream_t st) {
     const TokGeom g = tok_geom(t->D);
     const int nblk = ((B + g.spw - 1) / g.spw) * g.chunks;
@@ -543,18 +570,29 @@ static int launch_token_bwd(const m2m_tower* t, int b, const float* g_mid, int B
     // -- the token-weight gradients end in float atomics on the same few hundred addresses from every workgroup
     const int iters = nblk > 1024 ? (nblk + 1023) / 1024 : 1;
     const int grid = (nblk + iters - 1) / iters;
-    const size_t part_f = 2 * TM * TW_COLS > 2 * TW_NC * TW_LDW ? 2 * TM * TW_COLS : 2 * TW_NC * TW_LDW;
+    constexpr int NC = TokNC<NW>::value;
+    const size_t part_f = 2 * TM * TW_COLS > 2 * NC * TW_LDW ? 2 * TM * TW_COLS : 2 * NC * TW_LDW;
     const size_t lds = ((tok_lds_floats(t->N, g.spw, TM) + 3) & ~(size_t)3) * sizeof(float) +
-                       ((size_t)2 * TM * TW_LDW + TW_WAVES * part_f + 2 * t->N * TM + TM + t->N) * sizeof(float);
-    auto kern = token_bwd_cols_kernel<P, DM, TM>;
+                       ((size_t)2 * TM * TW_LDW + NW * part_f + 2 * t->N * TM + TM + t->N) * sizeof(float);
+    if (lds > 160 * 1024) { m2m_set_error("token backward: tokens x token_dim exceed the workgroup's LDS", __FILE__, __LINE__); return -1; }
+    auto kern = token_bwd_cols_kernel<P, DM, TM, NW>;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
         M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(TW_THREADS), lds, st, *t, b, g_mid, B, du, seed, step, step_dev, iters);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, *t, b, g_mid, B, du, seed, step, step_dev, iters);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
+}
+template <int P, int DM, int TM>
+static int launch_token_bwd(const m2m_tower* t, int b, const float* g_mid, int B, float* du, unsigned int seed, unsigned int step,
+                            const unsigned int* step_dev, hipStream_t st) {
+    const TokGeom g = tok_geom(t->D);
+    const int nw = tok_waves(((B + g.spw - 1) / g.spw) * g.chunks, TM);
+    if constexpr (TM <= 16) { if (nw == 16) return launch_token_bwd_nw<P, DM, TM, 16>(t, b, g_mid, B, du, seed, step, step_dev, st); }
+    if (nw >= 8) return launch_token_bwd_nw<P, DM, TM, 8>(t, b, g_mid, B, du, seed, step, step_dev, st);
+    return launch_token_bwd_nw<P, DM, TM, 4>(t, b, g_mid, B, du, seed, step, step_dev, st);
 }
 #define M2M_TOK_DISPATCH_TM(FN, TM_, training_, ...)                                                \
     do {                                                                                            \
