@@ -18,7 +18,9 @@ struct HeadArgs {
     m2m_head h[HEAD_MAXH];
 };
 
-template <bool BCE>
+// S: samples per workgroup (HEAD_S, or 4 at small batch: the kernel is a chain of dependent LDS loops whose lengths go with S,
+// and at the MM-IMDb cfg batch 32 samples x 3 heads were 6 workgroups)
+template <bool BCE, int S>
 __global__ __launch_bounds__(NTHREADS) void heads_kernel(const HeadArgs ha, const void* __restrict__ labels_v,
                                                          const float* __restrict__ pos_weight, int B, int D,
                                                          int K, float* __restrict__ logits_out, float* __restrict__ losses,
@@ -27,26 +29,26 @@ __global__ __launch_bounds__(NTHREADS) void heads_kernel(const HeadArgs ha, cons
     const float* targets = reinterpret_cast<const float*>(labels_v);          // BCE: multi-hot (B, K)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int DL = D + 1;
-    float* pl = reinterpret_cast<float*>(smem);          // pooled tile [HEAD_S][DL]
-    float* wl = pl + HEAD_S * DL;                         // weights     [K][DL]
-    float* lg = wl + HEAD_MAXK * DL;                      // logits / dlogits [HEAD_S][HEAD_MAXK]
-    float* red = lg + HEAD_S * HEAD_MAXK;                 // [HEAD_S] loss terms
-    float* tm = red + HEAD_S;                             // [HEAD_S][HEAD_MAXK] per-element loss terms (BCE)
+    float* pl = reinterpret_cast<float*>(smem);          // pooled tile [S][DL]
+    float* wl = pl + S * DL;                         // weights     [K][DL]
+    float* lg = wl + HEAD_MAXK * DL;                      // logits / dlogits [S][HEAD_MAXK]
+    float* red = lg + S * HEAD_MAXK;                 // [S] loss terms
+    float* tm = red + S;                             // [S][HEAD_MAXK] per-element loss terms (BCE)
 
     const int tid = threadIdx.x;
     const int hI = blockIdx.y;
     const m2m_head& hd = ha.h[hI];
-    const int s0 = blockIdx.x * HEAD_S;
-    const int ns = min(HEAD_S, B - s0);
+    const int s0 = blockIdx.x * S;
+    const int ns = min(S, B - s0);
 
-    for (int idx = tid; idx < HEAD_S * D; idx += NTHREADS) {
+    for (int idx = tid; idx < S * D; idx += NTHREADS) {
         const int s = idx / D, d = idx % D;
         pl[s * DL + d] = s < ns ? hd.pooled[(long)(s0 + s) * D + d] : 0.f;
     }
     for (int idx = tid; idx < K * D; idx += NTHREADS) wl[(idx / D) * DL + idx % D] = hd.w[idx];
     __syncthreads();
     // logits: 4 adjacent lanes split each D-long dot product
-    for (int idx = tid >> 2; idx < HEAD_S * K; idx += NTHREADS / 4) {
+    for (int idx = tid >> 2; idx < S * K; idx += NTHREADS / 4) {
         const int s = idx / K, k = idx % K, part = tid & 3;
         float a = 0.f;
         for (int d = part; d < D; d += 4) a = __builtin_fmaf(pl[s * DL + d], wl[k * DL + d], a);
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(NTHREADS) void heads_kernel(const HeadArgs ha, cons
     // the row, one thread per sample.
     if (BCE) {
         const float scale = hd.weight / ((float)B * (float)K);
-        for (int idx = tid; idx < HEAD_S * K; idx += NTHREADS) {
+        for (int idx = tid; idx < S * K; idx += NTHREADS) {
             const int s = idx / K, k = idx % K;
             float term = 0.f, dl = 0.f;
             if (s < ns) {
@@ -78,12 +80,12 @@ __global__ __launch_bounds__(NTHREADS) void heads_kernel(const HeadArgs ha, cons
             tm[s * HEAD_MAXK + k] = term;
         }
         __syncthreads();
-        if (tid < HEAD_S) {
+        if (tid < S) {
             float term = 0.f;
             for (int k = 0; k < K; ++k) term += tm[tid * HEAD_MAXK + k];      // label order, as the single-thread loop summed
             red[tid] = term / (float)K;
         }
-    } else if (tid < HEAD_S) {
+    } else if (tid < S) {
         float term = 0.f;
         if (tid < ns) {
             const int s = tid;
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(NTHREADS) void heads_kernel(const HeadArgs ha, cons
     __syncthreads();
     if (tid == 0) {
         float t = 0.f;
-        for (int s = 0; s < HEAD_S; ++s) t += red[s];
+        for (int s = 0; s < S; ++s) t += red[s];
         t /= (float)B;
         atomicAdd(losses + hI, t);
         atomicAdd(losses + nheads, t * hd.weight);
@@ -125,12 +127,12 @@ __global__ __launch_bounds__(NTHREADS) void heads_kernel(const HeadArgs ha, cons
         for (int idx = tid; idx < K * D; idx += NTHREADS) {
             const int k = idx / D, d = idx % D;
             float a = 0.f;
-            for (int s = 0; s < HEAD_S; ++s) a = __builtin_fmaf(lg[s * HEAD_MAXK + k], pl[s * DL + d], a);
+            for (int s = 0; s < S; ++s) a = __builtin_fmaf(lg[s * HEAD_MAXK + k], pl[s * DL + d], a);
             atomicAdd(hd.g_w + idx, a);
         }
         if (tid < K) {
             float a = 0.f;
-            for (int s = 0; s < HEAD_S; ++s) a += lg[s * HEAD_MAXK + tid];
+            for (int s = 0; s < S; ++s) a += lg[s * HEAD_MAXK + tid];
             atomicAdd(hd.g_b + tid, a);
         }
     }
@@ -140,6 +142,17 @@ __global__ __launch_bounds__(NTHREADS) void heads_kernel(const HeadArgs ha, cons
 // hipMemsetAsync node was observed to write stale bytes on hipGraph replay).
 __global__ void zero_floats_kernel(float* p, int n) {
     if ((int)threadIdx.x < n) p[threadIdx.x] = 0.f;
+}
+
+template <bool BCE, int S>
+static int launch_heads_s(const HeadArgs& ha, int nheads, const void* labels, const float* pos_weight, int B, int D, int K,
+                          float* logits, float* losses, int32_t* preds, hipStream_t st) {
+    const size_t lds = sizeof(float) * ((size_t)S * (D + 1) + (size_t)HEAD_MAXK * (D + 1) + 2 * S * HEAD_MAXK + S);
+    static bool done = false;
+    if (!done) { M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(heads_kernel<BCE, S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); done = true; }
+    hipLaunchKernelGGL((heads_kernel<BCE, S>), dim3((B + S - 1) / S, nheads), dim3(NTHREADS), lds, st, ha, labels, pos_weight, B, D, K, logits, losses, preds, nheads);
+    M2M_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 template <bool BCE>
@@ -154,12 +167,8 @@ static int launch_heads(const m2m_head* heads, int nheads, const void* labels, c
     for (int i = nheads; i < HEAD_MAXH; ++i) ha.h[i] = heads[0];
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (zero_losses) hipLaunchKernelGGL(zero_floats_kernel, dim3(1), dim3(64), 0, st, losses, nheads + 1);
-    const size_t lds = sizeof(float) * ((size_t)HEAD_S * (D + 1) + (size_t)HEAD_MAXK * (D + 1) + 2 * HEAD_S * HEAD_MAXK + HEAD_S);
-    static bool done = false;
-    if (!done) { M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(heads_kernel<BCE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); done = true; }
-    hipLaunchKernelGGL(heads_kernel<BCE>, dim3((B + HEAD_S - 1) / HEAD_S, nheads), dim3(NTHREADS), lds, st, ha, labels, pos_weight, B, D, K, logits, losses, preds, nheads);
-    M2M_CHECK_HIP(hipGetLastError());
-    return 0;
+    if (B <= 64) return launch_heads_s<BCE, 4>(ha, nheads, labels, pos_weight, B, D, K, logits, losses, preds, st);
+    return launch_heads_s<BCE, HEAD_S>(ha, nheads, labels, pos_weight, B, D, K, logits, losses, preds, st);
 }
 
 extern "C" int m2m_heads_ce(const m2m_head* heads, int nheads, const int64_t* labels, int B, int D, int K, float* logits,

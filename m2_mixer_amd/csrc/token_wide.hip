@@ -430,70 +430,91 @@ __global__ __launch_bounds__(NW * 64) void token_bwd_cols_kernel(const m2m_tower
 }
 
 // ---- backward, row part: dx_in = g_mid + LN1'(dU); gamma / beta gradients ------------------------------------------
-// 4 waves, each walks rows (row = wave, wave + 4, ...) of the workgroup's LN_ROWS rows; a lane holds columns lane + 64 i.
+// NWV waves, each walks rows (row = wave, wave + NWV, ...) of the workgroup's rows, two at a time (all six streams of a pair
+// requested before the first reduction); a lane holds columns lane + 64 i.  The gamma / beta sums of a workgroup meet in LDS
+// and leave as one float atomic per column: every workgroup of the launch adds to the same 2 D addresses, and same-address
+// atomics queue in L2 (~30 ns each) -- at the cfg batches that queue WAS this kernel (320-400 workgroups of 8 rows: 8-17 us
+// for 3 MB of traffic), so small launches take 16 waves and 32 rows per workgroup (a quarter of the atomics, same rows per wave).
 #define LN_ROWS 32
 // `dst` may alias `du` (dense, in place): a row's dU is read before its result is written.
-__global__ __launch_bounds__(256) void ln1_bwd_rows_kernel(const float* __restrict__ x_in, const float* __restrict__ g_mid,
-                                                           const float* du, const float* __restrict__ gamma,
-                                                           long rows, int N, int D, float* dst, long dst_ss,
-                                                           float* __restrict__ g_w, float* __restrict__ g_b, int rows_per_wg) {
-    __shared__ float acc_w[4][256], acc_b[4][256];
+template <int NWV>
+__global__ __launch_bounds__(NWV * 64) void ln1_bwd_rows_kernel(const float* __restrict__ x_in, const float* __restrict__ g_mid,
+                                                                const float* du, const float* __restrict__ gamma,
+                                                                long rows, int N, int D, float* dst, long dst_ss,
+                                                                float* __restrict__ g_w, float* __restrict__ g_b, int rows_per_wg) {
+    __shared__ float acc_w[NWV][256], acc_b[NWV][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float gw[4] = {0.f, 0.f, 0.f, 0.f}, gb[4] = {0.f, 0.f, 0.f, 0.f}, gm[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) gm[i] = (lane + 64 * i) < D ? gamma[lane + 64 * i] : 0.f;
     const long r0 = (long)blockIdx.x * rows_per_wg;
-    for (int rr = wave; rr < rows_per_wg; rr += 4) {
-        const long r = r0 + rr;
-        if (r >= rows) break;
-        const float* xr = x_in + r * D;
-        float v[4], u[4], gmid[4], s = 0.f;
+    constexpr int RB = 2;
+    for (int rr = wave; rr < rows_per_wg; rr += RB * NWV) {
+        float v[RB][4], u[RB][4], gmid[RB][4];
+        bool ok[RB];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {                        // all three streams of the row requested together
-            const int c = lane + 64 * i;
-            v[i] = c < D ? xr[c] : 0.f;
-            u[i] = c < D ? du[r * D + c] : 0.f;
-            gmid[i] = c < D ? g_mid[r * D + c] : 0.f;
-            s += v[i];
+        for (int j = 0; j < RB; ++j) {                      // all streams of the rows requested together
+            const long r = r0 + rr + j * NWV;
+            ok[j] = rr + j * NWV < rows_per_wg && r < rows;
+            const long rc = ok[j] ? r : r0;                 // (clamped: the loads stay unconditional, the result is dropped)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = lane + 64 * i;
+                v[j][i] = c < D ? x_in[rc * D + c] : 0.f;
+                u[j][i] = c < D ? du[rc * D + c] : 0.f;
+                gmid[j][i] = c < D ? g_mid[rc * D + c] : 0.f;
+            }
         }
-        s = wave_sum_xor(s, 64);
-        const float mean = s / (float)D;
-        float s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = lane + 64 * i;
-            v[i] = c < D ? v[i] - mean : 0.f;
-            s2 = __builtin_fmaf(v[i], v[i], s2);
-        }
-        s2 = wave_sum_xor(s2, 64);
-        const float vv = s2 / (float)D + 1e-5f;
-        float rstd = __builtin_amdgcn_rsqf(vv);
-        rstd = rstd * (1.5f - 0.5f * vv * rstd * rstd);
-        float gsum = 0.f, gxsum = 0.f, gg[4];
+        for (int j = 0; j < RB; ++j) {
+            const long r = r0 + rr + j * NWV;
+            float s = (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+            s = wave_sum_xor(s, 64);
+            const float mean = s / (float)D;
+            float s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            v[i] *= rstd;                                 // xhat
-            gg[i] = u[i] * gm[i];
-            gsum += gg[i];
-            gxsum = __builtin_fmaf(gg[i], v[i], gxsum);
-            gw[i] = __builtin_fmaf(u[i], v[i], gw[i]);
-            gb[i] += u[i];
-        }
-        gsum = wave_sum_xor(gsum, 64) / (float)D;
-        gxsum = wave_sum_xor(gxsum, 64) / (float)D;
-        float* orow = dst + (r / N) * dst_ss + (r % N) * D;
+            for (int i = 0; i < 4; ++i) {
+                const int c = lane + 64 * i;
+                v[j][i] = c < D ? v[j][i] - mean : 0.f;
+                s2 = __builtin_fmaf(v[j][i], v[j][i], s2);
+            }
+            s2 = wave_sum_xor(s2, 64);
+            const float vv = s2 / (float)D + 1e-5f;
+            float rstd = __builtin_amdgcn_rsqf(vv);
+            rstd = rstd * (1.5f - 0.5f * vv * rstd * rstd);
+            float gsum = 0.f, gxsum = 0.f, gg[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = lane + 64 * i;
-            if (c < D) orow[c] = gmid[i] + rstd * (gg[i] - gsum - v[i] * gxsum);
+            for (int i = 0; i < 4; ++i) {
+                v[j][i] *= rstd;                              // xhat
+                gg[i] = u[j][i] * gm[i];
+                gsum += gg[i];
+                gxsum = __builtin_fmaf(gg[i], v[j][i], gxsum);
+                if (ok[j]) {
+                    gw[i] = __builtin_fmaf(u[j][i], v[j][i], gw[i]);
+                    gb[i] += u[j][i];
+                }
+            }
+            gsum = wave_sum_xor(gsum, 64) / (float)D;
+            gxsum = wave_sum_xor(gxsum, 64) / (float)D;
+            if (ok[j]) {
+                float* orow = dst + (r / N) * dst_ss + (r % N) * D;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = lane + 64 * i;
+                    if (c < D) orow[c] = gmid[j][i] + rstd * (gg[i] - gsum - v[j][i] * gxsum);
+                }
+            }
         }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { acc_w[wave][lane + 64 * i] = gw[i]; acc_b[wave][lane + 64 * i] = gb[i]; }
     __syncthreads();
-    for (int c = threadIdx.x; c < D; c += 256) {
-        atomicAdd(g_w + c, (acc_w[0][c] + acc_w[1][c]) + (acc_w[2][c] + acc_w[3][c]));
-        atomicAdd(g_b + c, (acc_b[0][c] + acc_b[1][c]) + (acc_b[2][c] + acc_b[3][c]));
+    for (int c = threadIdx.x; c < D; c += NWV * 64) {
+        float sw = 0.f, sb = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) { sw += acc_w[w][c]; sb += acc_b[w][c]; }
+        atomicAdd(g_w + c, sw);
+        atomicAdd(g_b + c, sb);
     }
 }
 
@@ -677,9 +698,15 @@ int m2m_backward_wide(const m2m_tower* t, int B, const float* d_out, long d_out_
         const long dst_ss = b > 0 ? dense : d_x0_ss;
         // rows per workgroup: 32 (8 per wave) when there are plenty, 8 at small batch so that the chip is not left to 80
         // workgroups, 128 when there are so many that the gamma / beta atomics of thousands of workgroups queue up
-        const int rpw = rows >= 131072 ? 4 * LN_ROWS : (rows >= 16384 ? LN_ROWS : 8);   // (large: fewer workgroups on the same 2 D atomics)
-        hipLaunchKernelGGL(ln1_bwd_rows_kernel, dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(256), 0, st, bk.x_in, t->ws_b,
-                           t->ws_a, bk.ln1_w, rows, t->N, t->D, dst, dst_ss, bk.g_ln1_w, bk.g_ln1_b, rpw);
+        static const int ln_small = [] { const char* e = getenv("M2M_LN1_SMALL"); return e ? atoi(e) : 1; }();   // diagnostic (A/B)
+        if (rows < 16384 && ln_small) {                            // 16 waves x 2 rows
+            hipLaunchKernelGGL(ln1_bwd_rows_kernel<16>, dim3((unsigned)((rows + LN_ROWS - 1) / LN_ROWS)), dim3(1024), 0, st, bk.x_in, t->ws_b,
+                               t->ws_a, bk.ln1_w, rows, t->N, t->D, dst, dst_ss, bk.g_ln1_w, bk.g_ln1_b, LN_ROWS);
+        } else {
+            const int rpw = rows >= 131072 ? 4 * LN_ROWS : (rows >= 16384 ? LN_ROWS : 8);   // (large: fewer workgroups on the same 2 D atomics)
+            hipLaunchKernelGGL(ln1_bwd_rows_kernel<4>, dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(256), 0, st, bk.x_in, t->ws_b,
+                               t->ws_a, bk.ln1_w, rows, t->N, t->D, dst, dst_ss, bk.g_ln1_w, bk.g_ln1_b, rpw);
+        }
         M2M_CHECK_HIP(hipGetLastError());
         up = t->ws_a;
         up_ss = dense;

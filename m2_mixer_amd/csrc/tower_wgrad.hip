@@ -575,7 +575,7 @@ static int launch_wgrad_group(const m2m_tower* const* host, const m2m_tower* con
     if (nembeds) {
         n_embed_wgs = P == PREC_BF16 ? embed_wgrad_group_args_fast(ea, embeds, inputs, embed_towers, B) : 0;
         if (n_embed_wgs) lds_e = embed_wgrad_fast_lds<D, KG::THREADS>();
-        else if (KG::THREADS == 256) { n_embed_wgs = embed_wgrad_group_args(ea, embeds, inputs, d_x0s, B, 512); lds_e = embed_wgrad_lds<D, P>(); }
+        else if (KG::THREADS == 256) { static const int ewgs = wgrad_env("M2M_EMBED_WGS", D >= 256 ? 128 : 512);   /* every row group adds 64 x D floats with atomics: at D = 256 (MM-IMDb, batch 32) 512 workgroups were 34 MB of them */ n_embed_wgs = embed_wgrad_group_args(ea, embeds, inputs, d_x0s, B, ewgs); lds_e = embed_wgrad_lds<D, P>(); }
         else embeds_separately = true;
     }
     if (embeds_separately) {
