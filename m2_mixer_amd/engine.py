@@ -199,27 +199,28 @@ class _FlatEngine:
         rt.ensure_workspace(self.B)
         return rt
 
-    def _setup_wgrad(self, towers: Sequence[TowerRuntime], grouped: bool):
+    def _setup_wgrad(self, launches: Sequence[Sequence[TowerRuntime]]):
         """Options of the channel-mixing weight-gradient launch for a step that runs ONE backward per optimizer step:
           * overwrite: a tower whose gradient elements have a single owner writes them with "=" (no read of the old values)
             and the flat Adam leaves those ranges uncleared (-66 MB per step on M2-Mixer-B);
-          * slot: in the grouped launch a tower with twice the rows of its neighbours (the fusion tower) is split into two
-            row groups, the second storing into a slot that the flat Adam adds -- its workgroups no longer run twice as long
-            as everyone else's.
+          * slot: in a grouped launch a tower that needs two row groups (the fusion tower: twice the rows of its neighbours)
+            stores the second group's sums into a slot that the flat Adam adds -- plain stores instead of float atomics.
         M2M_WGRAD_OVERWRITE=0 / M2M_WGRAD_SLOT=0 switch them off (A/B)."""
         import os
         self._slot_towers, self._ranges_add, self._ranges_keep = [], [], []
         if os.environ.get("M2M_WGRAD_OVERWRITE", "1") == "0":
             return
-        bits = 0
-        if grouped and os.environ.get("M2M_WGRAD_SLOT", "1") != "0":
-            have = [t.alloc_wslot(self.flat_g) for t in towers]
-            bits = wgrad_slot_groups(towers, self.B) if all(have) else 0
+        # `launches`: the towers of each weight-gradient launch of the step (a launch of several towers is the grouped form)
+        cand = []                                    # (tower, takes a slot)
+        for towers in launches:
+            bits = 0
+            if len(towers) > 1 and os.environ.get("M2M_WGRAD_SLOT", "1") != "0":
+                have = [t.alloc_wslot(self.flat_g) for t in towers]
+                bits = wgrad_slot_groups(towers, self.B) if all(have) else 0
+            cand += [(t, bool(bits >> i & 1)) for i, t in enumerate(towers)]
         table = []                                   # all-or-nothing per tower (the kernel's range table holds MAX_GRAD_RANGES)
-        order = sorted(range(len(towers)), key=lambda i: -(bits >> i & 1))       # slot towers first: their ranges are mandatory
-        for i in order:
-            t = towers[i]
-            slot = bool(bits >> i & 1)
+        cand.sort(key=lambda c: not c[1])            # slot towers first: their ranges are mandatory
+        for t, slot in cand:
             if not slot:
                 t.clear_wslot()
             rng = t.channel_grad_ranges(self.flat_g)
@@ -564,10 +565,16 @@ class _TwoTowerEngine(_FlatEngine):
         self.d_fused = f(B, self.Nf, D)
         self.dx0_a, self.dx0_b = f(B * self.Na, D), f(B * self.Nb, D)
         self.preds = torch.zeros(self._preds_shape(), dtype=torch.int32, device=dev)
-        self._setup_wgrad([self.t_fus, self.t_a, self.t_b], grouped=True)
+        # M2M_EARLY_FUSION_WGRAD=1 (wide towers, small batch): the fusion tower's weight gradients on a side stream beside the
+        # two modality towers' backward launches instead of inside the merged launch at the end.  Measured on MM-IMDb at its
+        # cfg batch: 0.555 ms against 0.502 ms merged -- the extra fork / join of the replayed graph and a single-tower launch
+        # without its slot (80 steps) cost more than the shorter tail returns.  Off.
+        import os
+        self._early_fus_wgrad = (self.concurrent and self.t_fus.wide and B * self.Nf <= 8192 and
+                                 os.environ.get("M2M_EARLY_FUSION_WGRAD", "0") == "1")
+        self._setup_wgrad([[self.t_fus], [self.t_a, self.t_b]] if self._early_fus_wgrad else [[self.t_fus, self.t_a, self.t_b]])
         self._fused_heads = self._heads_are_ce() and self.t_fus.backward_heads_ok(B, 3, self.K)
         # the embeddings' weight gradients in their single-owner form: the tower backward leaves d_x0^T as packed blocks
-        import os
         self._embed_towers = []
         if os.environ.get("M2M_EMBED_FAST", "1") != "0" and self.t_a.enable_dx0_image(B) and self.t_b.enable_dx0_image(B):
             self._embed_towers = [self.t_a, self.t_b]
@@ -666,7 +673,13 @@ class _TwoTowerEngine(_FlatEngine):
         else:
             self.t_fus.backward(B, None, 0, self.dpool_fus, self.d_fused, fs, self.seed, 0, sd)
         d_b_part = self.d_fused.view(-1)[self.Na * D:]
-        main, s_a, _ = self._streams()
+        main, s_a, s_f = self._streams()
+        wg_towers = [self.t_fus, self.t_a, self.t_b]
+        if self._early_fus_wgrad:
+            s_f.wait_stream(main)
+            with torch.cuda.stream(s_f):
+                self.t_fus.wgrad(B, self.seed, 0, sd)
+            wg_towers = [self.t_a, self.t_b]
         s_e = self.s_emb if self.concurrent else main
         # The two tower chains fill the chip (128 + 128 workgroups) side by side; then ONE launch computes the channel-mixing
         # weight gradients of all three towers (the hardware dispatcher balances their ~300 workgroups; three launches on
@@ -685,15 +698,17 @@ class _TwoTowerEngine(_FlatEngine):
             self.t_b.backward(B, d_b_part, fs, self.dpool_b, self.dx0_b, self.Nb * D, self.seed, 0, sd)
             main.wait_stream(s_a)
         if can_group_embeds(self.e_a, self.e_b) and self.e_a.prec == self.t_a.prec and self.e_a.D == self.t_a.D:
-            towers_wgrad([self.t_fus, self.t_a, self.t_b], B, [self.e_a, self.e_b], [xa, xb], [self.dx0_a, self.dx0_b],
+            towers_wgrad(wg_towers, B, [self.e_a, self.e_b], [xa, xb], [self.dx0_a, self.dx0_b],
                          seed=self.seed, step=0, step_dev=sd, embed_towers=self._embed_towers)
         else:
             s_e.wait_stream(main)
             with torch.cuda.stream(s_e):
                 self.e_b.wgrad(xb, self.dx0_b, B)
                 self.e_a.wgrad(xa, self.dx0_a, B)
-            towers_wgrad([self.t_fus, self.t_a, self.t_b], B, seed=self.seed, step=0, step_dev=sd)
+            towers_wgrad(wg_towers, B, seed=self.seed, step=0, step_dev=sd)
             main.wait_stream(s_e)
+        if self._early_fus_wgrad:
+            main.wait_stream(s_f)
         if fused_update:
             self._update(1.0)
 
