@@ -65,6 +65,22 @@ template <int P, int D, int NMAX, int TG> struct BwdLds {
 #define M2M_SMALL_ATOMIC(p, v) atomicAdd(p, v)
 #endif
 TIMER_DECL(g_tm_bwd);
+__device__ int g_bwd_static_split = 0;      // 1: static split of the bf16 column loop (M2M_BWD_TICKETS=0), see tower_bwd_body
+// copies the environment's choice to the device once per process (before the first backward launch on any stream)
+static int bwd_split_mode_init(hipStream_t st) {
+    static bool done = false;
+    if (done) return 0;
+    const char* e = getenv("M2M_BWD_TICKETS");
+    const int v = (e && atoi(e) == 0) ? 1 : 0;
+    if (v) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cs);
+        if (cs != hipStreamCaptureStatusNone) { m2m_set_error("tower_backward: first launch with M2M_BWD_TICKETS=0 inside a stream capture (run one eager step first)", __FILE__, __LINE__); return -1; }
+        M2M_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_static_split), &v, sizeof(v)));
+    }
+    done = true;
+    return 0;
+}
 TIMER_READER(m2m_debug_timers_bwd, g_tm_bwd)
 
 // One workgroup's share of a tower backward: token tile `wg` of `nwg`.  TW is m2m_tower (single-tower launch) or
@@ -475,7 +491,10 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
         // is issue-bound and the waves do not run at the same pace (the older ones win the arbitration): with a static split
         // the fastest wave waited ~4 us per block at the barrier behind the loop.  The next ticket is drawn at the top of a step
         // and used at its prefetch point.  fp32 (parity) mode keeps the static split: reproducible summation order.
-        constexpr bool TICKETS = P == PREC_BF16 && M2M_TICKETS;
+        // M2M_BWD_TICKETS=0 in the environment (g_bwd_static_split, set before the first launch) selects the static split at run
+        // time: the column sums of dA then have a fixed order (reproducible bf16 runs; costs the 2-3 % the tickets gained).
+        constexpr bool TICKETS_CT = P == PREC_BF16 && M2M_TICKETS;
+        const bool TICKETS = TICKETS_CT && __builtin_amdgcn_readfirstlane(g_bwd_static_split) == 0;
         // The two waves of a SIMD (w and w + 4) run the same program and leave the barrier before the loop together: their MFMA
         // clusters and their VALU epilogues would collide.  M2M_STAGGER delays waves 4-7 by about half a step (s_sleep counts 64
         // cycles) so that one wave's matrix work lies beside its partner's vector work; with tickets the delayed waves simply
@@ -1210,6 +1229,7 @@ int m2m_backward_wide(const m2m_tower* t, int B, const float* d_out, long d_out_
 // Backward of the channel-mixing half of ONE block (+ final LayerNorm if the view has it) over B*N independent rows.
 int m2m_chain_backward_rows(const m2m_tower* t, int B, const float* d_out, long d_out_ss, const float* d_pooled, float* d_x0,
                             long d_x0_ss, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
+    if (int rc = bwd_split_mode_init(st)) return rc;
 #define M2M_BWDR_CASE(PP, DD) \
     if (t->prec == PP && t->D == DD) return launch_bwd<PP, DD, 0, 8>(t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step, step_dev, st);
     M2M_BWDR_CASE(PREC_BF16, 32) M2M_BWDR_CASE(PREC_BF16, 64) M2M_BWDR_CASE(PREC_BF16, 128) M2M_BWDR_CASE(PREC_BF16, 256)
@@ -1228,6 +1248,7 @@ int m2m_split_backward(const m2m_tower* const* towers, const m2m_tower_gio* io, 
 extern "C" int m2m_towers_backward(const m2m_tower* const* towers, const m2m_tower_gio* io, int ntowers, int B, uint32_t seed,
                                    uint32_t step, const uint32_t* step_dev, void* stream) {
     if (!towers || !io || ntowers != 2) { m2m_set_error("towers_backward: exactly two towers per launch", __FILE__, __LINE__); return -1; }
+    if (int rc = bwd_split_mode_init(reinterpret_cast<hipStream_t>(stream))) return rc;
     for (int i = 0; i < 2; ++i)
         if (int rc = m2m_check_tower(towers[i], B)) return rc;
     // the forward of this step took the split path under the same conditions (csrc/split.h)
@@ -1300,6 +1321,7 @@ extern "C" int m2m_tower_backward_heads(const m2m_tower* t, int B, const m2m_hea
                                         uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream) {
     if (!m2m_tower_backward_heads_ok(t, B, nheads, K)) { m2m_set_error("tower_backward_heads: unsupported tower / heads (see m2m_tower_backward_heads_ok)", __FILE__, __LINE__); return -1; }
     if (!heads || !labels || !logits || !losses || !preds || !d_x0 || own < 0 || own >= nheads) { m2m_set_error("tower_backward_heads: null argument", __FILE__, __LINE__); return -1; }
+    if (int rc = bwd_split_mode_init(reinterpret_cast<hipStream_t>(stream))) return rc;
     BwdHeads hd;
     memset(&hd, 0, sizeof(hd));
     for (int h = 0; h < nheads; ++h) {
@@ -1326,6 +1348,7 @@ extern "C" int m2m_tower_backward(const m2m_tower* t, int B, const float* d_out,
                                   float* d_x0, int64_t d_x0_ss, uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream) {
     if (int rc = m2m_check_tower(t, B)) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (int rc = bwd_split_mode_init(st)) return rc;
     if (m2m_is_wide(t)) return m2m_backward_wide(t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step, step_dev, st);
     if (m2m_split_eligible(t, B, 1)) {
         m2m_tower_gio io1;
