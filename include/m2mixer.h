@@ -121,6 +121,11 @@ typedef struct m2m_tower {
 } m2m_tower;
 #define M2M_WGRAD_OVERWRITE 1 /* wgrad_flags: g_ch_w1 / g_ch_b1 / g_ch_w2 are WRITTEN ("="), not accumulated ("+="): the caller
                                * neither zeroes nor accumulates them (the fused engines: one backward per optimizer step) */
+#define M2M_WGRAD_REDUCES_SMALL 2 /* wgrad_flags: every m2m_tower_backward of this tower is followed by an m2m_towers_wgrad /
+                               * m2m_tower_wgrad that includes it (same batch).  Where the backward launch collects its small
+                               * parameter gradients (LayerNorms, token MLP, ch_b2) in per-workgroup slots (m2m_tower.gpart), their
+                               * reduction then rides in that weight-gradient launch instead of being a launch of its own; the
+                               * small gradients are complete only after it. */
 
 /* Patch embedding = Conv2d(Cin, D, (ph,pw), stride=(ph,pw)) + 'b c h w -> b (h w) c'
  * (reference: modules/mixer.py:143-146) or, with H = N, ph = 1, pw = W = K, the plain

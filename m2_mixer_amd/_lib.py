@@ -57,6 +57,7 @@ class Tower(C.Structure):
 
 
 WGRAD_OVERWRITE = 1      # Tower.wgrad_flags (M2M_WGRAD_OVERWRITE)
+WGRAD_REDUCES_SMALL = 2  # Tower.wgrad_flags (M2M_WGRAD_REDUCES_SMALL)
 MAX_GRAD_RANGES = 16
 
 

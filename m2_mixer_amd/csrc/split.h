@@ -119,3 +119,67 @@ struct SplitReduceTower {
     float* losses;                                // [nheads + 1]: per head, then the total
 };
 struct SplitReduceArgs { SplitReduceTower t[2]; int ntow; };
+
+// ---- reduction of the per-workgroup slots (device body shared by split_mix.hip's launch and the weight-gradient launch) -----
+#define SPR_COLS 32        // slot entries per workgroup
+#define SPR_GROUPS 32      // workgroup-tile groups summed in parallel, then through LDS (1024-thread launch; NT / 32 in general)
+// One workgroup of NT threads: entries [bx * 32, bx * 32 + 32) of slot set L of tower `tw`.  red: [NT / 32][33] floats of LDS.
+template <int NT>
+static __device__ __forceinline__ void split_small_grads_body(const SplitReduceTower& tw, int bx, int L, float* red) {
+    constexpr int NG = NT / SPR_COLS, RLD = SPR_COLS + 1;
+    if (L >= tw.nlaunch) return;                                  // (uniform)
+    const int D = tw.D, N = tw.N, T = tw.T;
+    const int col = threadIdx.x % SPR_COLS, grp = threadIdx.x / SPR_COLS;
+    const int e = bx * SPR_COLS + col;
+    // slot entry -> destination
+    float* dst = nullptr;
+    bool shared_dst = false;
+    if (tw.nheads > 0 && L >= tw.head_set0) {                    // a classification head's slot set
+        const int h = L - tw.head_set0, KD = tw.K * D;
+        if (e < KD) dst = tw.g_hw[h] + e;
+        else if (e < KD + tw.K) dst = tw.g_hb[h] + (e - KD);
+        else if (e == KD + tw.K) dst = tw.losses + h;
+        else if (e == KD + tw.K + 1) { dst = tw.losses + tw.nheads; shared_dst = true; }   // the total: every head's set adds to it
+    } else if (e < SPP_STRIDE) {
+        const int ntok = 2 * T * N + T + N;
+        if (e < D) dst = tw.g_ln2_w[L] ? tw.g_ln2_w[L] + e : nullptr;
+        else if (e < 2 * D) dst = tw.g_ln2_b[L] ? tw.g_ln2_b[L] + (e - D) : nullptr;
+        else if (e < SPP_TOK(D) + ntok) {
+            const int i = e - SPP_TOK(D);
+            if (tw.g_tok_w1[L]) {
+                if (i < T * N) dst = tw.g_tok_w1[L] + i;
+                else if (i < 2 * T * N) dst = tw.g_tok_w2[L] + (i - T * N);
+                else if (i < 2 * T * N + T) dst = tw.g_tok_b1[L] + (i - 2 * T * N);
+                else dst = tw.g_tok_b2[L] + (i - 2 * T * N - T);
+            }
+        }
+        else if (e < SPP_LN1(D)) dst = nullptr;
+        else if (e < SPP_LN1(D) + D) dst = tw.g_ln1_w[L] ? tw.g_ln1_w[L] + (e - SPP_LN1(D)) : nullptr;
+        else if (e < SPP_LN1(D) + 2 * D) dst = tw.g_ln1_b[L] ? tw.g_ln1_b[L] + (e - SPP_LN1(D) - D) : nullptr;
+        else if (e < SPP_B2(D) + D) dst = tw.g_b2[L] ? tw.g_b2[L] + (e - SPP_B2(D)) : nullptr;
+        else if (e < SPP_LNF(D) + D) dst = (L == 0 && tw.g_lnf_w) ? tw.g_lnf_w + (e - SPP_LNF(D)) : nullptr;
+        else if (e < SPP_LNF(D) + 2 * D) dst = (L == 0 && tw.g_lnf_b) ? tw.g_lnf_b + (e - SPP_LNF(D) - D) : nullptr;
+    }
+    float s = 0.f;
+    if (dst && grp < NG) {
+        const float* p = tw.part + (long)L * tw.ntiles * SPP_STRIDE + e;
+#pragma unroll 8
+        for (int w = grp; w < tw.ntiles; w += NG) s += p[(long)w * SPP_STRIDE];
+    }
+    if (grp < NG) red[grp * RLD + col] = s;
+    __syncthreads();
+    if (grp == 0 && dst) {
+        float v = 0.f;
+#pragma unroll
+        for (int g2 = 0; g2 < NG; ++g2) v += red[g2 * RLD + col];
+        if (shared_dst) atomicAdd(dst, v);
+        else *dst += v;
+    }
+}
+#define SPR_NBX ((SPP_STRIDE + SPR_COLS - 1) / SPR_COLS)        // workgroups per (tower, slot set)
+
+// tower_bwd.hip: fills `x` for the slot reduction of tower t's fused single-tower backward launch at batch B; returns false if
+// that launch does not use slots.  (The caller reduces: immediately, or inside the next weight-gradient launch when the tower's
+// wgrad_flags carry M2M_WGRAD_REDUCES_SMALL.)
+bool m2m_small_part_deferred(SplitReduceTower& x, const m2m_tower* t, int B);
+int m2m_split_small_grads(const SplitReduceArgs& a, hipStream_t st);

@@ -551,66 +551,15 @@ __global__ __launch_bounds__(NTHREADS) void split_mix_bwd_kernel(const SplitMixB
 // ---------------------------------------------------------------------------------------------------------------------------
 // sum of the per-workgroup partial sums of one backward pass into the gradient buffers (+=), deterministic order
 // ---------------------------------------------------------------------------------------------------------------------------
-#define SPR_COLS 32        // slot entries per workgroup
-#define SPR_GROUPS 32      // workgroup-tile groups summed in parallel, then through LDS (256 slots: 8 loads per thread, one batch)
 __global__ __launch_bounds__(SPR_COLS * SPR_GROUPS) void split_small_grads_kernel(const SplitReduceArgs a) {
-    __shared__ float red[SPR_GROUPS][SPR_COLS + 1];
-    const SplitReduceTower& tw = a.t[blockIdx.z];
-    const int L = blockIdx.y;
-    if (L >= tw.nlaunch) return;
-    const int D = tw.D, N = tw.N, T = tw.T;
-    const int col = threadIdx.x % SPR_COLS, grp = threadIdx.x / SPR_COLS;
-    const int e = blockIdx.x * SPR_COLS + col;
-    // slot entry -> destination
-    float* dst = nullptr;
-    bool shared_dst = false;
-    if (tw.nheads > 0 && L >= tw.head_set0) {                    // a classification head's slot set
-        const int h = L - tw.head_set0, KD = tw.K * D;
-        if (e < KD) dst = tw.g_hw[h] + e;
-        else if (e < KD + tw.K) dst = tw.g_hb[h] + (e - KD);
-        else if (e == KD + tw.K) dst = tw.losses + h;
-        else if (e == KD + tw.K + 1) { dst = tw.losses + tw.nheads; shared_dst = true; }   // the total: every head's set adds to it
-    } else if (e < SPP_STRIDE) {
-        const int ntok = 2 * T * N + T + N;
-        if (e < D) dst = tw.g_ln2_w[L] ? tw.g_ln2_w[L] + e : nullptr;
-        else if (e < 2 * D) dst = tw.g_ln2_b[L] ? tw.g_ln2_b[L] + (e - D) : nullptr;
-        else if (e < SPP_TOK(D) + ntok) {
-            const int i = e - SPP_TOK(D);
-            if (tw.g_tok_w1[L]) {
-                if (i < T * N) dst = tw.g_tok_w1[L] + i;
-                else if (i < 2 * T * N) dst = tw.g_tok_w2[L] + (i - T * N);
-                else if (i < 2 * T * N + T) dst = tw.g_tok_b1[L] + (i - 2 * T * N);
-                else dst = tw.g_tok_b2[L] + (i - 2 * T * N - T);
-            }
-        }
-        else if (e < SPP_LN1(D)) dst = nullptr;
-        else if (e < SPP_LN1(D) + D) dst = tw.g_ln1_w[L] ? tw.g_ln1_w[L] + (e - SPP_LN1(D)) : nullptr;
-        else if (e < SPP_LN1(D) + 2 * D) dst = tw.g_ln1_b[L] ? tw.g_ln1_b[L] + (e - SPP_LN1(D) - D) : nullptr;
-        else if (e < SPP_B2(D) + D) dst = tw.g_b2[L] ? tw.g_b2[L] + (e - SPP_B2(D)) : nullptr;
-        else if (e < SPP_LNF(D) + D) dst = (L == 0 && tw.g_lnf_w) ? tw.g_lnf_w + (e - SPP_LNF(D)) : nullptr;
-        else if (e < SPP_LNF(D) + 2 * D) dst = (L == 0 && tw.g_lnf_b) ? tw.g_lnf_b + (e - SPP_LNF(D) - D) : nullptr;
-    }
-    float s = 0.f;
-    if (dst) {
-        const float* p = tw.part + (long)L * tw.ntiles * SPP_STRIDE + e;
-#pragma unroll 8
-        for (int w = grp; w < tw.ntiles; w += SPR_GROUPS) s += p[(long)w * SPP_STRIDE];
-    }
-    red[grp][col] = s;
-    __syncthreads();
-    if (grp == 0 && dst) {
-        float v = 0.f;
-#pragma unroll
-        for (int g2 = 0; g2 < SPR_GROUPS; ++g2) v += red[g2][col];
-        if (shared_dst) atomicAdd(dst, v);
-        else *dst += v;
-    }
+    __shared__ float red[SPR_GROUPS * (SPR_COLS + 1)];
+    split_small_grads_body<SPR_COLS * SPR_GROUPS>(a.t[blockIdx.z], blockIdx.x, blockIdx.y, red);
 }
 
 int m2m_split_small_grads(const SplitReduceArgs& a, hipStream_t st) {
     int nl = 0;
     for (int i = 0; i < a.ntow; ++i) nl = a.t[i].nlaunch > nl ? a.t[i].nlaunch : nl;
-    hipLaunchKernelGGL(split_small_grads_kernel, dim3((SPP_STRIDE + SPR_COLS - 1) / SPR_COLS, nl, a.ntow), dim3(SPR_COLS * SPR_GROUPS), 0, st, a);
+    hipLaunchKernelGGL(split_small_grads_kernel, dim3(SPR_NBX, nl, a.ntow), dim3(SPR_COLS * SPR_GROUPS), 0, st, a);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
 }

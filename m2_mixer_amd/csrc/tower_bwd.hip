@@ -1094,6 +1094,14 @@ static void m2m_small_part_reduce_args(SplitReduceTower& x, const m2m_tower* t, 
         x.g_b2[L] = k.g_ch_b2;
     }
 }
+bool m2m_split_eligible(const m2m_tower* t, int B, int training);
+// see split.h: the slot reduction of the fused single-tower backward launch (launch_bwd_dm) of tower t at batch B
+bool m2m_small_part_deferred(SplitReduceTower& x, const m2m_tower* t, int B) {
+    if (!t || m2m_is_wide(t) || t->N < 1 || t->N > 8 || !m2m_small_part(t) || m2m_split_eligible(t, B, 1)) return false;
+    const int SPW = BM / t->N;
+    m2m_small_part_reduce_args(x, t, (B + SPW - 1) / SPW);
+    return true;
+}
 template <int P, int D, int NMAX, int TG, int DM, bool PART = false, bool HREC = false>
 __global__ __launch_bounds__(NTHREADS) void tower_bwd_group_kernel(const BwdGroupArgs a, int B, unsigned int seed,
                                                                    unsigned int step_host, const unsigned int* __restrict__ step_dev) {
@@ -1176,7 +1184,7 @@ static int launch_bwd_dm(const m2m_tower* t, int B, const float* d_out, long d_o
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, st, *t, B, d_out, d_out_ss, d_pooled, d_x0, d_x0_ss, seed, step, step_dev);
     M2M_CHECK_HIP(hipGetLastError());
-    if (part) {
+    if (part && !(t->wgrad_flags & M2M_WGRAD_REDUCES_SMALL)) {       // (flagged: the next weight-gradient launch reduces the slots)
         SplitReduceArgs r;
         memset(&r, 0, sizeof(r));
         r.ntow = 1;

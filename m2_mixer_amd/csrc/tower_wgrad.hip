@@ -15,6 +15,7 @@
 // zeroed gradient with float atomics (a + b == b + a: still bit-deterministic).
 #include "tile.h"
 #include "embed_wgrad.h"
+#include "split.h"
 #include <stdlib.h>
 #include <string.h>
 bool m2m_split_eligible(const m2m_tower* t, int B, int training);     // split_api.hip
@@ -359,6 +360,7 @@ struct WgradGroupArgs {
     int dma;                                          // stored-operand form: every stream on LDS-DMA (wgrad_dma_body)
     int n_embed_first, n_embed_pad;                   // embedding workgroups dispatched FIRST: ids [0, n_embed_first), padded to a
                                                       // multiple of 8 (n_embed_pad) so that tower ids keep their XCD (id % 8)
+    int n_reduce, reduce_sets;                         // slot-reduction workgroups at the END of the grid: SPR_NBX x reduce_sets x ra.ntow
     unsigned int seed, step_host;
     const unsigned int* step_dev;
 };
@@ -373,9 +375,18 @@ struct WgradGroupArgs {
 // graph (~10 us each) and slows this kernel by contending for the same CUs.
 template <int P, int D, int RCDM>
 __global__ __launch_bounds__((WgradKernelGeom<P, D, RCDM>::THREADS), (WgradKernelGeom<P, D, RCDM>::MINWAVES)) void tower_wgrad_group_kernel(const WgradGroupArgs a,
-                                                                                                          const EmbedWgradGroupArgs ea) {
+                                                                                                          const EmbedWgradGroupArgs ea,
+                                                                                                          const SplitReduceArgs ra) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int id = blockIdx.x;
+    // The slot reduction of a preceding fused backward launch (M2M_WGRAD_REDUCES_SMALL): ~140 short workgroups at the end of the
+    // grid -- they run on the CUs the one-per-CU tower workgroups leave free, long before those finish.
+    if (a.n_reduce && id >= (int)gridDim.x - a.n_reduce) {
+        const int rid = id - ((int)gridDim.x - a.n_reduce);
+        const int bx = rid % SPR_NBX, L = (rid / SPR_NBX) % a.reduce_sets, z = rid / (SPR_NBX * a.reduce_sets);
+        split_small_grads_body<WgradKernelGeom<P, D, RCDM>::THREADS>(ra.t[z], bx, L, reinterpret_cast<float*>(smem));
+        return;
+    }
     if (id < a.n_embed_pad) {
         if (id < a.n_embed_first) embed_wgrad_group_body<P, D, WgradKernelGeom<P, D, RCDM>::THREADS>(ea, id, smem);
         return;
@@ -397,6 +408,8 @@ __global__ __launch_bounds__((WgradKernelGeom<P, D, RCDM>::THREADS), (WgradKerne
     wgrad_dispatch<P, D, RCDM>(tw, (int)a.job_block[job], slice, group, a.groups[t], a.slot[t], a.ntiles[t], a.tpg[t], a.rpt[t], a.seed,
                                step, a.dma, smem);
 }
+
+static_assert(sizeof(WgradGroupArgs) + sizeof(EmbedWgradGroupArgs) + sizeof(SplitReduceArgs) <= 3840, "kernel arguments are limited to 4 KiB");
 
 // The single-owner embedding gradients as a launch of their own (256 threads, in front of the tower launch on the same stream):
 // beside five-wave tower workgroups (one per CU, SIMD 0 full) an embedding workgroup finds room only on the 16 CUs the 240 tower
@@ -606,7 +619,23 @@ static int launch_wgrad_group(const m2m_tower* const* host, const m2m_tower* con
     // launch's end depends on where those land: 101-121 us measured from box to box, against a steady ~95 us).
     static const int embed_first = wgrad_env("M2M_EMBED_FIRST", 1);
     if (ea.fast && n_embed_wgs && embed_first) { a.n_embed_first = n_embed_wgs; a.n_embed_pad = (n_embed_wgs + 7) & ~7; n_embed_wgs = 0; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(a.n_embed_pad + a.n_tower_wgs + n_embed_wgs)), dim3(KG::THREADS), lds, st, a, ea);
+    // slot reductions deferred to this launch (towers flagged M2M_WGRAD_REDUCES_SMALL whose backward used slots): up to two
+    // ride here, more get the reduction launch of their own
+    SplitReduceArgs ra;
+    memset(&ra, 0, sizeof(ra));
+    for (int i = 0; i < n; ++i) {
+        if (!(host[i]->wgrad_flags & M2M_WGRAD_REDUCES_SMALL)) continue;
+        SplitReduceTower x;
+        if (!m2m_small_part_deferred(x, host[i], B)) continue;
+        if (ra.ntow < 2 && KG::THREADS % SPR_COLS == 0) { ra.t[ra.ntow++] = x; continue; }
+        SplitReduceArgs one;
+        memset(&one, 0, sizeof(one));
+        one.t[0] = x; one.ntow = 1;
+        if (int rc = m2m_split_small_grads(one, st)) return rc;
+    }
+    for (int i = 0; i < ra.ntow; ++i) a.reduce_sets = ra.t[i].nlaunch > a.reduce_sets ? ra.t[i].nlaunch : a.reduce_sets;
+    a.n_reduce = SPR_NBX * a.reduce_sets * ra.ntow;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.n_embed_pad + a.n_tower_wgs + n_embed_wgs + a.n_reduce)), dim3(KG::THREADS), lds, st, a, ea, ra);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -628,6 +657,14 @@ extern "C" int m2m_tower_wgrad(const m2m_tower* t, int B, uint32_t seed, uint32_
     if (int rc = m2m_check_tower(t, B)) return rc;
     if (t->nblocks == 0) return 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (t->wgrad_flags & M2M_WGRAD_REDUCES_SMALL) {              // the deferred slot reduction of this tower's backward: its own launch here
+        SplitReduceArgs one;
+        memset(&one, 0, sizeof(one));
+        if (m2m_small_part_deferred(one.t[0], t, B)) {
+            one.ntow = 1;
+            if (int rc = m2m_split_small_grads(one, st)) return rc;
+        }
+    }
     if (m2m_wgrad_recompute(t, B)) {
         if (m2m_drop_mode(1, t->p_drop) == DM_HALF) return launch_wgrad<PREC_BF16, 128, DM_HALF>(t, B, seed, step, step_dev, st);
         return launch_wgrad<PREC_BF16, 128, DM_NONE>(t, B, seed, step, step_dev, st);

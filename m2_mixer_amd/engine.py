@@ -574,6 +574,9 @@ class _TwoTowerEngine(_FlatEngine):
                                  os.environ.get("M2M_EARLY_FUSION_WGRAD", "0") == "1")
         self._setup_wgrad([[self.t_fus], [self.t_a, self.t_b]] if self._early_fus_wgrad else [[self.t_fus, self.t_a, self.t_b]])
         self._fused_heads = self._heads_are_ce() and self.t_fus.backward_heads_ok(B, 3, self.K)
+        # the fusion tower's backward is always followed by the weight-gradient launch (_backward): the reduction of its
+        # small-gradient slots rides there instead of being a launch between the two backward launches (M2M_DEFER_SMALL=0: A/B)
+        self.t_fus.set_wgrad_reduces_small(not self._fused_heads and os.environ.get("M2M_DEFER_SMALL", "1") != "0")
         # the embeddings' weight gradients in their single-owner form: the tower backward leaves d_x0^T as packed blocks
         self._embed_towers = []
         if os.environ.get("M2M_EMBED_FAST", "1") != "0" and self.t_a.enable_dx0_image(B) and self.t_b.enable_dx0_image(B):

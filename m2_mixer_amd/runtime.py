@@ -339,6 +339,11 @@ class TowerRuntime:
     def set_wgrad_overwrite(self, on: bool):
         self.desc.wgrad_flags = (self.desc.wgrad_flags | L.WGRAD_OVERWRITE) if on else (self.desc.wgrad_flags & ~L.WGRAD_OVERWRITE)
 
+    def set_wgrad_reduces_small(self, on: bool):
+        """Every backward of this tower is followed by a weight-gradient launch that includes it: the reduction of the backward's
+        per-workgroup slots (small parameter gradients) rides in that launch (include/m2mixer.h: M2M_WGRAD_REDUCES_SMALL)."""
+        self.desc.wgrad_flags = (self.desc.wgrad_flags | L.WGRAD_REDUCES_SMALL) if on else (self.desc.wgrad_flags & ~L.WGRAD_REDUCES_SMALL)
+
     def wgrad_fold(self):
         L.check(L.lib().m2m_wgrad_fold(C.byref(self.desc), L.stream_ptr()), "wgrad_fold")
 
