@@ -181,7 +181,8 @@ class _FlatEngine:
         self.s_b = torch.cuda.Stream(device=dev)
         self.s_fus = torch.cuda.Stream(device=dev)
         self.s_emb = torch.cuda.Stream(device=dev)
-        self.concurrent = True
+        import os
+        self.concurrent = os.environ.get("M2M_CONCURRENT", "1") != "0"      # 0: every launch on the main stream (A/B)
         self._build()
         self.pack()
 
@@ -243,9 +244,10 @@ class _FlatEngine:
         return dict(pooled=pooled, w=P[key + "weight"], b=P[key + "bias"], g_w=Gr[key + "weight"], g_b=Gr[key + "bias"],
                     d_pooled=d_pooled if with_grad else None, weight=weight)
 
-    def _streams(self):
+    def _streams(self, concurrent: Optional[bool] = None):
         main = torch.cuda.current_stream()
-        return main, (self.s_b if self.concurrent else main), (self.s_fus if self.concurrent else main)
+        conc = self.concurrent if concurrent is None else (concurrent and self.concurrent)
+        return main, (self.s_b if conc else main), (self.s_fus if conc else main)
 
     # ---- parameters --------------------------------------------------------------------------------------
     def reset_parameters(self, seed: int = 42):
@@ -827,6 +829,13 @@ class MimicEngine(_FlatEngine):
             raise RuntimeError("time hidden_dim / proj_dim, static output_dim and fusion hidden_dim must agree")
         self.Nt = ct["num_patch"]
         self.Nf = 1 + self.Nt
+        # Side streams (static MLP beside the time tower; the three parameter segments' weight gradients + Adam side by side):
+        # every fork / join edge of the replayed graph costs ~5 us, the launches they hide are 5-30 us at the cfg batch:
+        # measured 0.230 ms on one stream against 0.255 ms on three (fwd only 0.257, bwd only 0.25-0.27); at batch 8192 the
+        # launches are long enough: 2.445 ms on three streams against 2.492 on one.  M2M_MIMIC_STREAMS=fwd|bwd|both|none (A/B).
+        import os
+        mode = os.environ.get("M2M_MIMIC_STREAMS", "none" if self.B <= 1024 else "both")
+        self._conc_fwd, self._conc_bwd = mode in ("fwd", "both"), mode in ("bwd", "both")
         self.t_time = self._make_tower("time_mixer.", ct, self.Nt, 0)
         self.t_fus = self._make_tower("fusion_mixer.", cm, self.Nf, 2048)
         # (B, N, K) rows == a (B, 1, N, K) image cut into (1, K) patches
@@ -863,7 +872,7 @@ class MimicEngine(_FlatEngine):
         sd = self.drop_step if training else None
         fs = self.Nf * D
         time_part = self.fused.view(-1)[D:]                 # tokens 1..Nt of every sample
-        main, side, _ = self._streams()
+        main, side, _ = self._streams(self._conc_fwd)
         side.wait_stream(main)
         with torch.cuda.stream(side):                       # the static MLP beside the time tower: token 0 + its head's input
             self.mlp.forward(static, B, self.fused, fs, self.pool_static, training, self.seed, 0, sd)
@@ -883,7 +892,7 @@ class MimicEngine(_FlatEngine):
         sd = self.drop_step
         self.t_fus.backward(B, None, 0, self.dpool_fus, self.d_fused, fs, self.seed, 0, sd)
         d_time_part = self.d_fused.view(-1)[D:]
-        main, s_b, s_f = self._streams()
+        main, s_b, s_f = self._streams(self._conc_bwd)
         s_b.wait_stream(main)
         s_f.wait_stream(main)
         with torch.cuda.stream(s_b):                        # static MLP: gradient of token 0 + of its own head
