@@ -199,6 +199,10 @@ int m2m_tower_forward(const m2m_tower* t, const float* x0, int64_t x0_sample_str
  * instead of two launches on two streams: no cross-queue fork / join in a replayed graph.  Both towers must be on the
  * fused path, share precision, hidden_dim, dropout and token class, and have at most 4 blocks; otherwise -1 (launch them
  * separately).  Arguments per tower as for m2m_tower_forward. */
+/* 1: m2m_towers_forward / m2m_towers_backward take this pair at batch B in one launch per phase (fused-path pairs as described
+ * above; wide pairs -- N > 8 or D > 128 -- with hidden_dim 256, token_dim <= 16, equal block counts, at most 256 column blocks:
+ * MM-IMDb's two modality towers at its cfg batch: every launch of the pair is one launch on the caller's stream). */
+int m2m_towers_can_group(const m2m_tower* a, const m2m_tower* b, int B);
 typedef struct m2m_tower_io {
     const float* x0; int64_t x0_sample_stride;
     float* out; int64_t out_sample_stride;

@@ -124,6 +124,7 @@ SIGNATURES = {
     "m2m_tower_backward_heads": (C.c_int, [C.POINTER(Tower), C.c_int, C.POINTER(Head), C.c_int, C.c_int, _fp, C.c_int, _fp, _fp, _fp, _fp,
                                            C.c_int64, C.c_uint32, C.c_uint32, _fp, _fp]),
     "m2m_tower_wgrad": (C.c_int, [C.POINTER(Tower), C.c_int, C.c_uint32, C.c_uint32, _fp, _fp]),
+    "m2m_towers_can_group": (C.c_int, [C.POINTER(Tower), C.POINTER(Tower), C.c_int]),
     "m2m_towers_forward": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.POINTER(TowerIO), C.c_int, C.c_int, C.c_int, C.c_uint32,
                                      C.c_uint32, _fp, _fp]),
     "m2m_towers_backward": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.POINTER(TowerGIO), C.c_int, C.c_int, C.c_uint32, C.c_uint32,

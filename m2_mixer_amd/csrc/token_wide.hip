@@ -95,12 +95,11 @@ static __device__ __forceinline__ void tok_row_stats(const float* __restrict__ s
 }
 
 // ---- forward: x_mid = x + Dropout(W2 Dropout(GELU(W1 LN1(x)^T + b1)) + b2)^T  (modules/mixer.py:30-35, :43) ------
-template <int P, int DM, int TM, int NW>
-__global__ __launch_bounds__(NW * 64) void token_fwd_kernel(const m2m_tower tw, int b, const float* __restrict__ src, long src_ss,
-                                                               int B, float* __restrict__ x_mid, float* __restrict__ save_x_in,
-                                                               int training, unsigned int seed, unsigned int step_host,
-                                                               const unsigned int* __restrict__ step_dev) {
-    extern __shared__ __attribute__((aligned(16))) float smf[];
+template <int P, int DM, int TM, int NW, class TW>
+static __device__ __forceinline__ void token_fwd_body(const TW& tw, int b, int bx, const float* __restrict__ src, long src_ss,
+                                                      int B, float* __restrict__ x_mid, float* __restrict__ save_x_in,
+                                                      int training, unsigned int seed, unsigned int step_host,
+                                                      const unsigned int* __restrict__ step_dev, float* smf) {
     const int N = tw.N, T = tw.T, D = tw.D;
     const TokGeom tg = tok_geom(D);
     float* w1s = smf;
@@ -118,8 +117,8 @@ __global__ __launch_bounds__(NW * 64) void token_fwd_kernel(const m2m_tower tw, 
     const Drop dr_th = make_drop(training, tw.p_drop, seed, step, site + 0);
     const Drop dr_to = make_drop(training, tw.p_drop, seed, step, site + 1);
 
-    const int s_first = (blockIdx.x / tg.chunks) * tg.spw;
-    const int chunk = blockIdx.x % tg.chunks;
+    const int s_first = (bx / tg.chunks) * tg.spw;
+    const int chunk = bx % tg.chunks;
     const int ns = min(tg.spw, B - s_first);
     tok_stage_weights(bk, N, T, TM, w1s, w2s, b1s, b2s, tid, (NW * 64));
     tok_row_stats(src, src_ss, s_first, ns * N, N, D, stats, lane, wave, NW);
@@ -210,13 +209,41 @@ __global__ __launch_bounds__(NW * 64) void token_fwd_kernel(const m2m_tower tw, 
     }
 }
 
+template <int P, int DM, int TM, int NW>
+__global__ __launch_bounds__(NW * 64) void token_fwd_kernel(const m2m_tower tw, int b, const float* __restrict__ src, long src_ss,
+                                                               int B, float* __restrict__ x_mid, float* __restrict__ save_x_in,
+                                                               int training, unsigned int seed, unsigned int step_host,
+                                                               const unsigned int* __restrict__ step_dev) {
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    token_fwd_body<P, DM, TM, NW>(tw, b, blockIdx.x, src, src_ss, B, x_mid, save_x_in, training, seed, step_host, step_dev, smf);
+}
+// Two towers (same token_dim class, hidden_dim, dropout) in one launch: blockIdx.y = tower.  One launch on one stream instead
+// of two launches on two queues: no fork / join edges in the replayed graph (~5 us each).
+struct TokGroupArgs {
+    m2m_tower4 tw[2];
+    const float* src[2]; long src_ss[2];     // forward: block input rows
+    float* dst[2];                            // forward: x_mid; backward: dU
+    float* save[2];                           // forward: where to save the block input (or NULL)
+    const float* g_mid[2];                    // backward: gradient wrt x_mid
+    int nblk[2];                              // column blocks (= workgroups) of each tower
+};
+static_assert(sizeof(TokGroupArgs) <= 3584, "kernel arguments are limited to 4 KiB");
+template <int P, int DM, int TM, int NW>
+__global__ __launch_bounds__(NW * 64) void token_fwd_group_kernel(const TokGroupArgs a, int b, int B, int training, unsigned int seed,
+                                                                     unsigned int step_host, const unsigned int* __restrict__ step_dev) {
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    const int t = blockIdx.y;
+    if ((int)blockIdx.x >= a.nblk[t]) return;
+    token_fwd_body<P, DM, TM, NW>(a.tw[t], b, blockIdx.x, a.src[t], a.src_ss[t], B, a.dst[t], a.save[t], training, seed, step_host, step_dev, smf);
+}
+
 // ---- backward, column part: dU (gradient wrt LN1 output) + token-MLP parameter gradients --------------------------
 //   g_mid : gradient wrt x_mid (dense rows);  x_in : saved block input (dense rows);  du_out : receives dU (dense rows)
-template <int P, int DM, int TM, int NW>
-__global__ __launch_bounds__(NW * 64) void token_bwd_cols_kernel(const m2m_tower tw, int b, const float* __restrict__ g_mid, int B,
-                                                                    float* __restrict__ du_out, unsigned int seed,
-                                                                    unsigned int step_host, const unsigned int* __restrict__ step_dev, int iters) {
-    extern __shared__ __attribute__((aligned(16))) float smf[];
+template <int P, int DM, int TM, int NW, class TW>
+static __device__ __forceinline__ void token_bwd_cols_body(const TW& tw, int b, int bx, const float* __restrict__ g_mid, int B,
+                                                           float* __restrict__ du_out, unsigned int seed,
+                                                           unsigned int step_host, const unsigned int* __restrict__ step_dev, int iters,
+                                                           float* smf) {
     const int N = tw.N, T = tw.T, D = tw.D;
     const TokGeom tg = tok_geom(D);
     float* w1s = smf;
@@ -249,7 +276,7 @@ __global__ __launch_bounds__(NW * 64) void token_bwd_cols_kernel(const m2m_tower
     for (int i = tid; i < 2 * N * TM + TM + N; i += (NW * 64)) gw1s[i] = 0.f;
     const int nblk = ((B + tg.spw - 1) / tg.spw) * tg.chunks;   // column blocks of the launch
     for (int it = 0; it < iters; ++it) {
-    const int blk = blockIdx.x * iters + it;
+    const int blk = bx * iters + it;
     if (blk >= nblk) break;                                      // (uniform)
     const int s_first = (blk / tg.chunks) * tg.spw;
     const int chunk = blk % tg.chunks;
@@ -429,6 +456,22 @@ __global__ __launch_bounds__(NW * 64) void token_bwd_cols_kernel(const m2m_tower
     for (int n = tid; n < N; n += (NW * 64)) atomicAdd(bk.g_tok_b2 + n, gb2s[n]);
 }
 
+template <int P, int DM, int TM, int NW>
+__global__ __launch_bounds__(NW * 64) void token_bwd_cols_kernel(const m2m_tower tw, int b, const float* __restrict__ g_mid, int B,
+                                                                    float* __restrict__ du_out, unsigned int seed,
+                                                                    unsigned int step_host, const unsigned int* __restrict__ step_dev, int iters) {
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    token_bwd_cols_body<P, DM, TM, NW>(tw, b, blockIdx.x, g_mid, B, du_out, seed, step_host, step_dev, iters, smf);
+}
+template <int P, int DM, int TM, int NW>
+__global__ __launch_bounds__(NW * 64) void token_bwd_cols_group_kernel(const TokGroupArgs a, int b, int B, unsigned int seed,
+                                                                          unsigned int step_host, const unsigned int* __restrict__ step_dev) {
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    const int t = blockIdx.y;
+    if ((int)blockIdx.x >= a.nblk[t]) return;
+    token_bwd_cols_body<P, DM, TM, NW>(a.tw[t], b, blockIdx.x, a.g_mid[t], B, a.dst[t], seed, step_host, step_dev, 1, smf);
+}
+
 // ---- backward, row part: dx_in = g_mid + LN1'(dU); gamma / beta gradients ------------------------------------------
 // NWV waves, each walks rows (row = wave, wave + NWV, ...) of the workgroup's rows, two at a time (all six streams of a pair
 // requested before the first reduction); a lane holds columns lane + 64 i.  The gamma / beta sums of a workgroup meet in LDS
@@ -437,17 +480,21 @@ __global__ __launch_bounds__(NW * 64) void token_bwd_cols_kernel(const m2m_tower
 // for 3 MB of traffic), so small launches take 16 waves and 32 rows per workgroup (a quarter of the atomics, same rows per wave).
 #define LN_ROWS 32
 // `dst` may alias `du` (dense, in place): a row's dU is read before its result is written.
+struct Ln1Args {
+    const float* x_in; const float* g_mid; const float* du; const float* gamma;
+    long rows; int N, D; float* dst; long dst_ss; float* g_w; float* g_b;
+};
 template <int NWV>
-__global__ __launch_bounds__(NWV * 64) void ln1_bwd_rows_kernel(const float* __restrict__ x_in, const float* __restrict__ g_mid,
-                                                                const float* du, const float* __restrict__ gamma,
-                                                                long rows, int N, int D, float* dst, long dst_ss,
-                                                                float* __restrict__ g_w, float* __restrict__ g_b, int rows_per_wg) {
-    __shared__ float acc_w[NWV][256], acc_b[NWV][256];
+static __device__ __forceinline__ void ln1_bwd_rows_body(const float* __restrict__ x_in, const float* __restrict__ g_mid,
+                                                         const float* du, const float* __restrict__ gamma,
+                                                         long rows, int N, int D, float* dst, long dst_ss,
+                                                         float* __restrict__ g_w, float* __restrict__ g_b, int rows_per_wg, int bx,
+                                                         float (*acc_w)[256], float (*acc_b)[256]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float gw[4] = {0.f, 0.f, 0.f, 0.f}, gb[4] = {0.f, 0.f, 0.f, 0.f}, gm[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) gm[i] = (lane + 64 * i) < D ? gamma[lane + 64 * i] : 0.f;
-    const long r0 = (long)blockIdx.x * rows_per_wg;
+    const long r0 = (long)bx * rows_per_wg;
     constexpr int RB = 2;
     for (int rr = wave; rr < rows_per_wg; rr += RB * NWV) {
         float v[RB][4], u[RB][4], gmid[RB][4];
@@ -518,6 +565,23 @@ __global__ __launch_bounds__(NWV * 64) void ln1_bwd_rows_kernel(const float* __r
     }
 }
 
+template <int NWV>
+__global__ __launch_bounds__(NWV * 64) void ln1_bwd_rows_kernel(const float* __restrict__ x_in, const float* __restrict__ g_mid,
+                                                                const float* du, const float* __restrict__ gamma,
+                                                                long rows, int N, int D, float* dst, long dst_ss,
+                                                                float* __restrict__ g_w, float* __restrict__ g_b, int rows_per_wg) {
+    __shared__ float acc_w[NWV][256], acc_b[NWV][256];
+    ln1_bwd_rows_body<NWV>(x_in, g_mid, du, gamma, rows, N, D, dst, dst_ss, g_w, g_b, rows_per_wg, blockIdx.x, acc_w, acc_b);
+}
+struct Ln1GroupArgs { Ln1Args t[2]; };
+template <int NWV>
+__global__ __launch_bounds__(NWV * 64) void ln1_bwd_rows_group_kernel(const Ln1GroupArgs a, int rows_per_wg) {   // blockIdx.y = tower
+    __shared__ float acc_w[NWV][256], acc_b[NWV][256];
+    const Ln1Args& x = a.t[blockIdx.y];
+    if ((long)blockIdx.x * rows_per_wg >= x.rows) return;
+    ln1_bwd_rows_body<NWV>(x.x_in, x.g_mid, x.du, x.gamma, x.rows, x.N, x.D, x.dst, x.dst_ss, x.g_w, x.g_b, rows_per_wg, blockIdx.x, acc_w, acc_b);
+}
+
 // pooled[s][d] = mean over the N tokens of out[s]  (x.mean(dim=1), models/avmnist.py:271-272)
 __global__ void token_mean_kernel(const float* __restrict__ out, long out_ss, int B, int N, int D, float* __restrict__ pooled) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -534,6 +598,26 @@ __global__ void token_mean_kernel(const float* __restrict__ out, long out_ss, in
             if (n0 + j < N) a += v[j];
     }
     pooled[i] = a * (1.0f / (float)N);
+}
+
+struct MeanGroupArgs { const float* out[2]; long out_ss[2]; int N[2]; float* pooled[2]; };
+__global__ void token_mean_group_kernel(const MeanGroupArgs a, int B, int D) {                                    // blockIdx.y = tower
+    const int t = blockIdx.y;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * D || !a.pooled[t]) return;
+    const long s = i / D, d = i % D;
+    const float* col = a.out[t] + s * a.out_ss[t] + d;
+    const int N = a.N[t];
+    float acc = 0.f;
+    for (int n0 = 0; n0 < N; n0 += TW_UB) {
+        float v[TW_UB];
+#pragma unroll
+        for (int j = 0; j < TW_UB; ++j) v[j] = col[(long)min(n0 + j, N - 1) * D];
+#pragma unroll
+        for (int j = 0; j < TW_UB; ++j)
+            if (n0 + j < N) acc += v[j];
+    }
+    a.pooled[t][i] = acc * (1.0f / (float)N);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
@@ -640,6 +724,170 @@ static int token_fwd(const m2m_tower* t, int b, const float* src, long src_ss, i
 static int token_bwd(const m2m_tower* t, int b, const float* g_mid, int B, float* du, unsigned int seed, unsigned int step,
                      const unsigned int* step_dev, hipStream_t st) {
     M2M_TOK_DISPATCH(launch_token_bwd, 1, t, b, g_mid, B, du, seed, step, step_dev, st);
+}
+
+// ---- two wide towers per launch (m2m_towers_forward / _backward) ---------------------------------------------------------
+// Conditions (m2m_can_group_wide): same precision, hidden_dim 256, dropout, token_dim class and block count (<= 4), small launches
+// (one column block per workgroup).  MM-IMDb's image and text towers; every launch of the pair is then ONE launch on the main
+// stream: the two-queue form paid two fork / join pairs per step (~5 us per edge in a replayed graph) and staggered launches.
+int m2m_chain_forward_rows_group(const m2m_tower* const* v, const float* const* x0, const long* x0_ss, int B, float* const* out,
+                                 const long* out_ss, int training, unsigned int seed, unsigned int step, const unsigned int* step_dev,
+                                 hipStream_t st);                                                        // tower_fwd.hip
+int m2m_chain_backward_rows_group(const m2m_tower* const* v, int B, const float* const* d_out, const long* d_out_ss,
+                                  const float* const* d_pooled, float* const* d_x0, const long* d_x0_ss, unsigned int seed,
+                                  unsigned int step, const unsigned int* step_dev, hipStream_t st);     // tower_bwd.hip
+bool m2m_can_group_wide(const m2m_tower* a, const m2m_tower* b, int B) {
+    static const int off = [] { const char* e = getenv("M2M_WIDE_GROUP"); return e && e[0] == '0'; }();   // diagnostic (A/B)
+    if (off || !m2m_is_wide(a) || !m2m_is_wide(b)) return false;
+    if (a->prec != b->prec || a->D != b->D || a->D != 256 || a->p_drop != b->p_drop) return false;
+    if ((a->T <= 16) != (b->T <= 16) || a->T > 16) return false;        // (16 waves per workgroup: token_dim <= 16)
+    if (a->nblocks != b->nblocks || a->nblocks < 1 || a->nblocks > M2M_GROUP_BLOCKS) return false;
+    const TokGeom g = tok_geom(a->D);
+    return ((B + g.spw - 1) / g.spw) * g.chunks <= 256;                  // the 16-wave, one-block-per-workgroup regime
+}
+
+template <int P, int DM, int TM>
+static int launch_token_fwd_group(const TokGroupArgs& a, int b, int B, int N, int training, unsigned int seed, unsigned int step,
+                                  const unsigned int* step_dev, hipStream_t st) {
+    constexpr int NW = 16;
+    const TokGeom g = tok_geom(a.tw[0].D);
+    const size_t lds = ((tok_lds_floats(N, g.spw, TM) + 3) & ~(size_t)3) * sizeof(float) + (size_t)(NW + 1) * TM * TW_COLS * sizeof(float);
+    auto kern = token_fwd_group_kernel<P, DM, TM, NW>;
+    static size_t attr_lds = 48 * 1024;
+    if (lds > attr_lds) {
+        M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
+    }
+    const int mx = a.nblk[0] > a.nblk[1] ? a.nblk[0] : a.nblk[1];
+    hipLaunchKernelGGL(kern, dim3(mx, 2), dim3(NW * 64), lds, st, a, b, B, training, seed, step, step_dev);
+    M2M_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+template <int P, int DM, int TM>
+static int launch_token_bwd_group(const TokGroupArgs& a, int b, int B, int N, int training_unused, unsigned int seed, unsigned int step,
+                                  const unsigned int* step_dev, hipStream_t st) {
+    constexpr int NW = 16, NC = TokNC<NW>::value;
+    const TokGeom g = tok_geom(a.tw[0].D);
+    const size_t part_f = 2 * TM * TW_COLS > 2 * NC * TW_LDW ? 2 * TM * TW_COLS : 2 * NC * TW_LDW;
+    const size_t lds = ((tok_lds_floats(N, g.spw, TM) + 3) & ~(size_t)3) * sizeof(float) +
+                       ((size_t)2 * TM * TW_LDW + NW * part_f + 2 * N * TM + TM + N) * sizeof(float);
+    if (lds > 160 * 1024) { m2m_set_error("token backward (group): tokens x token_dim exceed the workgroup's LDS", __FILE__, __LINE__); return -1; }
+    auto kern = token_bwd_cols_group_kernel<P, DM, TM, NW>;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
+    }
+    const int mx = a.nblk[0] > a.nblk[1] ? a.nblk[0] : a.nblk[1];
+    hipLaunchKernelGGL(kern, dim3(mx, 2), dim3(NW * 64), lds, st, a, b, B, seed, step, step_dev);
+    M2M_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+// (both towers: token_dim <= 16 -- m2m_can_group_wide)
+#define M2M_TOKG_DISPATCH(FN, training_, p_drop_, prec_, ...)                                       \
+    do {                                                                                            \
+        const int dm_ = m2m_drop_mode(training_, p_drop_);                                         \
+        if (prec_ == PREC_BF16) {                                                                   \
+            if (dm_ == DM_NONE) return FN<PREC_BF16, DM_NONE, 16>(__VA_ARGS__);                    \
+            if (dm_ == DM_HALF) return FN<PREC_BF16, DM_HALF, 16>(__VA_ARGS__);                    \
+            return FN<PREC_BF16, DM_GEN, 16>(__VA_ARGS__);                                         \
+        }                                                                                           \
+        if (dm_ == DM_NONE) return FN<PREC_F32, DM_NONE, 16>(__VA_ARGS__);                         \
+        if (dm_ == DM_HALF) return FN<PREC_F32, DM_HALF, 16>(__VA_ARGS__);                         \
+        return FN<PREC_F32, DM_GEN, 16>(__VA_ARGS__);                                              \
+    } while (0)
+static int token_fwd_group(const TokGroupArgs& a, int b, int B, int N, int training, unsigned int seed, unsigned int step,
+                           const unsigned int* step_dev, hipStream_t st) {
+    M2M_TOKG_DISPATCH(launch_token_fwd_group, training, a.tw[0].p_drop, a.tw[0].prec, a, b, B, N, training, seed, step, step_dev, st);
+}
+static int token_bwd_group(const TokGroupArgs& a, int b, int B, int N, unsigned int seed, unsigned int step,
+                           const unsigned int* step_dev, hipStream_t st) {
+    M2M_TOKG_DISPATCH(launch_token_bwd_group, 1, a.tw[0].p_drop, a.tw[0].prec, a, b, B, N, 1, seed, step, step_dev, st);
+}
+
+int m2m_forward_wide_group(const m2m_tower* const* tw, const m2m_tower_io* io, int B, int training, unsigned int seed,
+                           unsigned int step, const unsigned int* step_dev, hipStream_t st) {
+    if (!tw[0]->ws_a || !tw[0]->ws_b || !tw[1]->ws_a || !tw[1]->ws_b) { m2m_set_error("wide path (N > 8 or D > 128) needs the ws_a / ws_b workspaces", __FILE__, __LINE__); return -1; }
+    const int nb = tw[0]->nblocks;
+    const TokGeom g = tok_geom(tw[0]->D);
+    const int nblk = ((B + g.spw - 1) / g.spw) * g.chunks;
+    const int Nmax = tw[0]->N > tw[1]->N ? tw[0]->N : tw[1]->N;
+    const float* src[2]; long src_ss[2]; long dense[2];
+    for (int i = 0; i < 2; ++i) {
+        if (io[i].x0_parts > 1) { m2m_set_error("towers_forward (wide): k-split inputs are not supported", __FILE__, __LINE__); return -1; }
+        src[i] = io[i].x0; src_ss[i] = (long)io[i].x0_sample_stride; dense[i] = (long)tw[i]->N * tw[i]->D;
+    }
+    for (int b = 0; b < nb; ++b) {
+        const bool last = b == nb - 1;
+        TokGroupArgs a;
+        memset(&a, 0, sizeof(a));
+        float* mid[2]; float* nxt[2]; long nxt_ss[2];
+        m2m_tower v[2]; const m2m_tower* vp[2] = {&v[0], &v[1]};
+        for (int i = 0; i < 2; ++i) {
+            const m2m_block& bk = tw[i]->blk[b];
+            mid[i] = training ? bk.x_mid : tw[i]->ws_a;
+            a.tw[i] = m2m_shrink(tw[i]);
+            a.src[i] = src[i]; a.src_ss[i] = src_ss[i]; a.dst[i] = mid[i];
+            a.save[i] = (training && src[i] != bk.x_in) ? bk.x_in : nullptr;
+            a.nblk[i] = nblk;
+            nxt[i] = last ? io[i].out : (training ? tw[i]->blk[b + 1].x_in : tw[i]->ws_b);
+            nxt_ss[i] = last ? (long)io[i].out_sample_stride : dense[i];
+            v[i] = block_view(tw[i], b);
+        }
+        if (int rc = token_fwd_group(a, b, B, Nmax, training, seed, step, step_dev, st)) return rc;
+        const float* midc[2] = {mid[0], mid[1]};
+        if (int rc = m2m_chain_forward_rows_group(vp, midc, dense, B, nxt, nxt_ss, training, seed, step, step_dev, st)) return rc;
+        for (int i = 0; i < 2; ++i) { src[i] = nxt[i]; src_ss[i] = nxt_ss[i]; }
+    }
+    if (io[0].pooled || io[1].pooled) {
+        MeanGroupArgs m;
+        for (int i = 0; i < 2; ++i) { m.out[i] = io[i].out; m.out_ss[i] = (long)io[i].out_sample_stride; m.N[i] = tw[i]->N; m.pooled[i] = io[i].pooled; }
+        const long n = (long)B * tw[0]->D;
+        hipLaunchKernelGGL(token_mean_group_kernel, dim3((unsigned)((n + 255) / 256), 2), dim3(256), 0, st, m, B, tw[0]->D);
+        M2M_CHECK_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+int m2m_backward_wide_group(const m2m_tower* const* tw, const m2m_tower_gio* io, int B, unsigned int seed, unsigned int step,
+                            const unsigned int* step_dev, hipStream_t st) {
+    if (!tw[0]->ws_a || !tw[0]->ws_b || !tw[1]->ws_a || !tw[1]->ws_b) { m2m_set_error("wide path (N > 8 or D > 128) needs the ws_a / ws_b workspaces", __FILE__, __LINE__); return -1; }
+    const int nb = tw[0]->nblocks;
+    const TokGeom g = tok_geom(tw[0]->D);
+    const int nblk = ((B + g.spw - 1) / g.spw) * g.chunks;
+    const int Nmax = tw[0]->N > tw[1]->N ? tw[0]->N : tw[1]->N;
+    const float* up[2]; long up_ss[2]; const float* up_pooled[2]; long dense[2]; long rows[2];
+    for (int i = 0; i < 2; ++i) {
+        up[i] = io[i].d_out; up_ss[i] = (long)io[i].d_out_sample_stride; up_pooled[i] = io[i].d_pooled;
+        dense[i] = (long)tw[i]->N * tw[i]->D; rows[i] = (long)B * tw[i]->N;
+    }
+    for (int b = nb - 1; b >= 0; --b) {
+        m2m_tower v[2]; const m2m_tower* vp[2] = {&v[0], &v[1]};
+        float* gmid[2];
+        for (int i = 0; i < 2; ++i) { v[i] = block_view(tw[i], b); gmid[i] = tw[i]->ws_b; }
+        // gradient wrt x_mid -> ws_b
+        if (int rc = m2m_chain_backward_rows_group(vp, B, up, up_ss, up_pooled, gmid, dense, seed, step, step_dev, st)) return rc;
+        // dU -> ws_a, token parameter gradients
+        TokGroupArgs a;
+        memset(&a, 0, sizeof(a));
+        for (int i = 0; i < 2; ++i) { a.tw[i] = m2m_shrink(tw[i]); a.g_mid[i] = tw[i]->ws_b; a.dst[i] = tw[i]->ws_a; a.nblk[i] = nblk; }
+        if (int rc = token_bwd_group(a, b, B, Nmax, seed, step, step_dev, st)) return rc;
+        // gradient wrt the block input -> ws_a in place (row-local), or the caller's buffer for the first block
+        Ln1GroupArgs l;
+        long maxrows = 0;
+        for (int i = 0; i < 2; ++i) {
+            const m2m_block& bk = tw[i]->blk[b];
+            Ln1Args& x = l.t[i];
+            x.x_in = bk.x_in; x.g_mid = tw[i]->ws_b; x.du = tw[i]->ws_a; x.gamma = bk.ln1_w; x.rows = rows[i]; x.N = tw[i]->N; x.D = tw[i]->D;
+            x.dst = b > 0 ? tw[i]->ws_a : io[i].d_x0; x.dst_ss = b > 0 ? dense[i] : (long)io[i].d_x0_sample_stride;
+            x.g_w = bk.g_ln1_w; x.g_b = bk.g_ln1_b;
+            maxrows = rows[i] > maxrows ? rows[i] : maxrows;
+        }
+        hipLaunchKernelGGL(ln1_bwd_rows_group_kernel<16>, dim3((unsigned)((maxrows + LN_ROWS - 1) / LN_ROWS), 2), dim3(1024), 0, st, l, LN_ROWS);
+        M2M_CHECK_HIP(hipGetLastError());
+        for (int i = 0; i < 2; ++i) { up[i] = tw[i]->ws_a; up_ss[i] = dense[i]; up_pooled[i] = nullptr; }
+    }
+    return 0;
 }
 
 int m2m_forward_wide(const m2m_tower* t, const float* x0, long x0_ss, int B, float* out, long out_ss, float* pooled,

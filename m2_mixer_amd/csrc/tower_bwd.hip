@@ -1253,6 +1253,29 @@ bool m2m_split_can_group(const m2m_tower* a, const m2m_tower* b);
 int m2m_split_backward(const m2m_tower* const* towers, const m2m_tower_gio* io, int ntow, int B, unsigned int seed, unsigned int step,
                        const unsigned int* step_dev, hipStream_t st);
 
+// Channel-mixing halves (wide path) of two towers' blocks in one launch (token_wide.hip: m2m_backward_wide_group).
+int m2m_chain_backward_rows_group(const m2m_tower* const* v, int B, const float* const* d_out, const long* d_out_ss,
+                                  const float* const* d_pooled, float* const* d_x0, const long* d_x0_ss, unsigned int seed,
+                                  unsigned int step, const unsigned int* step_dev, hipStream_t st) {
+    if (int rc = bwd_split_mode_init(st)) return rc;
+    BwdGroupArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int i = 0; i < 2; ++i) {
+        a.tw[i] = m2m_shrink(v[i]);
+        a.d_out[i] = d_out[i]; a.d_out_ss[i] = d_out_ss[i]; a.d_pooled[i] = d_pooled[i];
+        a.d_x0[i] = d_x0[i]; a.d_x0_ss[i] = d_x0_ss[i];
+        a.ntiles[i] = (int)(((long)B * v[i]->N + BM - 1) / BM);
+    }
+    const m2m_tower* t = v[0];
+    if (t->D == 256 && t->prec == PREC_BF16) return launch_bwd_group<PREC_BF16, 256, 0, 8>(a, B, seed, step, step_dev, st, false);
+    if (t->D == 256 && t->prec == PREC_F32) return launch_bwd_group<PREC_F32, 256, 0, 8>(a, B, seed, step, step_dev, st, false);
+    m2m_set_error("towers_backward (wide): hidden_dim 256 only", __FILE__, __LINE__);
+    return -1;
+}
+bool m2m_can_group_wide(const m2m_tower* a, const m2m_tower* b, int B);       // token_wide.hip
+int m2m_backward_wide_group(const m2m_tower* const* tw, const m2m_tower_gio* io, int B, unsigned int seed, unsigned int step,
+                            const unsigned int* step_dev, hipStream_t st);
+
 extern "C" int m2m_towers_backward(const m2m_tower* const* towers, const m2m_tower_gio* io, int ntowers, int B, uint32_t seed,
                                    uint32_t step, const uint32_t* step_dev, void* stream) {
     if (!towers || !io || ntowers != 2) { m2m_set_error("towers_backward: exactly two towers per launch", __FILE__, __LINE__); return -1; }
@@ -1262,6 +1285,8 @@ extern "C" int m2m_towers_backward(const m2m_tower* const* towers, const m2m_tow
     // the forward of this step took the split path under the same conditions (csrc/split.h)
     if (m2m_split_eligible(towers[0], B, 1) && m2m_split_eligible(towers[1], B, 1) && m2m_split_can_group(towers[0], towers[1]))
         return m2m_split_backward(towers, io, 2, B, seed, step, step_dev, reinterpret_cast<hipStream_t>(stream));
+    if (m2m_can_group_wide(towers[0], towers[1], B))
+        return m2m_backward_wide_group(towers, io, B, seed, step, step_dev, reinterpret_cast<hipStream_t>(stream));
     if (!m2m_can_group(towers[0], towers[1])) {
         m2m_set_error("towers_backward: the two towers do not share a kernel instantiation: launch them separately", __FILE__, __LINE__);
         return -1;

@@ -558,12 +558,39 @@ static int launch_fwd_group(const FwdGroupArgs& a, int B, int training, unsigned
     }
 }
 
+// Channel-mixing halves (wide path) of two towers' blocks in one launch: v[i] = block views (token_wide.hip: m2m_forward_wide_group).
+int m2m_chain_forward_rows_group(const m2m_tower* const* v, const float* const* x0, const long* x0_ss, int B, float* const* out,
+                                 const long* out_ss, int training, unsigned int seed, unsigned int step, const unsigned int* step_dev,
+                                 hipStream_t st) {
+    FwdGroupArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int i = 0; i < 2; ++i) {
+        a.tw[i] = m2m_shrink(v[i]);
+        a.x0[i] = x0[i]; a.x0_ss[i] = x0_ss[i]; a.x0_parts[i] = 1; a.x0_pstride[i] = 0;
+        a.out[i] = out[i]; a.out_ss[i] = out_ss[i]; a.pooled[i] = nullptr;
+        a.ntiles[i] = (int)(((long)B * v[i]->N + BM - 1) / BM);
+    }
+    const m2m_tower* t = v[0];
+    if (t->D == 256 && t->prec == PREC_BF16) return launch_fwd_group<PREC_BF16, 256, 0>(a, B, training, seed, step, step_dev, st);
+    if (t->D == 256 && t->prec == PREC_F32) return launch_fwd_group<PREC_F32, 256, 0>(a, B, training, seed, step, step_dev, st);
+    m2m_set_error("towers_forward (wide): hidden_dim 256 only", __FILE__, __LINE__);
+    return -1;
+}
+bool m2m_can_group_wide(const m2m_tower* a, const m2m_tower* b, int B);       // token_wide.hip
+int m2m_forward_wide_group(const m2m_tower* const* tw, const m2m_tower_io* io, int B, int training, unsigned int seed,
+                           unsigned int step, const unsigned int* step_dev, hipStream_t st);
+
 // True when two towers can share one chain launch: both on the fused path, same kernel instantiation, <= 4 blocks each.
 bool m2m_can_group(const m2m_tower* a, const m2m_tower* b) {
     if (m2m_is_wide(a) || m2m_is_wide(b)) return false;
     if (a->prec != b->prec || a->D != b->D || a->p_drop != b->p_drop) return false;
     if ((a->N <= 4) != (b->N <= 4) || (a->T % 16 == 0) != (b->T % 16 == 0)) return false;
     return a->nblocks <= M2M_GROUP_BLOCKS && b->nblocks <= M2M_GROUP_BLOCKS;
+}
+
+extern "C" int m2m_towers_can_group(const m2m_tower* a, const m2m_tower* b, int B) {
+    if (!a || !b || B < 1) return 0;
+    return (m2m_can_group(a, b) || m2m_can_group_wide(a, b, B)) ? 1 : 0;
 }
 
 extern "C" int m2m_towers_forward(const m2m_tower* const* towers, const m2m_tower_io* io, int ntowers, int B, int training,
@@ -575,6 +602,8 @@ extern "C" int m2m_towers_forward(const m2m_tower* const* towers, const m2m_towe
     if (m2m_split_eligible(towers[0], B, training) && m2m_split_eligible(towers[1], B, training) &&
         m2m_split_can_group(towers[0], towers[1]))
         return m2m_split_forward(towers, io, 2, B, training, seed, step, step_dev, reinterpret_cast<hipStream_t>(stream));
+    if (m2m_can_group_wide(towers[0], towers[1], B))
+        return m2m_forward_wide_group(towers, io, B, training, seed, step, step_dev, reinterpret_cast<hipStream_t>(stream));
     if (!m2m_can_group(towers[0], towers[1])) {
         m2m_set_error("towers_forward: the two towers do not share a kernel instantiation (fused path, precision, hidden_dim, "
                       "dropout, token class, <= 4 blocks): launch them separately", __FILE__, __LINE__);

@@ -557,8 +557,8 @@ class _TwoTowerEngine(_FlatEngine):
         B, D, dev = self.B, self.D, self.device
         f = lambda *s: torch.zeros(*s, device=dev)
         # embedding outputs; a long-K embedding (audio) is computed as k-split partial sums that the tower launch adds
-        grouped = can_group_embeds(self.e_a, self.e_b) and can_group(self.t_a, self.t_b)
-        self.x0_splits = (self.e_a.fwd_splits(), self.e_b.fwd_splits()) if grouped else (1, 1)
+        grouped = can_group_embeds(self.e_a, self.e_b) and can_group(self.t_a, self.t_b, self.B)
+        self.x0_splits = (self.e_a.fwd_splits(), self.e_b.fwd_splits()) if grouped and not self.t_a.wide else (1, 1)
         self._x0_a, self._x0_b = f(self.x0_splits[0], B * self.Na, D), f(self.x0_splits[1], B * self.Nb, D)
         self.x0_a, self.x0_b = self._x0_a[0], self._x0_b[0]
         self.fused, self.fus_out = f(B, self.Nf, D), f(B, self.Nf, D)
@@ -624,7 +624,7 @@ class _TwoTowerEngine(_FlatEngine):
         fs = self.Nf * D
         b_part = self.fused.view(-1)[self.Na * D:]
         main, side, _ = self._streams()
-        if self.concurrent and can_group(self.t_a, self.t_b):
+        if self.concurrent and can_group(self.t_a, self.t_b, self.B):
             # one launch for both patch embeddings, one for both towers (blockIdx.y = tower), all on the main stream: no
             # cross-queue fork / join in the graph (a join costs ~6 us even when its event fired long ago)
             sa, sb = self.x0_splits
@@ -692,7 +692,7 @@ class _TwoTowerEngine(_FlatEngine):
         # gradients, whose workgroups back-fill the CUs the tower workgroups leave idle: the whole step is one queue.
         # (Any side stream forks from and joins into `main` directly: a fork from a forked stream crashed hipGraph
         # capture on ROCm 7.2.)
-        if self.concurrent and can_group(self.t_a, self.t_b):
+        if self.concurrent and can_group(self.t_a, self.t_b, self.B):
             towers_backward([self.t_a, self.t_b],
                             [(self.d_fused, fs, self.dpool_a, self.dx0_a, self.Na * D), (d_b_part, fs, self.dpool_b, self.dx0_b, self.Nb * D)],
                             B, self.seed, 0, sd)

@@ -383,8 +383,11 @@ class TowerRuntime:
         return m
 
 
-def can_group(a: TowerRuntime, b: TowerRuntime) -> bool:
-    """Two towers may share one chain launch (m2m_towers_forward / _backward): fused path, same kernel instantiation."""
+def can_group(a: TowerRuntime, b: TowerRuntime, B: Optional[int] = None) -> bool:
+    """Two towers may share their launches (m2m_towers_forward / _backward): fused path, same kernel instantiation -- or, with the
+    batch size given, whatever the library takes as a pair at that batch (m2m_towers_can_group: also wide pairs at small batch)."""
+    if B is not None:
+        return bool(L.lib().m2m_towers_can_group(C.byref(a.desc), C.byref(b.desc), B))
     return (not a.wide and not b.wide and a.prec == b.prec and a.D == b.D and a.desc.p_drop == b.desc.p_drop
             and (a.N <= 4) == (b.N <= 4) and (a.T % 16 == 0) == (b.T % 16 == 0) and a.nblocks <= 4 and b.nblocks <= 4)
 

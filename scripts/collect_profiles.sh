@@ -32,4 +32,8 @@ echo "secondary done"
 timeout -k 10 300 python scripts/ddp_parity.py fp32 S 2> $O/ddp2_fp32.err | grep '^{' > $O/ddp2_parity_fp32.json || echo "ddp parity fp32 FAILED"
 timeout -k 10 300 python scripts/ddp_parity.py bf16 B 2> $O/ddp2_bf16.err | grep '^{' > $O/ddp2_parity_bf16.json || echo "ddp parity bf16 FAILED"
 M2M_DIST_BACKEND=gloo M2M_FORCE_DEVICE=0 timeout -k 10 300 python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_ddp2_gloo_rehearsal.json 2> $O/bench_ddp2.err || echo "ddp bench rehearsal FAILED"
+# launch timelines of the secondary configurations at their cfg batches, and the GPU suite at this commit
+bash scripts/sec_trace.sh > $O/sec_trace.log 2>&1 && cp gpurun_out/sec/*_step_timeline.txt $O/ || echo "sec trace FAILED"
+python -m pytest tests -m gpu -q > $O/gputest.log 2>&1 || echo "GPU TESTS FAILED"
+tail -1 $O/gputest.log
 echo "all done"

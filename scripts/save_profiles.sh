@@ -10,3 +10,5 @@ cp $F/pmc.json profiles/${R}_pmc.json
 cp $F/pmc_summary_table.md profiles/${R}_pmc_summary.md
 cp $F/secondary_configs.jsonl profiles/${R}_secondary_configs.jsonl
 for f in ddp2_parity_fp32.json ddp2_parity_bf16.json bench_ddp2_gloo_rehearsal.json; do [ -s $F/$f ] && cp $F/$f profiles/${R}_$f; done
+for f in mimic_b128_step_timeline.txt mmimdb_b32_step_timeline.txt; do [ -s $F/$f ] && cp $F/$f profiles/${R}_$f; done
+[ -s $F/gputest.log ] && tail -12 $F/gputest.log > profiles/${R}_gputest_tail.log || true
