@@ -5,12 +5,12 @@ set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p $R/gpurun_out/sec
 cd /tmp && export TMPDIR=/tmp
-for cfg in "mimic 128" "mmimdb 32"; do
+for cfg in "mimic 128 step_prologue" "mmimdb 32 embed_fwd_group"; do
   set -- $cfg
   export TASK=$1 B=$2
   rm -rf $R/gpurun_out/sec/tr_$1
   rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/sec/tr_$1 -o t -- python3 $R/scripts/sec_prof.py > $R/gpurun_out/sec/$1.out 2> $R/gpurun_out/sec/$1.err
-  python3 $R/scripts/timeline2.py $R/gpurun_out/sec/tr_$1 step_prologue > $R/gpurun_out/sec/$1_b$2_step_timeline.txt
+  python3 $R/scripts/timeline2.py $R/gpurun_out/sec/tr_$1 $3 > $R/gpurun_out/sec/$1_b$2_step_timeline.txt
   rm -rf $R/gpurun_out/sec/tr_$1
   echo "== $1 B=$2"; cat $R/gpurun_out/sec/$1_b$2_step_timeline.txt
 done
