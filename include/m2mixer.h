@@ -121,6 +121,10 @@ typedef struct m2m_tower {
 } m2m_tower;
 #define M2M_WGRAD_OVERWRITE 1 /* wgrad_flags: g_ch_w1 / g_ch_b1 / g_ch_w2 are WRITTEN ("="), not accumulated ("+="): the caller
                                * neither zeroes nor accumulates them (the fused engines: one backward per optimizer step) */
+#define M2M_WGRAD_GROUP_SLOTS 4  /* wgrad_flags: in the two-tower backward launch (m2m_towers_backward) this tower's small parameter
+                               * gradients go through per-workgroup slots (m2m_tower.gpart) instead of float atomics -- both
+                               * towers of the launch must carry the flag.  With M2M_WGRAD_REDUCES_SMALL the reduction rides in
+                               * the weight-gradient launch (free); without it, it is a launch of its own (a measured net loss). */
 #define M2M_WGRAD_REDUCES_SMALL 2 /* wgrad_flags: every m2m_tower_backward of this tower is followed by an m2m_towers_wgrad /
                                * m2m_tower_wgrad that includes it (same batch).  Where the backward launch collects its small
                                * parameter gradients (LayerNorms, token MLP, ch_b2) in per-workgroup slots (m2m_tower.gpart), their

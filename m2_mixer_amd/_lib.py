@@ -58,6 +58,7 @@ class Tower(C.Structure):
 
 WGRAD_OVERWRITE = 1      # Tower.wgrad_flags (M2M_WGRAD_OVERWRITE)
 WGRAD_REDUCES_SMALL = 2  # Tower.wgrad_flags (M2M_WGRAD_REDUCES_SMALL)
+WGRAD_GROUP_SLOTS = 4    # Tower.wgrad_flags (M2M_WGRAD_GROUP_SLOTS)
 MAX_GRAD_RANGES = 16
 
 

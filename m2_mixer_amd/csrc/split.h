@@ -118,7 +118,8 @@ struct SplitReduceTower {
     float* g_hw[3]; float* g_hb[3];
     float* losses;                                // [nheads + 1]: per head, then the total
 };
-struct SplitReduceArgs { SplitReduceTower t[2]; int ntow; };
+#define SPR_MAX_TOWERS 3
+struct SplitReduceArgs { SplitReduceTower t[SPR_MAX_TOWERS]; int ntow; };
 
 // ---- reduction of the per-workgroup slots (device body shared by split_mix.hip's launch and the weight-gradient launch) -----
 #define SPR_COLS 32        // slot entries per workgroup

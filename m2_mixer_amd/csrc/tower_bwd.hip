@@ -1303,8 +1303,19 @@ extern "C" int m2m_towers_backward(const m2m_tower* const* towers, const m2m_tow
     }
     // (two-tower launch: measured a net LOSS -- the slot form of this instantiation spills 7 registers around the column loop
     // and its reduction launch costs what the 128-way contended atomics cost -- so it stays opt-in: M2M_SMALL_PART=2)
+    // With M2M_WGRAD_GROUP_SLOTS + M2M_WGRAD_REDUCES_SMALL on both towers the reduction rides in the weight-gradient launch.
     static const bool group_part = [] { const char* e = getenv("M2M_SMALL_PART"); return e && e[0] == '2'; }();
-    const bool part = group_part && m2m_small_part(towers[0]) && m2m_small_part(towers[1]);
+    const bool flagged = (towers[0]->wgrad_flags & M2M_WGRAD_GROUP_SLOTS) && (towers[1]->wgrad_flags & M2M_WGRAD_GROUP_SLOTS);
+    const bool part = (group_part || flagged) && m2m_small_part(towers[0]) && m2m_small_part(towers[1]);
+    const bool defer = flagged && (towers[0]->wgrad_flags & M2M_WGRAD_REDUCES_SMALL) && (towers[1]->wgrad_flags & M2M_WGRAD_REDUCES_SMALL);
+    for (int i = 0; i < 2; ++i) {
+        const int f = towers[i]->wgrad_flags;
+        // (the weight-gradient launch decides from the flags alone whether a tower's slots hold this step's sums)
+        if (((f & M2M_WGRAD_GROUP_SLOTS) && !part) || ((f & M2M_WGRAD_REDUCES_SMALL) && !defer)) {
+            m2m_set_error("towers_backward: M2M_WGRAD_GROUP_SLOTS / M2M_WGRAD_REDUCES_SMALL must be set on both towers, with slot buffers (gpart)", __FILE__, __LINE__);
+            return -1;
+        }
+    }
     for (int i = 0; i < 2; ++i) a.part[i] = part ? towers[i]->gpart : nullptr;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const m2m_tower* t = towers[0];
@@ -1316,7 +1327,7 @@ extern "C" int m2m_towers_backward(const m2m_tower* const* towers, const m2m_tow
         return -1;
     }
     auto finish = [&](int rc) -> int {
-        if (rc || !part) return rc;
+        if (rc || !part || defer) return rc;
         SplitReduceArgs r;
         memset(&r, 0, sizeof(r));
         r.ntow = 2;

@@ -619,7 +619,7 @@ static int launch_wgrad_group(const m2m_tower* const* host, const m2m_tower* con
     // launch's end depends on where those land: 101-121 us measured from box to box, against a steady ~95 us).
     static const int embed_first = wgrad_env("M2M_EMBED_FIRST", 1);
     if (ea.fast && n_embed_wgs && embed_first) { a.n_embed_first = n_embed_wgs; a.n_embed_pad = (n_embed_wgs + 7) & ~7; n_embed_wgs = 0; }
-    // slot reductions deferred to this launch (towers flagged M2M_WGRAD_REDUCES_SMALL whose backward used slots): up to two
+    // slot reductions deferred to this launch (towers flagged M2M_WGRAD_REDUCES_SMALL whose backward used slots): up to three
     // ride here, more get the reduction launch of their own
     SplitReduceArgs ra;
     memset(&ra, 0, sizeof(ra));
@@ -627,7 +627,7 @@ static int launch_wgrad_group(const m2m_tower* const* host, const m2m_tower* con
         if (!(host[i]->wgrad_flags & M2M_WGRAD_REDUCES_SMALL)) continue;
         SplitReduceTower x;
         if (!m2m_small_part_deferred(x, host[i], B)) continue;
-        if (ra.ntow < 2 && KG::THREADS % SPR_COLS == 0) { ra.t[ra.ntow++] = x; continue; }
+        if (ra.ntow < SPR_MAX_TOWERS && KG::THREADS % SPR_COLS == 0) { ra.t[ra.ntow++] = x; continue; }
         SplitReduceArgs one;
         memset(&one, 0, sizeof(one));
         one.t[0] = x; one.ntow = 1;

@@ -579,6 +579,13 @@ class _TwoTowerEngine(_FlatEngine):
         # the fusion tower's backward is always followed by the weight-gradient launch (_backward): the reduction of its
         # small-gradient slots rides there instead of being a launch between the two backward launches (M2M_DEFER_SMALL=0: A/B)
         self.t_fus.set_wgrad_reduces_small(not self._fused_heads and os.environ.get("M2M_DEFER_SMALL", "1") != "0")
+        # the two modality towers' backward launch: slots instead of 128-way contended float atomics for the small gradients,
+        # their reduction in the weight-gradient launch as well (M2M_GROUP_SLOTS=0: atomics, A/B)
+        if (os.environ.get("M2M_GROUP_SLOTS", "1") != "0" and self.t_a.has_small_slots() and self.t_b.has_small_slots()
+                and can_group(self.t_a, self.t_b, self.B)):
+            for t in (self.t_a, self.t_b):
+                t.set_wgrad_group_slots(True)
+                t.set_wgrad_reduces_small(True)
         # the embeddings' weight gradients in their single-owner form: the tower backward leaves d_x0^T as packed blocks
         self._embed_towers = []
         if os.environ.get("M2M_EMBED_FAST", "1") != "0" and self.t_a.enable_dx0_image(B) and self.t_b.enable_dx0_image(B):

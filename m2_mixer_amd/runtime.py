@@ -344,6 +344,16 @@ class TowerRuntime:
         per-workgroup slots (small parameter gradients) rides in that launch (include/m2mixer.h: M2M_WGRAD_REDUCES_SMALL)."""
         self.desc.wgrad_flags = (self.desc.wgrad_flags | L.WGRAD_REDUCES_SMALL) if on else (self.desc.wgrad_flags & ~L.WGRAD_REDUCES_SMALL)
 
+    def has_small_slots(self) -> bool:
+        """The fused backward of this tower can collect its small parameter gradients in per-workgroup slots (ensure_split
+        allocates them; csrc/tower_bwd.hip: m2m_small_part)."""
+        return (not self.wide and self.prec == L.PREC_BF16 and self.D == 128 and self.nblocks > 0
+                and 2 * self.T * self.N + self.T + self.N <= 576)
+
+    def set_wgrad_group_slots(self, on: bool):
+        """Small parameter gradients of the two-tower backward launch through per-workgroup slots (M2M_WGRAD_GROUP_SLOTS)."""
+        self.desc.wgrad_flags = (self.desc.wgrad_flags | L.WGRAD_GROUP_SLOTS) if on else (self.desc.wgrad_flags & ~L.WGRAD_GROUP_SLOTS)
+
     def wgrad_fold(self):
         L.check(L.lib().m2m_wgrad_fold(C.byref(self.desc), L.stream_ptr()), "wgrad_fold")
 
