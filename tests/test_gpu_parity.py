@@ -390,6 +390,59 @@ def test_grouped_launches_match_single_launches(prec, dev):
         assert torch.equal(e._keep["wn"], w)
 
 
+@pytest.mark.parametrize("task", ["avmnist_slots", "mmimdb_pair_launches", "mimic_streams"])
+def test_launch_forms_of_a_step_agree(task, dev, monkeypatch):
+    """The launch forms the engines choose by default against the forms they replace, same parameters / batch / dropout
+    stream: (a) AV-MNIST B bf16: small parameter gradients of all three towers through per-workgroup slots reduced inside the
+    weight-gradient launch (M2M_WGRAD_GROUP_SLOTS / _REDUCES_SMALL) vs float atomics + a reduction launch of its own;
+    (b) MM-IMDb: both modality towers per launch on one stream (m2m_towers_forward / _backward with wide pairs) vs one launch
+    per tower on two streams; (c) MIMIC-H: one stream vs three.  Same arithmetic; only the order of fp32 sums may differ."""
+    from m2_mixer_amd.engine import AVMnistEngine, MimicEngine, MMIMDBEngine
+    if task == "avmnist_slots":
+        cfg, B, prec = dict(G.AVMNIST["B"]), 64, "bf16"
+        make = lambda: AVMnistEngine(cfg, B, device=dev, precision=prec, lr=1e-3, seed=3)
+        batch = G.avmnist_batch(B, 5, cfg)
+        alt_env = {"M2M_GROUP_SLOTS": "0", "M2M_DEFER_SMALL": "0"}
+    elif task == "mmimdb_pair_launches":
+        cfg, B, prec = dict(G.MMIMDB), 5, "fp32"
+        make = lambda: MMIMDBEngine(cfg, B, device=dev, precision=prec, lr=1e-3, seed=3)
+        batch = G.mmimdb_batch(B, 5, cfg)
+        alt_env = {"M2M_CONCURRENT": "0"}
+    else:
+        cfg, B, prec = dict(G.MIMIC_H), 16, "fp32"
+        make = lambda: MimicEngine(cfg, B, device=dev, precision=prec, lr=1e-3, seed=3)
+        batch = G.mimic_batch(B, 5, cfg)
+        alt_env = {"M2M_MIMIC_STREAMS": "both"}
+    batch = tuple(t.to(dev) for t in batch)
+    eng = make()
+    for k, v in alt_env.items():
+        monkeypatch.setenv(k, v)
+    alt = make()
+    alt.load_state_dict(eng.state_dict())
+    if task == "avmnist_slots":
+        assert eng.t_a.desc.wgrad_flags & 4 and eng.t_fus.desc.wgrad_flags & 2 and not (alt.t_a.desc.wgrad_flags & 6)
+    if task == "mmimdb_pair_launches":
+        from m2_mixer_amd.runtime import can_group
+        assert can_group(eng.t_a, eng.t_b, B) and eng.concurrent and not alt.concurrent
+    for e in (eng, alt):
+        e.forward_backward(*batch)
+    torch.cuda.synchronize()
+    # bf16: two runs of the SAME form already differ at rounding level (the backward column loop hands its steps to waves by a
+    # ticket: the order of the fp32 dA sums varies, and a last-bit difference can flip the bf16 rounding of an operand image):
+    # observed maxima 1.5e-3 - 2.8e-3 of a gradient's largest element, spread over all gradients
+    tol = 2e-4 if prec == "fp32" else 1e-2
+    assert relerr(eng.logits, alt.logits) < 1e-5
+    worst = 0.0
+    for k in eng.grads:
+        ga, gb = eng.grads[k], alt.grads[k]
+        if float(gb.abs().max()) == 0.0:
+            assert float(ga.abs().max()) == 0.0, k
+            continue
+        assert relerr(ga, gb) < tol, (k, relerr(ga, gb))
+        worst = max(worst, relerr(ga, gb))
+    observe(f"launch forms [{task}] gradients (rel to max)", worst, tol)
+
+
 def test_training_reduces_loss_bf16(dev):
     """A few dozen Adam steps on one fixed synthetic batch must overfit it (end-to-end sanity of fwd, bwd,
     wgrad, Adam and re-packing of the weights in bf16 mode with dropout on)."""
