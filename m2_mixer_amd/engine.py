@@ -842,6 +842,7 @@ class MimicEngine(_FlatEngine):
         # launches are long enough: 2.445 ms on three streams against 2.492 on one.  M2M_MIMIC_STREAMS=fwd|bwd|both|none (A/B).
         import os
         mode = os.environ.get("M2M_MIMIC_STREAMS", "none" if self.B <= 1024 else "both")
+        self._merged_tail = os.environ.get("M2M_MIMIC_MERGED_TAIL", "1") != "0"          # (A/B)
         self._conc_fwd, self._conc_bwd = mode in ("fwd", "both"), mode in ("bwd", "both")
         self.t_time = self._make_tower("time_mixer.", ct, self.Nt, 0)
         self.t_fus = self._make_tower("fusion_mixer.", cm, self.Nf, 2048)
@@ -899,6 +900,17 @@ class MimicEngine(_FlatEngine):
         sd = self.drop_step
         self.t_fus.backward(B, None, 0, self.dpool_fus, self.d_fused, fs, self.seed, 0, sd)
         d_time_part = self.d_fused.view(-1)[D:]
+        if not (self._conc_bwd and self.concurrent) and self._merged_tail:
+            # one stream (small batch): both towers' weight gradients in ONE launch, ONE Adam over the flat buffer, ONE re-pack
+            # (seven launches less than the per-segment form the three-stream step needs)
+            self.mlp.backward(static, B, self.d_fused, fs, self.dpool_static)
+            self.t_time.backward(B, d_time_part, fs, self.dpool_time, self.dx0_time, self.Nt * D, self.seed, 0, sd)
+            towers_wgrad([self.t_fus, self.t_time], B, seed=self.seed, step=0, step_dev=sd)
+            self.e_time.wgrad(time, self.dx0_time, B)
+            if fused_update:
+                self._adam(0, self.n_params, 1.0, False)
+                self.pack()
+            return
         main, s_b, s_f = self._streams(self._conc_bwd)
         s_b.wait_stream(main)
         s_f.wait_stream(main)
