@@ -247,8 +247,9 @@ __global__ __launch_bounds__(MLPM_T) void mlp_fwd_mfma_kernel(const m2m_mlp m, c
     const unsigned int step = step_host + (step_dev ? *step_dev : 0u);
     {
         const int din = m.dims[0], din4 = (din + 3) & ~3;
+        const Div d4(din4);                                // (runtime divisions were a third of these latency-bound kernels)
         for (int i = tid; i < MLPM_S * din4; i += MLPM_T) {
-            const int s = i / din4, k = i % din4;
+            const int s = d4.q(i), k = d4.r(i);
             a0[s * LD + k] = (s < ns && k < din) ? x[(long)(s0 + s) * din + k] : 0.f;
         }
     }
@@ -261,17 +262,18 @@ __global__ __launch_bounds__(MLPM_T) void mlp_fwd_mfma_kernel(const m2m_mlp m, c
         __syncthreads();                              // the previous layer is done with wt; cur is complete
         {
             const float* __restrict__ w = m.w[l];
+            const Div d4(din4);
             for (int i0 = tid; i0 < din4 * dout; i0 += MLP_SU * MLPM_T) {
                 float v[MLP_SU];
 #pragma unroll
                 for (int u = 0; u < MLP_SU; ++u) {
-                    const int i = i0 + u * MLPM_T, j = i / din4, k = i % din4;
+                    const int i = i0 + u * MLPM_T, j = d4.q(i), k = d4.r(i);
                     v[u] = (i < din4 * dout && k < din) ? w[j * din + k] : 0.f;
                 }
 #pragma unroll
                 for (int u = 0; u < MLP_SU; ++u) {
                     const int i = i0 + u * MLPM_T;
-                    if (i < din4 * dout) wt[(i % din4) * LD + i / din4] = v[u];
+                    if (i < din4 * dout) wt[d4.r(i) * LD + d4.q(i)] = v[u];
                 }
             }
         }
@@ -306,8 +308,9 @@ __global__ __launch_bounds__(MLPM_T) void mlp_fwd_mfma_kernel(const m2m_mlp m, c
     }
     __syncthreads();
     const int dl = m.dims[m.nlayers];
+    const Div ddl(dl);
     for (int i = tid; i < ns * dl; i += MLPM_T) {
-        const int s = i / dl, j = i % dl;
+        const int s = ddl.q(i), j = ddl.r(i);
         const float v = cur[s * LD + j];
         out[(long)(s0 + s) * out_ss + j] = v;
         if (out2) out2[(long)(s0 + s) * dl + j] = v;
@@ -328,8 +331,9 @@ __global__ __launch_bounds__(MLPM_T) void mlp_bwd_mfma_kernel(const m2m_mlp m, c
     const int ns = min(MLPM_S, B - s0);
     const float scale = 65536.0f / (float)m2m_drop_thr(m.p_drop);
     const int dl = m.dims[m.nlayers];
+    const Div ddl(dl);
     for (int i = tid; i < MLPM_S * dl; i += MLPM_T) {
-        const int s = i / dl, j = i % dl;
+        const int s = ddl.q(i), j = ddl.r(i);
         float v = 0.f;
         if (s < ns) {
             if (d_out) v = d_out[(long)(s0 + s) * d_out_ss + j];
@@ -344,6 +348,7 @@ __global__ __launch_bounds__(MLPM_T) void mlp_bwd_mfma_kernel(const m2m_mlp m, c
         const bool hidden = l < m.nlayers - m.has_out;
         const float* inp = l == 0 ? x : m.act[l - 1];
         __syncthreads();                              // gc complete; the previous layer is done with wl / ain
+        const Div ddi(din), ddo4(dout4);
         {
             const float* __restrict__ w = m.w[l];
             for (int i0 = tid; i0 < dout4 * din; i0 += MLP_SU * MLPM_T) {
@@ -351,17 +356,17 @@ __global__ __launch_bounds__(MLPM_T) void mlp_bwd_mfma_kernel(const m2m_mlp m, c
 #pragma unroll
                 for (int u = 0; u < MLP_SU; ++u) { const int i = i0 + u * MLPM_T; v[u] = i < dout * din ? w[i] : 0.f; }
 #pragma unroll
-                for (int u = 0; u < MLP_SU; ++u) { const int i = i0 + u * MLPM_T; if (i < dout4 * din) wl[(i / din) * LD + i % din] = v[u]; }
+                for (int u = 0; u < MLP_SU; ++u) { const int i = i0 + u * MLPM_T; if (i < dout4 * din) wl[ddi.q(i) * LD + ddi.r(i)] = v[u]; }
             }
             for (int i0 = tid; i0 < MLPM_S * din; i0 += MLP_SU * MLPM_T) {
                 float v[MLP_SU];
 #pragma unroll
                 for (int u = 0; u < MLP_SU; ++u) {
-                    const int i = i0 + u * MLPM_T, sI = i / din;
-                    v[u] = (i < MLPM_S * din && sI < ns) ? inp[(long)(s0 + sI) * din + i % din] : 0.f;
+                    const int i = i0 + u * MLPM_T, sI = ddi.q(i);
+                    v[u] = (i < MLPM_S * din && sI < ns) ? inp[(long)(s0 + sI) * din + ddi.r(i)] : 0.f;
                 }
 #pragma unroll
-                for (int u = 0; u < MLP_SU; ++u) { const int i = i0 + u * MLPM_T; if (i < MLPM_S * din) ain[(i / din) * LD + i % din] = v[u]; }
+                for (int u = 0; u < MLP_SU; ++u) { const int i = i0 + u * MLPM_T; if (i < MLPM_S * din) ain[ddi.q(i) * LD + ddi.r(i)] = v[u]; }
             }
         }
         {                                             // through Dropout and ReLU; columns j in [dout, dout4): zero (k padding of d_in)
@@ -370,15 +375,15 @@ __global__ __launch_bounds__(MLPM_T) void mlp_bwd_mfma_kernel(const m2m_mlp m, c
                 float o[MLP_SU];
 #pragma unroll
                 for (int u = 0; u < MLP_SU; ++u) {
-                    const int i = i0 + u * MLPM_T, sI = i / dout4, j = i % dout4;
+                    const int i = i0 + u * MLPM_T, sI = ddo4.q(i), j = ddo4.r(i);
                     o[u] = (hidden && i < MLPM_S * dout4 && sI < ns && j < dout) ? actl[(long)(s0 + sI) * dout + j] : 1.f;
                 }
 #pragma unroll
                 for (int u = 0; u < MLP_SU; ++u) {
                     const int i = i0 + u * MLPM_T;
                     if (i < MLPM_S * dout4) {
-                        const int j = i % dout4;
-                        float* gp = gc + (i / dout4) * LD + j;
+                        const int j = ddo4.r(i);
+                        float* gp = gc + ddo4.q(i) * LD + j;
                         if (j >= dout) *gp = 0.f;
                         else if (hidden) *gp = o[u] != 0.f ? *gp * scale : 0.f;
                     }

@@ -65,17 +65,17 @@ template <int P, int D, int NMAX, int TG> struct BwdLds {
 #define M2M_SMALL_ATOMIC(p, v) atomicAdd(p, v)
 #endif
 TIMER_DECL(g_tm_bwd);
-__device__ int g_bwd_static_split = 0;      // 1: static split of the bf16 column loop (M2M_BWD_TICKETS=0), see tower_bwd_body
+__device__ int g_bwd_static_split = 1;      // 1: static split of the bf16 column loop (default), 0: ticket counter (M2M_BWD_TICKETS=1)
 // copies the environment's choice to the device once per process (before the first backward launch on any stream)
 static int bwd_split_mode_init(hipStream_t st) {
     static bool done = false;
     if (done) return 0;
     const char* e = getenv("M2M_BWD_TICKETS");
-    const int v = (e && atoi(e) == 0) ? 1 : 0;
-    if (v) {
+    if (e && atoi(e) != 0) {
+        const int v = 0;
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(st, &cs);
-        if (cs != hipStreamCaptureStatusNone) { m2m_set_error("tower_backward: first launch with M2M_BWD_TICKETS=0 inside a stream capture (run one eager step first)", __FILE__, __LINE__); return -1; }
+        if (cs != hipStreamCaptureStatusNone) { m2m_set_error("tower_backward: first launch with M2M_BWD_TICKETS=1 inside a stream capture (run one eager step first)", __FILE__, __LINE__); return -1; }
         M2M_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_static_split), &v, sizeof(v)));
     }
     done = true;
@@ -491,8 +491,9 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
         // is issue-bound and the waves do not run at the same pace (the older ones win the arbitration): with a static split
         // the fastest wave waited ~4 us per block at the barrier behind the loop.  The next ticket is drawn at the top of a step
         // and used at its prefetch point.  fp32 (parity) mode keeps the static split: reproducible summation order.
-        // M2M_BWD_TICKETS=0 in the environment (g_bwd_static_split, set before the first launch) selects the static split at run
-        // time: the column sums of dA then have a fixed order (reproducible bf16 runs; costs the 2-3 % the tickets gained).
+        // Default since round 3: the STATIC split (g_bwd_static_split = 1): the column sums of dA have a fixed order.  The ticket
+        // counter (M2M_BWD_TICKETS=1 in the environment, read before the first launch) gained 2.6 % in round 2; in round 3, with
+        // the small-gradient atomics gone, three A/B runs on three boxes showed no difference.
         constexpr bool TICKETS_CT = P == PREC_BF16 && M2M_TICKETS;
         const bool TICKETS = TICKETS_CT && __builtin_amdgcn_readfirstlane(g_bwd_static_split) == 0;
         // The two waves of a SIMD (w and w + 4) run the same program and leave the barrier before the loop together: their MFMA

@@ -443,6 +443,28 @@ def test_launch_forms_of_a_step_agree(task, dev, monkeypatch):
     observe(f"launch forms [{task}] gradients (rel to max)", worst, tol)
 
 
+def test_bf16_step_is_reproducible_except_for_the_head_atomics(dev):
+    """Two engines, same parameters / batch / dropout stream, default launch forms (static split of the backward column loop,
+    small gradients and the second weight-gradient row group through slots, single-owner embedding gradients): every gradient
+    is BIT-identical between the runs, except the classifier heads' (the heads kernel adds its per-workgroup sums with float
+    atomics)."""
+    from m2_mixer_amd.engine import AVMnistEngine
+    cfg, B = dict(G.AVMNIST["B"]), 128
+    make = lambda: AVMnistEngine(cfg, B, device=dev, precision="bf16", lr=1e-3, seed=3)
+    eng = make()
+    alt = make()
+    alt.load_state_dict(eng.state_dict())
+    batch = tuple(t.to(dev) for t in G.avmnist_batch(B, 5, cfg))
+    for e in (eng, alt):
+        e.forward_backward(*batch)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.logits, alt.logits)
+    differing = [k for k in eng.grads if not torch.equal(eng.grads[k], alt.grads[k])]
+    assert all("classifier" in k for k in differing), differing
+    for k in differing:
+        assert relerr(eng.grads[k], alt.grads[k]) < 1e-5, k
+
+
 def test_training_reduces_loss_bf16(dev):
     """A few dozen Adam steps on one fixed synthetic batch must overfit it (end-to-end sanity of fwd, bwd,
     wgrad, Adam and re-packing of the weights in bf16 mode with dropout on)."""
