@@ -9,6 +9,8 @@ Tolerances
   bf16 mode (bf16 operands, fp32 accumulate): 3e-2 relative to the tensor's max for activations and
       gradients (observed ~5e-3), class predictions identical.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -427,10 +429,9 @@ def test_launch_forms_of_a_step_agree(task, dev, monkeypatch):
     for e in (eng, alt):
         e.forward_backward(*batch)
     torch.cuda.synchronize()
-    # bf16: two runs of the SAME form already differ at rounding level (the backward column loop hands its steps to waves by a
-    # ticket: the order of the fp32 dA sums varies, and a last-bit difference can flip the bf16 rounding of an operand image):
-    # observed maxima 1.5e-3 - 2.8e-3 of a gradient's largest element, spread over all gradients
-    tol = 2e-4 if prec == "fp32" else 1e-2
+    # (with the static split of the backward column loop -- the default -- bf16 forms differ like fp32 ones: observed 3e-7;
+    # under M2M_BWD_TICKETS=1 two bf16 runs of the SAME form differ by ~2e-3 of a gradient's largest element)
+    tol = 2e-4 if os.environ.get("M2M_BWD_TICKETS", "0") == "0" or prec == "fp32" else 1e-2
     assert relerr(eng.logits, alt.logits) < 1e-5
     worst = 0.0
     for k in eng.grads:
