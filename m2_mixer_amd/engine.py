@@ -20,6 +20,8 @@ from __future__ import annotations
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -34,7 +36,6 @@ def config_fused_update() -> bool:
     M2-Mixer-B it is slower (97 us against 45 + 19 us for the flat Adam launch followed by m2m_pack_all) -- the tile
     workgroups that must own a 32-column group of both weight matrices update W2 through 128-byte row segments with few
     loads in flight, the flat grid-stride Adam streams at the HBM roofline (profiles/)."""
-    import os
     return os.environ.get("M2M_FUSED_UPDATE", "0") == "1"
 
 
@@ -181,7 +182,6 @@ class _FlatEngine:
         self.s_b = torch.cuda.Stream(device=dev)
         self.s_fus = torch.cuda.Stream(device=dev)
         self.s_emb = torch.cuda.Stream(device=dev)
-        import os
         self.concurrent = os.environ.get("M2M_CONCURRENT", "1") != "0"      # 0: every launch on the main stream (A/B)
         self._build()
         self.pack()
@@ -207,7 +207,6 @@ class _FlatEngine:
           * slot: in a grouped launch a tower that needs two row groups (the fusion tower: twice the rows of its neighbours)
             stores the second group's sums into a slot that the flat Adam adds -- plain stores instead of float atomics.
         M2M_WGRAD_OVERWRITE=0 / M2M_WGRAD_SLOT=0 switch them off (A/B)."""
-        import os
         self._slot_towers, self._ranges_add, self._ranges_keep = [], [], []
         if os.environ.get("M2M_WGRAD_OVERWRITE", "1") == "0":
             return
@@ -571,7 +570,6 @@ class _TwoTowerEngine(_FlatEngine):
         # two modality towers' backward launches instead of inside the merged launch at the end.  Measured on MM-IMDb at its
         # cfg batch: 0.555 ms against 0.502 ms merged -- the extra fork / join of the replayed graph and a single-tower launch
         # without its slot (80 steps) cost more than the shorter tail returns.  Off.
-        import os
         self._early_fus_wgrad = (self.concurrent and self.t_fus.wide and B * self.Nf <= 8192 and
                                  os.environ.get("M2M_EARLY_FUSION_WGRAD", "0") == "1")
         self._setup_wgrad([[self.t_fus], [self.t_a, self.t_b]] if self._early_fus_wgrad else [[self.t_fus, self.t_a, self.t_b]])
@@ -840,7 +838,6 @@ class MimicEngine(_FlatEngine):
         # every fork / join edge of the replayed graph costs ~5 us, the launches they hide are 5-30 us at the cfg batch:
         # measured 0.230 ms on one stream against 0.255 ms on three (fwd only 0.257, bwd only 0.25-0.27); at batch 8192 the
         # launches are long enough: 2.445 ms on three streams against 2.492 on one.  M2M_MIMIC_STREAMS=fwd|bwd|both|none (A/B).
-        import os
         mode = os.environ.get("M2M_MIMIC_STREAMS", "none" if self.B <= 1024 else "both")
         self._merged_tail = os.environ.get("M2M_MIMIC_MERGED_TAIL", "1") != "0"          # (A/B)
         self._conc_fwd, self._conc_bwd = mode in ("fwd", "both"), mode in ("bwd", "both")
