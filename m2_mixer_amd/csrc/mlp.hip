@@ -255,6 +255,20 @@ __global__ __launch_bounds__(MLPM_T) void mlp_fwd_mfma_kernel(const m2m_mlp m, c
     }
     float* cur = a0;
     float* nxt = a1;
+    // the first batch of a layer's weights is requested one layer ahead (its round trip hides behind the previous layer's
+    // products; a 64 x 64 layer is one batch)
+    float wv[MLP_SU];
+    auto issue = [&](int l) {
+        const int din = m.dims[l], dout = m.dims[l + 1], din4 = (din + 3) & ~3;
+        const float* __restrict__ w = m.w[l];
+        const Div d4(din4);
+#pragma unroll
+        for (int u = 0; u < MLP_SU; ++u) {
+            const int i = tid + u * MLPM_T, j = d4.q(i), k = d4.r(i);
+            wv[u] = (i < din4 * dout && k < din) ? w[j * din + k] : 0.f;
+        }
+    };
+    issue(0);
     for (int l = 0; l < m.nlayers; ++l) {
         const int din = m.dims[l], dout = m.dims[l + 1], din4 = (din + 3) & ~3, dout4 = (dout + 3) & ~3;
         const bool hidden = l < m.nlayers - m.has_out;
@@ -263,7 +277,13 @@ __global__ __launch_bounds__(MLPM_T) void mlp_fwd_mfma_kernel(const m2m_mlp m, c
         {
             const float* __restrict__ w = m.w[l];
             const Div d4(din4);
-            for (int i0 = tid; i0 < din4 * dout; i0 += MLP_SU * MLPM_T) {
+#pragma unroll
+            for (int u = 0; u < MLP_SU; ++u) {
+                const int i = tid + u * MLPM_T;
+                if (i < din4 * dout) wt[d4.r(i) * LD + d4.q(i)] = wv[u];
+            }
+            if (l + 1 < m.nlayers) issue(l + 1);
+            for (int i0 = tid + MLP_SU * MLPM_T; i0 < din4 * dout; i0 += MLP_SU * MLPM_T) {
                 float v[MLP_SU];
 #pragma unroll
                 for (int u = 0; u < MLP_SU; ++u) {
@@ -343,53 +363,64 @@ __global__ __launch_bounds__(MLPM_T) void mlp_bwd_mfma_kernel(const m2m_mlp m, c
     }
     float* gc = g0;
     float* gn = g1;
+    // Everything a layer needs from global memory (its weights, its input activations, its output activations for the ReLU /
+    // dropout mask) is independent of the gradient stream: requested in ONE batch per layer, and the next layer's batch is
+    // requested before this layer's products, so that its round trip hides behind them.  (Three dependent round trips per layer
+    // were most of this kernel's 26 us at the MIMIC cfg batch.)
+    constexpr int AU = MLPM_S * MLP_MAXW / MLPM_T;     // activation elements per thread (16 samples x up to 128 columns)
+    float wv[MLP_SU], iv[AU], ov[AU];
+    auto issue = [&](int l) {
+        const int din = m.dims[l], dout = m.dims[l + 1], dout4 = (dout + 3) & ~3;
+        const bool hidden = l < m.nlayers - m.has_out;
+        const float* __restrict__ inp = l == 0 ? x : m.act[l - 1];
+        const float* __restrict__ w = m.w[l];
+        const float* __restrict__ actl = hidden ? m.act[l] : nullptr;
+        const Div ddi(din), ddo4(dout4);
+#pragma unroll
+        for (int u = 0; u < MLP_SU; ++u) { const int i = tid + u * MLPM_T; wv[u] = i < dout * din ? w[i] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+            const int i = tid + u * MLPM_T, sI = ddi.q(i);
+            iv[u] = (i < MLPM_S * din && sI < ns) ? inp[(long)(s0 + sI) * din + ddi.r(i)] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+            const int i = tid + u * MLPM_T, sI = ddo4.q(i), j = ddo4.r(i);
+            ov[u] = (hidden && i < MLPM_S * dout4 && sI < ns && j < dout) ? actl[(long)(s0 + sI) * dout + j] : 1.f;
+        }
+    };
+    issue(m.nlayers - 1);
     for (int l = m.nlayers - 1; l >= 0; --l) {
         const int din = m.dims[l], dout = m.dims[l + 1], dout4 = (dout + 3) & ~3;
         const bool hidden = l < m.nlayers - m.has_out;
-        const float* inp = l == 0 ? x : m.act[l - 1];
         __syncthreads();                              // gc complete; the previous layer is done with wl / ain
         const Div ddi(din), ddo4(dout4);
         {
             const float* __restrict__ w = m.w[l];
-            for (int i0 = tid; i0 < dout4 * din; i0 += MLP_SU * MLPM_T) {
+#pragma unroll
+            for (int u = 0; u < MLP_SU; ++u) { const int i = tid + u * MLPM_T; if (i < dout4 * din) wl[ddi.q(i) * LD + ddi.r(i)] = wv[u]; }
+            for (int i0 = tid + MLP_SU * MLPM_T; i0 < dout4 * din; i0 += MLP_SU * MLPM_T) {     // (layers wider than 64 x 64)
                 float v[MLP_SU];
 #pragma unroll
                 for (int u = 0; u < MLP_SU; ++u) { const int i = i0 + u * MLPM_T; v[u] = i < dout * din ? w[i] : 0.f; }
 #pragma unroll
                 for (int u = 0; u < MLP_SU; ++u) { const int i = i0 + u * MLPM_T; if (i < dout4 * din) wl[ddi.q(i) * LD + ddi.r(i)] = v[u]; }
             }
-            for (int i0 = tid; i0 < MLPM_S * din; i0 += MLP_SU * MLPM_T) {
-                float v[MLP_SU];
 #pragma unroll
-                for (int u = 0; u < MLP_SU; ++u) {
-                    const int i = i0 + u * MLPM_T, sI = ddi.q(i);
-                    v[u] = (i < MLPM_S * din && sI < ns) ? inp[(long)(s0 + sI) * din + ddi.r(i)] : 0.f;
-                }
+            for (int u = 0; u < AU; ++u) { const int i = tid + u * MLPM_T; if (i < MLPM_S * din) ain[ddi.q(i) * LD + ddi.r(i)] = iv[u]; }
+        }
+        // through Dropout and ReLU; columns j in [dout, dout4): zero (k padding of d_in)
 #pragma unroll
-                for (int u = 0; u < MLP_SU; ++u) { const int i = i0 + u * MLPM_T; if (i < MLPM_S * din) ain[ddi.q(i) * LD + ddi.r(i)] = v[u]; }
+        for (int u = 0; u < AU; ++u) {
+            const int i = tid + u * MLPM_T;
+            if (i < MLPM_S * dout4) {
+                const int j = ddo4.r(i);
+                float* gp = gc + ddo4.q(i) * LD + j;
+                if (j >= dout) *gp = 0.f;
+                else if (hidden) *gp = ov[u] != 0.f ? *gp * scale : 0.f;
             }
         }
-        {                                             // through Dropout and ReLU; columns j in [dout, dout4): zero (k padding of d_in)
-            const float* __restrict__ actl = hidden ? m.act[l] : nullptr;
-            for (int i0 = tid; i0 < MLPM_S * dout4; i0 += MLP_SU * MLPM_T) {
-                float o[MLP_SU];
-#pragma unroll
-                for (int u = 0; u < MLP_SU; ++u) {
-                    const int i = i0 + u * MLPM_T, sI = ddo4.q(i), j = ddo4.r(i);
-                    o[u] = (hidden && i < MLPM_S * dout4 && sI < ns && j < dout) ? actl[(long)(s0 + sI) * dout + j] : 1.f;
-                }
-#pragma unroll
-                for (int u = 0; u < MLP_SU; ++u) {
-                    const int i = i0 + u * MLPM_T;
-                    if (i < MLPM_S * dout4) {
-                        const int j = ddo4.r(i);
-                        float* gp = gc + ddo4.q(i) * LD + j;
-                        if (j >= dout) *gp = 0.f;
-                        else if (hidden) *gp = o[u] != 0.f ? *gp * scale : 0.f;
-                    }
-                }
-            }
-        }
+        if (l > 0) issue(l - 1);
         __syncthreads();
         // dW[j][k] += sum_s dz[s][j] in[s][k]: tiles (jt, kt) of 16 x 16, the 16 samples are the contraction
         const int njt = (dout + 15) >> 4, nkt = (din + 15) >> 4;
