@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define M2M_ABI_VERSION 14
+#define M2M_ABI_VERSION 15
 #define M2M_MAX_BLOCKS 8      /* MixerBlocks per m2m_tower; longer towers are chained by the caller */
 #define M2M_ROWS_PER_WG 16    /* token rows one workgroup keeps on chip */
 
@@ -283,7 +283,13 @@ typedef struct m2m_head {
     float* g_b;
     float* d_pooled;      /* (B, D) or NULL */
     float weight;         /* coefficient of this head's mean loss in the total */
+    float* g_part;        /* NULL: g_w / g_b += with float atomics (one add per workgroup: the order, hence the last bits, vary
+                           * from run to run).  Else (m2m_heads_ce, K*D + K + 2 <= M2M_SPLIT_GPART): every workgroup STORES its
+                           * sums at g_part + workgroup * M2M_SPLIT_GPART ([dW (K, D) | db (K) | 0 | 0]; m2m_heads_part_tiles(B)
+                           * workgroups; head h's buffer must follow head h - 1's) and the caller hands the heads to
+                           * m2m_towers_wgrad_heads, whose launch adds them to g_w / g_b in a fixed order. */
 } m2m_head;
+int m2m_heads_part_tiles(int B);      /* workgroups per head of m2m_heads_ce at batch B (the slots g_part needs) */
 int m2m_heads_ce(const m2m_head* heads, int nheads, const int64_t* labels, int B, int D, int K,
                  float* logits, float* losses, int32_t* preds, int zero_losses, void* stream);
                  /* losses are accumulated over workgroups: zero_losses != 0 clears them first (one more tiny launch);
@@ -293,6 +299,14 @@ int m2m_heads_ce(const m2m_head* heads, int nheads, const int64_t* labels, int B
  * pos_weight (K); per-head loss = mean over all B*K elements; preds (nheads, B, K) int32 = sigmoid(logits) > 0.5. */
 int m2m_heads_bce(const m2m_head* heads, int nheads, const float* targets, const float* pos_weight, int B, int D, int K,
                   float* logits, float* losses, int32_t* preds, int zero_losses, void* stream);
+
+/* m2m_towers_wgrad (above), which also adds the per-workgroup partial sums of the classification heads' weight gradients (m2m_head.g_part,
+ * written by m2m_heads_ce at the same batch) to g_w / g_b: heads == NULL or nheads == 0: exactly m2m_towers_wgrad. */
+int m2m_towers_wgrad_heads(const m2m_tower* const* towers, const m2m_tower* const* dev_towers, int ntowers,
+                           const m2m_embed* const* embeds, const float* const* inputs, const float* const* d_x0s,
+                           const m2m_tower* const* embed_towers, int nembeds,
+                           int B, uint32_t seed, uint32_t step, const uint32_t* step_dev,
+                           const m2m_head* heads, int nheads, int K, void* stream);
 
 /* m2m_tower_backward of the tower whose token mean carries head `own`, with the model's classification heads + multi-head
  * cross-entropy (m2m_heads_ce: models/avmnist.py:271-298) computed in the launch's prologue instead of a launch of their own:

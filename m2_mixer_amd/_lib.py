@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("M2M_LIB_PATH", os.path.join(_HERE, "libm2mixer.so"))   # override: diagnostic builds
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 MAX_BLOCKS = 8
 ROWS_PER_WG = 16
 HCHN_PAD = 4096          # >= the pad between operand streams the library uses (csrc/tile.h M2M_HCHN_PAD)
@@ -93,7 +93,7 @@ class Embed(C.Structure):
 class Head(C.Structure):
     """m2m_head"""
     _fields_ = [("pooled", _fp), ("w", _fp), ("b", _fp), ("g_w", _fp), ("g_b", _fp), ("d_pooled", _fp),
-                ("weight", C.c_float)]
+                ("weight", C.c_float), ("g_part", _fp)]
 
 
 MLP_MAX_LAYERS = 4
@@ -132,6 +132,10 @@ SIGNATURES = {
                                       _fp, _fp]),
     "m2m_towers_wgrad": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.POINTER(_fp), C.c_int, C.POINTER(C.POINTER(Embed)), C.POINTER(_fp),
                                    C.POINTER(_fp), C.POINTER(C.POINTER(Tower)), C.c_int, C.c_int, C.c_uint32, C.c_uint32, _fp, _fp]),
+    "m2m_towers_wgrad_heads": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.POINTER(_fp), C.c_int, C.POINTER(C.POINTER(Embed)), C.POINTER(_fp),
+                                         C.POINTER(_fp), C.POINTER(C.POINTER(Tower)), C.c_int, C.c_int, C.c_uint32, C.c_uint32, _fp,
+                                         C.POINTER(Head), C.c_int, C.c_int, _fp]),
+    "m2m_heads_part_tiles": (C.c_int, [C.c_int]),
     "m2m_wgrad_form": (C.c_int, [C.POINTER(Tower), C.c_int]),
     "m2m_embeds_wgrad_form": (C.c_int, [C.POINTER(C.POINTER(Embed)), C.POINTER(C.POINTER(Tower)), C.c_int, C.c_int]),
     "m2m_wgrad_groups": (C.c_int, [C.POINTER(Tower), C.c_int]),

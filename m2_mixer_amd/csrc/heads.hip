@@ -124,17 +124,22 @@ __global__ __launch_bounds__(NTHREADS) void heads_kernel(const HeadArgs ha, cons
             for (int k = 0; k < K; ++k) a = __builtin_fmaf(lg[s * HEAD_MAXK + k], wl[k * DL + d], a);
             hd.d_pooled[(long)(s0 + s) * D + d] = a;
         }
+        // g_part: this workgroup's sums go to its slot (plain stores; m2m_towers_wgrad_heads adds the slots in a fixed order)
+        float* slot = hd.g_part ? hd.g_part + (long)blockIdx.x * M2M_SPLIT_GPART : nullptr;
         for (int idx = tid; idx < K * D; idx += NTHREADS) {
             const int k = idx / D, d = idx % D;
             float a = 0.f;
             for (int s = 0; s < S; ++s) a = __builtin_fmaf(lg[s * HEAD_MAXK + k], pl[s * DL + d], a);
-            atomicAdd(hd.g_w + idx, a);
+            if (slot) slot[idx] = a;
+            else atomicAdd(hd.g_w + idx, a);
         }
         if (tid < K) {
             float a = 0.f;
             for (int s = 0; s < S; ++s) a += lg[s * HEAD_MAXK + tid];
-            atomicAdd(hd.g_b + tid, a);
+            if (slot) slot[K * D + tid] = a;
+            else atomicAdd(hd.g_b + tid, a);
         }
+        if (slot && tid < 2) slot[K * D + K + tid] = 0.f;           // (the slot layout's loss entries: the losses stay atomics)
     }
 }
 
@@ -155,6 +160,7 @@ static int launch_heads_s(const HeadArgs& ha, int nheads, const void* labels, co
     return 0;
 }
 
+static int heads_samples_per_wg(int B) { return B <= 64 ? 4 : HEAD_S; }
 template <bool BCE>
 static int launch_heads(const m2m_head* heads, int nheads, const void* labels, const float* pos_weight, int B, int D, int K,
                         float* logits, float* losses, int32_t* preds, int zero_losses, void* stream) {
@@ -163,13 +169,21 @@ static int launch_heads(const m2m_head* heads, int nheads, const void* labels, c
         return -1;
     }
     HeadArgs ha;
+    for (int i = 0; i < nheads; ++i) {
+        if (heads[i].g_part && (BCE || (long)K * D + K + 2 > M2M_SPLIT_GPART)) {
+            m2m_set_error("heads: g_part needs cross-entropy heads with K*D + K + 2 <= M2M_SPLIT_GPART", __FILE__, __LINE__);
+            return -1;
+        }
+    }
     for (int i = 0; i < nheads; ++i) ha.h[i] = heads[i];
     for (int i = nheads; i < HEAD_MAXH; ++i) ha.h[i] = heads[0];
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (zero_losses) hipLaunchKernelGGL(zero_floats_kernel, dim3(1), dim3(64), 0, st, losses, nheads + 1);
-    if (B <= 64) return launch_heads_s<BCE, 4>(ha, nheads, labels, pos_weight, B, D, K, logits, losses, preds, st);
+    if (heads_samples_per_wg(B) == 4) return launch_heads_s<BCE, 4>(ha, nheads, labels, pos_weight, B, D, K, logits, losses, preds, st);
     return launch_heads_s<BCE, HEAD_S>(ha, nheads, labels, pos_weight, B, D, K, logits, losses, preds, st);
 }
+
+extern "C" int m2m_heads_part_tiles(int B) { const int S = heads_samples_per_wg(B); return B < 1 ? 0 : (B + S - 1) / S; }
 
 extern "C" int m2m_heads_ce(const m2m_head* heads, int nheads, const int64_t* labels, int B, int D, int K, float* logits,
                             float* losses, int32_t* preds, int zero_losses, void* stream) {

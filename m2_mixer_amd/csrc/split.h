@@ -118,7 +118,7 @@ struct SplitReduceTower {
     float* g_hw[3]; float* g_hb[3];
     float* losses;                                // [nheads + 1]: per head, then the total
 };
-#define SPR_MAX_TOWERS 3
+#define SPR_MAX_TOWERS 4       // three towers' small gradients + the classification heads
 struct SplitReduceArgs { SplitReduceTower t[SPR_MAX_TOWERS]; int ntow; };
 
 // ---- reduction of the per-workgroup slots (device body shared by split_mix.hip's launch and the weight-gradient launch) -----
@@ -139,8 +139,8 @@ static __device__ __forceinline__ void split_small_grads_body(const SplitReduceT
         const int h = L - tw.head_set0, KD = tw.K * D;
         if (e < KD) dst = tw.g_hw[h] + e;
         else if (e < KD + tw.K) dst = tw.g_hb[h] + (e - KD);
-        else if (e == KD + tw.K) dst = tw.losses + h;
-        else if (e == KD + tw.K + 1) { dst = tw.losses + tw.nheads; shared_dst = true; }   // the total: every head's set adds to it
+        else if (e == KD + tw.K) dst = tw.losses ? tw.losses + h : nullptr;                 // (losses NULL: the slots carry no losses)
+        else if (e == KD + tw.K + 1) { dst = tw.losses ? tw.losses + tw.nheads : nullptr; shared_dst = true; }   // the total: every head's set adds to it
     } else if (e < SPP_STRIDE) {
         const int ntok = 2 * T * N + T + N;
         if (e < D) dst = tw.g_ln2_w[L] ? tw.g_ln2_w[L] + e : nullptr;

@@ -537,7 +537,8 @@ static void wgrad_group_plans(const m2m_tower* const* host, int n, int B, int co
 template <int P, int D, int RCDM>
 static int launch_wgrad_group(const m2m_tower* const* host, const m2m_tower* const* dev, int n, const m2m_embed* const* embeds,
                               const float* const* inputs, const float* const* d_x0s, const m2m_tower* const* embed_towers,
-                              int nembeds, int B, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
+                              int nembeds, int B, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st,
+                              const SplitReduceTower* heads_reduce = nullptr) {
     typedef WgradKernelGeom<P, D, RCDM> KG;
     WgradGroupArgs a;
     memset(&a, 0, sizeof(a));
@@ -633,6 +634,15 @@ static int launch_wgrad_group(const m2m_tower* const* host, const m2m_tower* con
         one.t[0] = x; one.ntow = 1;
         if (int rc = m2m_split_small_grads(one, st)) return rc;
     }
+    if (heads_reduce) {                                            // the classification heads' weight-gradient slots (m2m_head.g_part)
+        if (ra.ntow < SPR_MAX_TOWERS && KG::THREADS % SPR_COLS == 0) ra.t[ra.ntow++] = *heads_reduce;
+        else {
+            SplitReduceArgs one;
+            memset(&one, 0, sizeof(one));
+            one.t[0] = *heads_reduce; one.ntow = 1;
+            if (int rc = m2m_split_small_grads(one, st)) return rc;
+        }
+    }
     for (int i = 0; i < ra.ntow; ++i) a.reduce_sets = ra.t[i].nlaunch > a.reduce_sets ? ra.t[i].nlaunch : a.reduce_sets;
     a.n_reduce = SPR_NBX * a.reduce_sets * ra.ntow;
     hipLaunchKernelGGL(kern, dim3((unsigned)(a.n_embed_pad + a.n_tower_wgs + n_embed_wgs + a.n_reduce)), dim3(KG::THREADS), lds, st, a, ea, ra);
@@ -677,10 +687,30 @@ extern "C" int m2m_tower_wgrad(const m2m_tower* t, int B, uint32_t seed, uint32_
     return -1;
 }
 
-extern "C" int m2m_towers_wgrad(const m2m_tower* const* towers, const m2m_tower* const* dev_towers, int ntowers,
-                                const m2m_embed* const* embeds, const float* const* inputs, const float* const* d_x0s,
-                                const m2m_tower* const* embed_towers, int nembeds,
-                                int B, uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream) {
+extern "C" int m2m_heads_part_tiles(int B);
+static int towers_wgrad_impl(const m2m_tower* const* towers, const m2m_tower* const* dev_towers, int ntowers,
+                             const m2m_embed* const* embeds, const float* const* inputs, const float* const* d_x0s,
+                             const m2m_tower* const* embed_towers, int nembeds,
+                             int B, uint32_t seed, uint32_t step, const uint32_t* step_dev,
+                             const m2m_head* heads, int nheads, int K, void* stream) {
+    SplitReduceTower hr;
+    const SplitReduceTower* heads_reduce = nullptr;
+    if (heads && nheads > 0) {
+        if (nheads > 3 || K < 2 || !towers || ntowers < 1 || !towers[0]) { m2m_set_error("towers_wgrad_heads: 1..3 heads, K >= 2", __FILE__, __LINE__); return -1; }
+        const int D = towers[0]->D, tiles = m2m_heads_part_tiles(B);
+        if ((long)K * D + K + 2 > SPP_STRIDE) { m2m_set_error("towers_wgrad_heads: K*D + K + 2 exceeds the slot", __FILE__, __LINE__); return -1; }
+        memset(&hr, 0, sizeof(hr));
+        for (int h = 0; h < nheads; ++h) {
+            if (!heads[h].g_part || !heads[h].g_w || !heads[h].g_b || heads[h].g_part != heads[0].g_part + (long)h * tiles * SPP_STRIDE) {
+                m2m_set_error("towers_wgrad_heads: every head needs g_w, g_b and consecutive g_part buffers", __FILE__, __LINE__);
+                return -1;
+            }
+            hr.g_hw[h] = heads[h].g_w; hr.g_hb[h] = heads[h].g_b;
+        }
+        hr.part = heads[0].g_part; hr.ntiles = tiles; hr.nlaunch = nheads; hr.D = D; hr.head_set0 = 0; hr.nheads = nheads; hr.K = K;
+        hr.losses = nullptr;                                      // (the slots' loss entries are zero: see m2m_head.g_part)
+        heads_reduce = &hr;
+    }
     if (!towers || !dev_towers || ntowers < 1 || ntowers > WG_MAX_TOWERS) { m2m_set_error("towers_wgrad: 1..4 towers", __FILE__, __LINE__); return -1; }
     if (nembeds != 0 && (nembeds != EMB_GROUP || !embeds || !inputs || !d_x0s)) {
         m2m_set_error("towers_wgrad: no patch embeddings or exactly two", __FILE__, __LINE__);
@@ -711,15 +741,29 @@ extern "C" int m2m_towers_wgrad(const m2m_tower* const* towers, const m2m_tower*
     const m2m_tower* t = towers[0];
     if (m2m_wgrad_recompute(t, B)) {
         if (m2m_drop_mode(1, t->p_drop) == DM_HALF)
-            return launch_wgrad_group<PREC_BF16, 128, DM_HALF>(towers, dev_towers, ntowers, embeds, inputs, d_x0s, embed_towers, nembeds, B, seed, step, step_dev, st);
-        return launch_wgrad_group<PREC_BF16, 128, DM_NONE>(towers, dev_towers, ntowers, embeds, inputs, d_x0s, embed_towers, nembeds, B, seed, step, step_dev, st);
+            return launch_wgrad_group<PREC_BF16, 128, DM_HALF>(towers, dev_towers, ntowers, embeds, inputs, d_x0s, embed_towers, nembeds, B, seed, step, step_dev, st, heads_reduce);
+        return launch_wgrad_group<PREC_BF16, 128, DM_NONE>(towers, dev_towers, ntowers, embeds, inputs, d_x0s, embed_towers, nembeds, B, seed, step, step_dev, st, heads_reduce);
     }
-#define M2M_WGG_CASE(PP, DD) if (t->prec == PP && t->D == DD) return launch_wgrad_group<PP, DD, -1>(towers, dev_towers, ntowers, embeds, inputs, d_x0s, embed_towers, nembeds, B, seed, step, step_dev, st);
+#define M2M_WGG_CASE(PP, DD) if (t->prec == PP && t->D == DD) return launch_wgrad_group<PP, DD, -1>(towers, dev_towers, ntowers, embeds, inputs, d_x0s, embed_towers, nembeds, B, seed, step, step_dev, st, heads_reduce);
     M2M_WGG_CASE(PREC_BF16, 32) M2M_WGG_CASE(PREC_BF16, 64) M2M_WGG_CASE(PREC_BF16, 128) M2M_WGG_CASE(PREC_BF16, 256)
     M2M_WGG_CASE(PREC_F32, 32) M2M_WGG_CASE(PREC_F32, 64) M2M_WGG_CASE(PREC_F32, 128) M2M_WGG_CASE(PREC_F32, 256)
 #undef M2M_WGG_CASE
     m2m_set_error("towers_wgrad: unsupported (prec, D)", __FILE__, __LINE__);
     return -1;
+}
+
+extern "C" int m2m_towers_wgrad(const m2m_tower* const* towers, const m2m_tower* const* dev_towers, int ntowers,
+                                const m2m_embed* const* embeds, const float* const* inputs, const float* const* d_x0s,
+                                const m2m_tower* const* embed_towers, int nembeds,
+                                int B, uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream) {
+    return towers_wgrad_impl(towers, dev_towers, ntowers, embeds, inputs, d_x0s, embed_towers, nembeds, B, seed, step, step_dev, nullptr, 0, 0, stream);
+}
+extern "C" int m2m_towers_wgrad_heads(const m2m_tower* const* towers, const m2m_tower* const* dev_towers, int ntowers,
+                                      const m2m_embed* const* embeds, const float* const* inputs, const float* const* d_x0s,
+                                      const m2m_tower* const* embed_towers, int nembeds,
+                                      int B, uint32_t seed, uint32_t step, const uint32_t* step_dev,
+                                      const m2m_head* heads, int nheads, int K, void* stream) {
+    return towers_wgrad_impl(towers, dev_towers, ntowers, embeds, inputs, d_x0s, embed_towers, nembeds, B, seed, step, step_dev, heads, nheads, K, stream);
 }
 
 // 1: m2m_towers_wgrad(..., embeds, ..., embed_towers, ...) at batch B computes the embedding gradients in the single-owner form

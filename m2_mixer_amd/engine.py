@@ -577,6 +577,12 @@ class _TwoTowerEngine(_FlatEngine):
         # the fusion tower's backward is always followed by the weight-gradient launch (_backward): the reduction of its
         # small-gradient slots rides there instead of being a launch between the two backward launches (M2M_DEFER_SMALL=0: A/B)
         self.t_fus.set_wgrad_reduces_small(not self._fused_heads and os.environ.get("M2M_DEFER_SMALL", "1") != "0")
+        # the heads' weight gradients: per-workgroup slots added in a fixed order by the weight-gradient launch instead of float
+        # atomics -- with them a bf16 step is bit-reproducible (M2M_HEAD_SLOTS=0: atomics)
+        self._head_part, self._wgrad_heads = None, None
+        if (self._heads_are_ce() and not self._fused_heads and os.environ.get("M2M_HEAD_SLOTS", "1") != "0"
+                and self.K * D + self.K + 2 <= L.SPLIT_GPART):
+            self._head_part = torch.zeros(3, int(L.lib().m2m_heads_part_tiles(B)), L.SPLIT_GPART, device=dev)
         # the two modality towers' backward launch: slots instead of 128-way contended float atomics for the small gradients,
         # their reduction in the weight-gradient launch as well (M2M_GROUP_SLOTS=0: atomics, A/B)
         if (os.environ.get("M2M_GROUP_SLOTS", "1") != "0" and self.t_a.has_small_slots() and self.t_b.has_small_slots()
@@ -663,6 +669,11 @@ class _TwoTowerEngine(_FlatEngine):
         heads = [self._head(a, self.pool_a, self.dpool_a, hw[a], with_grad),
                  self._head(b, self.pool_b, self.dpool_b, hw[b], with_grad),
                  self._head("fusion", self.pool_fus, self.dpool_fus, hw["fusion"], with_grad)]
+        self._wgrad_heads = None
+        if training and with_grad and self._head_part is not None:
+            for i, h in enumerate(heads):
+                h["g_part"] = self._head_part[i]
+            self._wgrad_heads = heads                     # _backward's weight-gradient launch adds the slots to g_w / g_b
         self._heads = heads
         self._labels = labels
         if training and with_grad and self._fused_heads:
@@ -709,13 +720,13 @@ class _TwoTowerEngine(_FlatEngine):
             main.wait_stream(s_a)
         if can_group_embeds(self.e_a, self.e_b) and self.e_a.prec == self.t_a.prec and self.e_a.D == self.t_a.D:
             towers_wgrad(wg_towers, B, [self.e_a, self.e_b], [xa, xb], [self.dx0_a, self.dx0_b],
-                         seed=self.seed, step=0, step_dev=sd, embed_towers=self._embed_towers)
+                         seed=self.seed, step=0, step_dev=sd, embed_towers=self._embed_towers, heads=self._wgrad_heads, K=self.K)
         else:
             s_e.wait_stream(main)
             with torch.cuda.stream(s_e):
                 self.e_b.wgrad(xb, self.dx0_b, B)
                 self.e_a.wgrad(xa, self.dx0_a, B)
-            towers_wgrad(wg_towers, B, seed=self.seed, step=0, step_dev=sd)
+            towers_wgrad(wg_towers, B, seed=self.seed, step=0, step_dev=sd, heads=self._wgrad_heads, K=self.K)
             main.wait_stream(s_e)
         if self._early_fus_wgrad:
             main.wait_stream(s_f)

@@ -442,12 +442,14 @@ def wgrad_slot_groups(towers: Sequence[TowerRuntime], B: int) -> int:
 
 def towers_wgrad(towers: Sequence[TowerRuntime], B: int, embeds: Sequence["EmbedRuntime"] = (),
                  inputs: Sequence[torch.Tensor] = (), d_x0s: Sequence[torch.Tensor] = (), seed: int = 0, step: int = 0,
-                 step_dev: Optional[torch.Tensor] = None, embed_towers: Sequence[TowerRuntime] = ()):
+                 step_dev: Optional[torch.Tensor] = None, embed_towers: Sequence[TowerRuntime] = (),
+                 heads: Optional[Sequence[dict]] = None, K: int = 0):
     """Channel-mixing weight gradients of several towers (same precision / hidden_dim) in one launch; with `embeds`
     (the model's two patch embeddings, their inputs and d_x0) also the embedding gradients, in the same launch.
     seed / step / step_dev: the dropout stream of the forward (the recompute form regenerates the hidden keep-mask).
     embed_towers[i]: the tower embedding i feeds; with its d_x0^T image (enable_dx0_image) the embedding gradients take the
-    single-owner form (no atomics)."""
+    single-owner form (no atomics).
+    heads (dicts as for heads_ce, each with "g_part") + K: the launch also adds the heads' per-workgroup weight-gradient sums."""
     n, ne = len(towers), len(embeds)
     host = (C.POINTER(L.Tower) * n)(*[C.pointer(t.desc) for t in towers])
     dev = (C.c_void_p * n)(*[t.device_desc() for t in towers])
@@ -455,6 +457,11 @@ def towers_wgrad(towers: Sequence[TowerRuntime], B: int, embeds: Sequence["Embed
     ip = (C.c_void_p * max(ne, 1))(*[t.data_ptr() for t in inputs])
     dp = (C.c_void_p * max(ne, 1))(*[t.data_ptr() for t in d_x0s])
     et = (C.POINTER(L.Tower) * max(ne, 1))(*[C.pointer(t.desc) for t in embed_towers]) if len(embed_towers) == ne and ne else None
+    if heads:
+        # the classification heads' weight-gradient slots (heads_ce with "g_part") are added to g_w / g_b by this launch
+        L.check(L.lib().m2m_towers_wgrad_heads(host, dev, n, ep, ip, dp, et, ne, B, seed & 0xFFFFFFFF, step & 0xFFFFFFFF,
+                                               L.ptr(step_dev), _head_array(heads), len(heads), K, L.stream_ptr()), "towers_wgrad_heads")
+        return
     L.check(L.lib().m2m_towers_wgrad(host, dev, n, ep, ip, dp, et, ne, B, seed & 0xFFFFFFFF, step & 0xFFFFFFFF, L.ptr(step_dev),
                                      L.stream_ptr()), "towers_wgrad")
 
@@ -661,6 +668,7 @@ def _head_array(heads: Sequence[dict]):
         arr[i].pooled, arr[i].w, arr[i].b = h["pooled"].data_ptr(), h["w"].data_ptr(), h["b"].data_ptr()
         arr[i].g_w, arr[i].g_b, arr[i].d_pooled = L.ptr(h.get("g_w")), L.ptr(h.get("g_b")), L.ptr(h.get("d_pooled"))
         arr[i].weight = float(h["weight"])
+        arr[i].g_part = L.ptr(h.get("g_part"))
     return arr
 
 
