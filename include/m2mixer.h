@@ -183,6 +183,9 @@ typedef struct m2m_step_head {
 int m2m_embeds_forward(const m2m_embed* const* embeds, const float* const* inputs, float* const* x0s, const int* nsplits,
                        const int64_t* part_strides, int nembeds, int B, const m2m_step_head* head, void* stream);
 int m2m_embed_fwd_splits(const m2m_embed* e);
+/* m2m_embed_forward carrying the step prologue (head may be NULL): for models with ONE embedding whose launch is the first of the
+ * training step and reads none of the head's values (MIMIC-H: the time tower's input projection). */
+int m2m_embed_forward_head(const m2m_embed* e, const float* input, int B, float* x0, const m2m_step_head* head, void* stream);
 
 /* Blocks + final LayerNorm over a (B, N, D) input.  Replaces the `for mixer_block in self.mixer_blocks`
  * loop + self.layer_norm of MLPMixer/FusionMixer/MLPMixerNoPatching.forward (modules/mixer.py:125-132).

@@ -117,6 +117,7 @@ SIGNATURES = {
     "m2m_pack_embed": (C.c_int, [C.POINTER(Embed), _fp]),
     "m2m_pack_all": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.c_int, C.POINTER(C.POINTER(Embed)), C.c_int, _fp]),
     "m2m_embed_forward": (C.c_int, [C.POINTER(Embed), _fp, C.c_int, _fp, _fp]),
+    "m2m_embed_forward_head": (C.c_int, [C.POINTER(Embed), _fp, C.c_int, _fp, C.POINTER(StepHead), _fp]),
     "m2m_tower_forward": (C.c_int, [C.POINTER(Tower), _fp, C.c_int64, C.c_int, _fp, C.c_int64, _fp, C.c_int,
                                     C.c_uint32, C.c_uint32, _fp, _fp]),
     "m2m_tower_backward": (C.c_int, [C.POINTER(Tower), C.c_int, _fp, C.c_int64, _fp, _fp, C.c_int64,

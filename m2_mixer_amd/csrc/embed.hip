@@ -217,8 +217,14 @@ static inline bool embed_fwd_fast_ok(const m2m_embed* e, const float* in) {
 
 template <int P, int D, int RB>
 __global__ __launch_bounds__(NTHREADS) void embed_fwd_kernel(const m2m_embed em, const float* __restrict__ in, long M, int N,
-                                                             float* __restrict__ x0, int fast) {
+                                                             float* __restrict__ x0, int fast, const m2m_step_head head) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (blockIdx.x == 0) {                              // the step prologue rides here (m2m_embed_forward_head): see m2m_step_head
+        const int t = threadIdx.x;
+        if (t == 0 && head.adam_state) head.adam_state[0] += 1.0f;
+        if (t == 1 && head.drop_counter) *head.drop_counter += 1u;
+        if (head.losses && t < head.nlosses) head.losses[t] = 0.f;
+    }
     if (P == PREC_BF16 && fast) embed_fwd_fast_body<D>(em, in, M, N, x0, blockIdx.x, 0, 1, smem);
     else embed_fwd_body<P, D, RB>(em, in, M, N, x0, blockIdx.x, smem);
 }
@@ -294,7 +300,13 @@ int m2m_check_embed(const m2m_embed* e, int B) {
 }
 
 template <int P, int D>
-static int launch_embed_fwd(const m2m_embed* e, const float* in, int B, float* x0, hipStream_t st) {
+static int launch_embed_fwd(const m2m_embed* e, const float* in, int B, float* x0, hipStream_t st, const m2m_step_head* head = nullptr) {
+    m2m_step_head hd;
+    memset(&hd, 0, sizeof(hd));
+    if (head) {
+        if (head->nlosses < 0 || head->nlosses > 64) { m2m_set_error("embed_forward: step head nlosses must be in [0, 64]", __FILE__, __LINE__); return -1; }
+        hd = *head;
+    }
     const int N = (e->H / e->ph) * (e->W / e->pw);
     const long M = (long)B * N;
     // 16 rows per workgroup: the audio embedding (2048 rows at batch 512, 50 KB of input per sample) sits at the head of
@@ -304,7 +316,7 @@ static int launch_embed_fwd(const m2m_embed* e, const float* in, int B, float* x
     auto kern = embed_fwd_kernel<P, D, RB>;
     static bool done = false;
     if (!done) { M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)((M + RB - 1) / RB)), dim3(NTHREADS), lds, st, *e, in, M, N, x0, (int)embed_fwd_fast_ok(e, in));
+    hipLaunchKernelGGL(kern, dim3((unsigned)((M + RB - 1) / RB)), dim3(NTHREADS), lds, st, *e, in, M, N, x0, (int)embed_fwd_fast_ok(e, in), hd);
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -369,9 +381,12 @@ static int launch_embed_wgrad_group(const m2m_embed* const* es, const float* con
 }
 
 extern "C" int m2m_embed_forward(const m2m_embed* e, const float* input, int B, float* x0, void* stream) {
+    return m2m_embed_forward_head(e, input, B, x0, nullptr, stream);
+}
+extern "C" int m2m_embed_forward_head(const m2m_embed* e, const float* input, int B, float* x0, const m2m_step_head* head, void* stream) {
     if (int rc = m2m_check_embed(e, B)) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define M2M_EF_CASE(PP, DD) if (e->prec == PP && e->D == DD) return launch_embed_fwd<PP, DD>(e, input, B, x0, st);
+#define M2M_EF_CASE(PP, DD) if (e->prec == PP && e->D == DD) return launch_embed_fwd<PP, DD>(e, input, B, x0, st, head);
     M2M_EF_CASE(PREC_BF16, 32) M2M_EF_CASE(PREC_BF16, 64) M2M_EF_CASE(PREC_BF16, 128) M2M_EF_CASE(PREC_BF16, 256)
     M2M_EF_CASE(PREC_F32, 32) M2M_EF_CASE(PREC_F32, 64) M2M_EF_CASE(PREC_F32, 128) M2M_EF_CASE(PREC_F32, 256)
 #undef M2M_EF_CASE

@@ -882,17 +882,24 @@ class MimicEngine(_FlatEngine):
             m.pack(force=True)
 
     def _forward(self, static, time, labels, training: bool, with_grad: bool, prologue: bool = False):
-        if prologue:
-            self._prologue()
         B, D = self.B, self.D
         sd = self.drop_step if training else None
         fs = self.Nf * D
         time_part = self.fused.view(-1)[D:]                 # tokens 1..Nt of every sample
         main, side, _ = self._streams(self._conc_fwd)
+        head = None
+        if prologue and side is main:
+            # one stream: the step prologue rides in the input projection's launch, which then goes first (it reads none of the
+            # counters; the static MLP draws its dropout masks from the bumped one)
+            head = (self.adam_state, self.drop_step, self.losses)
+            self.e_time.forward(time, B, self.x0_time, step_head=head)
+        elif prologue:
+            self._prologue()
         side.wait_stream(main)
         with torch.cuda.stream(side):                       # the static MLP beside the time tower: token 0 + its head's input
             self.mlp.forward(static, B, self.fused, fs, self.pool_static, training, self.seed, 0, sd)
-        self.e_time.forward(time, B, self.x0_time)
+        if head is None:
+            self.e_time.forward(time, B, self.x0_time)
         self.t_time.forward(self.x0_time, self.Nt * D, B, time_part, fs, self.pool_time, training, self.seed, 0, sd)
         main.wait_stream(side)
         self.t_fus.forward(self.fused, fs, B, self.fus_out, fs, self.pool_fus, training, self.seed, 0, sd)

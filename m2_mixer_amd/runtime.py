@@ -560,8 +560,13 @@ class EmbedRuntime:
         """k-splits embeds_forward should use for this embedding (1: none)."""
         return int(L.lib().m2m_embed_fwd_splits(C.byref(self.desc)))
 
-    def forward(self, inp: torch.Tensor, B: int, x0: torch.Tensor):
-        L.check(L.lib().m2m_embed_forward(C.byref(self.desc), inp.data_ptr(), B, x0.data_ptr(), L.stream_ptr()),
+    def forward(self, inp: torch.Tensor, B: int, x0: torch.Tensor, step_head: Optional[tuple] = None):
+        """step_head = (adam_state, drop_counter, losses): the launch also does the step prologue (m2m_embed_forward_head)."""
+        head = None
+        if step_head is not None:
+            adam_state, drop_counter, losses = step_head
+            head = C.byref(L.StepHead(adam_state.data_ptr(), drop_counter.data_ptr(), losses.data_ptr(), losses.numel()))
+        L.check(L.lib().m2m_embed_forward_head(C.byref(self.desc), inp.data_ptr(), B, x0.data_ptr(), head, L.stream_ptr()),
                 "embed_forward")
 
     def wgrad(self, inp: torch.Tensor, d_x0: torch.Tensor, B: int):
