@@ -5,7 +5,7 @@ set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p $R/gpurun_out/sec
 cd /tmp && export TMPDIR=/tmp
-for cfg in "mimic 128 step_prologue" "mmimdb 32 embed_fwd_group"; do
+for cfg in "mimic 128 embed_fwd_kernel" "mmimdb 32 embed_fwd_group"; do
   set -- $cfg
   export TASK=$1 B=$2
   rm -rf $R/gpurun_out/sec/tr_$1
