@@ -434,6 +434,17 @@ void m2m_set_error(const char* msg, const char* file, int line);
         if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 32) \
             atomicAdd(&sym[threadIdx.x], _tm_lds[threadIdx.x]);                     \
     } while (0)
+// The same in SHADER CYCLES (s_memtime) for marks inside a hot loop: TIMER_CRESET() in front of the loop, TIMER_CMARK(i) at the
+// stage boundaries; slot i accumulates cycles (the reader's us conversion does not apply: scripts/bwd_loop_stamps.py).
+#define TIMER_CRESET() unsigned long long _tm_lastc = __builtin_amdgcn_s_memtime()
+#define TIMER_CMARK(i)                                                              \
+    do {                                                                            \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) { \
+            const unsigned long long _n = __builtin_amdgcn_s_memtime();             \
+            _tm_lds[i] += _n - _tm_lastc;                                           \
+            _tm_lastc = _n;                                                         \
+        }                                                                           \
+    } while (0)
 // every workgroup: [16] = earliest start, [17] = latest end (100 MHz wall clock), [18] = sum of workgroup durations, [19] = count,
 // [20] = latest start, [21] = earliest end
 #define TIMER_WG_BEGIN() const unsigned long long _tm_wg0 = __builtin_amdgcn_s_memrealtime()
@@ -464,6 +475,8 @@ void m2m_set_error(const char* msg, const char* file, int line);
 #define TIMER_LSTART()
 #define TIMER_LMARK(i)
 #define TIMER_LFLUSH(sym)
+#define TIMER_CRESET()
+#define TIMER_CMARK(i)
 #define TIMER_READER(name, sym)
 #define TIMER_WG_BEGIN()
 #define TIMER_WG_END(sym)

@@ -65,6 +65,10 @@ template <int P, int D, int NMAX, int TG> struct BwdLds {
 #define M2M_SMALL_ATOMIC(p, v) atomicAdd(p, v)
 #endif
 TIMER_DECL(g_tm_bwd);
+// occupancy the scheduler plans for (see the kernels' declarations)
+#ifndef M2M_BWD_KATTR
+#define M2M_BWD_KATTR
+#endif
 __device__ int g_bwd_static_split = 1;      // 1: static split of the bf16 column loop (default), 0: ticket counter (M2M_BWD_TICKETS=1)
 // copies the environment's choice to the device once per process (before the first backward launch on any stream)
 static int bwd_split_mode_init(hipStream_t st) {
@@ -514,9 +518,165 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
             if (M2M_PRIO_STATIC) __builtin_amdgcn_s_setprio(1);
             if (M2M_STAGGER > 0) __builtin_amdgcn_s_sleep(M2M_STAGGER);
         }
-        for (int q = TICKETS ? __builtin_amdgcn_readfirstlane(wave) : wave; q < npairs;) {
+        TIMER_CRESET();
+        // ---- staged form of the step (round 4; bf16, hidden_dim 128, table activation) -----------------------------------
+        // The ISA of the plain form below showed every one of a step's 16 table look-ups (ds_read_b64) and every one of the third
+        // product's 8 transposed operand reads followed at once by s_waitcnt lgkmcnt(0): 24 fully exposed LDS round trips per
+        // step although ~80 VGPRs were unused in the loop (the pre-RA scheduler sees the region at its pressure limit and sinks
+        // every load to its use), plus a burst of 16 weight loads that blocks the in-order wave until the texture addresser has
+        // taken them (in-kernel stamps, scripts/bwd_loop_stamps.py: of ~3400 cycles per step 990 went to waiting for the weights,
+        // 490 to issuing the prefetch, 700 to the third product's 8 MFMAs).  Here the step is written as ISSUE and CONSUME stages
+        // separated by scheduling barriers, so that nothing is moved back to its use: the weight prefetch in two halves around
+        // the table reads, all 16 table reads in flight together, the third product's 16 transposed reads and the next step's
+        // bias requested before the transposing MFMAs / packs / stores and consumed after them.  Arithmetic and summation order
+        // are those of the plain form (bit-identical results).
+#ifndef M2M_BWD_STAGED
+#define M2M_BWD_STAGED 1
+#endif
+        constexpr bool STAGED = M2M_BWD_STAGED && HOLD && W1LDS && MT == 1 && ActB<P>::USES_TABLE && M2M_BWD_HTAB && NF == 1;
+        f32x4_t bias_n[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};      // hidden bias of the step about to run
+        if constexpr (STAGED) {
+            const int q0 = min(TICKETS ? (int)__builtin_amdgcn_readfirstlane(wave) : wave, npairs - 1);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) bias_n[t] = *reinterpret_cast<const f32x4_t*>(bias_s + 32 * q0 + 16 * t + 4 * g);
+        }
+        // (the step index as a scalar in both split modes: the weight streams are then addressed scalar base + lane offset and the
+        //  "more steps" test is a scalar branch; as a per-lane value it cost 64-bit vector address arithmetic per load group)
+        for (int q = __builtin_amdgcn_readfirstlane(wave); q < npairs;) {
             unsigned int ticket = 0u;
             if (TICKETS && lane == 0) ticket = atomicAdd(qctr, 1u);
+            if constexpr (STAGED) {
+                typedef short s16x4 __attribute__((ext_vector_type(4)));
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                typedef __attribute__((address_space(3))) s16x4* lds_s16x4_p;
+                // (A) this step's weights have landed: park W1 for the third product, products 1 and 2
+                f32x4_t hacc[2] = {bias_n[0], bias_n[1]};
+                f32x4_t gacc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+                TIMER_CMARK(8);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int kb = 0; kb < KD; ++kb)
+                        *reinterpret_cast<u32x4_t*>(w1_wr + 4096 * t + 16 * ((4 * kb) ^ (swz_w & 12))) = w1f[t][kb].u;
+#pragma unroll
+                for (int kb = 0; kb < KD; ++kb) {
+                    const Frag a = ld_frag_lds(at, kb, lane);
+                    const Frag dy = ld_frag_lds(dyp, kb, lane);
+                    Pr::mma(hacc[0], w1f[0][kb], a);
+                    Pr::mma(hacc[1], w1f[1][kb], a);
+                    Pr::mma(gacc[0], w2f[0][kb], dy);
+                    Pr::mma(gacc[1], w2f[1][kb], dy);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                TIMER_CMARK(9);
+                const int qn = __builtin_amdgcn_readfirstlane(TICKETS ? (int)ticket : q + NWAVES);
+                const bool more = qn < npairs;
+                // (B1) first half of the next step's weights (W1: the park writes need it first) + this step's keep-word: both
+                //      independent of the products still in the matrix pipe
+                if (more) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int kb = 0; kb < KD; ++kb) w1f[t][kb] = ld_frag_global_u(p_w1n, (long)(2 * qn + t) * KD + kb, lane16);
+                }
+                const unsigned int word = drop_hidden_bits<DM>(dr_ch, (unsigned int)(row0 + il), q, Cp) >> (4 * g);
+                __builtin_amdgcn_sched_barrier(0);
+                // (B2) the 16 table cells of this lane's hidden elements: indices, then all reads in flight together
+                gtabB_t e[2][4];
+                {
+                    unsigned int idx[2][4];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            idx[t][r] = pwl_index(hacc[t][r]);
+                            if (DM != DM_NONE) idx[t][r] &= bit_to_mask(word, 16 * t + r);     // dropped: cell 0 = zeros
+                        }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) e[t][r] = gtab[idx[t][r]];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // (B3) second half of the weight prefetch: its issue lies beside the table reads' latency
+                if (more) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int kb = 0; kb < KD; ++kb) w2f[t][kb] = ld_frag_global_u(p_w2tn, (long)(2 * qn + t) * KD + kb, lane16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                TIMER_CMARK(10);
+                // (C) gelu / gelu' (both carry the dropout scale), dHpre = dHact * gelu', chained operand fragments
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float x = hacc[t][r];
+                        const float gl = __builtin_fmaf((float)e[t][r][1], x, (float)e[t][r][0]);
+                        const float dgl = __builtin_fmaf((float)e[t][r][3], x, (float)e[t][r][2]);
+                        gacc[t][r] *= dgl;
+                        hacc[t][r] = gl;
+                    }
+                Frag hf, af;
+                {
+                    Frag tmp[1];
+                    Chain<P>::make(gacc[0], gacc[1], tmp);
+                    hf = tmp[0];
+                    if constexpr (!HREC) { Chain<P>::make(hacc[0], hacc[1], tmp); af = tmp[0]; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                TIMER_CMARK(11);
+                // (D0) requests consumed two stages on: the third product's W1 operand (transposed reads of the parked fragments)
+                //      and the next step's hidden bias
+                Frag wf[DT];
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const char* pr = w1_rd + 16 * ((2 * dt) ^ (swz_r & 14));
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(pr));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(pr + 4096));
+                    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                    wf[dt].u = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
+                }
+                {
+                    const int qb = more ? qn : q;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) bias_n[t] = *reinterpret_cast<const f32x4_t*>(bias_s + 32 * qb + 16 * t + 4 * g);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // (D) operands of the weight-gradient pass: dHpre^T and Hact^T through the identity MFMA (see the plain form)
+                {
+                    const int u = tile_in_pair;
+                    const long npair = (nwg + TPP - 1) / TPP, pair = wg / TPP;
+                    const s16x4 id16 = __builtin_bit_cast(s16x4, u32x2{id_a, id_b});
+                    f32x4_t od[2], oa[2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        od[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, u32x2{hf.u[2 * t], hf.u[2 * t + 1]}), id16,
+                                                                          f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        if constexpr (!HREC)
+                            oa[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, u32x2{af.u[2 * t], af.u[2 * t + 1]}), id16,
+                                                                              f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    }
+                    const long off = (long)q * m2m_hchn_stride(npair) + (pair * 2 + u) * 1024 + lane * 16;
+                    const u32x4_t sd = u32x4_t{pack_bf2(od[0][0], od[0][1]), pack_bf2(od[0][2], od[0][3]),
+                                               pack_bf2(od[1][0], od[1][1]), pack_bf2(od[1][2], od[1][3])};
+                    __builtin_nontemporal_store(sd, reinterpret_cast<M2M_AS1 u32x4_t*>(p_dh + off));
+                    if constexpr (!HREC) {
+                        const u32x4_t sa = u32x4_t{pack_bf2(oa[0][0], oa[0][1]), pack_bf2(oa[0][2], oa[0][3]),
+                                                   pack_bf2(oa[1][0], oa[1][1]), pack_bf2(oa[1][2], oa[1][3])};
+                        __builtin_nontemporal_store(sa, reinterpret_cast<M2M_AS1 u32x4_t*>(p_h + off));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                TIMER_CMARK(12);
+                // (E) third product: dA += dHpre W1
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) Pr::mma(dacc[0][dt], hf, wf[dt]);
+                TIMER_CMARK(13);
+                q = qn;
+                continue;
+            }
             f32x4_t bias[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) bias[t] = *reinterpret_cast<const f32x4_t*>(bias_s + 32 * q + 16 * t + 4 * g);
@@ -528,6 +688,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                 gacc[mt][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
                 gacc[mt][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             }
+            TIMER_CMARK(8);    // loop step head: ticket, bias, accumulator init (+ previous step's tail)
             if constexpr (HOLD) {
             if (M2M_PRIO_FLIP) __builtin_amdgcn_s_setprio(1);
             if constexpr (W1LDS) {
@@ -579,6 +740,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
             // during the epilogue.  The scheduling barrier keeps the compiler from hoisting these loads above
             // the MFMAs that still read the current fragments (which would double the live registers).
             __builtin_amdgcn_sched_barrier(0);
+            TIMER_CMARK(9);    // wait for this step's weights, W1 park writes, A / dYd fragment reads, products 1-2 issued
             if (M2M_PRIO_FLIP) __builtin_amdgcn_s_setprio(0);
             Frag w3f[W1LDS ? 1 : NF][W1LDS ? 1 : DT];
             if constexpr (!W1LDS) {
@@ -587,7 +749,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) w3f[f][dt] = ld_frag_global_u(p_w1tc, (long)(q * NF + f) * DT + dt, lane16);
             }
-            const int qn = TICKETS ? (int)__builtin_amdgcn_readfirstlane(ticket) : q + NWAVES;
+            const int qn = __builtin_amdgcn_readfirstlane(TICKETS ? (int)ticket : q + NWAVES);
 #ifdef M2M_ABL_NOPF
             if (false) {
 #else
@@ -601,6 +763,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                         w2f[t][kb] = ld_frag_global_u(p_w2tn, (long)(2 * qn + t) * KD + kb, lane16);
                     }
             }
+            TIMER_CMARK(10);   // prefetch issue (next step's weights)
             Frag hf[MT][NF], af[MT][NF];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -637,6 +800,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
             // [c in registers][m across lanes]; an MFMA against an identity block turns them ([m][c] as the A operand,
             // chained k order) into [m in registers][c across lanes] = exactly the layout that pass consumes, exact in
             // the operand precision.  The MFMA pipe is mostly idle here, so the transpose is nearly free.
+            TIMER_CMARK(11);   // epilogue: products 1-2 complete, keep-words, table, chained fragments
 #ifndef M2M_ABL_NOTR
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -699,6 +863,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                 }
             }
 #endif   // M2M_ABL_NOTR
+            TIMER_CMARK(12);   // transposing MFMAs, packs, operand stores
 #ifdef M2M_ABL_NOP3
             asm volatile("" :: "v"(hf[0][0].u));
             q = qn;
@@ -728,9 +893,11 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) Pr::mma(dacc[mt][dt], hf[mt][f], w3f[f][dt]);
             }
+            TIMER_CMARK(13);   // third product (transposed reads of the parked W1 + MFMAs)
             q = qn;
         }
         if (TICKETS && M2M_PRIO_STATIC) __builtin_amdgcn_s_setprio(0);
+        TIMER_CMARK(14);   // (loop exit)
         TIMER_LMARK(2);   // C3 hidden-column loop (wave 0)
         int tb2 = tid;
         asm volatile("" : "+v"(tb2));
@@ -1034,7 +1201,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
 }
 
 template <int P, int D, int NMAX, int TG, int DM, bool PART = false, bool HREC = false>
-__global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw, int B, const float* __restrict__ d_out,
+__global__ __launch_bounds__(NTHREADS) M2M_BWD_KATTR void tower_bwd_kernel(const m2m_tower tw, int B, const float* __restrict__ d_out,
                                                              long d_out_ss, const float* __restrict__ d_pooled,
                                                              float* __restrict__ d_x0, long d_x0_ss, unsigned int seed,
                                                              unsigned int step_host, const unsigned int* __restrict__ step_dev) {
@@ -1044,7 +1211,7 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_kernel(const m2m_tower tw,
 }
 // the same with the classification heads in its prologue (BwdHeads); slot form only
 template <int P, int D, int NMAX, int TG, int DM, bool HREC>
-__global__ __launch_bounds__(NTHREADS) void tower_bwd_heads_kernel(const m2m_tower tw, const BwdHeads hd, int B, float* __restrict__ d_x0,
+__global__ __launch_bounds__(NTHREADS) M2M_BWD_KATTR void tower_bwd_heads_kernel(const m2m_tower tw, const BwdHeads hd, int B, float* __restrict__ d_x0,
                                                                    long d_x0_ss, unsigned int seed, unsigned int step_host,
                                                                    const unsigned int* __restrict__ step_dev) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1104,7 +1271,7 @@ bool m2m_small_part_deferred(SplitReduceTower& x, const m2m_tower* t, int B) {
     return true;
 }
 template <int P, int D, int NMAX, int TG, int DM, bool PART = false, bool HREC = false>
-__global__ __launch_bounds__(NTHREADS) void tower_bwd_group_kernel(const BwdGroupArgs a, int B, unsigned int seed,
+__global__ __launch_bounds__(NTHREADS) M2M_BWD_KATTR void tower_bwd_group_kernel(const BwdGroupArgs a, int B, unsigned int seed,
                                                                    unsigned int step_host, const unsigned int* __restrict__ step_dev) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // XCD-aware mapping: workgroups are dealt to the 8 XCDs round-robin (id % 8), each XCD has its own 4 MB L2.  Tower 0
@@ -1117,6 +1284,11 @@ __global__ __launch_bounds__(NTHREADS) void tower_bwd_group_kernel(const BwdGrou
                                                                 seed, step_host, step_dev, wg, a.ntiles[t], smem, PART ? a.part[t] : nullptr, a.dx0_chn[t]);
 }
 
+#ifdef M2M_ISA_PROBE
+// ISA probe (hipcc -S -DM2M_ISA_PROBE): only the instantiations of the benchmark's two backward launches, no host code
+template __global__ void tower_bwd_group_kernel<PREC_BF16, 128, 4, 8, DM_HALF, true, false>(const BwdGroupArgs, int, unsigned int, unsigned int, const unsigned int*);
+template __global__ void tower_bwd_kernel<PREC_BF16, 128, 8, 16, DM_HALF, true, false>(const m2m_tower, int, const float*, long, const float*, float*, long, unsigned int, unsigned int, const unsigned int*);
+#else
 template <int P, int D, int NMAX, int TG>
 static size_t bwd_lds_bytes(int nblocks, int N, int Cp) { return BwdLds<P, D, NMAX, TG>::bytes(nblocks, N, Cp); }
 
@@ -1412,3 +1584,4 @@ extern "C" int m2m_tower_backward(const m2m_tower* t, int B, const float* d_out,
     m2m_set_error("tower_backward: unsupported (prec, D)", __FILE__, __LINE__);
     return -1;
 }
+#endif   // M2M_ISA_PROBE

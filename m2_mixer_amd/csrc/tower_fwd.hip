@@ -475,6 +475,11 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_group_kernel(const FwdGrou
                                                 step_host, step_dev, wg, smem);
 }
 
+#ifdef M2M_ISA_PROBE
+// ISA probe (scripts/isa_probe.sh): only the instantiations of the benchmark's two forward launches, no host code
+template __global__ void tower_fwd_group_kernel<PREC_BF16, 128, 4, DM_HALF>(const FwdGroupArgs, int, int, unsigned int, unsigned int, const unsigned int*);
+template __global__ void tower_fwd_kernel<PREC_BF16, 128, 8, DM_HALF>(const m2m_tower, const float*, long, int, float*, long, float*, int, unsigned int, unsigned int, const unsigned int*);
+#else
 template <int P, int D, int NMAX>
 static size_t fwd_lds_bytes(int nblocks, int N, int Cp) { return FwdLds<P, D, NMAX>::bytes(nblocks, N, Cp); }
 
@@ -653,3 +658,4 @@ extern "C" int m2m_tower_forward(const m2m_tower* t, const float* x0, int64_t x0
     m2m_set_error("tower_forward: unsupported (prec, D)", __FILE__, __LINE__);
     return -1;
 }
+#endif   // M2M_ISA_PROBE
