@@ -198,7 +198,10 @@ static __device__ __forceinline__ void token_bwd_mfma(float* ub, const float* do
 
     // PU pairs per pass, stage by stage: one pair alone is a chain of ~10 dependent LDS / MFMA / VALU round trips, and the two
     // waves of a SIMD do not cover it (measured: 3.2 us per pair against 0.8 us of instruction issue)
-    constexpr int PU = 1;      // (2 was measured: the 64 extra accumulator registers spill around the phase, 165 -> 194 us per two-tower launch)
+#ifndef M2M_TOK_PU
+#define M2M_TOK_PU 1
+#endif
+    constexpr int PU = M2M_TOK_PU;      // (2 was measured: the 64 extra accumulator registers spill around the phase, 165 -> 194 us per two-tower launch)
     const int npair = ns * CP;
     for (int p0 = wave; p0 < npair; p0 += NWAVES * PU) {
         int sl[PU], d0[PU];
@@ -235,6 +238,48 @@ static __device__ __forceinline__ void token_bwd_mfma(float* ub, const float* do
             }
         }
         // dH = dG gelu'(H) keep scale, G = gelu(H) keep scale: element (column 16 ct + 4 g + r, hidden unit il + 16 tt)
+        // Staged form (table activation): the 16 cells of a pair are looked up TOGETHER -- indices, all reads, a scheduling barrier,
+        // then the arithmetic.  Written element by element (below), hipcc followed every ds_read_b64 with s_waitcnt lgkmcnt(0):
+        // 16 exposed LDS round trips per pair, half of this phase's time (the backward kernel sits at its register limit and the
+        // scheduler sinks every load to its use; tower_bwd.hip's column loop has the same cure).  The keep-mask is folded into
+        // the index (a dropped element reads cell 0 = zeros), as in the column loop.
+        constexpr bool TOK_STAGED = ActB<PREC_BF16>::USES_TABLE && M2M_BWD_HTAB && !(M2M_TOK_FORMULA & 2);
+        if constexpr (TOK_STAGED) {
+#pragma unroll
+            for (int u = 0; u < PU; ++u)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {                             // (8 cells at a time: 16 more registers, no spills)
+                    u32x4_t w4 = u32x4_t{~0u, ~0u, ~0u, ~0u};
+                    if (DM != DM_NONE) w4 = *reinterpret_cast<const u32x4_t*>(wth + sl[u] * D + d0[u] + 16 * ct + 4 * g);
+                    gtabB_t e[2][4];
+                    {
+                        unsigned int idx[2][4];
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                idx[tt][r] = pwl_index(H[u][ct][tt][r]);
+                                if (DM != DM_NONE) idx[tt][r] &= (unsigned int)(((int)(w4[r] << (31 - il - 16 * tt))) >> 31);
+                            }
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) e[tt][r] = gtab[idx[tt][r]];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float x = H[u][ct][tt][r];
+                            const float gl = __builtin_fmaf((float)e[tt][r][1], x, (float)e[tt][r][0]);
+                            const float dgl = __builtin_fmaf((float)e[tt][r][3], x, (float)e[tt][r][2]);
+                            dG[u][ct][tt][r] *= dgl;
+                            H[u][ct][tt][r] = gl;
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        } else {
 #pragma unroll
         for (int u = 0; u < PU; ++u)
 #pragma unroll
@@ -256,6 +301,7 @@ static __device__ __forceinline__ void token_bwd_mfma(float* ub, const float* do
                         }
                     }
             }
+        }
         Frag hB[PU][2];                                                      // k = the pair's 32 columns (chained), j = t
 #pragma unroll
         for (int u = 0; u < PU; ++u) {

@@ -411,6 +411,11 @@ __global__ __launch_bounds__((WgradKernelGeom<P, D, RCDM>::THREADS), (WgradKerne
 
 static_assert(sizeof(WgradGroupArgs) + sizeof(EmbedWgradGroupArgs) + sizeof(SplitReduceArgs) <= 3840, "kernel arguments are limited to 4 KiB");
 
+#ifdef M2M_ISA_PROBE
+// ISA probe (scripts/isa_probe.sh wgrad): only the benchmark's weight-gradient instantiation, no host code
+template __global__ void tower_wgrad_group_kernel<PREC_BF16, 128, -1>(const WgradGroupArgs, const EmbedWgradGroupArgs, const SplitReduceArgs);
+template __global__ void tower_wgrad_group_kernel<PREC_BF16, 128, DM_HALF>(const WgradGroupArgs, const EmbedWgradGroupArgs, const SplitReduceArgs);
+#else
 // The single-owner embedding gradients as a launch of their own (256 threads, in front of the tower launch on the same stream):
 // beside five-wave tower workgroups (one per CU, SIMD 0 full) an embedding workgroup finds room only on the 16 CUs the 240 tower
 // workgroups leave free, and ~100 latency-bound workgroups queued on 16 CUs outlast the towers by ~20 us.
@@ -792,3 +797,4 @@ extern "C" int m2m_wgrad_fold(const m2m_tower* t, void* stream) {
     }
     return 0;
 }
+#endif   // M2M_ISA_PROBE
