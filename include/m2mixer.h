@@ -116,7 +116,10 @@ typedef struct m2m_tower {
     /* ---- packed image of the gradient wrt the tower input (optional) ------------------------------------------------------
      * With it m2m_tower_backward / m2m_towers_backward also leave d_x0^T as packed operand blocks, laid out like at_chn
      * ([32-row pair][d tile][lane] 16 B, k = token row in chained order): the first operand of the patch-embedding weight
-     * gradient, which then needs neither LDS staging nor atomics (m2m_towers_wgrad, `embed_towers`). */
+     * gradient, which then needs neither LDS staging nor atomics (m2m_towers_wgrad, `embed_towers`).
+     * Precision note: in that single-owner form the embedding BIAS gradient is summed from this image too, i.e. from d_x0
+     * rounded to bf16 (2^-9 relative per summand), where the row-group form sums the fp32 d_x0; observed difference <= 3e-3 of
+     * the tensor's max (tests/test_gpu_parity.py, "bf16 embedding bias grad"); the reference has no fixture for it. */
     void* dx0_chn;
 } m2m_tower;
 #define M2M_WGRAD_OVERWRITE 1 /* wgrad_flags: g_ch_w1 / g_ch_b1 / g_ch_w2 are WRITTEN ("="), not accumulated ("+="): the caller

@@ -558,6 +558,19 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
 #pragma unroll
                     for (int kb = 0; kb < KD; ++kb)
                         *reinterpret_cast<u32x4_t*>(w1_wr + 4096 * t + 16 * ((4 * kb) ^ (swz_w & 12))) = w1f[t][kb].u;
+                // The next step's fragments are requested k-block by k-block right behind the four MFMAs that read this step's (an MFMA
+                // takes its operands when it issues; the load lands hundreds of cycles later): the texture addresser takes 16 cycles
+                // per 1 KiB load, the matrix pipe 16 per MFMA -- the loads' issue (which blocks the in-order wave while the
+                // addresser's queue is full: 490 cycles as one burst behind the products) lies under the products, and the prefetch
+                // distance grows by the length of this stage.  MEASURED (three interleaved repetitions in one process): no gain,
+                // 0.5074-0.5120 against 0.5066-0.5079 ms per step for the burst in two halves (stages B1 / B3) -- with the
+                // round trips gone the loop runs at ~72 % of the texture addresser's rate (18 KiB per wave and step at 64 B/clk:
+                // 2300 of ~3200 cycles per round) and the waves queue behind each other whatever the order.  Off.
+#ifndef M2M_BWD_PF_INTERLEAVE
+#define M2M_BWD_PF_INTERLEAVE 0
+#endif
+                const int qn = __builtin_amdgcn_readfirstlane(TICKETS ? (int)ticket : q + NWAVES);
+                const bool more = qn < npairs;
 #pragma unroll
                 for (int kb = 0; kb < KD; ++kb) {
                     const Frag a = ld_frag_lds(at, kb, lane);
@@ -566,14 +579,23 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                     Pr::mma(hacc[1], w1f[1][kb], a);
                     Pr::mma(gacc[0], w2f[0][kb], dy);
                     Pr::mma(gacc[1], w2f[1][kb], dy);
+                    if (M2M_BWD_PF_INTERLEAVE) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (more) {
+#pragma unroll
+                            for (int t = 0; t < 2; ++t) {
+                                w1f[t][kb] = ld_frag_global_u(p_w1n, (long)(2 * qn + t) * KD + kb, lane16);
+                                w2f[t][kb] = ld_frag_global_u(p_w2tn, (long)(2 * qn + t) * KD + kb, lane16);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 TIMER_CMARK(9);
-                const int qn = __builtin_amdgcn_readfirstlane(TICKETS ? (int)ticket : q + NWAVES);
-                const bool more = qn < npairs;
                 // (B1) first half of the next step's weights (W1: the park writes need it first) + this step's keep-word: both
                 //      independent of the products still in the matrix pipe
-                if (more) {
+                if (!M2M_BWD_PF_INTERLEAVE && more) {
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -599,7 +621,7 @@ static __device__ __forceinline__ void tower_bwd_body(const TW& tw, int B, const
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // (B3) second half of the weight prefetch: its issue lies beside the table reads' latency
-                if (more) {
+                if (!M2M_BWD_PF_INTERLEAVE && more) {
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -1458,6 +1480,14 @@ extern "C" int m2m_towers_backward(const m2m_tower* const* towers, const m2m_tow
     // the forward of this step took the split path under the same conditions (csrc/split.h)
     if (m2m_split_eligible(towers[0], B, 1) && m2m_split_eligible(towers[1], B, 1) && m2m_split_can_group(towers[0], towers[1]))
         return m2m_split_backward(towers, io, 2, B, seed, step, step_dev, reinterpret_cast<hipStream_t>(stream));
+    // (mixed eligibility -- only reachable through M2M_SPLIT / M2M_SPLIT_MIN_ROWS -- takes the fused launch below; a tower flagged
+    // M2M_WGRAD_REDUCES_SMALL that IS split-eligible would then have its slot reduction skipped by the weight-gradient launch
+    // (m2m_small_part_deferred decides per tower): refused instead of losing its LayerNorm / token-MLP / ch_b2 gradients)
+    for (int i = 0; i < 2; ++i)
+        if ((towers[i]->wgrad_flags & M2M_WGRAD_REDUCES_SMALL) && m2m_split_eligible(towers[i], B, 1)) {
+            m2m_set_error("towers_backward: a tower with M2M_WGRAD_REDUCES_SMALL is eligible for the column-split path but its partner is not: launch them separately", __FILE__, __LINE__);
+            return -1;
+        }
     if (m2m_can_group_wide(towers[0], towers[1], B))
         return m2m_backward_wide_group(towers, io, B, seed, step, step_dev, reinterpret_cast<hipStream_t>(stream));
     if (!m2m_can_group(towers[0], towers[1])) {

@@ -109,14 +109,30 @@ class PlateauLR:
         return self.lr
 
 
+def prepare_tail_engine(engine, data: "ResidentAVMnist", split: str, batch_size: int):
+    """The training engine of `split`'s ragged last batch, built NOW (before engine.capture()) and kept on the engine for
+    run_epoch; None when the split divides evenly."""
+    rem = data.num_samples(split) % batch_size
+    if rem == 0:
+        return None
+    tails = engine.__dict__.setdefault("_tail_engines", {})
+    if rem not in tails:
+        tails[rem] = engine.sibling(rem)
+    return tails[rem]
+
+
 def run_epoch(engine, data: ResidentAVMnist, split: str, batch_size: int, train: bool, log_interval_steps: int = 50,
-              replay=None, log=None, tail_engine=None, grad_sync=None) -> Dict[str, float]:
+              replay=None, log=None, tail_engine=None, grad_sync=None, epoch: int = 0, shuffle_seed: int = 0) -> Dict[str, float]:
     """One pass over EVERY sample of `split` (the reference's loaders keep the ragged last batch,
     datasets/avmnist.py:180-190).  train=True drives the captured step (`replay`, from engine.capture) or
     engine.train_step.  A last batch smaller than batch_size -- the captured graph and the engine's buffers have a static
     batch size -- goes through `tail_engine` (default: engine.sibling(remainder), same parameters / Adam state, built on
     first use and kept on the engine), eagerly; packed operand copies are re-synchronised around it.
-    Data parallel (world > 1): pass the `grad_sync` the replay was captured with -- EVERY training step exchanges gradients,
+    A TRAINING tail engine must exist before engine.capture() (engine.sibling narrows the gradient ranges the captured
+    optimizer leaves uncleared and refuses to do so under a captured graph): prepare_tail_engine(engine, data, split, batch).
+    Data parallel (world > 1): the test split is shuffled (as the reference's loader) with a generator seeded `shuffle_seed +
+    epoch` on EVERY rank (torch's DistributedSampler does the same), so the ranks' strided shards partition one permutation.
+    Pass the `grad_sync` the replay was captured with -- EVERY training step exchanges gradients,
     the eager ones (no replay, the ragged last batch) included, as Lightning's DDP does; the ranks see equally many samples
     (ResidentAVMnist.num_samples), hence the same sequence of collectives.  Returned metrics are this rank's (the reference
     logs without sync_dist).
@@ -136,15 +152,20 @@ def run_epoch(engine, data: ResidentAVMnist, split: str, batch_size: int, train:
     if train and grad_sync is None and getattr(data, "world", 1) > 1:
         raise RuntimeError("run_epoch: world > 1 needs the gradient exchange (grad_sync=parallel.GradSync(...))")
     nb = data.num_batches(split, batch_size)
-    for i, (image, audio, labels) in enumerate(data.batches(split, batch_size, shuffle=(split == "test"))):
+    shuffle, gen = split == "test", None
+    if shuffle and getattr(data, "world", 1) > 1:
+        gen = torch.Generator(device=data.device)
+        gen.manual_seed(int(shuffle_seed) + int(epoch))
+    for i, (image, audio, labels) in enumerate(data.batches(split, batch_size, shuffle=shuffle, generator=gen)):
         bs = labels.shape[0]
         eng = engine
         if bs != batch_size:                                       # the ragged last batch
             if tail_engine is None:
                 tail_engine = getattr(engine, "_tail_engines", {}).get(bs)
             if tail_engine is None:
-                tail_engine = engine.sibling(bs)
-                engine.__dict__.setdefault("_tail_engines", {})[bs] = tail_engine
+                tail_engine = engine.sibling(bs, trains=train)
+                if train:                                          # (an evaluating sibling is not kept as the training one)
+                    engine.__dict__.setdefault("_tail_engines", {})[bs] = tail_engine
             eng = tail_engine
             eng.pack()                                             # its packed copies missed every step since its last use
             image, audio, labels = image.contiguous(), audio.contiguous(), labels.contiguous()

@@ -331,18 +331,31 @@ class _FlatEngine:
     def _sibling_kwargs(self) -> dict:
         return {"fusion_loss_weight": self.fusion_loss_weight} if hasattr(self, "fusion_loss_weight") else {}
 
-    def sibling(self, batch_size: int):
+    def sibling(self, batch_size: int, trains: bool = True):
         """An engine for another batch size over THIS engine's parameters, gradients, Adam state and step counters
-        (constructor argument share=): the step that takes an epoch's ragged last batch, or a validation engine."""
+        (constructor argument share=): the step that takes an epoch's ragged last batch, or a validation engine.
+        trains=False: the sibling only evaluates (it never writes a gradient): nothing of this engine changes.
+
+        Both engines work on ONE gradient buffer.  A range one of them leaves uncleared ("keep": its own next backward
+        overwrites it) must be overwritten by the other one's backward too, or that one would accumulate onto stale values --
+        so the keep flags of both are narrowed to the ranges BOTH overwrite.  A captured graph holds its range table BY VALUE
+        (m2m_adam_step_ranges copies it into the kernel arguments), so narrowing after capture() would leave the graph with
+        the old flags: that is refused -- build training siblings before capture(), or capture again."""
         prec = {v: k for k, v in L.PREC_BY_NAME.items() if k in ("bf16", "fp32")}[self.prec]
         sib = type(self)(self.cfg, batch_size, device=self.device, precision=prec, lr=float(self.adam_state[1]),
                          betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, seed=self.seed, init=False,
                          share=self, **self._sibling_kwargs())
         if hasattr(self, "pos_weight"):                      # MM-IMDb: the LOADED criterion buffer, not cfg's (ADVICE r2)
             sib.pos_weight.copy_(self.pos_weight)
-        # Both engines work on ONE gradient buffer: a range one of them leaves uncleared ("keep": its own next backward
-        # overwrites it) must be overwritten by the other one's backward too, or that one would accumulate onto stale values.
+        if not trains:
+            sib._eval_only = True
+            return sib
         mine, theirs = {r[0] for r in self._ranges_add}, {r[0] for r in sib._ranges_add}
+        narrowed = [lo for lo, n, v, k in self._ranges_add if k and lo not in theirs]
+        if narrowed and self._graph is not None:
+            raise RuntimeError(f"sibling({batch_size}): this engine's captured graph keeps {len(narrowed)} gradient range(s) uncleared "
+                               "that the sibling's backward would not overwrite; build training siblings before capture() "
+                               "(or capture again afterwards)")
         for eng, other in ((self, theirs), (sib, mine)):
             eng._ranges_add = [(lo, n, v, int(k and lo in other)) for lo, n, v, k in eng._ranges_add]
             eng._ranges_keep = [(lo, n, None, k) for lo, n, _, k in eng._ranges_add]
@@ -386,17 +399,27 @@ class _FlatEngine:
         each element it consumes), so no separate fill pass is needed.  (Channel-mixing weight gradients of the
         overwriting towers -- _setup_wgrad -- are written, not added: those ranges need no clearing.)  On return flat_g
         holds the complete gradient: a row group the weight-gradient launch left in a slot is folded in here."""
+        self._check_trains()
+        self._slots_folded = False
         self._forward(*batch, training=True, with_grad=True, prologue=True)
         self._backward(*batch[:-1])
         for t in self._slot_towers:
             t.wgrad_fold()
-        self._slots_folded = True
+        self._slots_folded = True                       # (consumed by the optimizer_step that follows; fused_step resets it)
 
     def fused_step(self, *batch):
         """forward + backward + Adam + re-pack in one go (no gradient exchange: single-GPU training)."""
+        self._check_trains()
+        # (a forward_backward() without its optimizer_step() -- gradient inspection, a skipped step -- must not make THIS step's
+        # Adam skip the slot of the two-group tower: the slot is folded by forward_backward only)
+        self._slots_folded = False
         self._forward(*batch, training=True, with_grad=True, prologue=True)
         self._backward(*batch[:-1], fused_update=True)
         return self.losses
+
+    def _check_trains(self):
+        if getattr(self, "_eval_only", False):
+            raise RuntimeError("this engine was built with sibling(..., trains=False): it only evaluates")
 
     def _adam_pack_modules(self):
         """(towers, embeds) whose parameters all live in the flat buffers and whose operand copies one m2m_adam_pack_all

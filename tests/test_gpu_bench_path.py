@@ -274,7 +274,7 @@ def test_run_epoch_covers_every_sample_and_matches_the_oracle(dev, tmp_path):
     batch, datasets/avmnist.py:180-190): accumulated losses and all three heads' hit counts against the oracle evaluated
     over the same split; then one training epoch with a ragged last batch advances Adam once per batch."""
     from test_host_cpu import _write_avmnist
-    from m2_mixer_amd.data import ResidentAVMnist, run_epoch
+    from m2_mixer_amd.data import ResidentAVMnist, prepare_tail_engine, run_epoch
     from m2_mixer_amd.engine import AVMnistEngine
     root = str(tmp_path / "avmnist")
     _write_avmnist(root, 300, 37, seed=5, learnable=True)           # train 275, val 25, test 37
@@ -295,6 +295,8 @@ def test_run_epoch_covers_every_sample_and_matches_the_oracle(dev, tmp_path):
             assert abs(got[k] - float(ls[:, j].mean())) < FP32_ATOL, k
         assert [got["hits_image"], got["hits_audio"], got["hits"]] == [int(h) for h in hits]
     # training: 275 = 17 x 16 + 3 -> 18 optimizer steps, the last one through the 3-sample sibling engine
+    tail = prepare_tail_engine(eng, data, "train", B)               # the training sibling exists BEFORE the capture
+    assert tail is not None and tail.B == 3
     replay = eng.capture(*next(iter(data.batches("train", B))))
     tr = run_epoch(eng, data, "train", B, train=True, replay=replay)
     torch.cuda.synchronize()
@@ -306,6 +308,31 @@ def test_run_epoch_covers_every_sample_and_matches_the_oracle(dev, tmp_path):
         O.avmnist_train_step(image[sl], audio[sl], labels[sl], p2, cfg, state, lr=1e-3)
     va, (ls, hits) = run_epoch(eng, data, "val", B, train=False), _oracle_epoch(data, "val", B, p2, cfg)
     assert abs(va["loss"] - float((ls[:, 3] * ls[:, 4]).sum() / ls[:, 4].sum())) < 5e-3
+
+
+def test_sibling_that_changes_the_kept_ranges_is_refused_after_capture(dev, monkeypatch):
+    """a captured graph holds the Adam range table by value; a training sibling whose backward overwrites
+    FEWER ranges than the captured optimizer leaves uncleared would accumulate onto stale gradients.  engine.sibling refuses
+    that after capture(); an evaluating sibling (trains=False) changes nothing and cannot train."""
+    from m2_mixer_amd.engine import AVMnistEngine
+    cfg, B = dict(G.AVMNIST["S"], dropout=0.0), 16
+    eng = AVMnistEngine(cfg, B, device=dev, precision="bf16", lr=1e-3)
+    if not any(k for *_, k in eng._ranges_add):
+        pytest.skip("this configuration keeps no gradient range uncleared")
+    image, audio, labels = (t.to(dev) for t in G.avmnist_batch(B, 3, cfg))
+    before = list(eng._ranges_add)
+    ev = eng.sibling(5, trains=False)                              # validation engine: nothing narrows
+    assert eng._ranges_add == before
+    with pytest.raises(RuntimeError, match="only evaluates"):
+        ev.train_step(*(t[:5].contiguous() for t in (image, audio, labels)))
+    same = eng.sibling(7)                                          # same overwrite set: fine before and after capture
+    assert eng._ranges_add == before and same._ranges_add
+    eng.capture(image, audio, labels)
+    eng.sibling(9)
+    monkeypatch.setenv("M2M_WGRAD_OVERWRITE", "0")                 # a sibling that overwrites nothing
+    with pytest.raises(RuntimeError, match="before capture"):
+        eng.sibling(11)
+    assert eng._ranges_add == before                               # (and the refusal left this engine's table alone)
 
 
 def _lightning_ckpt(path, state_dict, epoch=3):

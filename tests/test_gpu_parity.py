@@ -6,8 +6,10 @@
 Tolerances
   fp32 mode (exact fp32 MFMA): logits / activations 1e-3 absolute as BASELINE.json's north_star states
       (observed ~1e-6), gradients 1e-3 relative to the tensor's max;
-  bf16 mode (bf16 operands, fp32 accumulate): 3e-2 relative to the tensor's max for activations and
-      gradients (observed ~5e-3), class predictions identical.
+  bf16 mode (bf16 operands, fp32 accumulate): logits / activations 2e-2 (BF16_REL; observed 5.5e-3), gradients 4e-2
+      relative to the tensor's max (BF16_GRAD_REL; observed 1.4e-2); class predictions: the argmax of the kernel's own logits,
+      equal to the oracle's wherever the oracle's top-2 margin exceeds twice the observed logit error (assert_preds_bf16) --
+      bit-exact predictions are asserted in fp32 mode only.  Observed maxima are printed in the test summary (conftest.observe).
 """
 import os
 
@@ -24,6 +26,7 @@ pytestmark = pytest.mark.gpu
 
 FP32_ATOL = 1e-3
 BF16_REL = 2e-2        # (observed maxima are printed in the test summary)
+BF16_GRAD_REL = 4e-2   # gradients, relative to the tensor's max (the same bar as tests/test_gpu_bench_path.py)
 
 
 @pytest.fixture(scope="module")
@@ -220,7 +223,7 @@ def test_avmnist_step_bf16_vs_oracle(size, B, dev):
     for k, g in ref["grads"].items():
         if k.endswith("token_mix.2.net.3.bias"):
             continue
-        assert relerr(eng.grads[k], g) < 6e-2, k
+        assert observe("bf16 gradients (rel to max)", relerr(eng.grads[k], g), BF16_GRAD_REL) < BF16_GRAD_REL, k
 
 
 @pytest.mark.parametrize("prec,B", [("fp32", 1), ("fp32", 3), ("bf16", 1), ("bf16", 5)])
@@ -367,8 +370,12 @@ def test_grouped_launches_match_single_launches(prec, dev):
         o = (g.data_ptr() - eng.flat_g.data_ptr()) // 4
         # (the single-owner embedding gradients of the merged launch sum the bf16 image of d_x0^T for the bias too; the
         # separate launch sums the fp32 d_x0: bf16 rounding of the summands, 2^-9 each)
-        tol = 3e-3 if (prec == "bf16" and k.endswith("to_patch_embedding.0.bias")) else 1e-4
-        assert relerr(g_merged[o:o + g.numel()].view_as(g), g) < tol, k
+        bias_bf16 = prec == "bf16" and k.endswith("to_patch_embedding.0.bias")
+        tol = 3e-3 if bias_bf16 else 1e-4
+        err = relerr(g_merged[o:o + g.numel()].view_as(g), g)
+        if bias_bf16:
+            observe("bf16 embedding bias grad, single-owner vs fp32 sum", err, tol)      # (parity unpinned by the reference)
+        assert err < tol, k
     # ---- operand packing: the whole model in one launch vs per tower / per embedding, bit for bit
     towers, embeds = [eng.t_a, eng.t_b, eng.t_fus], [eng.e_a, eng.e_b]
     pack_all(towers, embeds)
@@ -598,7 +605,7 @@ def test_wide_models_bf16_vs_oracle_and_training(task, dev):
     for k, leaf in leaves.items():
         if k.endswith("token_mix.2.net.3.bias"):      # exactly-zero true gradient
             continue
-        assert relerr(eng.grads[k], leaf.grad) < 6e-2, k
+        assert observe("bf16 gradients (rel to max)", relerr(eng.grads[k], leaf.grad), BF16_GRAD_REL) < BF16_GRAD_REL, k
     # training with dropout on
     eng = mk(cfg, 2e-3)
     eng.load_state_dict(params)
@@ -629,7 +636,7 @@ def test_mimic_large_batch_token_gradients_vs_oracle(prec, dev):
     leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     ref = O.mimic_forward(*batch, leaves, cfg)
     ref["loss"].backward()
-    tol_l, tol_g = (FP32_ATOL, 2e-3) if prec == "fp32" else (BF16_REL, 4e-2)
+    tol_l, tol_g = (FP32_ATOL, 2e-3) if prec == "fp32" else (BF16_REL, BF16_GRAD_REL)
     assert abserr(eng.logits[2], ref["logits"]) < tol_l * max(1.0, float(ref["logits"].detach().abs().max()))
     assert abs(float(eng.losses[3]) - float(ref["loss"].detach())) < (1e-3 if prec == "fp32" else 2e-2)
     for k, leaf in leaves.items():

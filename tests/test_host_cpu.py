@@ -526,7 +526,7 @@ class _StubEngine:
         self.exchanges = counter if counter is not None else [0]
         self.packs = 0
 
-    def sibling(self, bs):
+    def sibling(self, bs, trains=True):
         return _StubEngine(bs, self.flat_p, self.exchanges)
 
     def pack(self):
