@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense peaks, MI355X_MICROARCH.md "Chip-level parameters"
 # HBM bytes per launch come from the rocprofv3 PMC passes (counters cannot be collected from inside this process): the
 # summary scripts/collect_profiles.sh writes, keyed by kernel name and by the hash of the kernel sources it was taken on.
-PMC_JSON = os.path.join(ROOT, "profiles", "r03_pmc.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r04_pmc.json")
 LAUNCH_KERNEL = {"towers_bwd[image+audio]": "tower_bwd_group_kernel", "tower_bwd[fusion]": "tower_bwd_kernel",
                  "tower_bwd[fusion]+heads": "tower_bwd_heads_kernel",
                  "towers_fwd[image+audio]": "tower_fwd_group_kernel", "tower_fwd[fusion]": "tower_fwd_kernel",
@@ -39,7 +39,7 @@ LAUNCH_KERNEL = {"towers_bwd[image+audio]": "tower_bwd_group_kernel", "tower_bwd
 
 
 def pmc_traffic(launch, model, B, precision):
-    """HBM bytes (2 x FETCH_SIZE + WRITE_SIZE) of one launch of `launch` from profiles/r03_pmc.json -- None, with a
+    """HBM bytes (2 x FETCH_SIZE + WRITE_SIZE) of one launch of `launch` from profiles/r04_pmc.json -- None, with a
     warning, when the file is missing, was taken on other kernel sources, or covers another configuration."""
     if not (model == "B" and B == 512 and precision == "bf16"):
         return None
@@ -51,7 +51,7 @@ def pmc_traffic(launch, model, B, precision):
         return None
     from m2_mixer_amd import _lib
     if rec.get("csrc_sha256") != _lib.csrc_hash():
-        log("roofline.traffic: profiles/r03_pmc.json was collected on different kernel sources (stale) -> null; "
+        log("roofline.traffic: profiles/r04_pmc.json was collected on different kernel sources (stale) -> null; "
             "re-run scripts/collect_profiles.sh")
         return None
     names = LAUNCH_KERNEL.get(launch, "")
@@ -184,6 +184,62 @@ def cpu_baselines(budget_s=20.0):
     return main, extra
 
 
+def shader_clock_mhz(device, spin_ms=1.0):
+    """Median shader clock over the chip's 256 CUs while every CU runs MFMA + VALU work for ~spin_ms (m2m_clock_probe:
+    s_memtime cycles / s_memrealtime ticks x 100 MHz).  Recorded before and after the timed region: this launch-bound, partly
+    issue-bound step runs at 1.8-2.1 GHz depending on the box and on what the kernel does, far below the 2.4 GHz maximum."""
+    from m2_mixer_amd import _lib as L
+    nwg = 256
+    out = torch.zeros(2 * nwg, dtype=torch.int64, device=device)
+    L.check(L.lib().m2m_clock_probe(out.data_ptr(), nwg, int(spin_ms * 1e5), L.stream_ptr()), "clock_probe")
+    torch.cuda.synchronize()
+    v = out.view(nwg, 2).cpu().numpy().astype(np.float64)
+    ticks = np.bitwise_and(out.view(nwg, 2)[:, 1].cpu().numpy(), (1 << 62) - 1).astype(np.float64)
+    return round(float(np.median(v[:, 0] / np.maximum(ticks, 1.0))) * 100.0, 1)
+
+
+def module_path_point(cfg, B, device, precision, budget_s=4.0):
+    """BASELINE config 2 for the IMPORT-SWAP path: what a user of the reference gets from replacing `modules` by
+    `m2_mixer_amd.modules` and nothing else -- AVMnistMixerMultiLoss built from the cfg dicts through the registry
+    (modules/__init__.py:12-26), shared_step (models/avmnist.py:236-312) -> loss.backward() under torch autograd ->
+    torch.optim.Adam.step() (models/avmnist.py:413-415), eager launches, no graph, no fused optimizer.  Outside the timed region."""
+    import m2_mixer_amd as M
+    from m2_mixer_amd import models as MD
+    M.set_precision(precision)
+    mods = {"image": dict(cfg["image"], block_type="MLPMixer"), "audio": dict(cfg["audio"], block_type="MLPMixer"),
+            "multimodal": dict(cfg["multimodal"], block_type="FusionMixer", fusion_function="ConcatFusion"),
+            "classification": dict(classifier="StandardClassifier", num_classes=cfg["num_classes"],
+                                   input_shape=[B, n_patch(cfg["image"]) + n_patch(cfg["audio"]), cfg["multimodal"]["hidden_dim"]])}
+    torch.manual_seed(42)
+    net = MD.AVMnistMixerMultiLoss({"dropout": cfg["dropout"], "modalities": mods}, {"lr": 1e-2, "betas": (0.9, 0.999), "scheduler_patience": 2}).to(device)
+    net.train()
+    opt = net.configure_optimizers()["optimizer"]
+    image, audio, labels = make_batch(cfg, B, 1234, device)
+    batch = {"image": image, "audio": audio, "label": labels}
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = net.shared_step(batch, mode="train")
+        out["loss"].backward()
+        opt.step()
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    n = max(5, min(200, int(budget_s / max(time.perf_counter() - t0, 1e-4))))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": round(B * n / dt, 1), "unit": "samples/s", "ms_per_step": round(dt / n * 1e3, 4), "steps": n,
+            "what": "m2_mixer_amd.models.AVMnistMixerMultiLoss (registry-built m2_mixer_amd.modules towers under torch autograd): "
+                    f"shared_step -> loss.backward() -> torch.optim.Adam.step(), eager, {precision}, batch {B}"}
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -240,6 +296,7 @@ def main():
                     help="~this many ms of untimed steps (preheat_ms / 0.75 of them) before the W warm-up steps, so a fresh box's "
                          "clocks have ramped up when the warm-up starts (reported in config.preheat_ms; 0 disables)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-module-path", action="store_true", help="skip the import-swap module-path leg (outside the timed region)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--profile-steps", type=int, default=10, help="eager steps with HIP events around every launch")
     ap.add_argument("--launch-check", action="store_true",
@@ -311,6 +368,7 @@ def main():
         log(f"preheat: {n_pre} untimed steps (~{args.preheat_ms:.0f} ms)")
         run_steps(n_pre)
     barrier()
+    clk = [shader_clock_mhz(dev)] if rank == 0 else []             # (~1 ms of MFMA + VALU work per CU, BEFORE the warm-up steps)
     log("warm-up")
     run_steps(args.warmup)
     barrier()
@@ -319,6 +377,8 @@ def main():
     run_steps(args.steps)
     barrier()
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    if clk:
+        clk.append(shader_clock_mhz(dev))
     # the last step ran through the multi-step graph (its own per-step output slots) or through the single-step graph
     last_multi = multi is not None and args.steps >= spg and args.steps % spg == 0
     loss_end = float((multi.losses[-1] if last_multi else eng.losses)[3])
@@ -360,12 +420,17 @@ def main():
         "algorithmic_gflop_per_step": round(flops_step / 1e9, 2),
         "kernels_us": {k: round(v["us_per_step"], 1) for k, v in kern.items()},
         "final_loss": round(loss_end, 4),
+        "shader_clock_mhz": {"before": clk[0], "after": clk[1], "max": 2400,
+                             "how": "m2m_clock_probe: median over 256 CUs of s_memtime / s_memrealtime during ~1 ms of MFMA + VALU work"},
     }
     if world == 1 and not args.no_cpu_baseline:
         # baselines, all outside the timed region: the eager path on this GPU (BASELINE config 2's comparator), then the CPU
         log("eager torch-ROCm baseline (the oracle's ops on the GPU) ...")
         out["eager_rocm_baseline"] = [baseline_point(f"AV-MNIST M2-Mixer-{args.model}", cfg, B, dev, budget_s=3.0, autocast=ac)
                                       for ac in (None, torch.bfloat16)]
+        if not args.no_module_path:
+            log("module path (import-swap: m2_mixer_amd.modules under torch autograd + torch.optim.Adam) ...")
+            out["module_path"] = module_path_point(cfg, B, dev, args.precision)
         log("cpu baselines (oracle) ...")
         out["cpu_baseline"], out["cpu_baselines_other_configs"] = cpu_baselines(args.cpu_budget)
     print(json.dumps(out), flush=True)

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define M2M_ABI_VERSION 15
+#define M2M_ABI_VERSION 16
 #define M2M_MAX_BLOCKS 8      /* MixerBlocks per m2m_tower; longer towers are chained by the caller */
 #define M2M_ROWS_PER_WG 16    /* token rows one workgroup keeps on chip */
 
@@ -413,6 +413,12 @@ int m2m_gelu_probe(const float* x, float* y, float* dy, int64_t n, void* stream)
  * Exercises the fragment layouts end to end. */
 int m2m_gemm_probe(int prec, const float* A, const float* Bm, int I, int J, int K,
                    const float* Bc, int J2, float* C, float* C2, void* workspace, void* stream);
+
+/* Shader clock under load (bench.py records it next to the timings: boxes and power states differ by several percent).
+ * `nwg` workgroups of 512 threads (one per CU at nwg = 256) spin on MFMA + VALU work for `spin_ticks` ticks of the 100 MHz
+ * wall clock (s_memrealtime) and store {shader cycles (s_memtime), wall ticks} per workgroup: out[2 * w], out[2 * w + 1]
+ * (device memory, 2 * nwg uint64).  MHz = cycles / ticks * 100.  spin_ticks is capped at 1 000 000 (10 ms). */
+int m2m_clock_probe(uint64_t* out, int nwg, int spin_ticks, void* stream);
 
 #ifdef __cplusplus
 }

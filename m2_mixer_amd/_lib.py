@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("M2M_LIB_PATH", os.path.join(_HERE, "libm2mixer.so"))   # override: diagnostic builds
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 MAX_BLOCKS = 8
 ROWS_PER_WG = 16
 HCHN_PAD = 4096          # >= the pad between operand streams the library uses (csrc/tile.h M2M_HCHN_PAD)
@@ -167,6 +167,7 @@ SIGNATURES = {
     "m2m_dropout_mask": (C.c_int, [C.POINTER(Tower), C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, _fp, _fp]),
     "m2m_gelu_probe": (C.c_int, [_fp, _fp, _fp, C.c_int64, _fp]),
     "m2m_gemm_probe": (C.c_int, [C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, _fp, _fp, _fp]),
+    "m2m_clock_probe": (C.c_int, [_fp, C.c_int, C.c_int, _fp]),
 }
 
 _lib = None

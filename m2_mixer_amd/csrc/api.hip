@@ -878,3 +878,47 @@ extern "C" int m2m_gemm_probe(int prec, const float* A, const float* Bm, int I, 
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
 }
+
+// ---- shader clock under load (include/m2mixer.h: m2m_clock_probe) ---------------------------------------------------------
+// Every wave runs the same bounded loop: 32 bf16 MFMAs + a few VALU instructions per trip, the wall clock read once per trip;
+// the loop ends when spin_ticks have passed (an exit condition every wave reaches: the 100 MHz counter always advances).
+__global__ __launch_bounds__(512) void clock_probe_kernel(unsigned long long* __restrict__ out, unsigned int spin_ticks) {
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    Frag a, b;
+    const unsigned int seed = mix32(threadIdx.x * 2654435761u + blockIdx.x);
+    a.u = u32x4_t{0x3F803F80u ^ (seed & 0x00070007u), 0x3F003F00u, 0x3E803E80u ^ ((seed >> 8) & 0x00030003u), 0x3F803F00u};
+    b.u = u32x4_t{0x3F003F80u, 0x3E803F00u ^ ((seed >> 16) & 0x00070007u), 0x3F803E80u, 0x3F003F00u};
+    f32x4_t acc[4] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+    float v = (float)(seed & 1023u) * 1e-3f;
+    unsigned long long r1 = r0;
+    for (int guard = 0; guard < (1 << 22); ++guard) {                 // (hard bound on top of the time condition)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, acc[j], 0, 0, 0);
+            v = __builtin_fmaf(v, 0.999f, 0.001f);
+            v = __builtin_fmaf(v, 1.001f, -0.001f);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = acc[j] * 0.5f;           // keep the sums finite
+        r1 = __builtin_amdgcn_s_memrealtime();
+        if (r1 - r0 >= (unsigned long long)spin_ticks) break;
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    float sink = v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sink += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = c1 - c0;
+        out[2 * blockIdx.x + 1] = (r1 - r0) | (sink == 12345.678f ? 1ull << 63 : 0ull);     // (the sink keeps the work alive)
+    }
+}
+extern "C" int m2m_clock_probe(uint64_t* out, int nwg, int spin_ticks, void* stream) {
+    if (!out || nwg < 1 || nwg > 4096 || spin_ticks < 1) { m2m_set_error("clock_probe: bad arguments", __FILE__, __LINE__); return -1; }
+    if (spin_ticks > 1000000) spin_ticks = 1000000;
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(nwg), dim3(512), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<unsigned long long*>(out), (unsigned int)spin_ticks);
+    M2M_CHECK_HIP(hipGetLastError());
+    return 0;
+}

@@ -310,6 +310,19 @@ def test_run_epoch_covers_every_sample_and_matches_the_oracle(dev, tmp_path):
     assert abs(va["loss"] - float((ls[:, 3] * ls[:, 4]).sum() / ls[:, 4].sum())) < 5e-3
 
 
+@pytest.mark.parametrize("which,env", [("recomp", {"M2M_WGRAD_RECOMP": "1"}), ("fused_heads", {"M2M_FUSED_HEADS": "1"}),
+                                       ("tickets", {"M2M_BWD_TICKETS": "1"})])
+def test_opt_in_paths_vs_oracle(which, env, dev):
+    """The kernels that are OFF by default (recompute-form weight gradients, heads in the fusion backward's prologue, the
+    backward column loop's ticket counter) stay parity-green: each runs M2-Mixer-B / bf16 / B = 40 / dropout 0.5 against the
+    oracle in a child process (the library reads these switches once per process); the child asserts the path was taken."""
+    import subprocess
+    import sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "opt_in_child.py")
+    r = subprocess.run([sys.executable, child, which], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, f"{which}: {r.stdout[-2000:]}\n{r.stderr[-3000:]}"
+
+
 def test_sibling_that_changes_the_kept_ranges_is_refused_after_capture(dev, monkeypatch):
     """a captured graph holds the Adam range table by value; a training sibling whose backward overwrites
     FEWER ranges than the captured optimizer leaves uncleared would accumulate onto stale gradients.  engine.sibling refuses
