@@ -51,14 +51,29 @@ TIMER_READER(m2m_debug_timers_wgrad, g_tm_wg)
 
 #include "tower_wgrad_rc.h"   // WgOut, wgrad_write_w, the recompute form (bf16, hidden_dim 128)
 
+// Round 4 experiment, bf16 / hidden_dim 128 (-DM2M_WG48=1; OFF): FOUR waves x THREE 16-column tiles = 192 hidden columns per
+// workgroup, one wave per SIMD with up to 512 registers and a deeper register ring.  Idea: the five-wave form puts two waves on
+// SIMD 0 (2 x 36 MFMAs per 32-row step = 0.55 us against 0.28 us on the other SIMDs); here every SIMD issues 54 MFMAs per step
+// and the 196 workgroups of M2-Mixer-B leave 60 CUs to the embedding workgroups.  MEASURED (parity-green, two interleaved
+// repetitions in one process): merged launch 132-134 us (embedding workgroups first) / 116 us (last) against 105 us for the
+// five-wave form, ring depth 1 or 2 alike -- the step is not paced by SIMD 0's MFMAs but by the latency chain stage write ->
+// barrier -> LDS fragment reads -> MFMAs, which a lone wave per SIMD hides worse than five waves on four SIMDs do; the L2's
+// memory-side queue shows ~1200 cycles per read for this launch (profiles/r04_ea_read_latency.txt: HBM, not Infinity Cache).
+#ifndef M2M_WG48
+#define M2M_WG48 0
+#endif
+#ifndef WG48_DEPTH
+#define WG48_DEPTH 2
+#endif
 template <int P, int D> struct WgradGeom {
     static constexpr int NF = Chain<P>::NF;
-    static constexpr int WAVES = (P == PREC_BF16 && D == 128) ? WG_WAVES_WIDE : WG_WAVES;
+    static constexpr bool W48 = M2M_WG48 && P == PREC_BF16 && D == 128;
+    static constexpr int WAVES = W48 ? 4 : ((P == PREC_BF16 && D == 128) ? WG_WAVES_WIDE : WG_WAVES);
     static constexpr int THREADS = WAVES * 64;
 #ifdef WG_CPW_FORCE
     static constexpr int CPW = WG_CPW_FORCE;
 #else
-    static constexpr int CPW = (P == PREC_BF16 && D <= 128) ? 2 : 1;                 // 16-column tiles per wave
+    static constexpr int CPW = W48 ? 3 : ((P == PREC_BF16 && D <= 128) ? 2 : 1);     // 16-column tiles per wave
 #endif
     static constexpr int IMG_B = WBM * D * Prec<P>::ESZ;
     static constexpr int STAGE_B = 2 * IMG_B;                                          // A^T | dYd^T of one tile
@@ -72,11 +87,11 @@ template <int P, int D> struct WgradGeom {
     static constexpr int TPS = 1;
 #endif
     static constexpr int RING_REGS = NLD * 4 + CPW * 2 * NF * 4;                      // VGPRs of one tile in flight
-    static constexpr int DEPTH = (TPS == 1 && RING_REGS <= WG_RING_MAX) ? 2 : 1;      // steps of loads in flight
+    static constexpr int DEPTH = W48 ? WG48_DEPTH : ((TPS == 1 && RING_REGS <= WG_RING_MAX) ? 2 : 1);      // steps of loads in flight
     static constexpr int COLS = WAVES * CPW * 16;                                   // hidden columns per workgroup
     static constexpr int TR_B = WAVES * 16 * (D + 4) * 4;                          // dW1 write-out transpose: 16 x (D + 4) floats per wave
     static constexpr int LDS_B = 2 * TPS * STAGE_B > TR_B ? 2 * TPS * STAGE_B : TR_B;  // dynamic LDS of the kernel
-    static constexpr int MINWAVES = TPS > 2 ? 1 : 2;                                   // waves per SIMD the kernel is built for
+    static constexpr int MINWAVES = (W48 || TPS > 2) ? 1 : 2;                          // waves per SIMD the kernel is built for
     static_assert(TPS == 1 || DEPTH == 1, "multi-tile steps use a ring of one step");
 };
 
@@ -140,7 +155,29 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, const WgO
                 // read exactly once: non-temporal, so the stream does not evict the A^T / dYd^T tiles that the other column
                 // slices of this block re-read from L2
                 const long blk = (long)(ctl[0] >> 1) * m2m_hchn_stride(ntiles) + (long)tile * 2048 + lane * 16;
-                if (CPW == 2) {                              // the wave owns both tiles of the pair: one 16-byte load per half
+                if (CPW == 3) {
+                    // three tiles = a whole column-tile pair + one half of the neighbouring pair (wave-uniform: which half, and on
+                    // which side, follows from the parity of the wave's first tile): 16-byte loads for the pair, 8-byte loads for
+                    // the half slot (the other 8 bytes of those slots go to the neighbouring wave of this workgroup)
+                    typedef const M2M_GLOBAL_AS u32x4_t* g4_t;
+                    typedef const M2M_GLOBAL_AS u32x2_t* g2_t;
+                    const bool odd = (__builtin_amdgcn_readfirstlane(ct0) & 1) != 0;
+                    const int plast = (nct >> 1) - 1;
+                    const int pfull = min(odd ? (ct0 + 1) >> 1 : ct0 >> 1, plast), phalf = min(odd ? ct0 >> 1 : (ct0 + 2) >> 1, plast);
+                    const long strd = m2m_hchn_stride(ntiles);
+                    const long bf = (long)pfull * strd + (long)tile * 2048 + lane * 16;
+                    const long bh = (long)phalf * strd + (long)tile * 2048 + lane * 16 + (odd ? 8 : 0);
+                    const u32x4_t h0 = __builtin_nontemporal_load((g4_t)(src_h + bf)), h1 = __builtin_nontemporal_load((g4_t)(src_h + bf + 1024));
+                    const u32x4_t d0 = __builtin_nontemporal_load((g4_t)(src_dh + bf)), d1 = __builtin_nontemporal_load((g4_t)(src_dh + bf + 1024));
+                    const u32x2_t hh0 = __builtin_nontemporal_load((g2_t)(src_h + bh)), hh1 = __builtin_nontemporal_load((g2_t)(src_h + bh + 1024));
+                    const u32x2_t dd0 = __builtin_nontemporal_load((g2_t)(src_dh + bh)), dd1 = __builtin_nontemporal_load((g2_t)(src_dh + bh + 1024));
+                    const u32x4_t hf0 = u32x4_t{h0[0], h0[1], h1[0], h1[1]}, hf1 = u32x4_t{h0[2], h0[3], h1[2], h1[3]};
+                    const u32x4_t df0 = u32x4_t{d0[0], d0[1], d1[0], d1[1]}, df1 = u32x4_t{d0[2], d0[3], d1[2], d1[3]};
+                    const u32x4_t hhf = u32x4_t{hh0[0], hh0[1], hh1[0], hh1[1]}, dhf = u32x4_t{dd0[0], dd0[1], dd1[0], dd1[1]};
+                    p.h[u][0][0].u = odd ? hhf : hf0;  p.d[u][0][0].u = odd ? dhf : df0;
+                    p.h[u][1 % CPW][0].u = odd ? hf0 : hf1;  p.d[u][1 % CPW][0].u = odd ? df0 : df1;
+                    p.h[u][2 % CPW][0].u = odd ? hf1 : hhf;  p.d[u][2 % CPW][0].u = odd ? df1 : dhf;
+                } else if (CPW == 2) {                       // the wave owns both tiles of the pair: one 16-byte load per half
                     typedef const M2M_GLOBAL_AS u32x4_t* g4_t;
                     const u32x4_t h0 = __builtin_nontemporal_load((g4_t)(src_h + blk)), h1 = __builtin_nontemporal_load((g4_t)(src_h + blk + 1024));
                     const u32x4_t d0 = __builtin_nontemporal_load((g4_t)(src_dh + blk)), d1 = __builtin_nontemporal_load((g4_t)(src_dh + blk + 1024));
@@ -373,12 +410,16 @@ struct WgradGroupArgs {
 // Then -- dispatched last, back-filling the CUs whose tower workgroup has finished -- the workgroups of the model's two
 // patch-embedding weight gradients (embed_wgrad.h); a second launch beside this one costs a fork and a join in the replayed
 // graph (~10 us each) and slows this kernel by contending for the same CUs.
+#ifndef M2M_WG_KATTR
+#define M2M_WG_KATTR
+#endif
 template <int P, int D, int RCDM>
-__global__ __launch_bounds__((WgradKernelGeom<P, D, RCDM>::THREADS), (WgradKernelGeom<P, D, RCDM>::MINWAVES)) void tower_wgrad_group_kernel(const WgradGroupArgs a,
+__global__ __launch_bounds__((WgradKernelGeom<P, D, RCDM>::THREADS), (WgradKernelGeom<P, D, RCDM>::MINWAVES)) M2M_WG_KATTR void tower_wgrad_group_kernel(const WgradGroupArgs a,
                                                                                                           const EmbedWgradGroupArgs ea,
                                                                                                           const SplitReduceArgs ra) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int id = blockIdx.x;
+#ifndef M2M_WG_PROBE_TOWERS_ONLY        // (ISA probe: the tower path's own register need)
     // The slot reduction of a preceding fused backward launch (M2M_WGRAD_REDUCES_SMALL): ~140 short workgroups at the end of the
     // grid -- they run on the CUs the one-per-CU tower workgroups leave free, long before those finish.
     if (a.n_reduce && id >= (int)gridDim.x - a.n_reduce) {
@@ -396,6 +437,7 @@ __global__ __launch_bounds__((WgradKernelGeom<P, D, RCDM>::THREADS), (WgradKerne
         embed_wgrad_group_body<P, D, WgradKernelGeom<P, D, RCDM>::THREADS>(ea, id - a.n_tower_wgs, smem);
         return;
     }
+#endif
     const int xcd = id & 7, idx = id >> 3;
     if (idx >= a.xcd_len[xcd]) return;
     const int lin = a.xcd_start[xcd] + idx;
@@ -494,7 +536,7 @@ static WgradPlan wgrad_plan(const m2m_tower* t, int B, int cols, bool honour_ove
 }
 static int wgrad_cols(const m2m_tower* t, int B) {
     if (m2m_wgrad_recompute(t, B)) return RcGeom<128>::COLS;
-    if (t->prec == PREC_BF16 && t->D == 128) return WG_WAVES_WIDE * 32;
+    if (t->prec == PREC_BF16 && t->D == 128) return WgradGeom<PREC_BF16, 128>::COLS;
     return t->prec == PREC_BF16 && t->D < 128 ? WG_WAVES * 32 : WG_WAVES * 16;
 }
 extern "C" int m2m_wgrad_groups(const m2m_tower* t, int B) {
