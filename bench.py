@@ -292,6 +292,10 @@ def main():
                     help="N > 1: dtype of the gradient all-reduce.  none (default) = fp32: what the reference's DDP exchanges "
                          "(run.py:69-70).  bf16 = the equivalent of DDP's bf16_compress_hook, half the bytes on xGMI; its error is "
                          "bounded in tests/test_host_cpu.py::test_bf16_compressed_exchange_error_bound")
+    ap.add_argument("--grad-exchange", default="pipelined", choices=["pipelined", "single"],
+                    help="N > 1, fp32 exchange: pipelined (default) = one all-reduce per parameter segment on a communication stream, "
+                         "Adam + re-pack of segment k behind the all-reduce of segment k + 1 (parallel.PipelinedGradSync); single = ONE "
+                         "all-reduce of the flat gradient, then Adam + re-pack (parallel.GradSync).  Same arithmetic either way")
     ap.add_argument("--preheat-ms", type=float, default=300.0,
                     help="~this many ms of untimed steps (preheat_ms / 0.75 of them) before the W warm-up steps, so a fresh box's "
                          "clocks have ramped up when the warm-up starts (reported in config.preheat_ms; 0 disables)")
@@ -335,7 +339,14 @@ def main():
     eng.pack()
     image, audio, labels = make_batch(cfg, B, parallel.shard_batch_seed(1234, rank), dev)
     compress = None if args.grad_compress == "none" or args.precision == "fp32" else args.grad_compress
-    sync = parallel.GradSync(compress=compress, widen=False) if world > 1 else None      # Adam reads the bf16 sum directly
+    exchange = None
+    if world > 1:
+        if compress is None and args.grad_exchange == "pipelined":
+            sync, exchange = parallel.PipelinedGradSync(), "pipelined"
+        else:
+            sync, exchange = parallel.GradSync(compress=compress, widen=False), "single"      # (bf16: Adam reads the bf16 sum directly)
+    else:
+        sync = None
 
     spg = 1 if (args.no_graph or world > 1) else max(1, args.steps_per_graph)
     if args.no_graph:
@@ -343,7 +354,17 @@ def main():
             eng.train_step(image, audio, labels, grad_sync=sync)
         multi = None
     else:
-        replay = eng.capture(image, audio, labels, grad_sync=sync)
+        try:
+            replay = eng.capture(image, audio, labels, grad_sync=sync)
+        except Exception as e:                     # the pipelined exchange has only ever run over gloo (one-GPU boxes): if its first
+            if exchange != "pipelined":            # contact with RCCL fails on EVERY rank alike (same code path), fall back loudly
+                raise
+            log(f"rank {rank}: pipelined exchange failed at capture ({type(e).__name__}: {str(e)[:200]}); falling back to the single all-reduce")
+            sync, exchange = parallel.GradSync(), "single (fallback: the pipelined exchange failed at capture)"
+            eng = AVMnistEngine(cfg, B, device=dev, precision=args.precision, lr=1e-2, seed=42)
+            parallel.broadcast_parameters(eng.flat_p)
+            eng.pack()
+            replay = eng.capture(image, audio, labels, grad_sync=sync)
 
         def step():
             replay()
@@ -414,7 +435,7 @@ def main():
         "config": {"workload": f"AV-MNIST M2-Mixer-{args.model}: fwd + bwd + Adam, dropout {cfg['dropout']}, per-GPU batch {B}, "
                                f"global batch {B * world}, {eng.n_params} params",
                    "parallelism": f"dp{world}", "world_size": world, "launch": "eager" if args.no_graph else ("hipGraph" if spg == 1 else f"hipGraph, {spg} steps per graph"),
-                   "grad_allreduce": (compress or "fp32") if world > 1 else None, "preheat_ms": args.preheat_ms},
+                   "grad_allreduce": (compress or "fp32") if world > 1 else None, "grad_exchange": exchange, "preheat_ms": args.preheat_ms},
         "roofline": roof,
         "step_mfma_frac": round(world * B * args.steps / elapsed / world * flops_step / B / (peak * 1e12), 4),
         "algorithmic_gflop_per_step": round(flops_step / 1e9, 2),

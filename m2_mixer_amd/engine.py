@@ -456,8 +456,58 @@ class _FlatEngine:
         if grad_sync is None:
             return self.fused_step(*batch)
         self.forward_backward(*batch)
-        self.optimizer_step(grad_sync(self.flat_g), getattr(grad_sync, "reduced_bf16", None))
+        if getattr(grad_sync, "pipelined", False):
+            self._exchange_and_update_pipelined(grad_sync)
+        else:
+            self.optimizer_step(grad_sync(self.flat_g), getattr(grad_sync, "reduced_bf16", None))
         return self.losses
+
+    # ---- exchange pipelined with the optimizer (parallel.PipelinedGradSync) ------------------------------------------------
+    def _update_chunks(self):
+        """[(lo, hi, [modules to re-pack]), ...]: a partition of the flat buffers into pieces whose Adam update and operand
+        re-pack need nothing outside the piece -- the parameter segments (one per tower; the last also holds the heads).
+        Engines without per-segment packers return the whole buffer as one chunk."""
+        return [(0, self.n_params, None)]
+
+    def _adam_chunk(self, lo: int, hi: int, scale: float):
+        """Adam over flat elements [lo, hi) with the engine's kept ranges cut to the chunk (the slots were folded in by
+        forward_backward: `keep` is all that is left of the range table)."""
+        ranges = []
+        for rlo, rn, _, keep in self._ranges_keep:
+            a, b = max(rlo, lo), min(rlo + rn, hi)
+            if a < b:
+                ranges.append((a - lo, b - a, None, keep))
+        n, off = hi - lo, lo * 4
+        tail = (self.adam_state.data_ptr(), self.betas[0], self.betas[1], self.eps, self.weight_decay, -abs(scale), 0)
+        if ranges:
+            arr = (L.GradRange * len(ranges))()
+            for i, (rlo, rn, add, keep) in enumerate(ranges):
+                arr[i].lo, arr[i].n, arr[i].add, arr[i].keep = rlo, rn, None, int(keep)
+            L.check(L.lib().m2m_adam_step_ranges(self.flat_p.data_ptr() + off, self.flat_g.data_ptr() + off, None, self.flat_m.data_ptr() + off,
+                                                 self.flat_v.data_ptr() + off, n, *tail, arr, len(ranges), L.stream_ptr()), "adam_step_ranges")
+        else:
+            L.check(L.lib().m2m_adam_step(self.flat_p.data_ptr() + off, self.flat_g.data_ptr() + off, self.flat_m.data_ptr() + off,
+                                          self.flat_v.data_ptr() + off, n, *tail, L.stream_ptr()), "adam_step")
+
+    def _update_one_chunk(self, k: int, scale: float):
+        lo, hi, mods = self._update_chunks()[k]
+        self._adam_chunk(lo, hi, scale)
+        if mods is None:
+            self.pack()
+        else:
+            for m in mods:
+                m.pack(force=True)
+
+    def _exchange_and_update_pipelined(self, sync):
+        """all-reduce chunk k + 1 .. on the communication stream while chunk k's Adam + re-pack run here."""
+        if not self._slots_folded:
+            raise RuntimeError("the pipelined update follows forward_backward (which folds the weight-gradient slots)")
+        chunks = self._update_chunks()
+        scale = sync.start(self.flat_g, [(lo, hi) for lo, hi, _ in chunks])
+        for k in range(len(chunks)):
+            sync.wait(k)
+            self._update_one_chunk(k, scale)
+        self._slots_folded = False
 
     # ---- hipGraph capture -----------------------------------------------------------------------------------
     def capture(self, *batch, grad_sync=None, steps: int = 1):
@@ -485,6 +535,10 @@ class _FlatEngine:
             for _ in range(2):                       # warm-up: lazy inits (LDS attributes, allocations) happen here
                 if grad_sync is None:
                     self.fused_step(*st)
+                elif getattr(grad_sync, "pipelined", False):
+                    self.forward_backward(*st)
+                    self._exchange_and_update_pipelined(grad_sync)
+                    scale = 1.0 / getattr(grad_sync, "world", 1)
                 else:
                     self.forward_backward(*st)
                     scale = grad_sync(self.flat_g)
@@ -516,6 +570,18 @@ class _FlatEngine:
             if steps > 1:
                 self.losses, self.logits, self.preds = home
             graphs = (g1,)
+        elif getattr(grad_sync, "pipelined", False):
+            # forward + backward | per chunk: [its all-reduce lands] its Adam + re-pack (one small graph per chunk)
+            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                self.forward_backward(*st)
+            chunk_graphs = []
+            for k in range(len(self._update_chunks())):
+                gk = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gk, capture_error_mode="thread_local"):
+                    self._update_one_chunk(k, scale)
+                chunk_graphs.append(gk)
+            self._slots_folded = False
+            graphs = (g1, *chunk_graphs)
         else:
             g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1, capture_error_mode="thread_local"):
@@ -524,6 +590,7 @@ class _FlatEngine:
                 self.optimizer_step(scale, getattr(grad_sync, "reduced_bf16", None))   # (the buffer exists since the warm-up)
             graphs = (g1, g2)
         self._graph = graphs
+        pipelined = grad_sync is not None and getattr(grad_sync, "pipelined", False)
 
         def replay(*new_batch):
             if new_batch and new_batch[0] is not None:
@@ -533,7 +600,12 @@ class _FlatEngine:
                     for dst, src in zip(slots[i], new_batch[i * nb:(i + 1) * nb]):
                         dst.copy_(src, non_blocking=True)
             graphs[0].replay()
-            if grad_sync is not None:
+            if pipelined:
+                grad_sync.start(self.flat_g, [(lo, hi) for lo, hi, _ in self._update_chunks()])
+                for k in range(len(graphs) - 1):
+                    grad_sync.wait(k)
+                    graphs[1 + k].replay()
+            elif grad_sync is not None:
                 grad_sync(self.flat_g)
                 graphs[1].replay()
             return out_losses                     # this graph's own buffer: (4,) or, for a multi-step graph, (steps, 4)
@@ -759,6 +831,14 @@ class _TwoTowerEngine(_FlatEngine):
     def _adam_pack_modules(self):
         towers, embeds = [self.t_a, self.t_b, self.t_fus], [self.e_a, self.e_b]
         return (towers, embeds) if can_pack_all(towers, embeds) else None
+
+    def _update_chunks(self):
+        """One chunk per parameter segment, in flat order: modality a (its patch embedding + tower), modality b, fusion tower
+        + the three heads (heads have no packed copies)."""
+        a, b = self.MODS
+        mods = {a: [self.t_a, self.e_a], b: [self.t_b, self.e_b], "fusion": [self.t_fus]}
+        segs = sorted(self.segments.items(), key=lambda kv: kv[1][0])
+        return [(lo, hi, mods[name]) for name, (lo, hi) in segs]
 
     @torch.no_grad()
     def evaluate(self, xa, xb, labels):

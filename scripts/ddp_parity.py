@@ -45,6 +45,7 @@ def main():
     torch.cuda.set_device(dev)
     prec = sys.argv[1] if len(sys.argv) > 1 else "fp32"
     size = sys.argv[2] if len(sys.argv) > 2 else "S"
+    pipelined = len(sys.argv) > 3 and sys.argv[3] == "pipelined"       # parallel.PipelinedGradSync: per-segment exchange + update
     cfg = dict(G.AVMNIST[size], dropout=0.0)
     B, steps, lr = 8, 2, 1e-2
     shapes = G.avmnist_shapes(cfg)
@@ -57,7 +58,7 @@ def main():
         eng.load_state_dict(params0 if rank == 0 else {k: torch.zeros_like(v) for k, v in params0.items()})
         parallel.broadcast_parameters(eng.flat_p)       # DDP's initial broadcast: rank 1 starts from zeros on purpose
         eng.pack()
-        sync = parallel.GradSync()
+        sync = parallel.PipelinedGradSync() if pipelined else parallel.GradSync()
         mine = tuple(t.to(dev) for t in batches[rank])
         if captured:
             replay = eng.capture(*mine, grad_sync=sync)
@@ -69,7 +70,8 @@ def main():
         torch.cuda.synchronize()
         return eng
 
-    out = {"world": world, "precision": prec, "model": size, "per_rank_batch": B, "steps": steps}
+    out = {"world": world, "precision": prec, "model": size, "per_rank_batch": B, "steps": steps,
+           "exchange": "pipelined (one all-reduce per parameter segment, Adam + re-pack of segment k behind the all-reduce of k + 1)" if pipelined else "one all-reduce"}
     for captured in (False, True):
         eng = run(captured)
         tag = "captured" if captured else "eager"

@@ -725,6 +725,39 @@ def test_data_parallel_step_path_matches_fused_step(dev):
     assert float((da.sign() == db.sign()).float().mean()) > 0.995
 
 
+def test_pipelined_exchange_update_is_bit_identical_to_the_whole_buffer_update(dev):
+    """parallel.PipelinedGradSync: the step's tail runs per parameter segment (all-reduce of chunk k + 1 behind Adam + re-pack
+    of chunk k).  With one rank the exchange is the identity, so three captured steps must leave EXACTLY the parameters,
+    moments and packed operand copies of the whole-buffer form (forward + backward | exchange | Adam + pack_all): Adam is
+    elementwise, the chunks partition the buffers, the kept gradient ranges are cut at the chunk bounds."""
+    from m2_mixer_amd import parallel
+    from m2_mixer_amd.engine import AVMnistEngine
+    cfg, B = dict(G.AVMNIST["B"]), 64
+    batch = tuple(t.to(dev) for t in G.avmnist_batch(B, 5, cfg))
+    make = lambda: AVMnistEngine(cfg, B, device=dev, precision="bf16", lr=1e-3, seed=3)
+    a, b, c = make(), make(), make()
+    for e in (b, c):
+        e.load_state_dict(a.state_dict())
+    chunks = b._update_chunks()
+    assert [lo for lo, _, _ in chunks] == sorted(lo for lo, _, _ in chunks) and chunks[0][0] == 0 and chunks[-1][1] == b.n_params
+    assert len(chunks) == 3 and all(chunks[i][1] == chunks[i + 1][0] for i in range(2))
+    ra = a.capture(*batch, grad_sync=lambda flat: 1.0)              # whole-buffer form with an identity exchange
+    rb = b.capture(*batch, grad_sync=parallel.PipelinedGradSync())  # per-segment graphs
+    for _ in range(3):
+        ra(); rb()
+        c.train_step(*batch, grad_sync=parallel.PipelinedGradSync())     # the same, eager
+    torch.cuda.synchronize()
+    for e in (b, c):
+        assert torch.equal(a.flat_p, e.flat_p) and torch.equal(a.flat_m, e.flat_m) and torch.equal(a.flat_v, e.flat_v)
+        assert grads_cleared(e)
+        for ta, te in ((a.t_a, e.t_a), (a.t_b, e.t_b), (a.t_fus, e.t_fus)):
+            for i in range(ta.nblocks):
+                for k, v in ta._keep[f"packed{i}"].items():
+                    assert torch.equal(v, te._keep[f"packed{i}"][k]), k
+        for ea, ee in ((a.e_a, e.e_a), (a.e_b, e.e_b)):
+            assert torch.equal(ea._keep["wn"], ee._keep["wn"])
+
+
 def test_adam_from_bf16_gradient_equals_adam_from_widened_gradient(dev):
     """The data-parallel step hands Adam the all-reduced gradient as bf16 (GradSync(widen=False)); the update must be
     bit-identical to widening that bf16 gradient into the fp32 buffer first, and the fp32 buffer must come out cleared."""

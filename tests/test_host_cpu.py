@@ -258,6 +258,58 @@ def test_grad_sync_gloo_world2():
         assert seed == 1234 + rank
 
 
+def _pipelined_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from m2_mixer_amd import parallel
+    parallel.init_from_env(backend="gloo")
+    gen = torch.Generator().manual_seed(100 + rank)
+    g = torch.randn(5000, generator=gen)
+    ref = g.clone()
+    torch.distributed.all_reduce(ref)                              # what GradSync would leave in the buffer
+    sync = parallel.PipelinedGradSync()
+    bounds = [(0, 1700), (1700, 1701), (1701, 5000)]               # uneven chunks, one of a single element
+    order = []
+    scale = sync.start(g, bounds)
+    for k, (lo, hi) in enumerate(bounds):                          # the consumer's loop: chunk k is complete after wait(k)
+        sync.wait(k)
+        order.append(bool(torch.equal(g[lo:hi], ref[lo:hi])))
+    bad = []
+    for b in ([(0, 10), (20, 5000)], [(0, 5000), (5000, 5000)], [(0, 4000)]):      # gap / empty chunk / not covering
+        try:
+            parallel.PipelinedGradSync().start(torch.zeros(5000), b)
+            bad.append(b)
+        except ValueError:
+            pass
+    whole = torch.randn(64, generator=gen)
+    wref = whole.clone()
+    torch.distributed.all_reduce(wref)
+    s2 = parallel.PipelinedGradSync()(whole)                       # drop-in for GradSync: one chunk
+    q.put((rank, scale, order, bool(torch.equal(g, ref)), bad, s2, bool(torch.equal(whole, wref))))
+    torch.distributed.destroy_process_group()
+
+
+def test_pipelined_grad_sync_gloo_world2():
+    """parallel.PipelinedGradSync over gloo, two ranks: the chunks partition the buffer, chunk k holds the all-reduced values
+    once wait(k) returns (the optimizer's consumption order), the whole buffer equals ONE all-reduce bit for bit, malformed
+    chunk lists are refused, and called like a GradSync it reduces the buffer as one chunk."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_pipelined_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, scale, order, same, bad, s2, same2 in out:
+        assert scale == 0.5 and s2 == 0.5
+        assert order == [True, True, True] and same and same2
+        assert bad == []
+
+
 def test_bench_cli_contract_help():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True)
     assert r.returncode == 0
