@@ -390,6 +390,12 @@ int m2m_adam_pack_plan(const m2m_tower* const* towers, int ntowers, const m2m_em
                        float* param, float* grad, const void* grad_bf16, float* exp_avg, float* exp_avg_sq, int64_t n,
                        const float* state, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                        void* plan_host);
+/* the same with up to M2M_MAX_GRAD_RANGES special index ranges (the semantics of m2m_adam_step_ranges: a weight-gradient slot to
+ * add, and / or gradients the next backward overwrites and this launch therefore leaves uncleared); ranges: HOST array */
+int m2m_adam_pack_plan_ranges(const m2m_tower* const* towers, int ntowers, const m2m_embed* const* embeds, int nembeds,
+                              float* param, float* grad, const void* grad_bf16, float* exp_avg, float* exp_avg_sq, int64_t n,
+                              const float* state, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                              const m2m_grad_range* ranges, int nranges, void* plan_host);
 int m2m_adam_pack_all(const m2m_tower* const* towers, int ntowers, const m2m_embed* const* embeds, int nembeds,
                       const void* plan_dev, const void* plan_host, void* stream);
 

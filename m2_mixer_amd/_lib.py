@@ -163,6 +163,9 @@ SIGNATURES = {
     "m2m_adam_pack_plan_bytes": (C.c_int64, []),
     "m2m_adam_pack_plan": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.c_int, C.POINTER(C.POINTER(Embed)), C.c_int, _fp, _fp, _fp, _fp, _fp,
                                     C.c_int64, _fp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _fp]),
+    "m2m_adam_pack_plan_ranges": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.c_int, C.POINTER(C.POINTER(Embed)), C.c_int, _fp, _fp, _fp, _fp, _fp,
+                                           C.c_int64, _fp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                           C.POINTER(GradRange), C.c_int, _fp]),
     "m2m_adam_pack_all": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.c_int, C.POINTER(C.POINTER(Embed)), C.c_int, _fp, _fp, _fp]),
     "m2m_dropout_mask": (C.c_int, [C.POINTER(Tower), C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, _fp, _fp]),
     "m2m_gelu_probe": (C.c_int, [_fp, _fp, _fp, C.c_int64, _fp]),

@@ -494,6 +494,12 @@ struct AdamPackPlan {
     int nseg;
     long seg_lo[M2M_AP_MAXSEG], seg_hi[M2M_AP_MAXSEG];
     int seg_wg0[M2M_AP_MAXSEG + 1];          // first flat workgroup of each segment (1024 elements per workgroup)
+    // gradient ranges (m2m_adam_pack_plan_ranges; the semantics of m2m_adam_step_ranges): inside [lo, hi) the gradient is
+    // grad[i] + add[i - lo] (a weight-gradient slot) and / or is not cleared (keep: the next backward overwrites it)
+    int nrange;
+    long r_lo[M2M_MAX_GRAD_RANGES], r_hi[M2M_MAX_GRAD_RANGES];
+    const float* r_add[M2M_MAX_GRAD_RANGES];
+    int r_keep[M2M_MAX_GRAD_RANGES];
 };
 struct AdamConsts { float b1, b2, eps, wd, gscale, step_size, inv_sqrt_bc2; };
 static __device__ __forceinline__ AdamConsts adam_consts(const AdamPackPlan& pl) {
@@ -504,49 +510,139 @@ static __device__ __forceinline__ AdamConsts adam_consts(const AdamPackPlan& pl)
     c.inv_sqrt_bc2 = 1.0f / sqrtf(1.0f - powf(pl.b2, stepf));
     return c;
 }
-// one element: reads p, g (or its bf16 copy), m, v at flat index i; writes p, m, v, g = 0; returns the new parameter
-template <bool LOWP>
-static __device__ __forceinline__ float adam_elem(const AdamPackPlan& pl, const AdamConsts& c, long i) {
-    float g = (LOWP ? __uint_as_float((unsigned int)pl.gb[i] << 16) : pl.g[i]) * c.gscale;
-    pl.g[i] = 0.f;
-    const float pv = pl.p[i];
-    if (c.wd != 0.f) g = __builtin_fmaf(c.wd, pv, g);
-    const float mi = c.b1 * pl.m[i] + (1.0f - c.b1) * g;
-    const float vi = c.b2 * pl.v[i] + (1.0f - c.b2) * g * g;
-    pl.m[i] = mi;
-    pl.v[i] = vi;
-    const float pn = pv - c.step_size * (mi / (sqrtf(vi) * c.inv_sqrt_bc2 + c.eps));
-    pl.p[i] = pn;
-    return pn;
+// the Adam arithmetic of adam_one (api.hip above) on registers
+static __device__ __forceinline__ void adam_math(const AdamConsts& c, float g, float& p, float& m, float& v) {
+    g *= c.gscale;
+    if (c.wd != 0.f) g = __builtin_fmaf(c.wd, p, g);
+    m = c.b1 * m + (1.0f - c.b1) * g;
+    v = c.b2 * v + (1.0f - c.b2) * g * g;
+    p = p - c.step_size * (m / (sqrtf(v) * c.inv_sqrt_bc2 + c.eps));
 }
-// four consecutive elements (any 4-byte alignment: the flat offsets of the tensors are not multiples of 4 everywhere)
+// The four flat streams + the range of one tensor, as global-address-space pointers with scalar bases (the plan lives in
+// device memory: generic pointers read from it would give FLAT accesses and per-load pointer re-reads).
+struct AdamStreams {
+    M2M_AS1 float* p; M2M_AS1 float* g; const M2M_AS1 unsigned short* gb; M2M_AS1 float* m; M2M_AS1 float* v;
+    const M2M_AS1 float* add;      // slot of the tensor at hand (NULL: none), indexed like the flat buffers MINUS add_lo
+    long add_lo;
+    bool keep;
+};
+static __device__ __forceinline__ AdamStreams adam_streams(const AdamPackPlan& pl, long flat_off) {
+    AdamStreams s;
+    s.p = (M2M_AS1 float*)uniform_u64((unsigned long long)pl.p); s.g = (M2M_AS1 float*)uniform_u64((unsigned long long)pl.g);
+    s.gb = (const M2M_AS1 unsigned short*)uniform_u64((unsigned long long)pl.gb);
+    s.m = (M2M_AS1 float*)uniform_u64((unsigned long long)pl.m); s.v = (M2M_AS1 float*)uniform_u64((unsigned long long)pl.v);
+    s.add = nullptr; s.add_lo = 0; s.keep = false;
+    for (int r = 0; r < pl.nrange; ++r)
+        if (flat_off >= pl.r_lo[r] && flat_off < pl.r_hi[r]) {
+            s.add = (const M2M_AS1 float*)uniform_u64((unsigned long long)pl.r_add[r]); s.add_lo = pl.r_lo[r]; s.keep = pl.r_keep[r] != 0;
+        }
+    return s;
+}
+// NV float4 groups per thread at flat offsets off[k] (any 4-byte alignment; entries with ok[k] == false are skipped by the
+// stores -- their loads are clamped duplicates): EVERY load first, then the arithmetic, then the stores.  The first version of
+// this kernel updated element by element through generic pointers (load, store, load ... in series; the stores may alias the
+// next loads): 97 us for the model against 45 + 19 us for the flat Adam + m2m_pack_all it was meant to replace.
+template <bool LOWP, int NV>
+static __device__ __forceinline__ void adam_vec(const AdamStreams& s, const AdamConsts& c, const long (&off)[NV], const bool (&ok)[NV],
+                                                f32x4_t (&pn)[NV]) {
+    typedef M2M_AS1 f32x4_t* g4_t;
+    f32x4_t gv[NV], mv[NV], vv[NV], av[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        pn[k] = *(g4_t)(s.p + off[k]); mv[k] = *(g4_t)(s.m + off[k]); vv[k] = *(g4_t)(s.v + off[k]);
+        if (LOWP) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gv[k][e] = __uint_as_float((unsigned int)s.gb[off[k] + e] << 16);
+        } else gv[k] = *(g4_t)(s.g + off[k]);
+    }
+    if (s.add) {                                        // workgroup-uniform
+#pragma unroll
+        for (int k = 0; k < NV; ++k) av[k] = *(const g4_t)(const_cast<M2M_AS1 float*>(s.add) + (off[k] - s.add_lo));
+#pragma unroll
+        for (int k = 0; k < NV; ++k) gv[k] = gv[k] + av[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { float pp = pn[k][e], mm = mv[k][e], v1 = vv[k][e]; adam_math(c, gv[k][e], pp, mm, v1); pn[k][e] = pp; mv[k][e] = mm; vv[k][e] = v1; }
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+        if (ok[k]) {
+            *(g4_t)(s.p + off[k]) = pn[k]; *(g4_t)(s.m + off[k]) = mv[k]; *(g4_t)(s.v + off[k]) = vv[k];
+            if (!s.keep) *(g4_t)(s.g + off[k]) = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+}
+// one element (the ragged last column group of a tensor, embedding slots, the flat workgroups' range edges)
 template <bool LOWP>
-static __device__ __forceinline__ float4 adam_elem4(const AdamPackPlan& pl, const AdamConsts& c, long i) {
-    const float4 pv = *reinterpret_cast<const float4*>(pl.p + i), mv = *reinterpret_cast<const float4*>(pl.m + i);
-    const float4 vv = *reinterpret_cast<const float4*>(pl.v + i);
-    float gg[4];
-    if (LOWP) {
+static __device__ __forceinline__ float adam_elem(const AdamStreams& s, const AdamConsts& c, long i) {
+    float g = LOWP ? __uint_as_float((unsigned int)s.gb[i] << 16) : s.g[i];
+    if (s.add) g += s.add[i - s.add_lo];
+    float pp = s.p[i], mm = s.m[i], vv = s.v[i];
+    adam_math(c, g, pp, mm, vv);
+    s.p[i] = pp; s.m[i] = mm; s.v[i] = vv;
+    if (!s.keep) s.g[i] = 0.f;
+    return pp;
+}
+
+// (tower, block, 32-column group q) of hidden_dim DD: Adam on W1 rows [32q, 32q + 32) and W2 columns [32q, 32q + 32) with every
+// load in flight together (2 x DD / 32 float4 groups per thread and stream), the updated values into the LDS tiles, ch_b1, then
+// the packed copies from the tiles.
+template <int P, bool LOWP, int DD>
+static __device__ __forceinline__ void adam_pack_tile(const AdamPackPlan& pl, const AdamConsts& c, const m2m_tower4& tw, int block, int q, char* smem) {
+    const m2m_block& k = tw.blk[block];
+    constexpr int D = DD, L1 = DD + 1, L2 = 33, NV = 32 * (DD / 4) / 256;      // float4 groups per thread and tensor (256 threads)
+    const int C = tw.C, c0 = 32 * q, tid = threadIdx.x;
+    float* t1 = reinterpret_cast<float*>(smem);
+    float* t2 = t1 + 32 * L1;
+    const long o1 = k.ch_w1 - pl.p, o2 = k.ch_w2 - pl.p, ob = k.ch_b1 - pl.p;       // flat offsets of this block's tensors
+    const AdamStreams s1 = adam_streams(pl, o1), s2 = adam_streams(pl, o2), sb = adam_streams(pl, ob);
+    const bool full = c0 + 32 <= C;                     // (workgroup-uniform) the whole column group lies inside the tensor
+    {
+        long off[NV];
+        bool ok[NV];
+        int rr[NV], dd[NV];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) gg[e] = __uint_as_float((unsigned int)pl.gb[i + e] << 16);      // (i may be odd: 2-byte loads)
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * 256;
+            rr[i] = idx / (D / 4); dd[i] = (idx % (D / 4)) * 4;
+            ok[i] = c0 + rr[i] < C;
+            off[i] = o1 + (long)min(c0 + rr[i], C - 1) * D + dd[i];
+        }
+        f32x4_t pn[NV];
+        adam_vec<LOWP, NV>(s1, c, off, ok, pn);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float* o = t1 + rr[i] * L1 + dd[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = ok[i] ? pn[i][e] : 0.f;
+        }
+    }
+    if (full) {
+        long off[NV];
+        bool ok[NV];
+        int rd[NV], jj[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * 256;               // D rows x 8 float4 per row
+            rd[i] = idx >> 3; jj[i] = (idx & 7) * 4;
+            ok[i] = true;
+            off[i] = o2 + (long)rd[i] * C + c0 + jj[i];
+        }
+        f32x4_t pn[NV];
+        adam_vec<LOWP, NV>(s2, c, off, ok, pn);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t2[rd[i] * L2 + jj[i] + e] = pn[i][e];
     } else {
-        const float4 gv = *reinterpret_cast<const float4*>(pl.g + i);
-        gg[0] = gv.x; gg[1] = gv.y; gg[2] = gv.z; gg[3] = gv.w;
+        for (int idx = tid; idx < D * 32; idx += 256) {
+            const int d = idx >> 5, j = idx & 31;
+            t2[d * L2 + j] = c0 + j < C ? adam_elem<LOWP>(s2, c, o2 + (long)d * C + c0 + j) : 0.f;
+        }
     }
-    const float pp[4] = {pv.x, pv.y, pv.z, pv.w}, mm[4] = {mv.x, mv.y, mv.z, mv.w}, vq[4] = {vv.x, vv.y, vv.z, vv.w};
-    float pn[4], mn[4], vn[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        float g = gg[e] * c.gscale;
-        if (c.wd != 0.f) g = __builtin_fmaf(c.wd, pp[e], g);
-        mn[e] = c.b1 * mm[e] + (1.0f - c.b1) * g;
-        vn[e] = c.b2 * vq[e] + (1.0f - c.b2) * g * g;
-        pn[e] = pp[e] - c.step_size * (mn[e] / (sqrtf(vn[e]) * c.inv_sqrt_bc2 + c.eps));
-    }
-    *reinterpret_cast<float4*>(pl.p + i) = make_float4(pn[0], pn[1], pn[2], pn[3]);
-    *reinterpret_cast<float4*>(pl.m + i) = make_float4(mn[0], mn[1], mn[2], mn[3]);
-    *reinterpret_cast<float4*>(pl.v + i) = make_float4(vn[0], vn[1], vn[2], vn[3]);
-    *reinterpret_cast<float4*>(pl.g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-    return make_float4(pn[0], pn[1], pn[2], pn[3]);
+    if (tid < 32) k.ch_b1p[c0 + tid] = c0 + tid < C ? adam_elem<LOWP>(sb, c, ob + c0 + tid) : 0.f;
+    __syncthreads();
+    pack_emit_tile<P>(k, D, q, t1, t2);
 }
 
 template <int P, bool LOWP>
@@ -555,32 +651,19 @@ __global__ __launch_bounds__(256) void adam_pack_all_kernel(const PackAllArgs a,
     const AdamPackPlan& pl = *plan;
     const AdamConsts c = adam_consts(pl);
     int id = blockIdx.x;
-    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int tid = threadIdx.x;
     if (id < a.tile_end[M2M_PACK_TOWERS - 1]) {
         int t = 0;
         while (id >= a.tile_end[t]) ++t;
         if (t) id -= a.tile_end[t - 1];
         const m2m_tower4& tw = a.tw[t];
         const int nq = tw.Cp >> 5, block = id / nq, q = id % nq;
-        const m2m_block& k = tw.blk[block];
-        const int D = tw.D, C = tw.C, L1 = D + 1, L2 = 33, c0 = 32 * q;
-        float* t1 = reinterpret_cast<float*>(smem);
-        float* t2 = t1 + 32 * L1;
-        const long o1 = k.ch_w1 - pl.p, o2 = k.ch_w2 - pl.p, ob = k.ch_b1 - pl.p;       // flat offsets of this block's tensors
-        for (int idx = tid; idx < 32 * (D / 4); idx += nthr) {
-            const int r = idx / (D / 4), d4 = (idx % (D / 4)) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c0 + r < C) v = adam_elem4<LOWP>(pl, c, o1 + (long)(c0 + r) * D + d4);
-            float* o = t1 + r * L1 + d4;
-            o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        switch (tw.D) {                                  // (workgroup-uniform)
+            case 32:  adam_pack_tile<P, LOWP, 32>(pl, c, tw, block, q, smem); break;
+            case 64:  adam_pack_tile<P, LOWP, 64>(pl, c, tw, block, q, smem); break;
+            case 128: adam_pack_tile<P, LOWP, 128>(pl, c, tw, block, q, smem); break;
+            default:  adam_pack_tile<P, LOWP, 256>(pl, c, tw, block, q, smem); break;
         }
-        for (int idx = tid; idx < D * 32; idx += nthr) {
-            const int d = idx >> 5, j = idx & 31;
-            t2[d * L2 + j] = c0 + j < C ? adam_elem<LOWP>(pl, c, o2 + (long)d * C + c0 + j) : 0.f;
-        }
-        if (tid < 32) k.ch_b1p[c0 + tid] = c0 + tid < C ? adam_elem<LOWP>(pl, c, ob + c0 + tid) : 0.f;
-        __syncthreads();
-        pack_emit_tile<P>(k, D, q, t1, t2);
         return;
     }
     id -= a.tile_end[M2M_PACK_TOWERS - 1];
@@ -596,11 +679,29 @@ __global__ __launch_bounds__(256) void adam_pack_all_kernel(const PackAllArgs a,
         const int lane = (int)(slot & 63), g = lane >> 4, il = lane & 15;
         const long ib = blk / nKB, kb = blk % nKB;                 // NAT, i-major: m2m_pack_embed's layout
         const long i = ib * 16 + il, o = em.w - pl.p;
+        const AdamStreams se = adam_streams(pl, o);
+        // the slot's EPL weights are consecutive in k: all loads first (clamped), then the arithmetic, then the guarded stores
+        float gq[8], pq[8], mq[8], vq[8];
+        bool okq[8];
+#pragma unroll
+        for (int x = 0; x < Pr::EPL; ++x) {
+            const long kk = kb * Pr::KB + Pr::kmap(PACK_NAT, g, x);
+            okq[x] = i < em.D && kk < em.K;
+            const long at = o + min(i, (long)em.D - 1) * em.K + min(kk, (long)em.K - 1);
+            gq[x] = LOWP ? __uint_as_float((unsigned int)se.gb[at] << 16) : se.g[at];
+            pq[x] = se.p[at]; mq[x] = se.m[at]; vq[x] = se.v[at];
+        }
         float v[8];
 #pragma unroll
         for (int x = 0; x < Pr::EPL; ++x) {
             const long kk = kb * Pr::KB + Pr::kmap(PACK_NAT, g, x);
-            v[x] = (i < em.D && kk < em.K) ? adam_elem<LOWP>(pl, c, o + i * em.K + kk) : 0.f;
+            adam_math(c, gq[x], pq[x], mq[x], vq[x]);
+            v[x] = okq[x] ? pq[x] : 0.f;
+            if (okq[x]) {
+                const long at = o + i * em.K + kk;
+                se.p[at] = pq[x]; se.m[at] = mq[x]; se.v[at] = vq[x];
+                if (!se.keep) se.g[at] = 0.f;
+            }
         }
         Frag f;
         if (P == PREC_BF16) {
@@ -616,20 +717,66 @@ __global__ __launch_bounds__(256) void adam_pack_all_kernel(const PackAllArgs a,
     id -= embed_wgs;
     int sgm = 0;
     while (sgm + 1 < pl.nseg && id >= pl.seg_wg0[sgm + 1]) ++sgm;
-    const long lo = pl.seg_lo[sgm] + (long)(id - pl.seg_wg0[sgm]) * 1024, hi = pl.seg_hi[sgm];
-    for (long i = lo + tid; i < hi && i < lo + 1024; i += nthr) adam_elem<LOWP>(pl, c, i);
+    const long lo = pl.seg_lo[sgm] + (long)(id - pl.seg_wg0[sgm]) * 1024, hi = min(pl.seg_hi[sgm], lo + 1024);
+    // everything else: 1024 contiguous elements, four per thread, all loads first (the flat Adam's chunk: adam_kernel)
+    {
+        int cls = -1;                                            // -1 outside every range, r wholly inside range r, -2 straddling
+        for (int r = 0; r < pl.nrange; ++r) {
+            if (lo >= pl.r_lo[r] && hi <= pl.r_hi[r]) { cls = r; break; }
+            if (lo < pl.r_hi[r] && hi > pl.r_lo[r]) { cls = -2; break; }
+        }
+        if (cls != -2) {
+            const AdamStreams sf = adam_streams(pl, cls >= 0 ? pl.r_lo[cls] : -1);
+            float gq[4], pq[4], mq[4], vq[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const long i = min(lo + x * 256 + (long)tid, hi - 1);
+                gq[x] = LOWP ? __uint_as_float((unsigned int)sf.gb[i] << 16) : sf.g[i];
+                if (sf.add) gq[x] += sf.add[i - sf.add_lo];
+                pq[x] = sf.p[i]; mq[x] = sf.m[i]; vq[x] = sf.v[i];
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const long i = lo + x * 256 + (long)tid;
+                adam_math(c, gq[x], pq[x], mq[x], vq[x]);
+                if (i < hi) {
+                    sf.p[i] = pq[x]; sf.m[i] = mq[x]; sf.v[i] = vq[x];
+                    if (!sf.keep) sf.g[i] = 0.f;
+                }
+            }
+        } else {
+            for (long i = lo + tid; i < hi; i += 256) adam_elem<LOWP>(adam_streams(pl, i), c, i);
+        }
+    }
 }
 
 // Fills `plan_host` (sizeof == m2m_adam_pack_plan_bytes()) for the given model; the caller copies it to device memory and
 // passes that copy to m2m_adam_pack_all.  grad_bf16 != NULL: gradient values come from that bf16 copy of `grad`.
 extern "C" int64_t m2m_adam_pack_plan_bytes(void) { return (int64_t)sizeof(AdamPackPlan); }
+extern "C" int m2m_adam_pack_plan_ranges(const m2m_tower* const* towers, int ntowers, const m2m_embed* const* embeds, int nembeds,
+                                  float* param, float* grad, const void* grad_bf16, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                  const float* state, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                                  const m2m_grad_range* ranges, int nranges, void* plan_host);
 extern "C" int m2m_adam_pack_plan(const m2m_tower* const* towers, int ntowers, const m2m_embed* const* embeds, int nembeds,
                                   float* param, float* grad, const void* grad_bf16, float* exp_avg, float* exp_avg_sq, int64_t n,
                                   const float* state, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                                   void* plan_host) {
+    return m2m_adam_pack_plan_ranges(towers, ntowers, embeds, nembeds, param, grad, grad_bf16, exp_avg, exp_avg_sq, n, state, beta1, beta2,
+                                     eps, weight_decay, grad_scale, nullptr, 0, plan_host);
+}
+extern "C" int m2m_adam_pack_plan_ranges(const m2m_tower* const* towers, int ntowers, const m2m_embed* const* embeds, int nembeds,
+                                  float* param, float* grad, const void* grad_bf16, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                  const float* state, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                                  const m2m_grad_range* ranges, int nranges, void* plan_host) {
     if (!plan_host || !param || !grad || !exp_avg || !exp_avg_sq || !state || n <= 0) { m2m_set_error("adam_pack_plan: null argument", __FILE__, __LINE__); return -1; }
+    if (nranges < 0 || nranges > M2M_MAX_GRAD_RANGES || (nranges > 0 && !ranges)) { m2m_set_error("adam_pack_plan: bad ranges", __FILE__, __LINE__); return -1; }
     AdamPackPlan pl;
     memset(&pl, 0, sizeof(pl));
+    pl.nrange = nranges;
+    for (int r = 0; r < nranges; ++r) {
+        if (ranges[r].lo < 0 || ranges[r].n < 0 || ranges[r].lo + ranges[r].n > n) { m2m_set_error("adam_pack_plan: range outside the buffers", __FILE__, __LINE__); return -1; }
+        pl.r_lo[r] = (long)ranges[r].lo; pl.r_hi[r] = (long)(ranges[r].lo + ranges[r].n); pl.r_add[r] = ranges[r].add; pl.r_keep[r] = ranges[r].keep;
+    }
     pl.p = param; pl.g = grad; pl.gb = reinterpret_cast<const unsigned short*>(grad_bf16); pl.m = exp_avg; pl.v = exp_avg_sq; pl.state = state;
     pl.b1 = beta1; pl.b2 = beta2; pl.eps = eps; pl.wd = weight_decay; pl.gscale = grad_scale < 0.f ? -grad_scale : grad_scale;
     // the ranges the tile / embed workgroups own, sorted; the flat workgroups take the complement

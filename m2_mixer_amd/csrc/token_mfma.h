@@ -129,15 +129,24 @@ static __device__ __forceinline__ void token_fwd_mfma(const float* ub, float* xs
         f32x4_t o[TU];
 #pragma unroll
         for (int u = 0; u < TU; ++u) o[u] = mfma32(w2a, chain_bf16(hacc[u][0], hacc[u][1]), b2v);     // rows n, columns col
+        // residual update: ALL old values first (unconditional reads, row clamped into the sample), then the guarded stores.
+        // Written as one guarded "*px += ..." per element, every read-modify-write sat in its own basic block behind
+        // s_waitcnt lgkmcnt(0): TU x 4 = 16 LDS round trips in series per pass.
+        float xo[TU][4];
 #pragma unroll
         for (int u = 0; u < TU; ++u)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = 4 * g + r;
-                if (pv[u] && n < N) {
-                    float* px = xs + (sl[u] * N + n) * XLD + d0[u] + il;
-                    *px += ((wo[u] >> n) & 1u) ? o[u][r] * scale_to : 0.f;
-                }
+                xo[u][r] = xs[(sl[u] * N + (n < N ? n : N - 1)) * XLD + d0[u] + il];
+            }
+#pragma unroll
+        for (int u = 0; u < TU; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = 4 * g + r;
+                if (pv[u] && n < N)
+                    xs[(sl[u] * N + n) * XLD + d0[u] + il] = xo[u][r] + (((wo[u] >> n) & 1u) ? o[u][r] * scale_to : 0.f);
             }
     }
 }

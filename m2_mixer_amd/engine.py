@@ -433,17 +433,17 @@ class _FlatEngine:
         # the slot of a two-group tower: added inside Adam (fused step) unless forward_backward has folded it in already
         ranges = self._ranges_keep if (self._slots_folded or grad_bf16 is not None) else self._ranges_add
         self._slots_folded = False
-        if mods is None or ranges:
+        if mods is None:
             self._adam(0, self.n_params, grad_scale, False, grad_bf16, ranges)    # negative scale inside: clears the gradients
             self.pack()
             return
-        key = (abs(float(grad_scale)), 0 if grad_bf16 is None else grad_bf16.data_ptr())
+        key = (abs(float(grad_scale)), 0 if grad_bf16 is None else grad_bf16.data_ptr(), tuple((lo, n, 0 if v is None else v.data_ptr(), k) for lo, n, v, k in ranges))
         plan = self._adam_plans.get(key)
         if plan is None:
             if grad_bf16 is not None and (grad_bf16.dtype != torch.bfloat16 or grad_bf16.numel() != self.n_params or not grad_bf16.is_cuda):
                 raise RuntimeError("grad_bf16 must be a bf16 device copy of the whole flat gradient")
             plan = AdamPackPlan(mods[0], mods[1], self.flat_p, self.flat_g, grad_bf16, self.flat_m, self.flat_v, self.adam_state,
-                                self.betas, self.eps, self.weight_decay, grad_scale)
+                                self.betas, self.eps, self.weight_decay, grad_scale, ranges)
             self._adam_plans[key] = plan
         plan.run()
 

@@ -487,18 +487,23 @@ class AdamPackPlan:
     """Host + device copies of the plan of m2m_adam_pack_all (Adam and the operand re-pack of a whole model in one launch)."""
 
     def __init__(self, towers: Sequence[TowerRuntime], embeds: Sequence["EmbedRuntime"], flat_p, flat_g, grad_bf16, flat_m, flat_v,
-                 state, betas, eps: float, weight_decay: float, grad_scale: float):
+                 state, betas, eps: float, weight_decay: float, grad_scale: float, ranges=None):
+        """ranges: [(lo, n, slot tensor or None, keep), ...] -- the special gradient ranges of m2m_adam_step_ranges."""
         self.towers, self.embeds = list(towers), list(embeds)
         nt, ne = len(towers), len(embeds)
         self._tp = (C.POINTER(L.Tower) * max(nt, 1))(*[C.pointer(t.desc) for t in towers])
         self._ep = (C.POINTER(L.Embed) * max(ne, 1))(*[C.pointer(e.desc) for e in embeds])
         nbytes = int(L.lib().m2m_adam_pack_plan_bytes())
         self.host = C.create_string_buffer(nbytes)
-        L.check(L.lib().m2m_adam_pack_plan(self._tp, nt, self._ep, ne, flat_p.data_ptr(), flat_g.data_ptr(), L.ptr(grad_bf16),
-                                           flat_m.data_ptr(), flat_v.data_ptr(), flat_p.numel(), state.data_ptr(), betas[0], betas[1],
-                                           eps, weight_decay, abs(grad_scale), self.host), "adam_pack_plan")
+        ranges = list(ranges or [])
+        arr = (L.GradRange * max(len(ranges), 1))()
+        for i, (rlo, rn, add, keep) in enumerate(ranges):
+            arr[i].lo, arr[i].n, arr[i].add, arr[i].keep = rlo, rn, L.ptr(add), int(keep)
+        L.check(L.lib().m2m_adam_pack_plan_ranges(self._tp, nt, self._ep, ne, flat_p.data_ptr(), flat_g.data_ptr(), L.ptr(grad_bf16),
+                                                  flat_m.data_ptr(), flat_v.data_ptr(), flat_p.numel(), state.data_ptr(), betas[0], betas[1],
+                                                  eps, weight_decay, abs(grad_scale), arr, len(ranges), self.host), "adam_pack_plan_ranges")
         self.dev = torch.frombuffer(bytearray(self.host.raw), dtype=torch.uint8).to(flat_p.device)
-        self._keep = (flat_p, flat_g, grad_bf16, flat_m, flat_v, state)
+        self._keep = (flat_p, flat_g, grad_bf16, flat_m, flat_v, state, [r[2] for r in ranges])
 
     def run(self):
         L.check(L.lib().m2m_adam_pack_all(self._tp, len(self.towers), self._ep, len(self.embeds), self.dev.data_ptr(), self.host,

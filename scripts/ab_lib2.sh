@@ -6,7 +6,7 @@ for rep in $(seq 1 ${REPS:-2}); do
 for spec in "$@"; do
   name=${spec%%=*}; rest=${spec#*=}; lib=${rest%%,*}; envs=""
   [ "$rest" != "$lib" ] && envs=$(echo "${rest#*,}" | tr ',' ' ')
-  env M2M_LIB_PATH=$PWD/$lib $envs python bench.py --steps 200 --warmup 20 --no-cpu-baseline > gpurun_out/$tag/${name}_${rep}.json 2> gpurun_out/$tag/${name}_${rep}.err || { tail -5 gpurun_out/$tag/${name}_${rep}.err; exit 1; }
+  env M2M_LIB_PATH=$PWD/$lib $envs python bench.py --steps 200 --warmup 20 --no-cpu-baseline --profile-steps ${PSTEPS:-10} > gpurun_out/$tag/${name}_${rep}.json 2> gpurun_out/$tag/${name}_${rep}.err || { tail -5 gpurun_out/$tag/${name}_${rep}.err; exit 1; }
   python - <<PY
 import json
 d=json.loads(open("gpurun_out/$tag/${name}_${rep}.json").read().strip().split("\n")[-1])
