@@ -484,7 +484,7 @@ def profile_launches(eng, image, audio, labels, nsteps):
     emb = sum(alg[t]["embed"] for t in two)
     patches = [                                                       # (object, attribute, name, algorithmic FLOPs per launch)
         (E, "embeds_forward", "embeds_fwd[image+audio]", emb),
-        (E, "towers_forward", "towers_fwd[image+audio]", sum(f_tow(t) for t in two)),
+        (E, "towers_forward", "towers_fwd[image+audio]", sum(f_tow(t) for t in two) + (emb if getattr(eng, "_embed_fold", False) else 0)),
         (eng.t_fus, "forward", "tower_fwd[fusion]", f_tow("fusion")),
         (E, "heads_ce", "heads_ce", alg["heads"] * 3),
         (eng.t_fus, "backward", "tower_bwd[fusion]", b_tow("fusion")),

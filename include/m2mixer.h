@@ -222,6 +222,18 @@ typedef struct m2m_tower_io {
 } m2m_tower_io;
 int m2m_towers_forward(const m2m_tower* const* towers, const m2m_tower_io* io, int ntowers, int B, int training,
                        uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream);
+/* The same launch with the patch embeddings inside it (round 4; reference: models/avmnist.py:259-260 -- image_mixer(image),
+ * audio_mixer(audio): MLPMixer.forward = to_patch_embedding, then the blocks, modules/mixer.py:155-162).  embeds[i] != NULL:
+ * tower i's input tokens are the patch embedding of inputs[i], computed by the tower's own workgroups for their own 16 token
+ * rows (io[i].x0 is the dense (B N, D) scratch the rows pass through; x0_parts is ignored) -- the embedding launch of its own
+ * costs ~7 us of fixed time at the head of the step.  head (may be NULL): losses[0 .. nlosses) = 0 and adam_state[0] += 1 in
+ * workgroup 0; head->drop_counter must be NULL, because this launch READS the dropout counter (see m2m_towers_wgrad_tail).
+ * m2m_towers_forward_embeds_ok: 1 if the pair / embeddings are taken (fused-path pair, 16 % N == 0, same precision and
+ * hidden_dim, not on the column-split path), else 0: use m2m_embeds_forward + m2m_towers_forward. */
+int m2m_towers_forward_embeds_ok(const m2m_tower* const* towers, int ntowers, const m2m_embed* const* embeds, int B);
+int m2m_towers_forward_embeds(const m2m_tower* const* towers, const m2m_tower_io* io, int ntowers,
+                              const m2m_embed* const* embeds, const float* const* inputs, const m2m_step_head* head,
+                              int B, int training, uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream);
 
 /* ---- backward ----------------------------------------------------------------------------------- */
 /* Reverse pass through final LayerNorm + blocks.
@@ -313,6 +325,16 @@ int m2m_towers_wgrad_heads(const m2m_tower* const* towers, const m2m_tower* cons
                            const m2m_tower* const* embed_towers, int nembeds,
                            int B, uint32_t seed, uint32_t step, const uint32_t* step_dev,
                            const m2m_head* heads, int nheads, int K, void* stream);
+
+/* m2m_towers_wgrad_heads that also advances a device counter at its head: *bump_counter += 1 (NULL: none).  For a training step
+ * whose FIRST launch reads the dropout counter (m2m_towers_forward_embeds): the counter then holds "steps completed", every
+ * launch of the step is given step = 1, and this launch -- behind the last reader -- advances it.  Refused for the recompute
+ * form of the weight gradients (it reads the counter itself). */
+int m2m_towers_wgrad_tail(const m2m_tower* const* towers, const m2m_tower* const* dev_towers, int ntowers,
+                          const m2m_embed* const* embeds, const float* const* inputs, const float* const* d_x0s,
+                          const m2m_tower* const* embed_towers, int nembeds,
+                          int B, uint32_t seed, uint32_t step, const uint32_t* step_dev,
+                          const m2m_head* heads, int nheads, int K, uint32_t* bump_counter, void* stream);
 
 /* m2m_tower_backward of the tower whose token mean carries head `own`, with the model's classification heads + multi-head
  * cross-entropy (m2m_heads_ce: models/avmnist.py:271-298) computed in the launch's prologue instead of a launch of their own:

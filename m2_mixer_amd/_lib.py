@@ -129,6 +129,9 @@ SIGNATURES = {
     "m2m_towers_can_group": (C.c_int, [C.POINTER(Tower), C.POINTER(Tower), C.c_int]),
     "m2m_towers_forward": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.POINTER(TowerIO), C.c_int, C.c_int, C.c_int, C.c_uint32,
                                      C.c_uint32, _fp, _fp]),
+    "m2m_towers_forward_embeds_ok": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.c_int, C.POINTER(C.POINTER(Embed)), C.c_int]),
+    "m2m_towers_forward_embeds": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.POINTER(TowerIO), C.c_int, C.POINTER(C.POINTER(Embed)),
+                                            C.POINTER(_fp), C.POINTER(StepHead), C.c_int, C.c_int, C.c_uint32, C.c_uint32, _fp, _fp]),
     "m2m_towers_backward": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.POINTER(TowerGIO), C.c_int, C.c_int, C.c_uint32, C.c_uint32,
                                       _fp, _fp]),
     "m2m_towers_wgrad": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.POINTER(_fp), C.c_int, C.POINTER(C.POINTER(Embed)), C.POINTER(_fp),
@@ -136,6 +139,9 @@ SIGNATURES = {
     "m2m_towers_wgrad_heads": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.POINTER(_fp), C.c_int, C.POINTER(C.POINTER(Embed)), C.POINTER(_fp),
                                          C.POINTER(_fp), C.POINTER(C.POINTER(Tower)), C.c_int, C.c_int, C.c_uint32, C.c_uint32, _fp,
                                          C.POINTER(Head), C.c_int, C.c_int, _fp]),
+    "m2m_towers_wgrad_tail": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.POINTER(_fp), C.c_int, C.POINTER(C.POINTER(Embed)), C.POINTER(_fp),
+                                        C.POINTER(_fp), C.POINTER(C.POINTER(Tower)), C.c_int, C.c_int, C.c_uint32, C.c_uint32, _fp,
+                                        C.POINTER(Head), C.c_int, C.c_int, _fp, _fp]),
     "m2m_heads_part_tiles": (C.c_int, [C.c_int]),
     "m2m_wgrad_form": (C.c_int, [C.POINTER(Tower), C.c_int]),
     "m2m_embeds_wgrad_form": (C.c_int, [C.POINTER(C.POINTER(Embed)), C.POINTER(C.POINTER(Tower)), C.c_int, C.c_int]),

@@ -14,6 +14,7 @@
 //   the eight waves' partial Y are summed through LDS slabs, then bias + dropout + residual.
 #include "tile.h"
 #include "token_mfma.h"
+#include "embed_fwd.h"
 #include <algorithm>
 
 // LDS budget of the forward chain kernel (bytes): FIXED + nblocks * PB * 4
@@ -459,6 +460,16 @@ struct FwdGroupArgs {
     long out_ss[2];
     float* pooled[2];
     int ntiles[2];
+    // Optional (m2m_towers_forward_embeds): the patch embedding of a tower's OWN 16 token rows as the prologue of its workgroups
+    // (embed[i] != 0: x0[i] is the (B N, D) scratch the rows pass through), and the head of the training step (losses = 0,
+    // Adam step count += 1) in workgroup 0.  The embedding launch of its own cost ~7 us of fixed time on the step's critical
+    // path (launch, first loads, epilogue) for ~14 us of streaming.
+    m2m_embed em[2];
+    const float* ein[2];
+    int embed[2], efast[2];
+    float* head_losses;
+    float* head_adam_state;
+    int head_nlosses;
 };
 static_assert(sizeof(FwdGroupArgs) <= 3584, "kernel arguments are limited to 4 KiB");
 template <int P, int D, int NMAX, int DM>
@@ -470,7 +481,26 @@ __global__ __launch_bounds__(NTHREADS) void tower_fwd_group_kernel(const FwdGrou
     // towers' 4.5 MB would not fit) and each tower's weights are fetched by four L2s instead of eight.
     const int id = blockIdx.x, xcd = id & 7, t = xcd >> 2;
     const int wg = (id >> 3) * 4 + (xcd & 3);
+    if constexpr (NMAX > 0) {
+        if (blockIdx.x == 0) {                             // head of the training step (nothing in this launch reads these)
+            const int tt = threadIdx.x;
+            if (tt == 0 && a.head_adam_state) a.head_adam_state[0] += 1.0f;
+            if (a.head_losses && tt < a.head_nlosses) a.head_losses[tt] = 0.f;
+        }
+    }
     if (wg >= a.ntiles[t]) return;
+    if constexpr (NMAX > 0) {
+        if (a.embed[t]) {
+            // this workgroup's rows [16 wg, 16 wg + 16) of the embedding output (whole samples: 16 % N == 0, checked by the host),
+            // through the embedding bodies' own LDS use (nothing of the tower lives there yet) into the scratch the tower reads
+            const int N = a.tw[t].N;
+            float* x0w = const_cast<float*>(a.x0[t]);
+            if (P == PREC_BF16 && a.efast[t]) embed_fwd_fast_body<D>(a.em[t], a.ein[t], (long)B * N, N, x0w, wg, 0, 1, smem);
+            else embed_fwd_body<P, D, BM>(a.em[t], a.ein[t], (long)B * N, N, x0w, wg, smem);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's rows are in L2 ...
+            __syncthreads();                                      // ... and so are the other waves' (same CU: read back through L2)
+        }
+    }
     tower_fwd_body<m2m_tower4, P, D, NMAX, DM>(a.tw[t], a.x0[t], a.x0_ss[t], a.x0_parts[t], a.x0_pstride[t], B, a.out[t], a.out_ss[t], a.pooled[t], training, seed,
                                                 step_host, step_dev, wg, smem);
 }
@@ -598,8 +628,51 @@ extern "C" int m2m_towers_can_group(const m2m_tower* a, const m2m_tower* b, int 
     return (m2m_can_group(a, b) || m2m_can_group_wide(a, b, B)) ? 1 : 0;
 }
 
+int m2m_check_embed(const m2m_embed* e, int B);          // embed.hip
+// 1: m2m_towers_forward_embeds takes these towers / embeddings at batch B (fused-path pair, whole samples per 16-row tile,
+// embedding and tower of one hidden_dim / precision); 0: run m2m_embeds_forward + m2m_towers_forward
+extern "C" int m2m_towers_forward_embeds_ok(const m2m_tower* const* towers, int ntowers, const m2m_embed* const* embeds, int B) {
+    if (!towers || !embeds || ntowers != 2 || B < 1) return 0;
+    for (int i = 0; i < 2; ++i) {
+        if (!towers[i] || m2m_check_tower(towers[i], B) != 0) return 0;
+        if (m2m_is_wide(towers[i]) || BM % towers[i]->N != 0 || m2m_split_eligible(towers[i], B, 1)) return 0;
+        const m2m_embed* e = embeds[i];
+        if (!e) continue;
+        if (m2m_check_embed(e, B) != 0 || e->prec != towers[i]->prec || e->D != towers[i]->D) return 0;
+        if ((e->H / e->ph) * (e->W / e->pw) != towers[i]->N) return 0;
+    }
+    return m2m_can_group(towers[0], towers[1]) ? 1 : 0;
+}
+static int towers_forward_impl(const m2m_tower* const* towers, const m2m_tower_io* io, int ntowers, const m2m_embed* const* embeds,
+                               const float* const* inputs, const m2m_step_head* head, int B, int training,
+                               uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream);
 extern "C" int m2m_towers_forward(const m2m_tower* const* towers, const m2m_tower_io* io, int ntowers, int B, int training,
                                   uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream) {
+    return towers_forward_impl(towers, io, ntowers, nullptr, nullptr, nullptr, B, training, seed, step, step_dev, stream);
+}
+extern "C" int m2m_towers_forward_embeds(const m2m_tower* const* towers, const m2m_tower_io* io, int ntowers,
+                                         const m2m_embed* const* embeds, const float* const* inputs, const m2m_step_head* head,
+                                         int B, int training, uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream) {
+    if (!embeds || !inputs) { m2m_set_error("towers_forward_embeds: embeds / inputs are required", __FILE__, __LINE__); return -1; }
+    if (!m2m_towers_forward_embeds_ok(towers, ntowers, embeds, B)) {
+        m2m_set_error("towers_forward_embeds: unsupported towers / embeddings (see m2m_towers_forward_embeds_ok)", __FILE__, __LINE__);
+        return -1;
+    }
+    if (head && head->drop_counter) {
+        m2m_set_error("towers_forward_embeds: this launch READS the dropout counter; advance it behind the step's last reader (m2m_towers_wgrad_tail)", __FILE__, __LINE__);
+        return -1;
+    }
+    if (head && (head->nlosses < 0 || head->nlosses > 64)) { m2m_set_error("towers_forward_embeds: step head nlosses must be in [0, 64]", __FILE__, __LINE__); return -1; }
+    for (int i = 0; i < 2; ++i)
+        if (embeds[i] && (!inputs[i] || !io[i].x0 || io[i].x0_sample_stride != (int64_t)towers[i]->N * towers[i]->D)) {
+            m2m_set_error("towers_forward_embeds: an embedded tower needs its input and a dense (B N, D) x0 scratch", __FILE__, __LINE__);
+            return -1;
+        }
+    return towers_forward_impl(towers, io, ntowers, embeds, inputs, head, B, training, seed, step, step_dev, stream);
+}
+static int towers_forward_impl(const m2m_tower* const* towers, const m2m_tower_io* io, int ntowers, const m2m_embed* const* embeds,
+                               const float* const* inputs, const m2m_step_head* head, int B, int training,
+                               uint32_t seed, uint32_t step, const uint32_t* step_dev, void* stream) {
     if (!towers || !io || ntowers != 2) { m2m_set_error("towers_forward: exactly two towers per launch", __FILE__, __LINE__); return -1; }
     for (int i = 0; i < 2; ++i)
         if (int rc = m2m_check_tower(towers[i], B)) return rc;
@@ -615,10 +688,16 @@ extern "C" int m2m_towers_forward(const m2m_tower* const* towers, const m2m_towe
         return -1;
     }
     FwdGroupArgs a;
+    memset(&a, 0, sizeof(a));
+    if (head) { a.head_losses = head->losses; a.head_adam_state = head->adam_state; a.head_nlosses = head->nlosses; }
     for (int i = 0; i < 2; ++i) {
         a.tw[i] = m2m_shrink(towers[i]);
         a.x0[i] = io[i].x0; a.x0_ss[i] = (long)io[i].x0_sample_stride;
-        a.x0_parts[i] = io[i].x0_parts > 1 ? io[i].x0_parts : 1;
+        if (embeds && embeds[i]) {
+            a.embed[i] = 1; a.em[i] = *embeds[i]; a.ein[i] = inputs[i];
+            a.efast[i] = embed_fwd_fast_ok(embeds[i], inputs[i]) ? 1 : 0;
+        }
+        a.x0_parts[i] = (io[i].x0_parts > 1 && !a.embed[i]) ? io[i].x0_parts : 1;
         a.x0_pstride[i] = (long)io[i].x0_part_stride;
         if (a.x0_parts[i] > 4) { m2m_set_error("towers_forward: at most 4 input parts", __FILE__, __LINE__); return -1; }
         a.out[i] = io[i].out; a.out_ss[i] = (long)io[i].out_sample_stride;

@@ -400,6 +400,7 @@ struct WgradGroupArgs {
     int n_reduce, reduce_sets;                         // slot-reduction workgroups at the END of the grid: SPR_NBX x reduce_sets x ra.ntow
     unsigned int seed, step_host;
     const unsigned int* step_dev;
+    unsigned int* bump_counter;                        // m2m_towers_wgrad_tail: *bump_counter += 1 (the step's dropout counter, behind its last reader)
 };
 // The grid is one-dimensional.  Tower workgroups first, XCD-aware: the hardware deals consecutive workgroup ids to the 8 XCDs
 // round-robin (id % 8), each XCD has its own 4 MB L2, and what a workgroup re-reads -- the 32-row operand images of ITS
@@ -419,6 +420,7 @@ __global__ __launch_bounds__((WgradKernelGeom<P, D, RCDM>::THREADS), (WgradKerne
                                                                                                           const SplitReduceArgs ra) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int id = blockIdx.x;
+    if (a.bump_counter && blockIdx.x == 0 && threadIdx.x == 0) *a.bump_counter += 1u;     // (nothing in this launch reads it: stored-operand form)
 #ifndef M2M_WG_PROBE_TOWERS_ONLY        // (ISA probe: the tower path's own register need)
     // The slot reduction of a preceding fused backward launch (M2M_WGRAD_REDUCES_SMALL): ~140 short workgroups at the end of the
     // grid -- they run on the CUs the one-per-CU tower workgroups leave free, long before those finish.
@@ -585,7 +587,7 @@ template <int P, int D, int RCDM>
 static int launch_wgrad_group(const m2m_tower* const* host, const m2m_tower* const* dev, int n, const m2m_embed* const* embeds,
                               const float* const* inputs, const float* const* d_x0s, const m2m_tower* const* embed_towers,
                               int nembeds, int B, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st,
-                              const SplitReduceTower* heads_reduce = nullptr) {
+                              const SplitReduceTower* heads_reduce = nullptr, unsigned int* bump_counter = nullptr) {
     typedef WgradKernelGeom<P, D, RCDM> KG;
     WgradGroupArgs a;
     memset(&a, 0, sizeof(a));
@@ -624,6 +626,7 @@ static int launch_wgrad_group(const m2m_tower* const* host, const m2m_tower* con
     }
     a.njobs = njobs; a.n_tower_wgs = 8 * max_len;
     a.seed = seed; a.step_host = step; a.step_dev = step_dev;
+    a.bump_counter = bump_counter;
     a.dma = wgrad_use_dma();
     EmbedWgradGroupArgs ea;
     memset(&ea, 0, sizeof(ea));
@@ -739,7 +742,7 @@ static int towers_wgrad_impl(const m2m_tower* const* towers, const m2m_tower* co
                              const m2m_embed* const* embeds, const float* const* inputs, const float* const* d_x0s,
                              const m2m_tower* const* embed_towers, int nembeds,
                              int B, uint32_t seed, uint32_t step, const uint32_t* step_dev,
-                             const m2m_head* heads, int nheads, int K, void* stream) {
+                             const m2m_head* heads, int nheads, int K, void* stream, uint32_t* bump_counter = nullptr) {
     SplitReduceTower hr;
     const SplitReduceTower* heads_reduce = nullptr;
     if (heads && nheads > 0) {
@@ -786,12 +789,16 @@ static int towers_wgrad_impl(const m2m_tower* const* towers, const m2m_tower* co
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const m2m_tower* t = towers[0];
+    if (bump_counter && m2m_wgrad_recompute(t, B)) {
+        m2m_set_error("towers_wgrad_tail: the recompute form READS the dropout counter in this launch; advance it with m2m_counter_add", __FILE__, __LINE__);
+        return -1;
+    }
     if (m2m_wgrad_recompute(t, B)) {
         if (m2m_drop_mode(1, t->p_drop) == DM_HALF)
             return launch_wgrad_group<PREC_BF16, 128, DM_HALF>(towers, dev_towers, ntowers, embeds, inputs, d_x0s, embed_towers, nembeds, B, seed, step, step_dev, st, heads_reduce);
         return launch_wgrad_group<PREC_BF16, 128, DM_NONE>(towers, dev_towers, ntowers, embeds, inputs, d_x0s, embed_towers, nembeds, B, seed, step, step_dev, st, heads_reduce);
     }
-#define M2M_WGG_CASE(PP, DD) if (t->prec == PP && t->D == DD) return launch_wgrad_group<PP, DD, -1>(towers, dev_towers, ntowers, embeds, inputs, d_x0s, embed_towers, nembeds, B, seed, step, step_dev, st, heads_reduce);
+#define M2M_WGG_CASE(PP, DD) if (t->prec == PP && t->D == DD) return launch_wgrad_group<PP, DD, -1>(towers, dev_towers, ntowers, embeds, inputs, d_x0s, embed_towers, nembeds, B, seed, step, step_dev, st, heads_reduce, bump_counter);
     M2M_WGG_CASE(PREC_BF16, 32) M2M_WGG_CASE(PREC_BF16, 64) M2M_WGG_CASE(PREC_BF16, 128) M2M_WGG_CASE(PREC_BF16, 256)
     M2M_WGG_CASE(PREC_F32, 32) M2M_WGG_CASE(PREC_F32, 64) M2M_WGG_CASE(PREC_F32, 128) M2M_WGG_CASE(PREC_F32, 256)
 #undef M2M_WGG_CASE
@@ -811,6 +818,14 @@ extern "C" int m2m_towers_wgrad_heads(const m2m_tower* const* towers, const m2m_
                                       int B, uint32_t seed, uint32_t step, const uint32_t* step_dev,
                                       const m2m_head* heads, int nheads, int K, void* stream) {
     return towers_wgrad_impl(towers, dev_towers, ntowers, embeds, inputs, d_x0s, embed_towers, nembeds, B, seed, step, step_dev, heads, nheads, K, stream);
+}
+
+extern "C" int m2m_towers_wgrad_tail(const m2m_tower* const* towers, const m2m_tower* const* dev_towers, int ntowers,
+                                     const m2m_embed* const* embeds, const float* const* inputs, const float* const* d_x0s,
+                                     const m2m_tower* const* embed_towers, int nembeds,
+                                     int B, uint32_t seed, uint32_t step, const uint32_t* step_dev,
+                                     const m2m_head* heads, int nheads, int K, uint32_t* bump_counter, void* stream) {
+    return towers_wgrad_impl(towers, dev_towers, ntowers, embeds, inputs, d_x0s, embed_towers, nembeds, B, seed, step, step_dev, heads, nheads, K, stream, bump_counter);
 }
 
 // 1: m2m_towers_wgrad(..., embeds, ..., embed_towers, ...) at batch B computes the embedding gradients in the single-owner form

@@ -28,7 +28,7 @@ from . import _lib as L
 from . import config
 from .runtime import (AdamPackPlan, BLOCK_FIELDS, BLOCK_KEYS, EmbedRuntime, MlpRuntime, TowerRuntime, block_param_shapes, heads_bce,
                       heads_ce, can_group, can_group_embeds, can_pack_all, embeds_forward, pack_all,
-                      towers_backward, towers_forward, towers_wgrad, wgrad_slot_groups)
+                      towers_backward, towers_forward, towers_forward_embeds_ok, towers_wgrad, wgrad_slot_groups)
 
 
 def config_fused_update() -> bool:
@@ -702,6 +702,21 @@ class _TwoTowerEngine(_FlatEngine):
                 self._ranges_add.sort(key=lambda r: r[0])
                 self._ranges_keep = [(lo, n, None, k) for lo, n, _, k in self._ranges_add]
 
+        # Patch embeddings inside the two-tower forward launch (m2m_towers_forward_embeds: -1 launch at the head of the step).
+        # The step head then splits: losses = 0 / Adam step += 1 ride in that launch, the dropout counter -- which that launch
+        # READS -- holds "steps completed", every launch of a training step is given step = 1 and the merged weight-gradient
+        # launch (the last reader is long done) advances it.  Observable counter values are those of the prologue form.
+        # OFF by default (M2M_EMBED_FOLD=1 enables it).  Measured on M2-Mixer-B, batch 512, three interleaved repetitions in one
+        # process: towers forward 103-105 us with the embeddings inside against 84-85 + 21-22 us as two launches, step
+        # 0.5116-0.5163 against 0.5067-0.5121 ms -- the audio tower's 128 workgroups each stream the whole 800 KB embedding
+        # weight + 200 KB of input alone (+19 us, not the 7.5 us the CU's 64 B/clk would allow) while the image tower's 128 CUs
+        # wait; the launch of its own spreads that work over 256 + 128 workgroups (k-split).  Parity-green either way.
+        self._embed_fold = (os.environ.get("M2M_EMBED_FOLD", "0") == "1" and grouped and self.concurrent and not self._early_fus_wgrad
+                            and self.x0_splits is not None and self.e_a.prec == self.t_a.prec and self.e_a.D == self.t_a.D
+                            and towers_forward_embeds_ok([self.t_a, self.t_b], [self.e_a, self.e_b], B)
+                            and self.t_a.wgrad_form(B) == 0 and self.t_fus.wgrad_form(B) == 0)
+        self._pending_bump = False
+
     def _preds_shape(self):
         return (3, self.B)
 
@@ -730,7 +745,17 @@ class _TwoTowerEngine(_FlatEngine):
         fs = self.Nf * D
         b_part = self.fused.view(-1)[self.Na * D:]
         main, side, _ = self._streams()
-        if self.concurrent and can_group(self.t_a, self.t_b, self.B):
+        so = 0                                               # host step offset of this pass's launches (see _embed_fold)
+        self._pending_bump = False
+        if self._embed_fold and training and prologue:
+            # both patch embeddings inside the two-tower launch; head of the step: losses = 0, Adam step += 1 in that launch,
+            # the dropout counter advances in the weight-gradient launch of _backward (every launch in between gets step = 1)
+            so, self._pending_bump = 1, True
+            towers_forward([self.t_a, self.t_b],
+                           [(self.x0_a, self.Na * D, self.fused, fs, self.pool_a), (self.x0_b, self.Nb * D, b_part, fs, self.pool_b)],
+                           B, training, self.seed, so, sd, embeds=[self.e_a, self.e_b], inputs=[xa, xb],
+                           head=(self.adam_state, self.losses))
+        elif self.concurrent and can_group(self.t_a, self.t_b, self.B):
             # one launch for both patch embeddings, one for both towers (blockIdx.y = tower), all on the main stream: no
             # cross-queue fork / join in the graph (a join costs ~6 us even when its event fired long ago)
             sa, sb = self.x0_splits
@@ -758,7 +783,7 @@ class _TwoTowerEngine(_FlatEngine):
             self.e_a.forward(xa, B, self.x0_a)
             self.t_a.forward(self.x0_a, self.Na * D, B, self.fused, fs, self.pool_a, training, self.seed, 0, sd)
             main.wait_stream(side)
-        self.t_fus.forward(self.fused, fs, B, self.fus_out, fs, self.pool_fus, training, self.seed, 0, sd)
+        self.t_fus.forward(self.fused, fs, B, self.fus_out, fs, self.pool_fus, training, self.seed, so, sd)
         a, b = self.MODS
         hw = self.head_weights
         heads = [self._head(a, self.pool_a, self.dpool_a, hw[a], with_grad),
@@ -782,19 +807,20 @@ class _TwoTowerEngine(_FlatEngine):
         fs = self.Nf * D
         sd = self.drop_step
         a, b = self.MODS
+        so = 1 if self._pending_bump else 0                 # (the forward of this step left the dropout counter un-advanced)
         if self._fused_heads:
             # the three heads + multi-head CE in the prologue of this launch (m2m_tower_backward_heads): one launch less
             self.t_fus.backward_heads(B, self._heads, 2, self._labels, self.K, (self.logits, self.losses, self.preds),
-                                      self.d_fused, fs, self.seed, 0, sd)
+                                      self.d_fused, fs, self.seed, so, sd)
         else:
-            self.t_fus.backward(B, None, 0, self.dpool_fus, self.d_fused, fs, self.seed, 0, sd)
+            self.t_fus.backward(B, None, 0, self.dpool_fus, self.d_fused, fs, self.seed, so, sd)
         d_b_part = self.d_fused.view(-1)[self.Na * D:]
         main, s_a, s_f = self._streams()
         wg_towers = [self.t_fus, self.t_a, self.t_b]
         if self._early_fus_wgrad:
             s_f.wait_stream(main)
             with torch.cuda.stream(s_f):
-                self.t_fus.wgrad(B, self.seed, 0, sd)
+                self.t_fus.wgrad(B, self.seed, so, sd)
             wg_towers = [self.t_a, self.t_b]
         s_e = self.s_emb if self.concurrent else main
         # The two tower chains fill the chip (128 + 128 workgroups) side by side; then ONE launch computes the channel-mixing
@@ -806,23 +832,28 @@ class _TwoTowerEngine(_FlatEngine):
         if self.concurrent and can_group(self.t_a, self.t_b, self.B):
             towers_backward([self.t_a, self.t_b],
                             [(self.d_fused, fs, self.dpool_a, self.dx0_a, self.Na * D), (d_b_part, fs, self.dpool_b, self.dx0_b, self.Nb * D)],
-                            B, self.seed, 0, sd)
+                            B, self.seed, so, sd)
         else:
             s_a.wait_stream(main)
             with torch.cuda.stream(s_a):
-                self.t_a.backward(B, self.d_fused, fs, self.dpool_a, self.dx0_a, self.Na * D, self.seed, 0, sd)
-            self.t_b.backward(B, d_b_part, fs, self.dpool_b, self.dx0_b, self.Nb * D, self.seed, 0, sd)
+                self.t_a.backward(B, self.d_fused, fs, self.dpool_a, self.dx0_a, self.Na * D, self.seed, so, sd)
+            self.t_b.backward(B, d_b_part, fs, self.dpool_b, self.dx0_b, self.Nb * D, self.seed, so, sd)
             main.wait_stream(s_a)
+        bump = self.drop_step if self._pending_bump else None
         if can_group_embeds(self.e_a, self.e_b) and self.e_a.prec == self.t_a.prec and self.e_a.D == self.t_a.D:
             towers_wgrad(wg_towers, B, [self.e_a, self.e_b], [xa, xb], [self.dx0_a, self.dx0_b],
-                         seed=self.seed, step=0, step_dev=sd, embed_towers=self._embed_towers, heads=self._wgrad_heads, K=self.K)
+                         seed=self.seed, step=so, step_dev=sd, embed_towers=self._embed_towers, heads=self._wgrad_heads, K=self.K,
+                         bump=bump)
         else:
+            if bump is not None:
+                raise RuntimeError("the embedding fold needs the merged weight-gradient launch (it advances the dropout counter)")
             s_e.wait_stream(main)
             with torch.cuda.stream(s_e):
                 self.e_b.wgrad(xb, self.dx0_b, B)
                 self.e_a.wgrad(xa, self.dx0_a, B)
-            towers_wgrad(wg_towers, B, seed=self.seed, step=0, step_dev=sd, heads=self._wgrad_heads, K=self.K)
+            towers_wgrad(wg_towers, B, seed=self.seed, step=so, step_dev=sd, heads=self._wgrad_heads, K=self.K)
             main.wait_stream(s_e)
+        self._pending_bump = False
         if self._early_fus_wgrad:
             main.wait_stream(s_f)
         if fused_update:

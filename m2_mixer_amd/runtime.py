@@ -402,10 +402,21 @@ def can_group(a: TowerRuntime, b: TowerRuntime, B: Optional[int] = None) -> bool
             and (a.N <= 4) == (b.N <= 4) and (a.T % 16 == 0) == (b.T % 16 == 0) and a.nblocks <= 4 and b.nblocks <= 4)
 
 
+def towers_forward_embeds_ok(towers: Sequence[TowerRuntime], embeds: Sequence["EmbedRuntime"], B: int) -> bool:
+    """towers_forward(..., embeds=, inputs=) takes this pair: the patch embeddings ride in the towers' launch."""
+    n = len(towers)
+    host = (C.POINTER(L.Tower) * n)(*[C.pointer(t.desc) for t in towers])
+    ep = (C.POINTER(L.Embed) * n)(*[C.pointer(e.desc) for e in embeds])
+    return bool(L.lib().m2m_towers_forward_embeds_ok(host, n, ep, B))
+
+
 def towers_forward(towers: Sequence[TowerRuntime], ios: Sequence[tuple], B: int, training: bool, seed: int, step: int,
-                   step_dev: Optional[torch.Tensor] = None):
+                   step_dev: Optional[torch.Tensor] = None, embeds: Sequence["EmbedRuntime"] = (), inputs: Sequence[torch.Tensor] = (),
+                   head: Optional[tuple] = None):
     """ios[i] = (x0, x0_ss, out, out_ss, pooled or None[, x0_parts, x0_part_stride]): two towers, one launch.  With
-    x0_parts > 1 the input is the sum of that many buffers (the k-split partial sums of embeds_forward)."""
+    x0_parts > 1 the input is the sum of that many buffers (the k-split partial sums of embeds_forward).
+    embeds + inputs (one per tower): the launch computes the patch embeddings itself (m2m_towers_forward_embeds; ios[i][0] is
+    the (B N, D) scratch); head = (adam_state, losses): Adam step count += 1 and losses = 0 at the head of the launch."""
     n = len(towers)
     for t in towers:
         if training:
@@ -416,6 +427,17 @@ def towers_forward(towers: Sequence[TowerRuntime], ios: Sequence[tuple], B: int,
     for i, (x0, x0_ss, out, out_ss, pooled, *parts) in enumerate(ios):
         io[i].x0, io[i].x0_ss, io[i].out, io[i].out_ss, io[i].pooled = x0.data_ptr(), x0_ss, out.data_ptr(), out_ss, L.ptr(pooled)
         io[i].x0_parts, io[i].x0_part_stride = parts if parts else (1, 0)
+    if len(embeds):
+        ep = (C.POINTER(L.Embed) * n)(*[C.pointer(e.desc) for e in embeds])
+        ip = (C.c_void_p * n)(*[t.data_ptr() for t in inputs])
+        hd = None
+        if head is not None:
+            hd = L.StepHead()
+            hd.adam_state, hd.drop_counter, hd.losses, hd.nlosses = L.ptr(head[0]), None, L.ptr(head[1]), int(head[1].numel())
+        L.check(L.lib().m2m_towers_forward_embeds(host, io, n, ep, ip, C.byref(hd) if hd is not None else None, B, int(training),
+                                                  seed & 0xFFFFFFFF, step & 0xFFFFFFFF, L.ptr(step_dev), L.stream_ptr()),
+                "towers_forward_embeds")
+        return
     L.check(L.lib().m2m_towers_forward(host, io, n, B, int(training), seed & 0xFFFFFFFF, step & 0xFFFFFFFF, L.ptr(step_dev),
                                        L.stream_ptr()), "towers_forward")
 
@@ -443,7 +465,7 @@ def wgrad_slot_groups(towers: Sequence[TowerRuntime], B: int) -> int:
 def towers_wgrad(towers: Sequence[TowerRuntime], B: int, embeds: Sequence["EmbedRuntime"] = (),
                  inputs: Sequence[torch.Tensor] = (), d_x0s: Sequence[torch.Tensor] = (), seed: int = 0, step: int = 0,
                  step_dev: Optional[torch.Tensor] = None, embed_towers: Sequence[TowerRuntime] = (),
-                 heads: Optional[Sequence[dict]] = None, K: int = 0):
+                 heads: Optional[Sequence[dict]] = None, K: int = 0, bump: Optional[torch.Tensor] = None):
     """Channel-mixing weight gradients of several towers (same precision / hidden_dim) in one launch; with `embeds`
     (the model's two patch embeddings, their inputs and d_x0) also the embedding gradients, in the same launch.
     seed / step / step_dev: the dropout stream of the forward (the recompute form regenerates the hidden keep-mask).
@@ -457,6 +479,12 @@ def towers_wgrad(towers: Sequence[TowerRuntime], B: int, embeds: Sequence["Embed
     ip = (C.c_void_p * max(ne, 1))(*[t.data_ptr() for t in inputs])
     dp = (C.c_void_p * max(ne, 1))(*[t.data_ptr() for t in d_x0s])
     et = (C.POINTER(L.Tower) * max(ne, 1))(*[C.pointer(t.desc) for t in embed_towers]) if len(embed_towers) == ne and ne else None
+    if bump is not None:
+        # the step's dropout counter advances in this launch, behind its last reader (m2m_towers_wgrad_tail)
+        L.check(L.lib().m2m_towers_wgrad_tail(host, dev, n, ep, ip, dp, et, ne, B, seed & 0xFFFFFFFF, step & 0xFFFFFFFF,
+                                              L.ptr(step_dev), _head_array(heads) if heads else None, len(heads) if heads else 0, K,
+                                              bump.data_ptr(), L.stream_ptr()), "towers_wgrad_tail")
+        return
     if heads:
         # the classification heads' weight-gradient slots (heads_ce with "g_part") are added to g_w / g_b by this launch
         L.check(L.lib().m2m_towers_wgrad_heads(host, dev, n, ep, ip, dp, et, ne, B, seed & 0xFFFFFFFF, step & 0xFFFFFFFF,

@@ -11,6 +11,6 @@ for spec in "$@"; do
 import json
 d=json.loads(open("gpurun_out/$tag/${name}_${rep}.json").read().strip().split("\n")[-1])
 k=d["kernels_us"]
-print("${name} rep${rep}: %d samples/s %.4f ms | wgrad %.1f adam+pack %.1f bwd %.1f+%.1f fwd %.1f+%.1f heads %.1f embeds %.1f" % (d["value"], d["ms_per_step"], k["towers_wgrad[all+embeds]"], k["adam+pack"], k.get("tower_bwd[fusion]", 0.0) + k.get("tower_bwd[fusion]+heads", 0.0), k["towers_bwd[image+audio]"], k["towers_fwd[image+audio]"], k["tower_fwd[fusion]"], k.get("heads_ce", 0.0), k["embeds_fwd[image+audio]"]))
+print("${name} rep${rep}: %d samples/s %.4f ms | wgrad %.1f adam+pack %.1f bwd %.1f+%.1f fwd %.1f+%.1f heads %.1f embeds %.1f" % (d["value"], d["ms_per_step"], k["towers_wgrad[all+embeds]"], k["adam+pack"], k.get("tower_bwd[fusion]", 0.0) + k.get("tower_bwd[fusion]+heads", 0.0), k["towers_bwd[image+audio]"], k["towers_fwd[image+audio]"], k["tower_fwd[fusion]"], k.get("heads_ce", 0.0), k.get("embeds_fwd[image+audio]", 0.0)))
 PY
 done; done

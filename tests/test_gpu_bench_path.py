@@ -310,6 +310,25 @@ def test_run_epoch_covers_every_sample_and_matches_the_oracle(dev, tmp_path):
     assert abs(va["loss"] - float((ls[:, 3] * ls[:, 4]).sum() / ls[:, 4].sum())) < 5e-3
 
 
+def test_embeddings_inside_the_tower_forward_launch_vs_oracle(dev, monkeypatch):
+    """M2M_EMBED_FOLD=1 (off by default: measured no faster): the two patch embeddings computed by the tower workgroups
+    themselves (m2m_towers_forward_embeds), the step head split between that launch (losses = 0, Adam step) and the merged
+    weight-gradient launch (dropout counter, m2m_towers_wgrad_tail).  Same oracle comparison as the default path at a ragged
+    batch, and the counters end where the prologue form leaves them."""
+    from m2_mixer_amd.engine import AVMnistEngine
+    monkeypatch.setenv("M2M_EMBED_FOLD", "1")
+    cfg, B = dict(G.AVMNIST["B"], dropout=0.5), 40
+    probe = AVMnistEngine(cfg, B, device=dev, precision="bf16", lr=1e-2, init=False)
+    assert probe._embed_fold, "M2M_EMBED_FOLD=1 did not select the folded launch"
+    batch = tuple(t.to(dev) for t in G.avmnist_batch(B, 18, cfg))
+    for k in range(1, 4):
+        probe.train_step(*batch)
+        torch.cuda.synchronize()
+        assert float(probe.adam_state[0]) == float(k) and int(probe.drop_step[0]) == k
+    del probe
+    test_bench_instantiation_with_dropout_vs_oracle(0.5, B, dev)
+
+
 @pytest.mark.parametrize("which,env", [("recomp", {"M2M_WGRAD_RECOMP": "1"}), ("fused_heads", {"M2M_FUSED_HEADS": "1"}),
                                        ("tickets", {"M2M_BWD_TICKETS": "1"})])
 def test_opt_in_paths_vs_oracle(which, env, dev):
