@@ -169,6 +169,10 @@ int m2m_pack_embed(const m2m_embed* e, void* stream);
  * precision.  What the engines run after the fused Adam (replaces the per-module repack implied by
  * torch.optim.Adam.step updating the weights the next forward reads, models/avmnist.py:412-414). */
 int m2m_pack_all(const m2m_tower* const* towers, int ntowers, const m2m_embed* const* embeds, int nembeds, void* stream);
+/* 1: m2m_pack_all / m2m_adam_pack_all leave this tower's w1tc copies unwritten, because nothing reads them (bf16, hidden_dim 128:
+ * the backward chain takes that operand from the W1 fragments it parks in LDS; no slab buffer: not on the column-split path).
+ * m2m_pack_tower always writes every copy. */
+int m2m_pack_skips_w1tc(const m2m_tower* t);
 
 /* ---- forward ------------------------------------------------------------------------------------ */
 /* x0 (B*N, D) = patches(input) W^T + b.   Replaces MLPMixer.to_patch_embedding / MLPMixerNoPatching.proj. */

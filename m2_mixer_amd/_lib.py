@@ -115,6 +115,7 @@ SIGNATURES = {
     "m2m_pack": (C.c_int, [C.c_int, C.c_int, C.c_int, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _fp, _fp]),
     "m2m_pack_tower": (C.c_int, [C.POINTER(Tower), _fp]),
     "m2m_pack_embed": (C.c_int, [C.POINTER(Embed), _fp]),
+    "m2m_pack_skips_w1tc": (C.c_int, [C.POINTER(Tower)]),
     "m2m_pack_all": (C.c_int, [C.POINTER(C.POINTER(Tower)), C.c_int, C.POINTER(C.POINTER(Embed)), C.c_int, _fp]),
     "m2m_embed_forward": (C.c_int, [C.POINTER(Embed), _fp, C.c_int, _fp, _fp]),
     "m2m_embed_forward_head": (C.c_int, [C.POINTER(Embed), _fp, C.c_int, _fp, C.POINTER(StepHead), _fp]),

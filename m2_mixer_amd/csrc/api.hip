@@ -161,13 +161,25 @@ extern "C" int m2m_pack_tower(const m2m_tower* t, void* stream) {
 // five launches forked over side streams).  Grid layout: see pack_all_kernel.
 #define M2M_PACK_TOWERS 3
 #define M2M_PACK_EMBEDS 2
+#ifndef M2M_W1TC_SKIP
+#define M2M_W1TC_SKIP 1
+#endif
 struct PackAllArgs {
     m2m_tower4 tw[M2M_PACK_TOWERS];
     m2m_embed em[M2M_PACK_EMBEDS];
     int nt, ne;
     int tile_end[M2M_PACK_TOWERS];     // running count of (block, 32-column group) tiles up to and including tower t
     int embed_wgs0;                    // workgroups (256 slots each) of embedding 0
+    int skip_w1tc[M2M_PACK_TOWERS];    // 1: nothing reads this tower's w1tc copy (pack_skips_w1tc): a quarter of the re-pack's writes
 };
+// The W1^T (CHN) copy feeds the third product of the backward chain -- except in the bf16 / hidden_dim 128 instantiation, which
+// takes that operand from the W1 fragments it parks in LDS (tower_bwd.hip, W1LDS); the only other reader is the column-split
+// path, which needs the tower's slab buffer.  Such towers skip the copy in the whole-model re-pack (8.4 MB of 100 MB on
+// M2-Mixer-B).  m2m_pack_tower / m2m_pack (per-tower, tests, the module path) always write all copies.
+static inline int pack_skips_w1tc(const m2m_tower* t) {
+    return t->prec == PREC_BF16 && t->D == 128 && !m2m_is_wide(t) && t->slabs == nullptr && M2M_W1TC_SKIP;
+}
+extern "C" int m2m_pack_skips_w1tc(const m2m_tower* t) { return t ? pack_skips_w1tc(t) : 0; }
 static_assert(sizeof(PackAllArgs) <= 4096, "kernel arguments are limited to 4 KiB");
 
 // One workgroup = one 32-column group q of one block: W1 rows [32q, 32q + 32) (one contiguous 32 x D chunk) and W2 columns
@@ -177,7 +189,7 @@ static_assert(sizeof(PackAllArgs) <= 4096, "kernel arguments are limited to 4 Ki
 // Second half of a tile workgroup: the four packed copies (+ ch_b1p is written by the caller) from the LDS tiles
 //   t1 [32][D + 1] = W1[32q + r][d],  t2 [D][33] = W2[d][32q + j]   (rows / columns past C are zero)
 template <int P>
-static __device__ __forceinline__ void pack_emit_tile(const m2m_block& k, int D, int q, const float* t1, const float* t2) {
+static __device__ __forceinline__ void pack_emit_tile(const m2m_block& k, int D, int q, const float* t1, const float* t2, bool skip_w1tc = false) {
     typedef Prec<P> Pr;
     const int L1 = D + 1, L2 = 33;
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -220,13 +232,13 @@ static __device__ __forceinline__ void pack_emit_tile(const m2m_block& k, int D,
             v2[e] = t2[d * L2 + j];
         }
         const long blk = (long)(CB * q + h) * nIB + ib;
-        emit((char*)k.w1tc, blk, lane, v1);
+        if (!skip_w1tc) emit((char*)k.w1tc, blk, lane, v1);
         emit((char*)k.w2c, blk, lane, v2);
     }
 }
 
 template <int P, class TW>
-static __device__ __forceinline__ void pack_block_tile(const TW& tw, int block, int q, char* smem) {
+static __device__ __forceinline__ void pack_block_tile(const TW& tw, int block, int q, char* smem, bool skip_w1tc = false) {
     const m2m_block& k = tw.blk[block];
     const int D = tw.D, C = tw.C, L1 = D + 1, L2 = 33;
     float* t1 = reinterpret_cast<float*>(smem);            // [32][D + 1]   W1[32q + r][d]
@@ -246,7 +258,7 @@ static __device__ __forceinline__ void pack_block_tile(const TW& tw, int block, 
     }
     if (tid < 32) k.ch_b1p[c0 + tid] = c0 + tid < C ? k.ch_b1[c0 + tid] : 0.f;
     __syncthreads();
-    pack_emit_tile<P>(k, D, q, t1, t2);
+    pack_emit_tile<P>(k, D, q, t1, t2, skip_w1tc);
 }
 
 // blockIdx.x: the towers' (block, column group) tiles first -- tower t owns tile_end[t - 1] .. tile_end[t] -- then the
@@ -260,7 +272,7 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const PackAllArgs a) {
         while (id >= a.tile_end[t]) ++t;
         if (t) id -= a.tile_end[t - 1];
         const int nq = a.tw[t].Cp >> 5;
-        pack_block_tile<P>(a.tw[t], id / nq, id % nq, smem);
+        pack_block_tile<P>(a.tw[t], id / nq, id % nq, smem, a.skip_w1tc[t] != 0);
         return;
     }
     id -= a.tile_end[M2M_PACK_TOWERS - 1];
@@ -288,6 +300,7 @@ extern "C" int m2m_pack_all(const m2m_tower* const* towers, int ntowers, const m
             if (prec < 0) prec = towers[i]->prec;
             if (towers[i]->prec != prec) { m2m_set_error("pack_all: one precision per launch", __FILE__, __LINE__); return -1; }
             a.tw[i] = m2m_shrink(towers[i]);
+            a.skip_w1tc[i] = pack_skips_w1tc(towers[i]);
             tiles += towers[i]->nblocks * (towers[i]->Cp / 32);
             maxD = std::max(maxD, (int)towers[i]->D);
         }
@@ -588,7 +601,7 @@ static __device__ __forceinline__ float adam_elem(const AdamStreams& s, const Ad
 // load in flight together (2 x DD / 32 float4 groups per thread and stream), the updated values into the LDS tiles, ch_b1, then
 // the packed copies from the tiles.
 template <int P, bool LOWP, int DD>
-static __device__ __forceinline__ void adam_pack_tile(const AdamPackPlan& pl, const AdamConsts& c, const m2m_tower4& tw, int block, int q, char* smem) {
+static __device__ __forceinline__ void adam_pack_tile(const AdamPackPlan& pl, const AdamConsts& c, const m2m_tower4& tw, int block, int q, char* smem, bool skip_w1tc) {
     const m2m_block& k = tw.blk[block];
     constexpr int D = DD, L1 = DD + 1, L2 = 33, NV = 32 * (DD / 4) / 256;      // float4 groups per thread and tensor (256 threads)
     const int C = tw.C, c0 = 32 * q, tid = threadIdx.x;
@@ -642,7 +655,7 @@ static __device__ __forceinline__ void adam_pack_tile(const AdamPackPlan& pl, co
     }
     if (tid < 32) k.ch_b1p[c0 + tid] = c0 + tid < C ? adam_elem<LOWP>(sb, c, ob + c0 + tid) : 0.f;
     __syncthreads();
-    pack_emit_tile<P>(k, D, q, t1, t2);
+    pack_emit_tile<P>(k, D, q, t1, t2, skip_w1tc);
 }
 
 template <int P, bool LOWP>
@@ -659,10 +672,10 @@ __global__ __launch_bounds__(256) void adam_pack_all_kernel(const PackAllArgs a,
         const m2m_tower4& tw = a.tw[t];
         const int nq = tw.Cp >> 5, block = id / nq, q = id % nq;
         switch (tw.D) {                                  // (workgroup-uniform)
-            case 32:  adam_pack_tile<P, LOWP, 32>(pl, c, tw, block, q, smem); break;
-            case 64:  adam_pack_tile<P, LOWP, 64>(pl, c, tw, block, q, smem); break;
-            case 128: adam_pack_tile<P, LOWP, 128>(pl, c, tw, block, q, smem); break;
-            default:  adam_pack_tile<P, LOWP, 256>(pl, c, tw, block, q, smem); break;
+            case 32:  adam_pack_tile<P, LOWP, 32>(pl, c, tw, block, q, smem, a.skip_w1tc[t] != 0); break;
+            case 64:  adam_pack_tile<P, LOWP, 64>(pl, c, tw, block, q, smem, a.skip_w1tc[t] != 0); break;
+            case 128: adam_pack_tile<P, LOWP, 128>(pl, c, tw, block, q, smem, a.skip_w1tc[t] != 0); break;
+            default:  adam_pack_tile<P, LOWP, 256>(pl, c, tw, block, q, smem, a.skip_w1tc[t] != 0); break;
         }
         return;
     }
@@ -840,6 +853,7 @@ extern "C" int m2m_adam_pack_all(const m2m_tower* const* towers, int ntowers, co
             if (prec < 0) prec = towers[i]->prec;
             if (towers[i]->prec != prec) { m2m_set_error("adam_pack_all: one precision per launch", __FILE__, __LINE__); return -1; }
             a.tw[i] = m2m_shrink(towers[i]);
+            a.skip_w1tc[i] = pack_skips_w1tc(towers[i]);
             tiles += towers[i]->nblocks * (towers[i]->Cp / 32);
             maxD = std::max(maxD, (int)towers[i]->D);
         }

@@ -210,7 +210,7 @@ static __device__ __forceinline__ void token_bwd_mfma(float* ub, const float* do
 #ifndef M2M_TOK_PU
 #define M2M_TOK_PU 1
 #endif
-    constexpr int PU = M2M_TOK_PU;      // (2 was measured: the 64 extra accumulator registers spill around the phase, 165 -> 194 us per two-tower launch)
+    constexpr int PU = NMAX == 4 ? M2M_TOK_PU : 1;      // (pairs per pass; NMAX 4: a 16-row tile holds 4 samples = 16 pairs, two per wave.  2 was measured in rounds 2 and 4 (-DM2M_TOK_PU=2): the 64 extra accumulator registers spill around the phase (58 VGPRs), two-tower launch 165 -> 194 us / 120 -> 145 us)
     const int npair = ns * CP;
     for (int p0 = wave; p0 < npair; p0 += NWAVES * PU) {
         int sl[PU], d0[PU];

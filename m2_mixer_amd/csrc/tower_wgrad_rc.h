@@ -25,7 +25,9 @@
 #pragma once
 #include "tile.h"
 
+#ifndef RC_WAVES
 #define RC_WAVES 4
+#endif
 #define RC_THREADS (RC_WAVES * 64)
 #ifndef RC_NR
 #define RC_NR 3           // LDS ring slots of a wave's dHpre^T stream: RC_NR - 1 steps in flight (3: 76 KB per workgroup, two per CU)

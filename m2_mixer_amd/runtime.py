@@ -115,6 +115,10 @@ class TowerRuntime:
             cur += [bp["ch_w1"]._version, bp["ch_w2"]._version, bp["ch_b1"]._version]
         return cur
 
+    def pack_all_skips_w1tc(self) -> bool:
+        """pack_all leaves this tower's w1tc copies unwritten (nothing reads them: m2m_pack_skips_w1tc)."""
+        return bool(L.lib().m2m_pack_skips_w1tc(C.byref(self.desc)))
+
     def mark_packed(self):
         self._packed_for = self._pack_versions()
 

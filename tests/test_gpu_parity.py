@@ -394,6 +394,8 @@ def test_grouped_launches_match_single_launches(prec, dev):
     for t, pt in zip(towers, packed):
         for i in range(t.nblocks):
             for k, v in t._keep[f"packed{i}"].items():
+                if k == "w1tc" and t.pack_all_skips_w1tc():      # (pack_all leaves the copy nothing reads unwritten)
+                    continue
                 assert torch.equal(v, pt[i][k]), k
     for e, w in zip(embeds, wn):
         assert torch.equal(e._keep["wn"], w)
@@ -753,6 +755,8 @@ def test_pipelined_exchange_update_is_bit_identical_to_the_whole_buffer_update(d
         for ta, te in ((a.t_a, e.t_a), (a.t_b, e.t_b), (a.t_fus, e.t_fus)):
             for i in range(ta.nblocks):
                 for k, v in ta._keep[f"packed{i}"].items():
+                    if k == "w1tc" and ta.pack_all_skips_w1tc():     # (written by the per-tower re-pack only; nothing reads it)
+                        continue
                     assert torch.equal(v, te._keep[f"packed{i}"][k]), k
         for ea, ee in ((a.e_a, e.e_a), (a.e_b, e.e_b)):
             assert torch.equal(ea._keep["wn"], ee._keep["wn"])
