@@ -92,6 +92,12 @@ template <int P, int D> struct WgradGeom {
     static constexpr int TR_B = WAVES * 16 * (D + 4) * 4;                          // dW1 write-out transpose: 16 x (D + 4) floats per wave
     static constexpr int LDS_B = 2 * TPS * STAGE_B > TR_B ? 2 * TPS * STAGE_B : TR_B;  // dynamic LDS of the kernel
     static constexpr int MINWAVES = (W48 || TPS > 2) ? 1 : 2;                          // waves per SIMD the kernel is built for
+    // the wave's own Hact^T / dHpre^T fragments (the HBM stream: read once, ~1200 cycles per read under load) requested TWO
+    // steps ahead, the shared stage (L2-resident images) one step ahead: 16 registers more than a ring of one step
+#ifndef M2M_WG_HD2
+#define M2M_WG_HD2 1
+#endif
+    static constexpr bool HD2 = M2M_WG_HD2 && !W48 && P == PREC_BF16 && D == 128 && TPS == 1 && DEPTH == 1;
     static_assert(TPS == 1 || DEPTH == 1, "multi-tile steps use a ring of one step");
 };
 
@@ -274,6 +280,75 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, const WgO
     const int t_begin = group * tiles_per_group;
     const int t_end = min(ntiles, t_begin + tiles_per_group);
     if (t_begin >= t_end) return;
+    if constexpr (G::HD2) {
+        // ---- stage one step ahead, own fragments two steps ahead (all loads unconditional, tile clamped) ----
+        static_assert(CPW == 2 && NF == 1, "the two-tile bf16 form");
+        typedef const M2M_GLOBAL_AS u32x4_t* g4_t;
+        struct HD { u32x4_t h0, h1, d0, d1; };
+        const long hbase = (long)(ctl[0] >> 1) * m2m_hchn_stride(ntiles) + lane * 16;
+        auto load_hd = [&](HD& x, int tile) {
+            const long blk = hbase + (long)tile * 2048;
+            x.h0 = __builtin_nontemporal_load((g4_t)(src_h + blk)); x.h1 = __builtin_nontemporal_load((g4_t)(src_h + blk + 1024));
+            x.d0 = __builtin_nontemporal_load((g4_t)(src_dh + blk)); x.d1 = __builtin_nontemporal_load((g4_t)(src_dh + blk + 1024));
+        };
+        u32x4_t st[NLD];
+        auto load_st = [&](int tile) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int o = min((i * G::THREADS + tid) * 16, STAGE_B - 16);
+                const gptr_t sp = o < IMG_B ? src_at : src_dyt;
+                st[i] = *(const M2M_GLOBAL_AS u32x4_t*)(sp + (long)tile * IMG_B + (o < IMG_B ? o : o - IMG_B));
+            }
+        };
+        auto step2 = [&](HD& x, int tile, int i) {
+            char* cur = smem + (i & 1) * STAGE_B;
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int o = (k * G::THREADS + tid) * 16;
+                if (o < STAGE_B) *reinterpret_cast<u32x4_t*>(cur + o) = st[k];
+            }
+            Frag hf[CPW], df[CPW];
+#pragma unroll
+            for (int j = 0; j < CPW; ++j) {
+                hf[j].u = u32x4_t{x.h0[2 * j], x.h0[2 * j + 1], x.h1[2 * j], x.h1[2 * j + 1]};
+                df[j].u = u32x4_t{x.d0[2 * j], x.d0[2 * j + 1], x.d1[2 * j], x.d1[2 * j + 1]};
+            }
+            // the next step's stage FIRST, then the fragments of the step after next: at the next step's top only the four
+            // youngest loads (those fragments) may still be in flight
+            load_st(min(tile + 1, t_end - 1));
+            load_hd(x, min(tile + 2, t_end - 1));
+            __syncthreads();
+            constexpr int NQ = DT;
+            constexpr int LA = WG_LA < NQ ? WG_LA : NQ;
+            Frag aq[LA], dq[LA];
+#pragma unroll
+            for (int q = 0; q < LA; ++q) { aq[q] = ld_frag_lds(cur, q, lane); dq[q] = ld_frag_lds(cur + IMG_B, q, lane); }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const Frag at = aq[q % LA], dyt = dq[q % LA];
+                if (q + LA < NQ) { aq[q % LA] = ld_frag_lds(cur, q + LA, lane); dq[q % LA] = ld_frag_lds(cur + IMG_B, q + LA, lane); }
+#pragma unroll
+                for (int j = 0; j < CPW; ++j) {
+                    Pr::mma(dw1[j][q], df[j], at);
+                    Pr::mma(dw2[j][q], hf[j], dyt);
+                }
+                if (q == NQ - 1) {
+#pragma unroll
+                    for (int j = 0; j < CPW; ++j) Pr::mma(db1[j], df[j], ones);
+                }
+            }
+        };
+        HD ring[2];
+        load_hd(ring[0], t_begin);
+        load_st(t_begin);
+        load_hd(ring[1], min(t_begin + 1, t_end - 1));
+        int tile = t_begin, it = 0;
+        for (; tile + 2 <= t_end; tile += 2) {
+            step2(ring[0], tile, it++);
+            step2(ring[1], tile + 1, it++);
+        }
+        if (tile < t_end) step2(ring[0], tile, it++);
+    } else {
     Pre p[DEPTH];
 #pragma unroll
     for (int k = 0; k < DEPTH; ++k) tile_load(p[k], min(t_begin + k * TPS, t_end - 1), t_end);
@@ -288,6 +363,7 @@ static __device__ __forceinline__ void wgrad_body(const m2m_block& bk, const WgO
 #pragma unroll
         for (int k = 0; k + 1 < DEPTH; ++k)
             if (tile + k < t_end) step(p[k], tile + k, t_end, it++);
+    }
     }
 
     __syncthreads();                                         // every wave is done reading the stage

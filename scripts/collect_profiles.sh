@@ -31,6 +31,9 @@ echo "secondary done"
 # two ranks on this one GPU over gloo: N ranks x batch B + exchange == one rank on N x B == the oracle (scripts/ddp_parity.py)
 timeout -k 10 300 python scripts/ddp_parity.py fp32 S 2> $O/ddp2_fp32.err | grep '^{' > $O/ddp2_parity_fp32.json || echo "ddp parity fp32 FAILED"
 timeout -k 10 300 python scripts/ddp_parity.py bf16 B 2> $O/ddp2_bf16.err | grep '^{' > $O/ddp2_parity_bf16.json || echo "ddp parity bf16 FAILED"
+# the same with the exchange pipelined with the optimizer (parallel.PipelinedGradSync: one all-reduce per parameter segment)
+timeout -k 10 300 python scripts/ddp_parity.py fp32 S pipelined 2> $O/ddp2_fp32_pipe.err | grep '^{' > $O/ddp2_parity_fp32_pipelined.json || echo "ddp parity fp32 pipelined FAILED"
+timeout -k 10 300 python scripts/ddp_parity.py bf16 B pipelined 2> $O/ddp2_bf16_pipe.err | grep '^{' > $O/ddp2_parity_bf16_pipelined.json || echo "ddp parity bf16 pipelined FAILED"
 M2M_DIST_BACKEND=gloo M2M_FORCE_DEVICE=0 timeout -k 10 300 python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_ddp2_gloo_rehearsal.json 2> $O/bench_ddp2.err || echo "ddp bench rehearsal FAILED"
 # launch timelines of the secondary configurations at their cfg batches, and the GPU suite at this commit
 bash scripts/sec_trace.sh > $O/sec_trace.log 2>&1 && cp gpurun_out/sec/*_step_timeline.txt $O/ || echo "sec trace FAILED"
