@@ -31,12 +31,16 @@ from .runtime import (AdamPackPlan, BLOCK_FIELDS, BLOCK_KEYS, EmbedRuntime, MlpR
                       towers_backward, towers_forward, towers_forward_embeds_ok, towers_wgrad, wgrad_slot_groups)
 
 
-def config_fused_update() -> bool:
-    """M2M_FUSED_UPDATE=1: Adam and the operand re-pack as ONE launch (m2m_adam_pack_all).  Off by default: measured on
-    M2-Mixer-B it is slower (97 us against 45 + 19 us for the flat Adam launch followed by m2m_pack_all) -- the tile
-    workgroups that must own a 32-column group of both weight matrices update W2 through 128-byte row segments with few
-    loads in flight, the flat grid-stride Adam streams at the HBM roofline (profiles/)."""
-    return os.environ.get("M2M_FUSED_UPDATE", "0") == "1"
+def config_fused_update(n_params: int = 0) -> bool:
+    """Adam and the operand re-pack as ONE launch (m2m_adam_pack_all) or as two (flat Adam, then m2m_pack_all).
+    M2M_FUSED_UPDATE=1 / 0 forces either; default: one launch for small models (<= 4 M parameters), two for large ones.
+    Measured (round 4, kernel rewritten with every load of a tile in flight): M2-Mixer-B (8.3 M parameters) 75-78 us fused
+    against 62-65 us as two launches -- the tile workgroups read W2 in 128-byte row segments 12 KB apart, the flat Adam streams
+    contiguously at the HBM rate; MM-IMDb (2.7 M parameters, latency-bound launches) 0.4602 against 0.4637 ms per step fused."""
+    env = os.environ.get("M2M_FUSED_UPDATE")
+    if env is not None:
+        return env == "1"
+    return 0 < n_params <= 4_000_000
 
 
 def _num_patch(c: dict) -> int:
@@ -429,7 +433,7 @@ class _FlatEngine:
     def _update(self, grad_scale: float = 1.0, grad_bf16: Optional[torch.Tensor] = None):
         """Adam over every parameter + operand re-pack.  One launch (m2m_adam_pack_all) where the model allows it: the
         re-pack then takes the updated weights from the workgroup that computed them instead of re-reading the masters."""
-        mods = self._adam_pack_modules() if config_fused_update() else None
+        mods = self._adam_pack_modules() if config_fused_update(self.n_params) else None
         # the slot of a two-group tower: added inside Adam (fused step) unless forward_backward has folded it in already
         ranges = self._ranges_keep if (self._slots_folded or grad_bf16 is not None) else self._ranges_add
         self._slots_folded = False
@@ -1015,6 +1019,10 @@ class MimicEngine(_FlatEngine):
         for m in towers + embeds:
             m.pack(force=True)
 
+    def _adam_pack_modules(self):
+        towers, embeds = [self.t_time, self.t_fus], [self.e_time]
+        return (towers, embeds) if can_pack_all(towers, embeds) else None
+
     def _forward(self, static, time, labels, training: bool, with_grad: bool, prologue: bool = False):
         B, D = self.B, self.D
         sd = self.drop_step if training else None
@@ -1057,8 +1065,7 @@ class MimicEngine(_FlatEngine):
             towers_wgrad([self.t_fus, self.t_time], B, seed=self.seed, step=0, step_dev=sd)
             self.e_time.wgrad(time, self.dx0_time, B)
             if fused_update:
-                self._adam(0, self.n_params, 1.0, False)
-                self.pack()
+                self._update(1.0)                       # one launch for small models (config_fused_update), else Adam + pack_all
             return
         main, s_b, s_f = self._streams(self._conc_bwd)
         s_b.wait_stream(main)
