@@ -100,6 +100,10 @@ def main():
     tol = 1e-3 if prec == "fp32" else 2 * steps * lr * 1.05
     if rank == 0:
         out["tolerance"] = tol
+        if prec != "fp32":
+            out["tolerance_note"] = ("bf16: the MAXIMUM deviation is bounded by Adam's 2 lr per step and sign flip of a rounding-level "
+                                     "gradient (steps x 2 lr x 1.05); what says the ranks computed the same step is ranks_max_diff == 0 and "
+                                     "the MEAN deviation (<= 1e-3, observed ~6e-7)")
         out["ok"] = all(v <= tol for k, v in out.items() if k.endswith(("_vs_one_rank", "_vs_oracle"))) and \
             all(v <= 1e-3 for k, v in out.items() if k.endswith("_vs_one_rank_mean")) and \
             all(v == 0.0 for k, v in out.items() if k.endswith("_ranks_max_diff"))
