@@ -164,12 +164,16 @@ extern "C" int m2m_pack_tower(const m2m_tower* t, void* stream) {
 #ifndef M2M_W1TC_SKIP
 #define M2M_W1TC_SKIP 1
 #endif
+#ifndef M2M_PACK_NT_DEFAULT
+#define M2M_PACK_NT_DEFAULT 0
+#endif
 struct PackAllArgs {
     m2m_tower4 tw[M2M_PACK_TOWERS];
     m2m_embed em[M2M_PACK_EMBEDS];
     int nt, ne;
     int tile_end[M2M_PACK_TOWERS];     // running count of (block, 32-column group) tiles up to and including tower t
     int embed_wgs0;                    // workgroups (256 slots each) of embedding 0
+    int nt_loads;                      // 1: the fp32 masters are read with non-temporal loads (M2M_PACK_NT)
     int skip_w1tc[M2M_PACK_TOWERS];    // 1: nothing reads this tower's w1tc copy (pack_skips_w1tc): a quarter of the re-pack's writes
 };
 // The W1^T (CHN) copy feeds the third product of the backward chain -- except in the bf16 / hidden_dim 128 instantiation, which
@@ -238,7 +242,7 @@ static __device__ __forceinline__ void pack_emit_tile(const m2m_block& k, int D,
 }
 
 template <int P, class TW>
-static __device__ __forceinline__ void pack_block_tile(const TW& tw, int block, int q, char* smem, bool skip_w1tc = false) {
+static __device__ __forceinline__ void pack_block_tile(const TW& tw, int block, int q, char* smem, bool skip_w1tc = false, bool nt_loads = false) {
     const m2m_block& k = tw.blk[block];
     const int D = tw.D, C = tw.C, L1 = D + 1, L2 = 33;
     float* t1 = reinterpret_cast<float*>(smem);            // [32][D + 1]   W1[32q + r][d]
@@ -248,13 +252,19 @@ static __device__ __forceinline__ void pack_block_tile(const TW& tw, int block, 
     for (int idx = tid; idx < 32 * (D / 4); idx += nthr) {
         const int r = idx / (D / 4), d4 = (idx % (D / 4)) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c0 + r < C) v = *reinterpret_cast<const float4*>(k.ch_w1 + (long)(c0 + r) * D + d4);
+        if (c0 + r < C) {
+            // nt_loads (workgroup-uniform): the masters are read once per step -- past the memory-side cache (see adam_kernel)
+            const f32x4_t* src = reinterpret_cast<const f32x4_t*>(k.ch_w1 + (long)(c0 + r) * D + d4);
+            const f32x4_t x = nt_loads ? __builtin_nontemporal_load(src) : *src;
+            v = make_float4(x[0], x[1], x[2], x[3]);
+        }
         float* o = t1 + r * L1 + d4;
         o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
     }
     for (int idx = tid; idx < D * 32; idx += nthr) {
         const int d = idx >> 5, j = idx & 31;
-        t2[d * L2 + j] = c0 + j < C ? k.ch_w2[(long)d * C + c0 + j] : 0.f;
+        const float* src = k.ch_w2 + (long)d * C + c0 + j;
+        t2[d * L2 + j] = c0 + j < C ? (nt_loads ? __builtin_nontemporal_load(src) : *src) : 0.f;
     }
     if (tid < 32) k.ch_b1p[c0 + tid] = c0 + tid < C ? k.ch_b1[c0 + tid] : 0.f;
     __syncthreads();
@@ -272,7 +282,7 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const PackAllArgs a) {
         while (id >= a.tile_end[t]) ++t;
         if (t) id -= a.tile_end[t - 1];
         const int nq = a.tw[t].Cp >> 5;
-        pack_block_tile<P>(a.tw[t], id / nq, id % nq, smem, a.skip_w1tc[t] != 0);
+        pack_block_tile<P>(a.tw[t], id / nq, id % nq, smem, a.skip_w1tc[t] != 0, a.nt_loads != 0);
         return;
     }
     id -= a.tile_end[M2M_PACK_TOWERS - 1];
@@ -292,6 +302,8 @@ extern "C" int m2m_pack_all(const m2m_tower* const* towers, int ntowers, const m
     PackAllArgs a;
     memset(&a, 0, sizeof(a));
     a.nt = ntowers; a.ne = nembeds;
+    static const int pack_nt = [] { const char* e = getenv("M2M_PACK_NT"); return e ? atoi(e) : M2M_PACK_NT_DEFAULT; }();
+    a.nt_loads = pack_nt;
     int prec = -1, tiles = 0, maxD = 0;
     for (int i = 0; i < M2M_PACK_TOWERS; ++i) {
         if (i < ntowers) {
@@ -367,7 +379,16 @@ static __device__ __forceinline__ void adam_one(const AdamK& k, float g, float& 
     const float denom = sqrtf(v) * k.inv_sqrt_bc2 + k.eps;
     p = p - k.step_size * (m / denom);
 }
-template <bool LOWP>
+// NT (bit mask): which streams use non-temporal accesses -- they pass the memory-side cache (Infinity Cache) without allocating,
+// so what the chain kernels keep there (weights, the stored operands of the last backward blocks: m2m_handoff_resident_blocks)
+// survives the optimizer's 230 MB.  1: exp_avg / exp_avg_sq (read once, written once per step), 2: parameter loads,
+// 4: parameter stores (the re-pack then reads the parameters from HBM), 8: gradient loads.
+#ifndef M2M_ADAM_NT_DEFAULT
+#define M2M_ADAM_NT_DEFAULT 1
+#endif
+template <bool ON> static __device__ __forceinline__ float ld_maybe_nt(const float* p) { return ON ? __builtin_nontemporal_load(p) : *p; }
+template <bool ON> static __device__ __forceinline__ void st_maybe_nt(float* p, float v) { if (ON) __builtin_nontemporal_store(v, p); else *p = v; }
+template <bool LOWP, int NT>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ gr, const unsigned short* __restrict__ gb,
                                                    float* __restrict__ m, float* __restrict__ v, long n, const float* __restrict__ state,
                                                    float b1, float b2, float eps, float wd, float gscale_in, const AdamRanges rg) {
@@ -401,8 +422,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
 #pragma unroll
             for (int q = 0; q < EPT; ++q) {
                 const long i = min(c0 + q * 256 + (long)threadIdx.x, c1 - 1);       // (clamped: unconditional loads)
-                g[q] = LOWP ? __uint_as_float((unsigned int)gb[i] << 16) : gr[i];
-                pp[q] = p[i]; mm[q] = m[i]; vv[q] = v[i];
+                g[q] = LOWP ? __uint_as_float((unsigned int)gb[i] << 16) : ld_maybe_nt<(NT & 8) != 0>(gr + i);
+                pp[q] = ld_maybe_nt<(NT & 2) != 0>(p + i); mm[q] = ld_maybe_nt<(NT & 1) != 0>(m + i); vv[q] = ld_maybe_nt<(NT & 1) != 0>(v + i);
             }
             if (add) {                                           // workgroup-uniform
 #pragma unroll
@@ -414,7 +435,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                 adam_one(k, g[q], pp[q], mm[q], vv[q]);
                 if (i < c1) {
                     if (consume && !keep) gr[i] = 0.f;
-                    m[i] = mm[q]; v[i] = vv[q]; p[i] = pp[q];
+                    st_maybe_nt<(NT & 1) != 0>(m + i, mm[q]); st_maybe_nt<(NT & 1) != 0>(v + i, vv[q]); st_maybe_nt<(NT & 4) != 0>(p + i, pp[q]);
                 }
             }
         } else {
@@ -455,10 +476,14 @@ static int adam_launch(float* param, float* grad, const void* grad_bf16, float* 
     auto launch = [&](float* p_, float* g_, const unsigned short* gb_, float* m_, float* v_, long n_, const AdamRanges& r_) {
         long grid = ceil_div(n_, 1024);
         if (grid > 2048) grid = 2048;
-        if (gb_) hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, p_, g_, gb_, m_, v_, n_, state, beta1, beta2, eps,
-                                    weight_decay, grad_scale, r_);
-        else hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, p_, g_, gb_, m_, v_, n_, state, beta1, beta2, eps,
-                                weight_decay, grad_scale, r_);
+        static const int nt = [] { const char* e = getenv("M2M_ADAM_NT"); return e ? atoi(e) : M2M_ADAM_NT_DEFAULT; }();
+#define M2M_ADAM_GO(LP, N) hipLaunchKernelGGL((adam_kernel<LP, N>), dim3((unsigned)grid), dim3(256), 0, st, p_, g_, gb_, m_, v_, n_, state, beta1, beta2, \
+                                              eps, weight_decay, grad_scale, r_)
+#define M2M_ADAM_SW(LP) switch (nt) { case 1: M2M_ADAM_GO(LP, 1); break; case 3: M2M_ADAM_GO(LP, 3); break; case 7: M2M_ADAM_GO(LP, 7); break; \
+                                      case 15: M2M_ADAM_GO(LP, 15); break; default: M2M_ADAM_GO(LP, 0); break; }
+        if (gb_) { M2M_ADAM_SW(true) } else { M2M_ADAM_SW(false) }
+#undef M2M_ADAM_SW
+#undef M2M_ADAM_GO
     };
     if (head > 0) {
         // scalar head: a 1-chunk launch whose only chunk is shorter than a full chunk goes element by element

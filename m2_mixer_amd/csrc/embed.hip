@@ -42,8 +42,11 @@ struct EmbedFwdGroupArgs {
     float* losses;
     int nlosses, prologue;
 };
+// bf16, hidden_dim <= 128: built for TWO workgroups per CU (4 waves per SIMD, <= 128 VGPRs; the fast body's ring holds two stages):
+// M2-Mixer-B's launch is 384 workgroups -- 256 of the audio embedding, 128 short ones of the image embedding -- and with one
+// workgroup per CU it ran as a full round plus a half-empty one (21.3 -> 16 us, profiles/r04_ab_results.txt r5a).
 template <int P, int D, int RB>
-__global__ __launch_bounds__(NTHREADS) void embed_fwd_group_kernel(const EmbedFwdGroupArgs a) {
+__global__ __launch_bounds__(NTHREADS, (P == PREC_BF16 && D <= 128) ? 4 : 1) void embed_fwd_group_kernel(const EmbedFwdGroupArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (a.prologue && blockIdx.x == 0) {
         const int t = threadIdx.x;
@@ -226,7 +229,10 @@ extern "C" int m2m_embeds_wgrad(const m2m_embed* const* embeds, const float* con
 // enough for the weight stream to dominate (the audio spectrogram patches), else 1.
 extern "C" int m2m_embed_fwd_splits(const m2m_embed* e) {
     if (!e) return 1;
-    return (embed_fwd_fast_ok(e, nullptr) && e->Kp >= 4 * EMB_FKS) ? 2 : 1;
+    static const int forced = [] { const char* v = getenv("M2M_EMBED_SPLITS"); return v ? atoi(v) : 0; }();    // diagnostic (1..4)
+    const bool pays = embed_fwd_fast_ok(e, nullptr) && e->Kp >= 4 * EMB_FKS;
+    if (pays && forced >= 1 && forced <= 4) return forced;
+    return pays ? 2 : 1;
 }
 
 extern "C" int m2m_embeds_forward(const m2m_embed* const* embeds, const float* const* inputs, float* const* x0s, const int* nsplits,

@@ -124,7 +124,9 @@ static __device__ __forceinline__ void embed_fwd_body(const m2m_embed& em, const
 // ~7 us are fixed (launch, first loads, epilogue), ~5 us the 25.7 MB of input at the HBM roofline and ~6 us the packed weight
 // streamed from L2 by every workgroup (measured by removing either stream).
 #define EMB_FKS 256
-#define EMB_FDEPTH 3
+#ifndef EMB_FDEPTH
+#define EMB_FDEPTH 2        // (3 stages in flight need 146 VGPRs: one workgroup per CU; see embed_fwd_group_kernel)
+#endif
 template <int D>
 static __device__ __forceinline__ void embed_fwd_fast_body(const m2m_embed& em, const float* __restrict__ in, long M, int N,
                                                            float* __restrict__ x0, int wg, int split, int nsplit, char* smem) {

@@ -337,6 +337,35 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
             }
             // bias is already in; GELU + dropout on the accumulators (row c = 32q + 16t + 4g + r, column m = il)
             Frag hf[MT][NF];
+#ifndef M2M_FWD_STAGED
+#define M2M_FWD_STAGED 1
+#endif
+            if constexpr (M2M_FWD_STAGED && Act<P>::USES_TABLE && MT == 1) {
+                // the eight table look-ups as one batch (indices, then all reads in flight, then the fmas): left to itself the
+                // compiler issues them 1 + 3 + 1 + 3 with a full LDS wait after each group
+                const unsigned int m = (unsigned int)(row0 + il);
+                const unsigned int word = drop_hidden_bits<DM>(dr_ch, m, q, Cp) >> (4 * g);
+                unsigned int idx[2][4];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) idx[t][r] = pwl_index(hacc[0][t][r]);
+                __builtin_amdgcn_sched_barrier(0);
+                gtab2_t e[2][4];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) e[t][r] = gtab[idx[t][r]];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = __builtin_fmaf(e[t][r][1], hacc[0][t][r], e[t][r][0]);
+                        hacc[0][t][r] = DM == DM_NONE ? v : mask_f(v, bit_to_mask(word, 16 * t + r));
+                    }
+                Chain<P>::make(hacc[0][0], hacc[0][1], hf[0]);
+            } else {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const unsigned int m = (unsigned int)(row0 + mt * 16 + il);
@@ -350,6 +379,7 @@ static __device__ __forceinline__ void tower_fwd_body(const TW& tw, const float*
                     }
                 }
                 Chain<P>::make(hacc[mt][0], hacc[mt][1], hf[mt]);
+            }
             }
 #pragma unroll
             for (int f = 0; f < NF; ++f)
