@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define M2M_ABI_VERSION 16
+#define M2M_ABI_VERSION 17
 #define M2M_MAX_BLOCKS 8      /* MixerBlocks per m2m_tower; longer towers are chained by the caller */
 #define M2M_ROWS_PER_WG 16    /* token rows one workgroup keeps on chip */
 
@@ -310,6 +310,12 @@ typedef struct m2m_head {
                            * sums at g_part + workgroup * M2M_SPLIT_GPART ([dW (K, D) | db (K) | 0 | 0]; m2m_heads_part_tiles(B)
                            * workgroups; head h's buffer must follow head h - 1's) and the caller hands the heads to
                            * m2m_towers_wgrad_heads, whose launch adds them to g_w / g_b in a fixed order. */
+    const float* tokens;  /* NULL: the head reads `pooled`.  Else (ABI 17; m2m_heads_ce / m2m_heads_bce only) the head computes
+                           * x.mean(dim=1) itself from the tower output tokens (B, ntok, D) -- sample stride tok_sample_stride floats,
+                           * tokens in order, the same sum as the towers' token-mean launch -- and `pooled` is not read: a wide
+                           * tower (MM-IMDb, MIMIC-H) called with pooled == NULL then skips that launch. */
+    int64_t tok_sample_stride;
+    int32_t ntok;
 } m2m_head;
 int m2m_heads_part_tiles(int B);      /* workgroups per head of m2m_heads_ce at batch B (the slots g_part needs) */
 int m2m_heads_ce(const m2m_head* heads, int nheads, const int64_t* labels, int B, int D, int K,

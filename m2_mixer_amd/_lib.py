@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("M2M_LIB_PATH", os.path.join(_HERE, "libm2mixer.so"))   # override: diagnostic builds
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 MAX_BLOCKS = 8
 ROWS_PER_WG = 16
 HCHN_PAD = 4096          # >= the pad between operand streams the library uses (csrc/tile.h M2M_HCHN_PAD)
@@ -93,7 +93,7 @@ class Embed(C.Structure):
 class Head(C.Structure):
     """m2m_head"""
     _fields_ = [("pooled", _fp), ("w", _fp), ("b", _fp), ("g_w", _fp), ("g_b", _fp), ("d_pooled", _fp),
-                ("weight", C.c_float), ("g_part", _fp)]
+                ("weight", C.c_float), ("g_part", _fp), ("tokens", _fp), ("tok_sample_stride", C.c_int64), ("ntok", C.c_int32)]
 
 
 MLP_MAX_LAYERS = 4

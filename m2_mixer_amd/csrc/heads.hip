@@ -3,7 +3,8 @@
 // Reference: models/avmnist.py:271-298 -- classifier_image/audio = nn.Linear on tokens.mean(dim=1),
 // classifier_fusion = StandardClassifier (mean over tokens -> Linear, modules/classification.py:89-90),
 // three nn.CrossEntropyLoss() (mean), loss = (w Lf + ow Li + ow La) * 3, preds = softmax(.).argmax(1).
-// The token means ("pooled") are produced by the tower forward kernel; this kernel consumes them.
+// The token means ("pooled") are produced by the tower forward kernel and consumed here -- or, for towers whose forward does not
+// own whole samples (the wide path), computed here from the tower output (m2m_head.tokens).
 // BCE = true is the MM-IMDb variant (models/mmimdb.py:47-50, :115-133): nn.BCEWithLogitsLoss(pos_weight) with mean
 // reduction over all B*K elements per head, preds = sigmoid(logits) > 0.5 per label.
 #include "tile.h"
@@ -54,7 +55,24 @@ __global__ __launch_bounds__(NTHREADS) void heads_kernel(const HeadArgs ha, cons
         for (int i = 0; i < NP; ++i) {
             const int idx = tid + i * NTHREADS, sI = idx / D4, c = (idx % D4) * 4;
             pv[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            if (idx < S * D4 && sI < ns) pv[i] = *reinterpret_cast<const f32x4_t*>(hd.pooled + (long)(s0 + sI) * D + c);
+            if (idx < S * D4 && sI < ns) {
+                if (hd.tokens) {
+                    // the head pools the tower output itself: x.mean(dim=1), tokens in order, eight loads in flight per round trip
+                    // (the order and the 1 / N product of the towers' token-mean launch this replaces: same bits)
+                    const float* col = hd.tokens + (long)(s0 + sI) * hd.tok_sample_stride + c;
+                    const int N = hd.ntok;
+                    f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    for (int n0 = 0; n0 < N; n0 += 8) {
+                        f32x4_t t8[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) t8[j] = *reinterpret_cast<const f32x4_t*>(col + (long)min(n0 + j, N - 1) * D);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (n0 + j < N) a += t8[j];
+                    }
+                    pv[i] = a * (1.0f / (float)N);
+                } else pv[i] = *reinterpret_cast<const f32x4_t*>(hd.pooled + (long)(s0 + sI) * D + c);
+            }
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
@@ -253,6 +271,12 @@ static int launch_heads(const m2m_head* heads, int nheads, const void* labels, c
     }
     HeadArgs ha;
     for (int i = 0; i < nheads; ++i) {
+        if (heads[i].tokens ? (heads[i].ntok < 1 || heads[i].tok_sample_stride < (int64_t)heads[i].ntok * D || (heads[i].tok_sample_stride & 3) ||
+                               (reinterpret_cast<uintptr_t>(heads[i].tokens) & 15))
+                            : !heads[i].pooled) {
+            m2m_set_error("heads: a head needs pooled, or 16-byte aligned tokens with ntok >= 1 and a sample stride >= ntok * D (multiple of 4)", __FILE__, __LINE__);
+            return -1;
+        }
         if (heads[i].g_part && (BCE || (long)K * D + K + 2 > M2M_SPLIT_GPART)) {
             m2m_set_error("heads: g_part needs cross-entropy heads with K*D + K + 2 <= M2M_SPLIT_GPART", __FILE__, __LINE__);
             return -1;

@@ -233,6 +233,25 @@ __global__ __launch_bounds__(MLP_T) void mlp_bwd_kernel(const m2m_mlp m, const f
 static __device__ __forceinline__ f32x4_t mlp_mfma4(float a, float b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+// A k-ordered chain of 16x16x4 products over n4 (a multiple of 4) values of k, the operands of FOUR steps requested together: the
+// trip count is a run-time value, so the plain loop was one exposed LDS round trip per product (16 per 64-wide layer).  Same
+// products in the same order: bit-identical sums.
+template <class FA, class FB>
+static __device__ __forceinline__ f32x4_t mlp_chain(int n4, FA fa, FB fb, f32x4_t acc) {
+    for (int k0 = 0; k0 < n4; k0 += 16) {
+        float a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = min(k0 + 4 * u, n4 - 4);
+            a[u] = fa(k);
+            b[u] = fb(k);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k0 + 4 * u < n4) acc = mlp_mfma4(a[u], b[u], acc);      // (uniform)
+    }
+    return acc;
+}
 __global__ __launch_bounds__(MLPM_T) void mlp_fwd_mfma_kernel(const m2m_mlp m, const float* __restrict__ x, int B, float* __restrict__ out,
                                                               long out_ss, float* __restrict__ out2, int training, unsigned int seed,
                                                               unsigned int step_host, const unsigned int* __restrict__ step_dev) {
@@ -303,11 +322,9 @@ __global__ __launch_bounds__(MLPM_T) void mlp_fwd_mfma_kernel(const m2m_mlp m, c
             const bool jv = j < dout;
             const float bj = jv ? m.b[l][j] : 0.f;
             f32x4_t acc = f32x4_t{bj, bj, bj, bj};
-            for (int k0 = 0; k0 < din4; k0 += 4) {
-                const float a = cur[il * LD + k0 + g];                        // A[i = sample il][k]
-                const float b = jv ? wt[(k0 + g) * LD + j] : 0.f;             // B[k][j = output]
-                acc = mlp_mfma4(a, b, acc);
-            }
+            const int jc = jv ? j : 0;
+            acc = mlp_chain(din4, [&](int k) { return cur[il * LD + k + g]; },                  // A[i = sample il][k]
+                            [&](int k) { const float b = wt[(k + g) * LD + jc]; return jv ? b : 0.f; }, acc);   // B[k][j = output]
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int s = 4 * g + r;
@@ -447,11 +464,9 @@ __global__ __launch_bounds__(MLPM_T) void mlp_bwd_mfma_kernel(const m2m_mlp m, c
                 const int k = kt * 16 + il;
                 const bool kv = k < din;
                 f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                for (int j0 = 0; j0 < dout4; j0 += 4) {
-                    const float a = gc[il * LD + j0 + g];                     // A[i = sample il][j]
-                    const float b = kv ? wl[(j0 + g) * LD + k] : 0.f;         // B[j][k]
-                    acc = mlp_mfma4(a, b, acc);
-                }
+                const int kc = kv ? k : 0;
+                acc = mlp_chain(dout4, [&](int j) { return gc[il * LD + j + g]; },              // A[i = sample il][j]
+                                [&](int j) { const float b = wl[(j + g) * LD + kc]; return kv ? b : 0.f; }, acc);   // B[j][k]
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (kv) gn[(4 * g + r) * LD + k] = acc[r];

@@ -673,6 +673,9 @@ class _TwoTowerEngine(_FlatEngine):
                                  os.environ.get("M2M_EARLY_FUSION_WGRAD", "0") == "1")
         self._setup_wgrad([[self.t_fus], [self.t_a, self.t_b]] if self._early_fus_wgrad else [[self.t_fus, self.t_a, self.t_b]])
         self._fused_heads = self._heads_are_ce() and self.t_fus.backward_heads_ok(B, 3, self.K)
+        # Wide towers (MM-IMDb): their forward cannot pool inside the chain launch (a workgroup does not own whole samples) and
+        # appends a token-mean launch; the heads kernel pools the tower outputs itself instead (m2m_head.tokens): two launches less.
+        self._heads_pool = (self.t_a.wide and self.t_b.wide and self.t_fus.wide and os.environ.get("M2M_HEADS_POOL", "1") != "0")
         # the fusion tower's backward is always followed by the weight-gradient launch (_backward): the reduction of its
         # small-gradient slots rides there instead of being a launch between the two backward launches (M2M_DEFER_SMALL=0: A/B)
         self.t_fus.set_wgrad_reduces_small(not self._fused_heads and os.environ.get("M2M_DEFER_SMALL", "1") != "0")
@@ -750,13 +753,14 @@ class _TwoTowerEngine(_FlatEngine):
         b_part = self.fused.view(-1)[self.Na * D:]
         main, side, _ = self._streams()
         so = 0                                               # host step offset of this pass's launches (see _embed_fold)
+        pa, pb, pf = (None, None, None) if self._heads_pool else (self.pool_a, self.pool_b, self.pool_fus)
         self._pending_bump = False
         if self._embed_fold and training and prologue:
             # both patch embeddings inside the two-tower launch; head of the step: losses = 0, Adam step += 1 in that launch,
             # the dropout counter advances in the weight-gradient launch of _backward (every launch in between gets step = 1)
             so, self._pending_bump = 1, True
             towers_forward([self.t_a, self.t_b],
-                           [(self.x0_a, self.Na * D, self.fused, fs, self.pool_a), (self.x0_b, self.Nb * D, b_part, fs, self.pool_b)],
+                           [(self.x0_a, self.Na * D, self.fused, fs, pa), (self.x0_b, self.Nb * D, b_part, fs, pb)],
                            B, training, self.seed, so, sd, embeds=[self.e_a, self.e_b], inputs=[xa, xb],
                            head=(self.adam_state, self.losses))
         elif self.concurrent and can_group(self.t_a, self.t_b, self.B):
@@ -774,8 +778,8 @@ class _TwoTowerEngine(_FlatEngine):
                 self.e_a.forward(xa, B, self.x0_a)
                 self.e_b.forward(xb, B, self.x0_b)
             towers_forward([self.t_a, self.t_b],
-                           [(self.x0_a, self.Na * D, self.fused, fs, self.pool_a, sa, B * self.Na * D),
-                            (self.x0_b, self.Nb * D, b_part, fs, self.pool_b, sb, B * self.Nb * D)],
+                           [(self.x0_a, self.Na * D, self.fused, fs, pa, sa, B * self.Na * D),
+                            (self.x0_b, self.Nb * D, b_part, fs, pb, sb, B * self.Nb * D)],
                            B, training, self.seed, 0, sd)
         else:
             if prologue:
@@ -783,16 +787,20 @@ class _TwoTowerEngine(_FlatEngine):
             side.wait_stream(main)
             with torch.cuda.stream(side):                   # second tower beside the first
                 self.e_b.forward(xb, B, self.x0_b)
-                self.t_b.forward(self.x0_b, self.Nb * D, B, b_part, fs, self.pool_b, training, self.seed, 0, sd)
+                self.t_b.forward(self.x0_b, self.Nb * D, B, b_part, fs, pb, training, self.seed, 0, sd)
             self.e_a.forward(xa, B, self.x0_a)
-            self.t_a.forward(self.x0_a, self.Na * D, B, self.fused, fs, self.pool_a, training, self.seed, 0, sd)
+            self.t_a.forward(self.x0_a, self.Na * D, B, self.fused, fs, pa, training, self.seed, 0, sd)
             main.wait_stream(side)
-        self.t_fus.forward(self.fused, fs, B, self.fus_out, fs, self.pool_fus, training, self.seed, so, sd)
+        self.t_fus.forward(self.fused, fs, B, self.fus_out, fs, pf, training, self.seed, so, sd)
         a, b = self.MODS
         hw = self.head_weights
         heads = [self._head(a, self.pool_a, self.dpool_a, hw[a], with_grad),
                  self._head(b, self.pool_b, self.dpool_b, hw[b], with_grad),
                  self._head("fusion", self.pool_fus, self.dpool_fus, hw["fusion"], with_grad)]
+        if self._heads_pool:
+            heads[0]["tokens"] = (self.fused, self.Na, fs)
+            heads[1]["tokens"] = (b_part.data_ptr(), self.Nb, fs)
+            heads[2]["tokens"] = (self.fus_out, self.Nf, fs)
         self._wgrad_heads = None
         if training and with_grad and self._head_part is not None:
             for i, h in enumerate(heads):
@@ -990,6 +998,7 @@ class MimicEngine(_FlatEngine):
         mode = os.environ.get("M2M_MIMIC_STREAMS", "none" if self.B <= 1024 else "both")
         self._merged_tail = os.environ.get("M2M_MIMIC_MERGED_TAIL", "1") != "0"          # (A/B)
         self._conc_fwd, self._conc_bwd = mode in ("fwd", "both"), mode in ("bwd", "both")
+        self._heads_pool = os.environ.get("M2M_HEADS_POOL", "1") != "0"       # (both towers are wide: N = 24 / 25)
         self.t_time = self._make_tower("time_mixer.", ct, self.Nt, 0)
         self.t_fus = self._make_tower("fusion_mixer.", cm, self.Nf, 2048)
         # (B, N, K) rows == a (B, 1, N, K) image cut into (1, K) patches
@@ -1042,13 +1051,17 @@ class MimicEngine(_FlatEngine):
             self.mlp.forward(static, B, self.fused, fs, self.pool_static, training, self.seed, 0, sd)
         if head is None:
             self.e_time.forward(time, B, self.x0_time)
-        self.t_time.forward(self.x0_time, self.Nt * D, B, time_part, fs, self.pool_time, training, self.seed, 0, sd)
+        hp = self._heads_pool                               # the heads pool the two towers' outputs themselves (m2m_head.tokens)
+        self.t_time.forward(self.x0_time, self.Nt * D, B, time_part, fs, None if hp else self.pool_time, training, self.seed, 0, sd)
         main.wait_stream(side)
-        self.t_fus.forward(self.fused, fs, B, self.fus_out, fs, self.pool_fus, training, self.seed, 0, sd)
+        self.t_fus.forward(self.fused, fs, B, self.fus_out, fs, None if hp else self.pool_fus, training, self.seed, 0, sd)
         hw = self.head_weights
         heads = [self._head("static", self.pool_static, self.dpool_static, hw["static"], with_grad),
                  self._head("time", self.pool_time, self.dpool_time, hw["time"], with_grad),
                  self._head("fusion", self.pool_fus, self.dpool_fus, hw["fusion"], with_grad)]
+        if hp:
+            heads[1]["tokens"] = (time_part.data_ptr(), self.Nt, fs)
+            heads[2]["tokens"] = (self.fus_out, self.Nf, fs)
         heads_ce(heads, labels, B, D, self.K, out=(self.logits, self.losses, self.preds), zero_losses=not training)
 
     def _backward(self, static, time, fused_update: bool = False):

@@ -707,7 +707,13 @@ def _head_array(heads: Sequence[dict]):
     nh = len(heads)
     arr = (L.Head * nh)()
     for i, h in enumerate(heads):
-        arr[i].pooled, arr[i].w, arr[i].b = h["pooled"].data_ptr(), h["w"].data_ptr(), h["b"].data_ptr()
+        arr[i].pooled, arr[i].w, arr[i].b = L.ptr(h.get("pooled")), h["w"].data_ptr(), h["b"].data_ptr()
+        tok = h.get("tokens")                               # (tensor or data pointer, ntok, sample stride in floats): the head pools itself
+        if tok is not None:
+            arr[i].tokens = tok[0] if isinstance(tok[0], int) else tok[0].data_ptr()
+            arr[i].ntok, arr[i].tok_sample_stride = int(tok[1]), int(tok[2])
+        elif h.get("pooled") is None:
+            raise ValueError("a head needs `pooled` or `tokens`")
         arr[i].g_w, arr[i].g_b, arr[i].d_pooled = L.ptr(h.get("g_w")), L.ptr(h.get("g_b")), L.ptr(h.get("d_pooled"))
         arr[i].weight = float(h["weight"])
         arr[i].g_part = L.ptr(h.get("g_part"))

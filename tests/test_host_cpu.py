@@ -45,7 +45,8 @@ def test_struct_layouts_match_header(lib):
     assert lib.Tower.slabs.offset == 96 + lib.MAX_BLOCKS * C.sizeof(lib.Block)
     assert lib.Tower.blk.offset == 96
     assert C.sizeof(lib.Embed) == 40 + 5 * 8 + 8
-    assert C.sizeof(lib.Head) == 6 * 8 + 8 + 8 and lib.Head.g_part.offset == 56
+    assert C.sizeof(lib.Head) == 6 * 8 + 8 + 8 + 8 + 8 + 8 and lib.Head.g_part.offset == 56       # ABI 17: + tokens, tok_sample_stride, ntok
+    assert lib.Head.tokens.offset == 64 and lib.Head.tok_sample_stride.offset == 72 and lib.Head.ntok.offset == 80
 
 
 def test_struct_layouts_against_the_c_compiler(lib, tmp_path):
