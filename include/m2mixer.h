@@ -382,6 +382,18 @@ int m2m_mlp_forward(const m2m_mlp* m, const float* x, int B, float* out, int64_t
 /* gradient wrt the output = d_out (strided, or NULL) + d_out_dense (or NULL); accumulates g_w / g_b.  The input is data. */
 int m2m_mlp_backward(const m2m_mlp* m, const float* x, int B, const float* d_out, int64_t d_out_sample_stride,
                      const float* d_out_dense, void* stream);
+/* The MLP as EXTRA WORKGROUPS of a wide tower's token-mixing launch (ABI 17; models/mimic.py:98-106: the static MLP is independent of
+ * the time tower that runs beside it).  m2m_mlp_forward_ride / m2m_mlp_backward_ride only RECORD the call (same arguments as
+ * above, no stream; batch <= 2048; one pending call per host thread); the NEXT m2m_tower_forward / m2m_tower_backward of a wide
+ * tower on this thread whose token-mixing launch is small (<= 256 workgroups, token_dim <= 16) carries the MLP's workgroups in
+ * its first such launch -- the MLP then runs on that call's stream, concurrently with the token mixing, instead of as a launch
+ * of its own in front of it.  m2m_mlp_ride_flush(stream) launches a recorded call nothing carried (returns 0 if none is
+ * pending): call it before anything consumes the MLP's results.  Results are those of m2m_mlp_forward / m2m_mlp_backward (same code). */
+int m2m_mlp_forward_ride(const m2m_mlp* m, const float* x, int B, float* out, int64_t out_sample_stride, float* out_dense,
+                         int training, uint32_t seed, uint32_t step, const uint32_t* step_dev);
+int m2m_mlp_backward_ride(const m2m_mlp* m, const float* x, int B, const float* d_out, int64_t d_out_sample_stride,
+                          const float* d_out_dense);
+int m2m_mlp_ride_flush(void* stream);
 
 /* ---- optimizer (torch.optim.Adam as configured at models/avmnist.py:413-415) ---------------------- */
 /* state: device float[4] = {step (as float count), lr, unused, unused}; the kernel reads lr and the

@@ -163,6 +163,9 @@ SIGNATURES = {
     "m2m_mlp_forward": (C.c_int, [C.POINTER(Mlp), _fp, C.c_int, _fp, C.c_int64, _fp, C.c_int, C.c_uint32, C.c_uint32,
                                   _fp, _fp]),
     "m2m_mlp_backward": (C.c_int, [C.POINTER(Mlp), _fp, C.c_int, _fp, C.c_int64, _fp, _fp]),
+    "m2m_mlp_forward_ride": (C.c_int, [C.POINTER(Mlp), _fp, C.c_int, _fp, C.c_int64, _fp, C.c_int, C.c_uint32, C.c_uint32, _fp]),
+    "m2m_mlp_backward_ride": (C.c_int, [C.POINTER(Mlp), _fp, C.c_int, _fp, C.c_int64, _fp]),
+    "m2m_mlp_ride_flush": (C.c_int, [_fp]),
     "m2m_adam_step": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, _fp, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_float, C.c_int, _fp]),
     "m2m_adam_step_bf16": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int64, _fp, C.c_float, C.c_float, C.c_float, C.c_float,

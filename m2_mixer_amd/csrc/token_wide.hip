@@ -11,6 +11,7 @@
 // (workgroups sharing a sample repeat that; the rows come from L2), then each lane walks its column.
 // The token MLP (N x T, T <= 32) runs on the VALU with the weights broadcast from LDS; h[t] lives in registers.
 #include "tile.h"
+#include "mlp_body.h"
 
 #define TW_COLS 64                 // columns (lanes) per workgroup
 #define TW_TMAX 32                 // token_dim upper bound; the kernels are instantiated for TM = 16 and 32 hidden units (h[] registers,
@@ -216,6 +217,27 @@ __global__ __launch_bounds__(NW * 64) void token_fwd_kernel(const m2m_tower tw, 
                                                                const unsigned int* __restrict__ step_dev) {
     extern __shared__ __attribute__((aligned(16))) float smf[];
     token_fwd_body<P, DM, TM, NW>(tw, b, blockIdx.x, src, src_ss, B, x_mid, save_x_in, training, seed, step_host, step_dev, smf);
+}
+// ---- the MLP tower as extra workgroups of a token-mixing launch (MIMIC-H: static features beside the time tower) -------------------
+// At the cfg batch the MLP's two launches (8 workgroups, a chain of dependent layers: 14 / 22 us) are independent of the time
+// tower's launches that run before / after them on the same queue, and those launches leave most of the chip idle.  A second
+// stream costs a fork and a join in the replayed graph (~5 us per edge: measured); here the MLP's
+// workgroups ride in the time tower's token-mixing launch instead: m2m_mlp_forward_ride / m2m_mlp_backward_ride record the call,
+// the next eligible token launch (one tower, 16 waves per workgroup) carries it as its FIRST workgroups, m2m_mlp_ride_flush
+// launches whatever was not picked up.  Same bodies (mlp_body.h), same results.
+struct MlpRideFwd { m2m_mlp m; const float* x; int B; float* out; long out_ss; float* out2; int training; unsigned int seed, step; const unsigned int* step_dev; };
+struct MlpRideBwd { m2m_mlp m; const float* x; int B; const float* d_out; long d_out_ss; const float* d_out2; };
+template <int P, int DM, int TM>
+__global__ __launch_bounds__(1024) void token_fwd_ride_kernel(const m2m_tower tw, int b, const float* __restrict__ src, long src_ss,
+                                                              int B, float* __restrict__ x_mid, float* __restrict__ save_x_in,
+                                                              int training, unsigned int seed, unsigned int step_host,
+                                                              const unsigned int* __restrict__ step_dev, int n_ride, const MlpRideFwd r) {
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    if ((int)blockIdx.x < n_ride) {
+        mlp_fwd_mfma_body<1024>(r.m, r.x, r.B, r.out, r.out_ss, r.out2, r.training, r.seed, r.step, r.step_dev, blockIdx.x, smf);
+        return;
+    }
+    token_fwd_body<P, DM, TM, 16>(tw, b, blockIdx.x - n_ride, src, src_ss, B, x_mid, save_x_in, training, seed, step_host, step_dev, smf);
 }
 // Two towers (same token_dim class, hidden_dim, dropout) in one launch: blockIdx.y = tower.  One launch on one stream instead
 // of two launches on two queues: no fork / join edges in the replayed graph (~5 us each).
@@ -463,6 +485,18 @@ __global__ __launch_bounds__(NW * 64) void token_bwd_cols_kernel(const m2m_tower
     extern __shared__ __attribute__((aligned(16))) float smf[];
     token_bwd_cols_body<P, DM, TM, NW>(tw, b, blockIdx.x, g_mid, B, du_out, seed, step_host, step_dev, iters, smf);
 }
+template <int P, int DM, int TM>
+__global__ __launch_bounds__(1024) void token_bwd_cols_ride_kernel(const m2m_tower tw, int b, const float* __restrict__ g_mid, int B,
+                                                                   float* __restrict__ du_out, unsigned int seed, unsigned int step_host,
+                                                                   const unsigned int* __restrict__ step_dev, int iters, int n_ride,
+                                                                   const MlpRideBwd r) {
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    if ((int)blockIdx.x < n_ride) {
+        mlp_bwd_mfma_body<1024>(r.m, r.x, r.B, r.d_out, r.d_out_ss, r.d_out2, blockIdx.x, smf);
+        return;
+    }
+    token_bwd_cols_body<P, DM, TM, 16>(tw, b, blockIdx.x - n_ride, g_mid, B, du_out, seed, step_host, step_dev, iters, smf);
+}
 template <int P, int DM, int TM, int NW>
 __global__ __launch_bounds__(NW * 64) void token_bwd_cols_group_kernel(const TokGroupArgs a, int b, int B, unsigned int seed,
                                                                           unsigned int step_host, const unsigned int* __restrict__ step_dev) {
@@ -640,6 +674,11 @@ static int tok_waves(int nblk, int TM) {
     return nw;
 }
 
+// the recorded MLP call (per host thread; kind 0 none, 1 forward, 2 backward)
+struct MlpRidePending { int kind; MlpRideFwd f; MlpRideBwd b; };
+static thread_local MlpRidePending g_ride = {};
+static size_t mlp_ride_lds(bool bwd) { return sizeof(float) * ((size_t)(bwd ? 3 : 2) * MLPM_S + MLP_MAXW) * (MLP_MAXW + 1); }
+
 template <int P, int DM, int TM, int NW>
 static int launch_token_fwd_nw(const m2m_tower* t, int b, const float* src, long src_ss, int B, float* x_mid, float* save_x_in,
                             int training, unsigned int seed, unsigned int step, const unsigned int* step_dev, hipStream_t st) {
@@ -647,6 +686,24 @@ static int launch_token_fwd_nw(const m2m_tower* t, int b, const float* src, long
     const int grid = ((B + g.spw - 1) / g.spw) * g.chunks;
     const size_t lds = ((tok_lds_floats(t->N, g.spw, TM) + 3) & ~(size_t)3) * sizeof(float) +
                        (size_t)(NW + 1) * TM * TW_COLS * sizeof(float);
+    if constexpr (NW == 16 && TM <= 16) {
+        if (g_ride.kind == 1 && grid <= 256) {
+            const MlpRideFwd r = g_ride.f;
+            g_ride.kind = 0;
+            const int n_ride = (r.B + MLPM_S - 1) / MLPM_S;
+            const size_t rl = std::max(lds, mlp_ride_lds(false));
+            auto rk = token_fwd_ride_kernel<P, DM, TM>;
+            static size_t ride_attr = 0;
+            if (rl > ride_attr) {
+                M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
+                ride_attr = rl;
+            }
+            hipLaunchKernelGGL(rk, dim3(grid + n_ride), dim3(1024), rl, st, *t, b, src, src_ss, B, x_mid, save_x_in, training, seed, step, step_dev,
+                               n_ride, r);
+            M2M_CHECK_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     auto kern = token_fwd_kernel<P, DM, TM, NW>;
     static size_t attr_lds = 48 * 1024;
     if (lds > attr_lds) {
@@ -680,6 +737,23 @@ static int launch_token_bwd_nw(const m2m_tower* t, int b, const float* g_mid, in
     const size_t lds = ((tok_lds_floats(t->N, g.spw, TM) + 3) & ~(size_t)3) * sizeof(float) +
                        ((size_t)2 * TM * TW_LDW + NW * part_f + 2 * t->N * TM + TM + t->N) * sizeof(float);
     if (lds > 160 * 1024) { m2m_set_error("token backward: tokens x token_dim exceed the workgroup's LDS", __FILE__, __LINE__); return -1; }
+    if constexpr (NW == 16 && TM <= 16) {
+        if (g_ride.kind == 2 && grid <= 256) {
+            const MlpRideBwd r = g_ride.b;
+            g_ride.kind = 0;
+            const int n_ride = (r.B + MLPM_S - 1) / MLPM_S;
+            const size_t rl = std::max(lds, mlp_ride_lds(true));
+            auto rk = token_bwd_cols_ride_kernel<P, DM, TM>;
+            static size_t ride_attr = 0;
+            if (rl > ride_attr) {
+                M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
+                ride_attr = rl;
+            }
+            hipLaunchKernelGGL(rk, dim3(grid + n_ride), dim3(1024), rl, st, *t, b, g_mid, B, du, seed, step, step_dev, iters, n_ride, r);
+            M2M_CHECK_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     auto kern = token_bwd_cols_kernel<P, DM, TM, NW>;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
@@ -959,6 +1033,43 @@ int m2m_backward_wide(const m2m_tower* t, int B, const float* d_out, long d_out_
         up = t->ws_a;
         up_ss = dense;
         up_pooled = nullptr;
+    }
+    return 0;
+}
+
+// ---- the MLP tower riding in a token-mixing launch (see token_fwd_ride_kernel) --------------------------------------------------------
+static int mlp_ride_ok(const m2m_mlp* m, int B) {
+    if (!m || B < 1 || B > 2048 || m->nlayers < 1 || m->nlayers > M2M_MLP_MAX_LAYERS) return 0;
+    for (int i = 0; i <= m->nlayers; ++i)
+        if (m->dims[i] < 1 || m->dims[i] > MLP_MAXW) return 0;
+    return 1;
+}
+extern "C" int m2m_mlp_forward_ride(const m2m_mlp* m, const float* x, int B, float* out, int64_t out_sample_stride, float* out_dense,
+                                    int training, uint32_t seed, uint32_t step, const uint32_t* step_dev) {
+    if (!mlp_ride_ok(m, B) || !x || !out) { m2m_set_error("mlp_forward_ride: bad argument (batch <= 2048, widths <= 128)", __FILE__, __LINE__); return -1; }
+    if (g_ride.kind) { m2m_set_error("mlp_forward_ride: another MLP call is still pending (m2m_mlp_ride_flush)", __FILE__, __LINE__); return -1; }
+    g_ride.f = MlpRideFwd{*m, x, B, out, (long)out_sample_stride, out_dense, training, seed, step, step_dev};
+    g_ride.kind = 1;
+    return 0;
+}
+extern "C" int m2m_mlp_backward_ride(const m2m_mlp* m, const float* x, int B, const float* d_out, int64_t d_out_sample_stride,
+                                     const float* d_out_dense) {
+    if (!mlp_ride_ok(m, B) || !x) { m2m_set_error("mlp_backward_ride: bad argument (batch <= 2048, widths <= 128)", __FILE__, __LINE__); return -1; }
+    if (g_ride.kind) { m2m_set_error("mlp_backward_ride: another MLP call is still pending (m2m_mlp_ride_flush)", __FILE__, __LINE__); return -1; }
+    g_ride.b = MlpRideBwd{*m, x, B, d_out, (long)d_out_sample_stride, d_out_dense};
+    g_ride.kind = 2;
+    return 0;
+}
+extern "C" int m2m_mlp_ride_flush(void* stream) {
+    const int kind = g_ride.kind;
+    g_ride.kind = 0;
+    if (kind == 1) {
+        const MlpRideFwd& r = g_ride.f;
+        return m2m_mlp_forward(&r.m, r.x, r.B, r.out, r.out_ss, r.out2, r.training, r.seed, r.step, r.step_dev, stream);
+    }
+    if (kind == 2) {
+        const MlpRideBwd& r = g_ride.b;
+        return m2m_mlp_backward(&r.m, r.x, r.B, r.d_out, r.d_out_ss, r.d_out2, stream);
     }
     return 0;
 }

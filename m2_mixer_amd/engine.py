@@ -999,6 +999,8 @@ class MimicEngine(_FlatEngine):
         self._merged_tail = os.environ.get("M2M_MIMIC_MERGED_TAIL", "1") != "0"          # (A/B)
         self._conc_fwd, self._conc_bwd = mode in ("fwd", "both"), mode in ("bwd", "both")
         self._heads_pool = os.environ.get("M2M_HEADS_POOL", "1") != "0"       # (both towers are wide: N = 24 / 25)
+        # the static MLP's two launches as extra workgroups of the time tower's token-mixing launches (MlpRuntime.forward_ride)
+        self._mlp_ride = os.environ.get("M2M_MLP_RIDE", "1") != "0" and self.B <= 2048
         self.t_time = self._make_tower("time_mixer.", ct, self.Nt, 0)
         self.t_fus = self._make_tower("fusion_mixer.", cm, self.Nf, 2048)
         # (B, N, K) rows == a (B, 1, N, K) image cut into (1, K) patches
@@ -1046,13 +1048,16 @@ class MimicEngine(_FlatEngine):
             self.e_time.forward(time, B, self.x0_time, step_head=head)
         elif prologue:
             self._prologue()
+        ride = self._mlp_ride and side is main              # one stream: the MLP's workgroups ride in the time tower's token-mixing launch
         side.wait_stream(main)
         with torch.cuda.stream(side):                       # the static MLP beside the time tower: token 0 + its head's input
-            self.mlp.forward(static, B, self.fused, fs, self.pool_static, training, self.seed, 0, sd)
+            (self.mlp.forward_ride if ride else self.mlp.forward)(static, B, self.fused, fs, self.pool_static, training, self.seed, 0, sd)
         if head is None:
             self.e_time.forward(time, B, self.x0_time)
         hp = self._heads_pool                               # the heads pool the two towers' outputs themselves (m2m_head.tokens)
         self.t_time.forward(self.x0_time, self.Nt * D, B, time_part, fs, None if hp else self.pool_time, training, self.seed, 0, sd)
+        if ride:
+            self.mlp.ride_flush()                           # (a launch of its own if no token launch took it)
         main.wait_stream(side)
         self.t_fus.forward(self.fused, fs, B, self.fus_out, fs, None if hp else self.pool_fus, training, self.seed, 0, sd)
         hw = self.head_weights
@@ -1073,8 +1078,10 @@ class MimicEngine(_FlatEngine):
         if not (self._conc_bwd and self.concurrent) and self._merged_tail:
             # one stream (small batch): both towers' weight gradients in ONE launch, ONE Adam over the flat buffer, ONE re-pack
             # (seven launches less than the per-segment form the three-stream step needs)
-            self.mlp.backward(static, B, self.d_fused, fs, self.dpool_static)
+            (self.mlp.backward_ride if self._mlp_ride else self.mlp.backward)(static, B, self.d_fused, fs, self.dpool_static)
             self.t_time.backward(B, d_time_part, fs, self.dpool_time, self.dx0_time, self.Nt * D, self.seed, 0, sd)
+            if self._mlp_ride:
+                self.mlp.ride_flush()
             towers_wgrad([self.t_fus, self.t_time], B, seed=self.seed, step=0, step_dev=sd)
             self.e_time.wgrad(time, self.dx0_time, B)
             if fused_update:

@@ -702,6 +702,24 @@ class MlpRuntime:
         L.check(L.lib().m2m_mlp_backward(C.byref(self.desc), x.data_ptr(), B, L.ptr(d_out), d_out_ss, L.ptr(d_out_dense),
                                          L.stream_ptr()), "mlp_backward")
 
+    # The same two calls RECORDED (m2m_mlp_forward_ride / _backward_ride): the next wide tower's forward / backward on this thread
+    # carries the MLP's workgroups in its first token-mixing launch; ride_flush() launches a recorded call nothing carried.
+    def forward_ride(self, x: torch.Tensor, B: int, out: torch.Tensor, out_ss: int, out_dense: Optional[torch.Tensor],
+                     training: bool, seed: int, step: int, step_dev: Optional[torch.Tensor] = None):
+        _check_tensor(x, (B, self.dims[0]), "mlp input")
+        self.ensure_buffers(B, x.device)
+        L.check(L.lib().m2m_mlp_forward_ride(C.byref(self.desc), x.data_ptr(), B, out.data_ptr(), out_ss, L.ptr(out_dense),
+                                             int(training), seed & 0xFFFFFFFF, step & 0xFFFFFFFF, L.ptr(step_dev)), "mlp_forward_ride")
+
+    def backward_ride(self, x: torch.Tensor, B: int, d_out: Optional[torch.Tensor], d_out_ss: int,
+                      d_out_dense: Optional[torch.Tensor]):
+        L.check(L.lib().m2m_mlp_backward_ride(C.byref(self.desc), x.data_ptr(), B, L.ptr(d_out), d_out_ss, L.ptr(d_out_dense)),
+                "mlp_backward_ride")
+
+    @staticmethod
+    def ride_flush():
+        L.check(L.lib().m2m_mlp_ride_flush(L.stream_ptr()), "mlp_ride_flush")
+
 
 def _head_array(heads: Sequence[dict]):
     nh = len(heads)

@@ -401,29 +401,32 @@ def test_grouped_launches_match_single_launches(prec, dev):
         assert torch.equal(e._keep["wn"], w)
 
 
-@pytest.mark.parametrize("task", ["avmnist_slots", "mmimdb_pair_launches", "mimic_streams"])
+@pytest.mark.parametrize("task", ["avmnist_slots", "mmimdb_pair_launches", "mimic_streams", "mimic_mlp_ride_heads_pool", "mmimdb_heads_pool"])
 def test_launch_forms_of_a_step_agree(task, dev, monkeypatch):
     """The launch forms the engines choose by default against the forms they replace, same parameters / batch / dropout
     stream: (a) AV-MNIST B bf16: small parameter gradients of all three towers through per-workgroup slots reduced inside the
     weight-gradient launch (M2M_WGRAD_GROUP_SLOTS / _REDUCES_SMALL) vs float atomics + a reduction launch of its own;
     (b) MM-IMDb: both modality towers per launch on one stream (m2m_towers_forward / _backward with wide pairs) vs one launch
-    per tower on two streams; (c) MIMIC-H: one stream vs three.  Same arithmetic; only the order of fp32 sums may differ."""
+    per tower on two streams; (c) MIMIC-H: one stream vs three; (d) MIMIC-H: the static MLP riding in the time tower's token-mixing
+    launches (m2m_mlp_forward_ride / _backward_ride) and the heads pooling the tower outputs (m2m_head.tokens) vs the MLP's own
+    launches and the token-mean launches; (e) MM-IMDb: heads pooling vs token-mean launches.  Same arithmetic; only the order of
+    fp32 sums may differ."""
     from m2_mixer_amd.engine import AVMnistEngine, MimicEngine, MMIMDBEngine
     if task == "avmnist_slots":
         cfg, B, prec = dict(G.AVMNIST["B"]), 64, "bf16"
         make = lambda: AVMnistEngine(cfg, B, device=dev, precision=prec, lr=1e-3, seed=3)
         batch = G.avmnist_batch(B, 5, cfg)
         alt_env = {"M2M_GROUP_SLOTS": "0", "M2M_DEFER_SMALL": "0"}
-    elif task == "mmimdb_pair_launches":
+    elif task in ("mmimdb_pair_launches", "mmimdb_heads_pool"):
         cfg, B, prec = dict(G.MMIMDB), 5, "fp32"
         make = lambda: MMIMDBEngine(cfg, B, device=dev, precision=prec, lr=1e-3, seed=3)
         batch = G.mmimdb_batch(B, 5, cfg)
-        alt_env = {"M2M_CONCURRENT": "0"}
+        alt_env = {"M2M_CONCURRENT": "0"} if task == "mmimdb_pair_launches" else {"M2M_HEADS_POOL": "0"}
     else:
         cfg, B, prec = dict(G.MIMIC_H), 16, "fp32"
         make = lambda: MimicEngine(cfg, B, device=dev, precision=prec, lr=1e-3, seed=3)
         batch = G.mimic_batch(B, 5, cfg)
-        alt_env = {"M2M_MIMIC_STREAMS": "both"}
+        alt_env = {"M2M_MIMIC_STREAMS": "both"} if task == "mimic_streams" else {"M2M_MLP_RIDE": "0", "M2M_HEADS_POOL": "0"}
     batch = tuple(t.to(dev) for t in batch)
     eng = make()
     for k, v in alt_env.items():
@@ -432,6 +435,10 @@ def test_launch_forms_of_a_step_agree(task, dev, monkeypatch):
     alt.load_state_dict(eng.state_dict())
     if task == "avmnist_slots":
         assert eng.t_a.desc.wgrad_flags & 4 and eng.t_fus.desc.wgrad_flags & 2 and not (alt.t_a.desc.wgrad_flags & 6)
+    if task == "mimic_mlp_ride_heads_pool":
+        assert eng._mlp_ride and eng._heads_pool and not alt._mlp_ride and not alt._heads_pool
+    if task == "mmimdb_heads_pool":
+        assert eng._heads_pool and not alt._heads_pool
     if task == "mmimdb_pair_launches":
         from m2_mixer_amd.runtime import can_group
         assert can_group(eng.t_a, eng.t_b, B) and eng.concurrent and not alt.concurrent
