@@ -269,7 +269,8 @@ int m2m_wgrad_form(const m2m_tower* t, int B);
  * device-resident byte copy of *towers[i] (kernel arguments are limited to 4 KiB; the caller refreshes the copy whenever
  * a pointer in the descriptor changes, outside any graph capture).
  * nembeds = 2: the same launch also computes m2m_embed_wgrad for the model's two patch embeddings (inputs[i], d_x0s[i]
- * as there) in extra workgroups that back-fill the CUs the tower workgroups leave idle; nembeds = 0: towers only. */
+ * as there) in extra workgroups that back-fill the CUs the tower workgroups leave idle; nembeds = 1 (ABI 17): one embedding
+ * (MIMIC-H's input projection; row-group form); nembeds = 0: towers only. */
 int m2m_towers_wgrad(const m2m_tower* const* towers, const m2m_tower* const* dev_towers, int ntowers,
                      const m2m_embed* const* embeds, const float* const* inputs, const float* const* d_x0s,
                      const m2m_tower* const* embed_towers, int nembeds,

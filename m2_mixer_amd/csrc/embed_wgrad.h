@@ -376,8 +376,15 @@ static inline int embed_wgrad_group_args_fast(EmbedWgradGroupArgs& a, const m2m_
 
 // Fills the group arguments (embedding with more row tiles per workgroup first); returns the number of workgroups.
 static inline int embed_wgrad_group_args(EmbedWgradGroupArgs& a, const m2m_embed* const* es, const float* const* ins,
-                                         const float* const* dx0s, int B, int target_wgs) {
+                                         const float* const* dx0s, int B, int target_wgs, int n = EMB_GROUP) {
     memset(&a, 0, sizeof(a));
+    if (n == 1) {                                     // one embedding (MIMIC-H's input projection): slot 1 stays empty (0 workgroups)
+        const EmbedWgradPlan p0 = embed_wgrad_plan(es[0], B, target_wgs);
+        a.em[0] = *es[0]; a.in[0] = ins[0]; a.dx0[0] = dx0s[0];
+        a.M[0] = p0.M; a.N[0] = p0.N; a.tpg[0] = p0.tpg; a.nchunks[0] = p0.nchunks; a.groups[0] = p0.groups;
+        a.em[1] = *es[0];
+        return p0.nchunks * p0.groups;
+    }
     EmbedWgradPlan pl[EMB_GROUP];
     for (int i = 0; i < EMB_GROUP; ++i) pl[i] = embed_wgrad_plan(es[i], B, target_wgs);
     const int first = pl[1].tpg > pl[0].tpg ? 1 : 0;

@@ -713,13 +713,14 @@ static int launch_wgrad_group(const m2m_tower* const* host, const m2m_tower* con
     size_t lds_e = 0;
     bool embeds_separately = false;
     if (nembeds) {
-        n_embed_wgs = P == PREC_BF16 ? embed_wgrad_group_args_fast(ea, embeds, inputs, embed_towers, B) : 0;
+        n_embed_wgs = (P == PREC_BF16 && nembeds == EMB_GROUP) ? embed_wgrad_group_args_fast(ea, embeds, inputs, embed_towers, B) : 0;
         if (n_embed_wgs) lds_e = embed_wgrad_fast_lds<D, KG::THREADS>();
-        else if (KG::THREADS == 256) { static const int ewgs = wgrad_env("M2M_EMBED_WGS", D >= 256 ? 128 : 512);   /* every row group adds 64 x D floats with atomics: at D = 256 (MM-IMDb, batch 32) 512 workgroups were 34 MB of them */ n_embed_wgs = embed_wgrad_group_args(ea, embeds, inputs, d_x0s, B, ewgs); lds_e = embed_wgrad_lds<D, P>(); }
+        else if (KG::THREADS == 256) { static const int ewgs = wgrad_env("M2M_EMBED_WGS", D >= 256 ? 128 : 512);   /* every row group adds 64 x D floats with atomics: at D = 256 (MM-IMDb, batch 32) 512 workgroups were 34 MB of them */ n_embed_wgs = embed_wgrad_group_args(ea, embeds, inputs, d_x0s, B, ewgs, nembeds); lds_e = embed_wgrad_lds<D, P>(); }
         else embeds_separately = true;
     }
     if (embeds_separately) {
-        if (int rc = m2m_embeds_wgrad(embeds, inputs, d_x0s, nembeds, B, (void*)st)) return rc;
+        if (nembeds == 1) { if (int rc = m2m_embed_wgrad(embeds[0], inputs[0], d_x0s[0], B, (void*)st)) return rc; }
+        else if (int rc = m2m_embeds_wgrad(embeds, inputs, d_x0s, nembeds, B, (void*)st)) return rc;
     }
     if constexpr (P == PREC_BF16) {
         static const int merged = wgrad_env("M2M_EMBED_MERGED", 1);
@@ -838,8 +839,8 @@ static int towers_wgrad_impl(const m2m_tower* const* towers, const m2m_tower* co
         heads_reduce = &hr;
     }
     if (!towers || !dev_towers || ntowers < 1 || ntowers > WG_MAX_TOWERS) { m2m_set_error("towers_wgrad: 1..4 towers", __FILE__, __LINE__); return -1; }
-    if (nembeds != 0 && (nembeds != EMB_GROUP || !embeds || !inputs || !d_x0s)) {
-        m2m_set_error("towers_wgrad: no patch embeddings or exactly two", __FILE__, __LINE__);
+    if (nembeds != 0 && (nembeds < 1 || nembeds > EMB_GROUP || !embeds || !inputs || !d_x0s)) {
+        m2m_set_error("towers_wgrad: at most two patch embeddings", __FILE__, __LINE__);
         return -1;
     }
     for (int i = 0; i < ntowers; ++i) {

@@ -1082,8 +1082,13 @@ class MimicEngine(_FlatEngine):
             self.t_time.backward(B, d_time_part, fs, self.dpool_time, self.dx0_time, self.Nt * D, self.seed, 0, sd)
             if self._mlp_ride:
                 self.mlp.ride_flush()
-            towers_wgrad([self.t_fus, self.t_time], B, seed=self.seed, step=0, step_dev=sd)
-            self.e_time.wgrad(time, self.dx0_time, B)
+            if os.environ.get("M2M_MIMIC_EMBED_WGRAD_MERGED", "1") != "0":
+                # the input projection's weight gradient in the towers' weight-gradient launch (one launch less)
+                towers_wgrad([self.t_fus, self.t_time], B, embeds=[self.e_time], inputs=[time], d_x0s=[self.dx0_time],
+                             seed=self.seed, step=0, step_dev=sd)
+            else:
+                towers_wgrad([self.t_fus, self.t_time], B, seed=self.seed, step=0, step_dev=sd)
+                self.e_time.wgrad(time, self.dx0_time, B)
             if fused_update:
                 self._update(1.0)                       # one launch for small models (config_fused_update), else Adam + pack_all
             return
