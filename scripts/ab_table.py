@@ -74,5 +74,30 @@ def main():
         print()
 
 
+SEC = collections.OrderedDict([
+    ('r5c', ("classification heads pool the wide towers' outputs themselves (m2m_head.tokens, M2M_HEADS_POOL) vs the token-mean launches; MLPOLD = the MLP product chains before their operand reads were batched",
+             {'POOL': 'heads pool (default)', 'SEP': 'token-mean launches', 'MLPOLD': 'heads pool, old MLP chains'})),
+    ('r5d', ("MIMIC-H: the static MLP as extra workgroups of the time tower's token-mixing launches (M2M_MLP_RIDE)", {'RIDE': 'MLP rides (default)', 'NORIDE': "MLP's own two launches"})),
+    ('r5e', ("MIMIC-H: the input projection's weight gradient in the towers' weight-gradient launch (M2M_MIMIC_EMBED_WGRAD_MERGED)", {'MERGED': 'merged (default)', 'SEP': 'launch of its own'})),
+])
+
+
+def secondary():
+    print("Secondary configurations at their cfg batches (scripts/ab_sec.sh: scripts/bench_configs.py --cfg-batch-only, 200 steps, three interleaved repetitions; ms per step):\n")
+    for tag, (title, names) in SEC.items():
+        print(f"== {tag}: {title}")
+        for k, label in names.items():
+            rows = collections.OrderedDict()
+            for f in sorted(glob.glob(f'gpurun_out/{tag}_{k}_*.jsonl')):
+                for l in open(f):
+                    if l.startswith('{'):
+                        d = json.loads(l)
+                        rows.setdefault(f"{d['metric'].split()[2]} B={d['batch']}", []).append(d['ms_per_step'])
+            if rows:
+                print(f"  {label:32s} " + "   ".join(f"{m}: " + ", ".join(f"{v:.4f}" for v in vs) for m, vs in rows.items()))
+        print()
+
+
 if __name__ == "__main__":
     main()
+    secondary()
