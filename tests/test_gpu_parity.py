@@ -654,6 +654,47 @@ def test_mimic_large_batch_token_gradients_vs_oracle(prec, dev):
         assert relerr(eng.grads[k], leaf.grad) < tol_g, k
 
 
+def test_mlp_ride_is_the_mlp_launch_with_or_without_a_carrier(dev):
+    """m2m_mlp_forward_ride / _backward_ride record the MLP call; a small token-mixing launch of a wide tower carries it, or
+    m2m_mlp_ride_flush launches it on its own.  Either way the results are those of m2m_mlp_forward / _backward, bit for bit
+    (same device code); a second recorded call while one is pending is refused; a flush with nothing pending is a no-op."""
+    from m2_mixer_amd import _lib as L
+    from m2_mixer_amd.runtime import MlpRuntime
+    cs = G.MIMIC_H["static"]
+    B, p_drop = 48, 0.3
+    shapes = {k: v for k, v in G.mimic_shapes(G.MIMIC_H).items() if k.startswith("static_extractor.")}
+    params = {k: v.to(dev) for k, v in G.make_params(shapes, 3).items()}
+    keys = [f"static_extractor.module_list.{i}." for i in (0, 3, 6)]
+    dims = [cs["input_dim"], cs["hidden_dim"], cs["hidden_dim"], cs["output_dim"]]
+    x = torch.randn(B, cs["input_dim"], device=dev)
+    d1, d2 = torch.randn(B, 3, cs["output_dim"], device=dev), torch.randn(B, cs["output_dim"], device=dev)
+
+    def run(ride: bool):
+        grads = {k: torch.zeros_like(v) for k, v in params.items()}
+        rt = MlpRuntime(dims, True, p_drop, 77)
+        rt.bind([(params[k + "weight"], params[k + "bias"]) for k in keys], [(grads[k + "weight"], grads[k + "bias"]) for k in keys], B)
+        out = torch.zeros(B, 3, cs["output_dim"], device=dev)
+        dense = torch.zeros(B, cs["output_dim"], device=dev)
+        if ride:
+            rt.forward_ride(x, B, out, 3 * cs["output_dim"], dense, True, 123, 1)
+            with pytest.raises(RuntimeError):                 # one pending call per host thread
+                rt.forward_ride(x, B, out, 3 * cs["output_dim"], dense, True, 123, 1)
+            rt.ride_flush()                                   # no carrier: a launch of its own
+            rt.ride_flush()                                   # nothing pending: no-op
+            rt.backward_ride(x, B, d1, 3 * cs["output_dim"], d2)
+            rt.ride_flush()
+        else:
+            rt.forward(x, B, out, 3 * cs["output_dim"], dense, True, 123, 1)
+            rt.backward(x, B, d1, 3 * cs["output_dim"], d2)
+        torch.cuda.synchronize()
+        return out, dense, grads
+
+    a, b = run(False), run(True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for k in a[2]:
+        assert relerr(a[2][k], b[2][k]) < 1e-6, k            # (weight gradients: float atomics over 3 workgroups)
+
+
 def test_static_mlp_dropout_consistency(dev):
     """The MIMIC static MLP (Linear-ReLU-Dropout x2 + Linear) with dropout on: forward equals the oracle under the
     masks the kernel drew (read back from the saved activations), backward equals autograd through those masks."""
