@@ -289,7 +289,22 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const PackAllArgs a) {
     const int e = id < a.embed_wgs0 ? 0 : 1;
     if (e) id -= a.embed_wgs0;
     const m2m_embed& em = a.em[e];
-    pack_slot<P>(em.w, em.K, 1, em.D, em.K, em.D, em.Kp, PACK_NAT, 0, (char*)em.wn, (long)id * 256 + threadIdx.x);
+    const long slot = (long)id * 256 + threadIdx.x;
+    if constexpr (P == PREC_BF16) {
+        // a slot is eight consecutive k of one row: two 16-byte loads when the row length / alignment allow it -- the four k-groups of
+        // a row then share a 128-byte line per instruction; the generic gather below touches 64 lines per 4-byte load instruction
+        const long nKB = em.Kp / 32, blk = slot >> 6;
+        const int lane = (int)(slot & 63), g = lane >> 4, il = lane & 15;
+        const long i = (blk / nKB) * 16 + il, k0 = (blk % nKB) * 32 + 8 * g;
+        if (slot < (long)(em.D / 16) * nKB * 64 && (em.K & 3) == 0 && (reinterpret_cast<uintptr_t>(em.w) & 15) == 0 && i < em.D && k0 + 8 <= em.K) {
+            const f32x4_t* src = reinterpret_cast<const f32x4_t*>(em.w + i * em.K + k0);
+            const f32x4_t x0 = src[0], x1 = src[1];
+            *reinterpret_cast<u32x4_t*>((char*)em.wn + slot * 16) =
+                u32x4_t{pack_bf2(x0[0], x0[1]), pack_bf2(x0[2], x0[3]), pack_bf2(x1[0], x1[1]), pack_bf2(x1[2], x1[3])};
+            return;
+        }
+    }
+    pack_slot<P>(em.w, em.K, 1, em.D, em.K, em.D, em.Kp, PACK_NAT, 0, (char*)em.wn, slot);
 }
 
 extern "C" int m2m_pack_all(const m2m_tower* const* towers, int ntowers, const m2m_embed* const* embeds, int nembeds,
@@ -721,6 +736,24 @@ __global__ __launch_bounds__(256) void adam_pack_all_kernel(const PackAllArgs a,
         // the slot's EPL weights are consecutive in k: all loads first (clamped), then the arithmetic, then the guarded stores
         float gq[8], pq[8], mq[8], vq[8];
         bool okq[8];
+        // bf16: the slot's eight weights are eight consecutive k of one row (32 bytes).  16-byte accesses when the row length and the
+        // buffers' offsets allow it (workgroup-uniform): the four k-groups of a row then share a 128-byte line per instruction instead
+        // of every lane of every instruction touching a line of its own (rows are K floats apart)
+        const long k0 = kb * Pr::KB + Pr::kmap(PACK_NAT, g, 0);
+        const bool vec = P == PREC_BF16 && !LOWP && (em.K & 3) == 0 && (o & 3) == 0 && i < em.D && k0 + 8 <= em.K &&
+                         ((reinterpret_cast<uintptr_t>(se.p) | reinterpret_cast<uintptr_t>(se.g) | reinterpret_cast<uintptr_t>(se.m) |
+                           reinterpret_cast<uintptr_t>(se.v)) & 15) == 0;
+        if (vec) {
+            const long at = o + i * em.K + k0;
+            f32x4_t g4[2], p4[2], m4[2], v4[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                g4[h] = *reinterpret_cast<const M2M_AS1 f32x4_t*>(se.g + at + 4 * h); p4[h] = *reinterpret_cast<const M2M_AS1 f32x4_t*>(se.p + at + 4 * h);
+                m4[h] = *reinterpret_cast<const M2M_AS1 f32x4_t*>(se.m + at + 4 * h); v4[h] = *reinterpret_cast<const M2M_AS1 f32x4_t*>(se.v + at + 4 * h);
+            }
+#pragma unroll
+            for (int x = 0; x < 8; ++x) { gq[x] = g4[x >> 2][x & 3]; pq[x] = p4[x >> 2][x & 3]; mq[x] = m4[x >> 2][x & 3]; vq[x] = v4[x >> 2][x & 3]; okq[x] = true; }
+        } else {
 #pragma unroll
         for (int x = 0; x < Pr::EPL; ++x) {
             const long kk = kb * Pr::KB + Pr::kmap(PACK_NAT, g, x);
@@ -729,7 +762,20 @@ __global__ __launch_bounds__(256) void adam_pack_all_kernel(const PackAllArgs a,
             gq[x] = LOWP ? __uint_as_float((unsigned int)se.gb[at] << 16) : se.g[at];
             pq[x] = se.p[at]; mq[x] = se.m[at]; vq[x] = se.v[at];
         }
+        }
         float v[8];
+        if (vec) {
+#pragma unroll
+            for (int x = 0; x < 8; ++x) { adam_math(c, gq[x], pq[x], mq[x], vq[x]); v[x] = pq[x]; }
+            const long at = o + i * em.K + k0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                *reinterpret_cast<M2M_AS1 f32x4_t*>(se.p + at + 4 * h) = f32x4_t{pq[4 * h], pq[4 * h + 1], pq[4 * h + 2], pq[4 * h + 3]};
+                *reinterpret_cast<M2M_AS1 f32x4_t*>(se.m + at + 4 * h) = f32x4_t{mq[4 * h], mq[4 * h + 1], mq[4 * h + 2], mq[4 * h + 3]};
+                *reinterpret_cast<M2M_AS1 f32x4_t*>(se.v + at + 4 * h) = f32x4_t{vq[4 * h], vq[4 * h + 1], vq[4 * h + 2], vq[4 * h + 3]};
+                if (!se.keep) *reinterpret_cast<M2M_AS1 f32x4_t*>(se.g + at + 4 * h) = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
 #pragma unroll
         for (int x = 0; x < Pr::EPL; ++x) {
             const long kk = kb * Pr::KB + Pr::kmap(PACK_NAT, g, x);
@@ -740,6 +786,7 @@ __global__ __launch_bounds__(256) void adam_pack_all_kernel(const PackAllArgs a,
                 se.p[at] = pq[x]; se.m[at] = mq[x]; se.v[at] = vq[x];
                 if (!se.keep) se.g[at] = 0.f;
             }
+        }
         }
         Frag f;
         if (P == PREC_BF16) {
