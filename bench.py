@@ -285,9 +285,11 @@ def main():
     ap.add_argument("--model", default="B", choices=["B", "S"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--steps-per-graph", type=int, default=10,
-                    help="N = 1: training steps captured per hipGraph (each with its own input slot); the replay gap between "
-                         "graphs is ~17 us.  Remainder steps run through a single-step graph")
+    ap.add_argument("--steps-per-graph", type=int, default=1,
+                    help="N = 1: training steps captured per hipGraph (each with its own input slot).  Round 1 measured a ~17 us "
+                         "gap between replays and used 10; since the step prologue moved into the kernels the one-step graph "
+                         "replays back to back and is 0.3-0.8 %% faster than the ten-step one (scripts/spg_probe.sh), so 1 is the "
+                         "default.  Remainder steps run through a single-step graph")
     ap.add_argument("--grad-compress", default="none", choices=["none", "bf16"],
                     help="N > 1: dtype of the gradient all-reduce.  none (default) = fp32: what the reference's DDP exchanges "
                          "(run.py:69-70).  bf16 = the equivalent of DDP's bf16_compress_hook, half the bytes on xGMI; its error is "
@@ -384,13 +386,15 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # The clock probe (~1 ms of back-to-back MFMA + VALU work per CU, then a host read-back) goes in FRONT of the preheat: between
+    # the preheat and the timed region it left the chip in another power state for the next few milliseconds -- with the driver's
+    # 20 timed steps (10 ms) that cost 4-8 % (K = 20: 0.516-0.535 ms per step against 0.495 at K = 200 on the same box; with the
+    # probe moved the two agree).  Preheat, warm-up and the timed steps now run back to back, separated only by the barriers.
+    clk = [shader_clock_mhz(dev)] if rank == 0 else []
     if args.preheat_ms > 0:
         n_pre = int(args.preheat_ms / 0.75)                 # a fixed step count: every rank must issue the same collectives
         log(f"preheat: {n_pre} untimed steps (~{args.preheat_ms:.0f} ms)")
         run_steps(n_pre)
-    barrier()
-    clk = [shader_clock_mhz(dev)] if rank == 0 else []             # (~1 ms of MFMA + VALU work per CU, BEFORE the warm-up steps)
-    log("warm-up")
     run_steps(args.warmup)
     barrier()
     log(f"timing {args.steps} steps")
