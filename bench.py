@@ -285,11 +285,12 @@ def main():
     ap.add_argument("--model", default="B", choices=["B", "S"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--steps-per-graph", type=int, default=1,
-                    help="N = 1: training steps captured per hipGraph (each with its own input slot).  Round 1 measured a ~17 us "
-                         "gap between replays and used 10; since the step prologue moved into the kernels the one-step graph "
-                         "replays back to back and is 0.3-0.8 %% faster than the ten-step one (scripts/spg_probe.sh), so 1 is the "
-                         "default.  Remainder steps run through a single-step graph")
+    ap.add_argument("--steps-per-graph", type=int, default=10,
+                    help="N = 1: training steps captured per hipGraph, EACH WITH ITS OWN INPUT SLOT (ten distinct synthetic batches, "
+                         "270 MB: a step reads its batch from HBM, as a training epoch does).  The one-step graph replays just as "
+                         "densely and measures 0.3-0.8 %% faster (scripts/spg_probe.sh) -- because it re-reads ONE 27 MB batch that "
+                         "stays in the 256 MiB Infinity Cache, which no real epoch does: not the default.  Remainder steps run "
+                         "through a single-step graph")
     ap.add_argument("--grad-compress", default="none", choices=["none", "bf16"],
                     help="N > 1: dtype of the gradient all-reduce.  none (default) = fp32: what the reference's DDP exchanges "
                          "(run.py:69-70).  bf16 = the equivalent of DDP's bf16_compress_hook, half the bytes on xGMI; its error is "
