@@ -527,6 +527,8 @@ class _FlatEngine:
             raise ValueError("steps > 1 is only supported without a gradient exchange")
         nb = len(batch)
         slots = [tuple(t.clone() for t in batch) for _ in range(steps)]
+        if steps > 1 and os.environ.get("M2M_CAPTURE_SHARE_SLOTS", "0") == "1":
+            slots = [slots[0]] * steps                  # diagnostic (scripts/spg_probe.sh): every step reads the SAME (cache-resident) batch
         self._static = slots[0] if steps == 1 else slots
         st = slots[0]
         # The warm-up below runs REAL training steps (lazy initialisation of the launches must happen outside the capture).
