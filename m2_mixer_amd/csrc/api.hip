@@ -174,6 +174,7 @@ struct PackAllArgs {
     int tile_end[M2M_PACK_TOWERS];     // running count of (block, 32-column group) tiles up to and including tower t
     int embed_wgs0;                    // workgroups (256 slots each) of embedding 0
     int nt_loads;                      // 1: the fp32 masters are read with non-temporal loads (M2M_PACK_NT)
+    int rowtiles[M2M_PACK_TOWERS];     // m2m_adam_pack_all, bf16: > 0 = W2 in 8-row x AP_W-column tiles, this many column chunks per row group
     int skip_w1tc[M2M_PACK_TOWERS];    // 1: nothing reads this tower's w1tc copy (pack_skips_w1tc): a quarter of the re-pack's writes
 };
 // The W1^T (CHN) copy feeds the third product of the backward chain -- except in the bf16 / hidden_dim 128 instantiation, which
@@ -192,7 +193,7 @@ static_assert(sizeof(PackAllArgs) <= 4096, "kernel arguments are limited to 4 Ki
 // 4-byte loads in 64-byte segments: 28 us for the whole model against ~100 MB of unavoidable traffic.)
 // Second half of a tile workgroup: the four packed copies (+ ch_b1p is written by the caller) from the LDS tiles
 //   t1 [32][D + 1] = W1[32q + r][d],  t2 [D][33] = W2[d][32q + j]   (rows / columns past C are zero)
-template <int P>
+template <int P, bool DO1 = true, bool DO2 = true>
 static __device__ __forceinline__ void pack_emit_tile(const m2m_block& k, int D, int q, const float* t1, const float* t2, bool skip_w1tc = false) {
     typedef Prec<P> Pr;
     const int L1 = D + 1, L2 = 33;
@@ -217,12 +218,12 @@ static __device__ __forceinline__ void pack_emit_tile(const m2m_block& k, int D,
 #pragma unroll
         for (int e = 0; e < Pr::EPL; ++e) {
             const int d = kb * Pr::KB + Pr::kmap(PACK_NAT, g, e);
-            v1[e] = t1[r * L1 + d];
-            v2[e] = t2[d * L2 + r];
+            v1[e] = DO1 ? t1[r * L1 + d] : 0.f;
+            v2[e] = DO2 ? t2[d * L2 + r] : 0.f;
         }
         const long blk = (long)(2 * q + h) * nKB + kb;
-        emit((char*)k.w1n, blk, lane, v1);
-        emit((char*)k.w2tn, blk, lane, v2);
+        if (DO1) emit((char*)k.w1n, blk, lane, v1);
+        if (DO2) emit((char*)k.w2tn, blk, lane, v2);
     }
     // CHN copies, k-major, X[i = d][k = c]: blocks (kb = CB q + h, ib); w1tc from t1[c][d], w2c from t2[d][c]
     for (int s = tid; s < CB * nIB * 64; s += nthr) {
@@ -232,12 +233,12 @@ static __device__ __forceinline__ void pack_emit_tile(const m2m_block& k, int D,
 #pragma unroll
         for (int e = 0; e < Pr::EPL; ++e) {
             const int j = h * Pr::KB + Pr::kmap(PACK_CHN, g, e);
-            v1[e] = t1[j * L1 + d];
-            v2[e] = t2[d * L2 + j];
+            v1[e] = DO1 ? t1[j * L1 + d] : 0.f;
+            v2[e] = DO2 ? t2[d * L2 + j] : 0.f;
         }
         const long blk = (long)(CB * q + h) * nIB + ib;
-        if (!skip_w1tc) emit((char*)k.w1tc, blk, lane, v1);
-        emit((char*)k.w2c, blk, lane, v2);
+        if (DO1 && !skip_w1tc) emit((char*)k.w1tc, blk, lane, v1);
+        if (DO2) emit((char*)k.w2c, blk, lane, v2);
     }
 }
 
@@ -595,14 +596,18 @@ static __device__ __forceinline__ AdamStreams adam_streams(const AdamPackPlan& p
 // stores -- their loads are clamped duplicates): EVERY load first, then the arithmetic, then the stores.  The first version of
 // this kernel updated element by element through generic pointers (load, store, load ... in series; the stores may alias the
 // next loads): 97 us for the model against 45 + 19 us for the flat Adam + m2m_pack_all it was meant to replace.
-template <bool LOWP, int NV>
+// NTMV (compile time -- a run-time choice between a plain and a non-temporal store of the same value is merged into ONE plain
+// store by the compiler): exp_avg / exp_avg_sq past the memory-side cache (large models, see adam_kernel's NT)
+template <bool LOWP, int NV, bool NTMV = false>
 static __device__ __forceinline__ void adam_vec(const AdamStreams& s, const AdamConsts& c, const long (&off)[NV], const bool (&ok)[NV],
                                                 f32x4_t (&pn)[NV]) {
     typedef M2M_AS1 f32x4_t* g4_t;
     f32x4_t gv[NV], mv[NV], vv[NV], av[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-        pn[k] = *(g4_t)(s.p + off[k]); mv[k] = *(g4_t)(s.m + off[k]); vv[k] = *(g4_t)(s.v + off[k]);
+        pn[k] = *(g4_t)(s.p + off[k]);
+        if constexpr (NTMV) { mv[k] = __builtin_nontemporal_load((g4_t)(s.m + off[k])); vv[k] = __builtin_nontemporal_load((g4_t)(s.v + off[k])); }
+        else { mv[k] = *(g4_t)(s.m + off[k]); vv[k] = *(g4_t)(s.v + off[k]); }
         if (LOWP) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) gv[k][e] = __uint_as_float((unsigned int)s.gb[off[k] + e] << 16);
@@ -621,7 +626,9 @@ static __device__ __forceinline__ void adam_vec(const AdamStreams& s, const Adam
 #pragma unroll
     for (int k = 0; k < NV; ++k)
         if (ok[k]) {
-            *(g4_t)(s.p + off[k]) = pn[k]; *(g4_t)(s.m + off[k]) = mv[k]; *(g4_t)(s.v + off[k]) = vv[k];
+            *(g4_t)(s.p + off[k]) = pn[k];
+            if constexpr (NTMV) { __builtin_nontemporal_store(mv[k], (g4_t)(s.m + off[k])); __builtin_nontemporal_store(vv[k], (g4_t)(s.v + off[k])); }
+            else { *(g4_t)(s.m + off[k]) = mv[k]; *(g4_t)(s.v + off[k]) = vv[k]; }
             if (!s.keep) *(g4_t)(s.g + off[k]) = f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
 }
@@ -640,7 +647,7 @@ static __device__ __forceinline__ float adam_elem(const AdamStreams& s, const Ad
 // (tower, block, 32-column group q) of hidden_dim DD: Adam on W1 rows [32q, 32q + 32) and W2 columns [32q, 32q + 32) with every
 // load in flight together (2 x DD / 32 float4 groups per thread and stream), the updated values into the LDS tiles, ch_b1, then
 // the packed copies from the tiles.
-template <int P, bool LOWP, int DD>
+template <int P, bool LOWP, int DD, bool NTMV>
 static __device__ __forceinline__ void adam_pack_tile(const AdamPackPlan& pl, const AdamConsts& c, const m2m_tower4& tw, int block, int q, char* smem, bool skip_w1tc) {
     const m2m_block& k = tw.blk[block];
     constexpr int D = DD, L1 = DD + 1, L2 = 33, NV = 32 * (DD / 4) / 256;      // float4 groups per thread and tensor (256 threads)
@@ -662,7 +669,7 @@ static __device__ __forceinline__ void adam_pack_tile(const AdamPackPlan& pl, co
             off[i] = o1 + (long)min(c0 + rr[i], C - 1) * D + dd[i];
         }
         f32x4_t pn[NV];
-        adam_vec<LOWP, NV>(s1, c, off, ok, pn);
+        adam_vec<LOWP, NV, NTMV>(s1, c, off, ok, pn);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             float* o = t1 + rr[i] * L1 + dd[i];
@@ -682,7 +689,7 @@ static __device__ __forceinline__ void adam_pack_tile(const AdamPackPlan& pl, co
             off[i] = o2 + (long)rd[i] * C + c0 + jj[i];
         }
         f32x4_t pn[NV];
-        adam_vec<LOWP, NV>(s2, c, off, ok, pn);
+        adam_vec<LOWP, NV, NTMV>(s2, c, off, ok, pn);
 #pragma unroll
         for (int i = 0; i < NV; ++i)
 #pragma unroll
@@ -698,7 +705,99 @@ static __device__ __forceinline__ void adam_pack_tile(const AdamPackPlan& pl, co
     pack_emit_tile<P>(k, D, q, t1, t2, skip_w1tc);
 }
 
-template <int P, bool LOWP>
+// ---- row-tile form (bf16): W1 and W2 as tiles of their own, each read and written in long contiguous runs -------------------------------
+// The (block, 32-column group) tile above touches W2 -- (D, C) row-major, the reference's nn.Linear layout -- in 128-byte segments
+// 4 C bytes apart: four streams of DRAM row misses, 3.4 TB/s for the model against 5.3 for the flat Adam.  Here W1 keeps its tile
+// (32 rows of W1 are one contiguous 32 x D chunk) and W2 is walked in tiles of 8 rows x AP_W columns (2 KiB runs): a packed NAT slot
+// of W2^T is eight consecutive d of one column -- exactly the tile's eight rows --, a packed CHN slot of W2 eight columns of one
+// row, so both images come out of the tile (128- and 256-byte runs of 16-byte slots).
+#define AP_W 512
+template <int P, bool LOWP, int DD, bool NTMV>
+static __device__ __forceinline__ void adam_pack_w1_tile(const AdamPackPlan& pl, const AdamConsts& c, const m2m_tower4& tw, int block, int q, char* smem, bool skip_w1tc) {
+    const m2m_block& k = tw.blk[block];
+    constexpr int D = DD, L1 = DD + 1, NV = 32 * (DD / 4) / 256;
+    const int C = tw.C, c0 = 32 * q, tid = threadIdx.x;
+    float* t1 = reinterpret_cast<float*>(smem);
+    const long o1 = k.ch_w1 - pl.p, ob = k.ch_b1 - pl.p;
+    const AdamStreams s1 = adam_streams(pl, o1), sb = adam_streams(pl, ob);
+    long off[NV];
+    bool ok[NV];
+    int rr[NV], dd[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = tid + i * 256;
+        rr[i] = idx / (D / 4); dd[i] = (idx % (D / 4)) * 4;
+        ok[i] = c0 + rr[i] < C;
+        off[i] = o1 + (long)min(c0 + rr[i], C - 1) * D + dd[i];
+    }
+    f32x4_t pn[NV];
+    adam_vec<LOWP, NV, NTMV>(s1, c, off, ok, pn);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float* o = t1 + rr[i] * L1 + dd[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = ok[i] ? pn[i][e] : 0.f;
+    }
+    if (tid < 32) k.ch_b1p[c0 + tid] = c0 + tid < C ? adam_elem<LOWP>(sb, c, ob + c0 + tid) : 0.f;
+    __syncthreads();
+    pack_emit_tile<P, true, false>(k, D, q, t1, t1, skip_w1tc);
+}
+template <bool LOWP, bool NTMV>
+static __device__ __forceinline__ void adam_pack_w2_rows(const AdamPackPlan& pl, const AdamConsts& c, const m2m_tower4& tw, int block, int dgrp, int chunk, char* smem) {
+    const m2m_block& k = tw.blk[block];
+    constexpr int W = AP_W, LD = AP_W + 4, NV = 8 * (AP_W / 4) / 256;
+    const int D = tw.D, C = tw.C, Cp = tw.Cp, tid = threadIdx.x;
+    const int d0 = 8 * dgrp, c0 = W * chunk;
+    float* t = reinterpret_cast<float*>(smem);           // [8][LD]: W2[d0 + r][c0 + j] (columns past C: zero)
+    const long o2 = k.ch_w2 - pl.p;
+    const AdamStreams s2 = adam_streams(pl, o2);
+    if (c0 + W <= C) {                                    // (workgroup-uniform)
+        long off[NV];
+        bool ok[NV];
+        int rr[NV], jj[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * 256;                // 8 rows x W / 4 float4 per row
+            rr[i] = idx / (W / 4); jj[i] = (idx % (W / 4)) * 4;
+            ok[i] = true;
+            off[i] = o2 + (long)(d0 + rr[i]) * C + c0 + jj[i];
+        }
+        f32x4_t pn[NV];
+        adam_vec<LOWP, NV, NTMV>(s2, c, off, ok, pn);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            *reinterpret_cast<f32x4_t*>(t + rr[i] * LD + jj[i]) = pn[i];
+    } else {
+        for (int idx = tid; idx < 8 * W; idx += 256) {
+            const int r = idx / W, j = idx % W;
+            t[r * LD + j] = c0 + j < C ? adam_elem<LOWP>(s2, c, o2 + (long)(d0 + r) * C + c0 + j) : 0.f;
+        }
+    }
+    __syncthreads();
+    const int nIB = D / 16, nKB = D / 32, ncb = (min(W, Cp - c0)) >> 5;      // 32-column blocks of this chunk
+    auto emit = [&](char* dst, long blk, int lane, const float (&v)[8]) {
+        *reinterpret_cast<u32x4_t*>(dst + (blk * 64 + lane) * 16) =
+            u32x4_t{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+    };
+    // w2c: CHN, k-major, X[i = d][k = c]: blocks (kb = c / 32, ib = d / 16), lane (g, il = d % 16): the row's columns 32 kb + {4g..4g+3, 16+4g..}
+    for (int sl = tid; sl < 8 * 4 * ncb; sl += 256) {
+        const int r = sl & 7, g = (sl >> 3) & 3, kbl = sl >> 5;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = t[r * LD + 32 * kbl + 16 * (e >> 2) + 4 * g + (e & 3)];
+        emit((char*)k.w2c, (long)(c0 / 32 + kbl) * nIB + d0 / 16, g * 16 + (d0 & 15) + r, v);
+    }
+    // w2tn: NAT, X[i = c][k = d]: blocks (ib = c / 16, kb = d / 32), lane (g = (d % 32) / 8, il = c % 16): the column's eight rows
+    for (int j = tid; j < 32 * ncb; j += 256) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = t[e * LD + j];
+        const int cc = c0 + j;
+        emit((char*)k.w2tn, (long)(cc / 16) * nKB + d0 / 32, ((d0 & 31) >> 3) * 16 + (cc & 15), v);
+    }
+}
+
+template <int P, bool LOWP, bool NTMV>
 __global__ __launch_bounds__(256) void adam_pack_all_kernel(const PackAllArgs a, const AdamPackPlan* __restrict__ plan, int embed_wgs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const AdamPackPlan& pl = *plan;
@@ -710,12 +809,27 @@ __global__ __launch_bounds__(256) void adam_pack_all_kernel(const PackAllArgs a,
         while (id >= a.tile_end[t]) ++t;
         if (t) id -= a.tile_end[t - 1];
         const m2m_tower4& tw = a.tw[t];
+        if constexpr (P == PREC_BF16) {
+            if (a.rowtiles[t] > 0) {                     // (workgroup-uniform) row-tile form: W1 tiles, then W2 row tiles, per block
+                const int nq = tw.Cp >> 5, nch = a.rowtiles[t], per_block = nq + (tw.D / 8) * nch;
+                const int block = id / per_block, r = id % per_block;
+                if (r < nq) {
+                    switch (tw.D) {
+                        case 32:  adam_pack_w1_tile<P, LOWP, 32, NTMV>(pl, c, tw, block, r, smem, a.skip_w1tc[t] != 0); break;
+                        case 64:  adam_pack_w1_tile<P, LOWP, 64, NTMV>(pl, c, tw, block, r, smem, a.skip_w1tc[t] != 0); break;
+                        case 128: adam_pack_w1_tile<P, LOWP, 128, NTMV>(pl, c, tw, block, r, smem, a.skip_w1tc[t] != 0); break;
+                        default:  adam_pack_w1_tile<P, LOWP, 256, NTMV>(pl, c, tw, block, r, smem, a.skip_w1tc[t] != 0); break;
+                    }
+                } else adam_pack_w2_rows<LOWP, NTMV>(pl, c, tw, block, (r - nq) / nch, (r - nq) % nch, smem);
+                return;
+            }
+        }
         const int nq = tw.Cp >> 5, block = id / nq, q = id % nq;
         switch (tw.D) {                                  // (workgroup-uniform)
-            case 32:  adam_pack_tile<P, LOWP, 32>(pl, c, tw, block, q, smem, a.skip_w1tc[t] != 0); break;
-            case 64:  adam_pack_tile<P, LOWP, 64>(pl, c, tw, block, q, smem, a.skip_w1tc[t] != 0); break;
-            case 128: adam_pack_tile<P, LOWP, 128>(pl, c, tw, block, q, smem, a.skip_w1tc[t] != 0); break;
-            default:  adam_pack_tile<P, LOWP, 256>(pl, c, tw, block, q, smem, a.skip_w1tc[t] != 0); break;
+            case 32:  adam_pack_tile<P, LOWP, 32, NTMV>(pl, c, tw, block, q, smem, a.skip_w1tc[t] != 0); break;
+            case 64:  adam_pack_tile<P, LOWP, 64, NTMV>(pl, c, tw, block, q, smem, a.skip_w1tc[t] != 0); break;
+            case 128: adam_pack_tile<P, LOWP, 128, NTMV>(pl, c, tw, block, q, smem, a.skip_w1tc[t] != 0); break;
+            default:  adam_pack_tile<P, LOWP, 256, NTMV>(pl, c, tw, block, q, smem, a.skip_w1tc[t] != 0); break;
         }
         return;
     }
@@ -818,14 +932,18 @@ __global__ __launch_bounds__(256) void adam_pack_all_kernel(const PackAllArgs a,
                 const long i = min(lo + x * 256 + (long)tid, hi - 1);
                 gq[x] = LOWP ? __uint_as_float((unsigned int)sf.gb[i] << 16) : sf.g[i];
                 if (sf.add) gq[x] += sf.add[i - sf.add_lo];
-                pq[x] = sf.p[i]; mq[x] = sf.m[i]; vq[x] = sf.v[i];
+                pq[x] = sf.p[i];
+                if constexpr (NTMV) { mq[x] = __builtin_nontemporal_load(sf.m + i); vq[x] = __builtin_nontemporal_load(sf.v + i); }
+                else { mq[x] = sf.m[i]; vq[x] = sf.v[i]; }
             }
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
                 const long i = lo + x * 256 + (long)tid;
                 adam_math(c, gq[x], pq[x], mq[x], vq[x]);
                 if (i < hi) {
-                    sf.p[i] = pq[x]; sf.m[i] = mq[x]; sf.v[i] = vq[x];
+                    sf.p[i] = pq[x];
+                    if constexpr (NTMV) { __builtin_nontemporal_store(mq[x], sf.m + i); __builtin_nontemporal_store(vq[x], sf.v + i); }
+                    else { sf.m[i] = mq[x]; sf.v[i] = vq[x]; }
                     if (!sf.keep) sf.g[i] = 0.f;
                 }
             }
@@ -918,6 +1036,7 @@ extern "C" int m2m_adam_pack_all(const m2m_tower* const* towers, int ntowers, co
     memset(&a, 0, sizeof(a));
     a.nt = ntowers; a.ne = nembeds;
     int prec = -1, tiles = 0, maxD = 0;
+    bool all_rowtiles = true;
     for (int i = 0; i < M2M_PACK_TOWERS; ++i) {
         if (i < ntowers) {
             if (int rc = m2m_check_tower(towers[i], 1)) return rc;
@@ -926,7 +1045,14 @@ extern "C" int m2m_adam_pack_all(const m2m_tower* const* towers, int ntowers, co
             if (towers[i]->prec != prec) { m2m_set_error("adam_pack_all: one precision per launch", __FILE__, __LINE__); return -1; }
             a.tw[i] = m2m_shrink(towers[i]);
             a.skip_w1tc[i] = pack_skips_w1tc(towers[i]);
-            tiles += towers[i]->nblocks * (towers[i]->Cp / 32);
+            static const int rowtiles = [] { const char* e = getenv("M2M_AP_ROWTILES"); return e ? atoi(e) : 1; }();
+            if (rowtiles && prec == PREC_BF16 && towers[i]->Cp >= AP_W) {      // (narrow towers keep the column-group tiles)
+                a.rowtiles[i] = (int)ceil_div((long)towers[i]->Cp, AP_W);
+                tiles += towers[i]->nblocks * (towers[i]->Cp / 32 + (towers[i]->D / 8) * a.rowtiles[i]);
+            } else {
+                tiles += towers[i]->nblocks * (towers[i]->Cp / 32);
+                all_rowtiles = false;
+            }
             maxD = std::max(maxD, (int)towers[i]->D);
         }
         a.tile_end[i] = tiles;
@@ -942,26 +1068,37 @@ extern "C" int m2m_adam_pack_all(const m2m_tower* const* towers, int ntowers, co
         embed_wgs += wgs;
     }
     const int flat_wgs = ph->seg_wg0[ph->nseg];
-    const size_t lds = (size_t)(32 * (maxD + 1) + maxD * 33) * sizeof(float);
+    // row-tile form everywhere: a workgroup needs the W1 tile OR the W2 row tile (half the LDS: twice the workgroups per CU)
+    const size_t lds = all_rowtiles ? std::max((size_t)32 * (maxD + 1), (size_t)8 * (AP_W + 4)) * sizeof(float)
+                                    : (size_t)(32 * (maxD + 1) + maxD * 33) * sizeof(float);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool lowp = ph->gb != nullptr;
-    const void* fn = prec == PREC_BF16 ? (lowp ? reinterpret_cast<const void*>(adam_pack_all_kernel<PREC_BF16, true>) : reinterpret_cast<const void*>(adam_pack_all_kernel<PREC_BF16, false>))
-                                       : (lowp ? reinterpret_cast<const void*>(adam_pack_all_kernel<PREC_F32, true>) : reinterpret_cast<const void*>(adam_pack_all_kernel<PREC_F32, false>));
-    static size_t attr_lds[4] = {0, 0, 0, 0};
-    const int pi = (prec == PREC_BF16 ? 0 : 2) + (lowp ? 1 : 0);
-    if (lds > attr_lds[pi]) {
-        M2M_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_lds[pi] = lds;
-    }
+    // the two moment streams past the memory-side cache for models it cannot hold anyway (> 4 M parameters: 64+ MB of moments);
+    // small models keep them plain (they stay resident from step to step).  M2M_ADAM_NT=0 / 1 forces either.
+    static const int nt_env = [] { const char* e = getenv("M2M_ADAM_NT"); return e ? atoi(e) : -1; }();
+    long n_own = 0;
+    for (int i = 0; i < ntowers; ++i) n_own += 2L * towers[i]->nblocks * towers[i]->C * towers[i]->D;
+    const bool ntmv = nt_env >= 0 ? (nt_env & 1) != 0 : n_own > 4000000L;
     const dim3 grid((unsigned)(tiles + embed_wgs + flat_wgs));
     const AdamPackPlan* pd = reinterpret_cast<const AdamPackPlan*>(plan_dev);
+    static size_t attr_lds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define M2M_APA_GO(PP, LP, NT, slot_)                                                                                                         \
+    do {                                                                                                                                      \
+        auto kern = adam_pack_all_kernel<PP, LP, NT>;                                                                                         \
+        if (lds > attr_lds[slot_]) {                                                                                                          \
+            M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+            attr_lds[slot_] = lds;                                                                                                            \
+        }                                                                                                                                     \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a, pd, embed_wgs);                                                                 \
+    } while (0)
     if (prec == PREC_BF16) {
-        if (lowp) hipLaunchKernelGGL((adam_pack_all_kernel<PREC_BF16, true>), grid, dim3(256), lds, st, a, pd, embed_wgs);
-        else hipLaunchKernelGGL((adam_pack_all_kernel<PREC_BF16, false>), grid, dim3(256), lds, st, a, pd, embed_wgs);
+        if (lowp) { if (ntmv) M2M_APA_GO(PREC_BF16, true, true, 0); else M2M_APA_GO(PREC_BF16, true, false, 1); }
+        else { if (ntmv) M2M_APA_GO(PREC_BF16, false, true, 2); else M2M_APA_GO(PREC_BF16, false, false, 3); }
     } else {
-        if (lowp) hipLaunchKernelGGL((adam_pack_all_kernel<PREC_F32, true>), grid, dim3(256), lds, st, a, pd, embed_wgs);
-        else hipLaunchKernelGGL((adam_pack_all_kernel<PREC_F32, false>), grid, dim3(256), lds, st, a, pd, embed_wgs);
+        if (lowp) { if (ntmv) M2M_APA_GO(PREC_F32, true, true, 4); else M2M_APA_GO(PREC_F32, true, false, 5); }
+        else { if (ntmv) M2M_APA_GO(PREC_F32, false, true, 6); else M2M_APA_GO(PREC_F32, false, false, 7); }
     }
+#undef M2M_APA_GO
     M2M_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -132,6 +132,7 @@ class _FlatEngine:
         self.shapes = self._param_shapes(cfg)
         n = sum(int(torch.Size(s).numel()) for s in self.shapes.values())
         self.n_params = n
+        self._fused_update = config_fused_update(n)          # (read once: the environment at construction decides)
         dev = self.device
         if share is not None:
             if share.n_params != n or list(share.shapes.items()) != list(self.shapes.items()) or share.device != dev:
@@ -433,7 +434,7 @@ class _FlatEngine:
     def _update(self, grad_scale: float = 1.0, grad_bf16: Optional[torch.Tensor] = None):
         """Adam over every parameter + operand re-pack.  One launch (m2m_adam_pack_all) where the model allows it: the
         re-pack then takes the updated weights from the workgroup that computed them instead of re-reading the masters."""
-        mods = self._adam_pack_modules() if config_fused_update(self.n_params) else None
+        mods = self._adam_pack_modules() if self._fused_update else None
         # the slot of a two-group tower: added inside Adam (fused step) unless forward_backward has folded it in already
         ranges = self._ranges_keep if (self._slots_folded or grad_bf16 is not None) else self._ranges_add
         self._slots_folded = False

@@ -197,6 +197,42 @@ def test_adam_moments_and_parameters_vs_oracle(size, B, seed, fused_update, dev,
     assert sum(int(v.sum()) for v in significant.values()) > 0.3 * eng.n_params
 
 
+@pytest.mark.parametrize("rowtiles", ["1", "0"])
+def test_one_launch_update_is_bit_identical_to_adam_then_repack_bf16(rowtiles, dev, monkeypatch):
+    """M2-Mixer-B, bf16: two training steps with the one-launch Adam + re-pack (m2m_adam_pack_all; M2M_AP_ROWTILES=1: W2 in 8-row x
+    512-column tiles, the fusion tower's ragged last chunk included; 0: the 32-column-group tiles) against the flat Adam followed by
+    m2m_pack_all: same arithmetic per element, so parameters, both moments, the cleared gradient and every packed operand copy the
+    chain kernels read must agree BIT FOR BIT."""
+    from m2_mixer_amd.engine import AVMnistEngine
+    cfg, B = dict(G.AVMNIST["B"]), 16
+    batch = tuple(t.to(dev) for t in G.avmnist_batch(B, 5, cfg))
+    monkeypatch.setenv("M2M_AP_ROWTILES", rowtiles)
+    engs = []
+    for fused in ("0", "1"):
+        monkeypatch.setenv("M2M_FUSED_UPDATE", fused)
+        e = AVMnistEngine(cfg, B, device=dev, precision="bf16", lr=1e-2, seed=3)
+        if engs:
+            e.load_state_dict(engs[0].state_dict())
+            e.pack()
+        engs.append(e)
+    sep, fus = engs
+    assert fus._fused_update and not sep._fused_update
+    for _ in range(2):
+        for e in engs:
+            e.train_step(*batch)
+    torch.cuda.synchronize()
+    assert torch.equal(sep.flat_p, fus.flat_p) and torch.equal(sep.flat_m, fus.flat_m) and torch.equal(sep.flat_v, fus.flat_v)
+    assert torch.equal(sep.flat_g, fus.flat_g)
+    for ts, tf in zip((sep.t_a, sep.t_b, sep.t_fus), (fus.t_a, fus.t_b, fus.t_fus)):
+        for i in range(ts.nblocks):
+            for k, v in ts._keep[f"packed{i}"].items():
+                if k == "w1tc" and ts.pack_all_skips_w1tc():
+                    continue
+                assert torch.equal(v, tf._keep[f"packed{i}"][k]), (i, k)
+    for es, ef in zip((sep.e_a, sep.e_b), (fus.e_a, fus.e_b)):
+        assert torch.equal(es._keep["wn"], ef._keep["wn"])
+
+
 @pytest.mark.parametrize("task,B", [("mimic", 128), ("mmimdb", 32), ("mmimdb", 256)])
 def test_wide_models_bf16_at_config_batches_vs_oracle(task, B, dev):
     """MIMIC-H at its cfg batch (128), MM-IMDb at its cfg batch (32 per GPU) and at 256 (the D = 256 token backward
