@@ -34,7 +34,7 @@ PMC_JSON = os.path.join(ROOT, "profiles", "r04_pmc.json")
 LAUNCH_KERNEL = {"towers_bwd[image+audio]": "tower_bwd_group_kernel", "tower_bwd[fusion]": "tower_bwd_kernel",
                  "tower_bwd[fusion]+heads": "tower_bwd_heads_kernel",
                  "towers_fwd[image+audio]": "tower_fwd_group_kernel", "tower_fwd[fusion]": "tower_fwd_kernel",
-                 "towers_wgrad[all+embeds]": "tower_wgrad_group_kernel", "adam+pack": ("adam_kernel", "pack_all_kernel"),
+                 "towers_wgrad[all+embeds]": "tower_wgrad_group_kernel", "adam+pack": "adam_pack_all_kernel",
                  "embeds_fwd[image+audio]": "embed_fwd_group_kernel", "heads_ce": "heads_kernel"}
 
 

@@ -596,6 +596,9 @@ static __device__ __forceinline__ AdamStreams adam_streams(const AdamPackPlan& p
 // stores -- their loads are clamped duplicates): EVERY load first, then the arithmetic, then the stores.  The first version of
 // this kernel updated element by element through generic pointers (load, store, load ... in series; the stores may alias the
 // next loads): 97 us for the model against 45 + 19 us for the flat Adam + m2m_pack_all it was meant to replace.
+#ifndef M2M_AP_NT_P
+#define M2M_AP_NT_P 0
+#endif
 // NTMV (compile time -- a run-time choice between a plain and a non-temporal store of the same value is merged into ONE plain
 // store by the compiler): exp_avg / exp_avg_sq past the memory-side cache (large models, see adam_kernel's NT)
 template <bool LOWP, int NV, bool NTMV = false>
@@ -605,7 +608,8 @@ static __device__ __forceinline__ void adam_vec(const AdamStreams& s, const Adam
     f32x4_t gv[NV], mv[NV], vv[NV], av[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-        pn[k] = *(g4_t)(s.p + off[k]);
+        // (the big masters too when M2M_AP_NT_P: in the one-launch form nothing re-reads them before the next step's Adam)
+        if constexpr (NTMV && M2M_AP_NT_P) pn[k] = __builtin_nontemporal_load((g4_t)(s.p + off[k])); else pn[k] = *(g4_t)(s.p + off[k]);
         if constexpr (NTMV) { mv[k] = __builtin_nontemporal_load((g4_t)(s.m + off[k])); vv[k] = __builtin_nontemporal_load((g4_t)(s.v + off[k])); }
         else { mv[k] = *(g4_t)(s.m + off[k]); vv[k] = *(g4_t)(s.v + off[k]); }
         if (LOWP) {
@@ -626,7 +630,7 @@ static __device__ __forceinline__ void adam_vec(const AdamStreams& s, const Adam
 #pragma unroll
     for (int k = 0; k < NV; ++k)
         if (ok[k]) {
-            *(g4_t)(s.p + off[k]) = pn[k];
+            if constexpr (NTMV && M2M_AP_NT_P) __builtin_nontemporal_store(pn[k], (g4_t)(s.p + off[k])); else *(g4_t)(s.p + off[k]) = pn[k];
             if constexpr (NTMV) { __builtin_nontemporal_store(mv[k], (g4_t)(s.m + off[k])); __builtin_nontemporal_store(vv[k], (g4_t)(s.v + off[k])); }
             else { *(g4_t)(s.m + off[k]) = mv[k]; *(g4_t)(s.v + off[k]) = vv[k]; }
             if (!s.keep) *(g4_t)(s.g + off[k]) = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -711,7 +715,9 @@ static __device__ __forceinline__ void adam_pack_tile(const AdamPackPlan& pl, co
 // (32 rows of W1 are one contiguous 32 x D chunk) and W2 is walked in tiles of 8 rows x AP_W columns (2 KiB runs): a packed NAT slot
 // of W2^T is eight consecutive d of one column -- exactly the tile's eight rows --, a packed CHN slot of W2 eight columns of one
 // row, so both images come out of the tile (128- and 256-byte runs of 16-byte slots).
+#ifndef AP_W
 #define AP_W 512
+#endif
 template <int P, bool LOWP, int DD, bool NTMV>
 static __device__ __forceinline__ void adam_pack_w1_tile(const AdamPackPlan& pl, const AdamConsts& c, const m2m_tower4& tw, int block, int q, char* smem, bool skip_w1tc) {
     const m2m_block& k = tw.blk[block];

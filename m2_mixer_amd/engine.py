@@ -33,14 +33,15 @@ from .runtime import (AdamPackPlan, BLOCK_FIELDS, BLOCK_KEYS, EmbedRuntime, MlpR
 
 def config_fused_update(n_params: int = 0) -> bool:
     """Adam and the operand re-pack as ONE launch (m2m_adam_pack_all) or as two (flat Adam, then m2m_pack_all).
-    M2M_FUSED_UPDATE=1 / 0 forces either; default: one launch for small models (<= 4 M parameters), two for large ones.
-    Measured (round 4, kernel rewritten with every load of a tile in flight): M2-Mixer-B (8.3 M parameters) 75-78 us fused
-    against 62-65 us as two launches -- the tile workgroups read W2 in 128-byte row segments 12 KB apart, the flat Adam streams
-    contiguously at the HBM rate; MM-IMDb (2.7 M parameters, latency-bound launches) 0.4602 against 0.4637 ms per step fused."""
+    M2M_FUSED_UPDATE=1 / 0 forces either; default: one launch.
+    Measured (round 4): with 32-column-group tiles the one-launch form read W2 in 128-byte row segments 12 KB apart (M2-Mixer-B:
+    70-78 us against 60-65 us as two launches); with W2 in 8-row x 512-column tiles (2 KiB runs) and the moment streams
+    non-temporal it takes 55-56 us and the step 0.4856 against 0.4912 ms (profiles/r04_ab_results.txt r5l-r5n); MM-IMDb
+    (2.7 M parameters, latency-bound launches) 0.4602 against 0.4637 ms per step."""
     env = os.environ.get("M2M_FUSED_UPDATE")
     if env is not None:
         return env == "1"
-    return 0 < n_params <= 4_000_000
+    return n_params > 0
 
 
 def _num_patch(c: dict) -> int:
