@@ -41,6 +41,12 @@ LABELS = collections.OrderedDict([
     ('r5a', ("VALID comparison after the revert (operand stores non-temporal again): Adam's moment streams non-temporal (M2M_ADAM_NT=1) and the embedding launch at two workgroups per CU -- both kept",
              {'OLD': 'committed library', 'NEW': 'reverted stores + staged forward', 'A1': '+ Adam m/v non-temporal', 'EMBD2': '+ embedding ring 2 / 2 workgroups per CU', 'A1E': 'both'})),
     ('r5b', ("k-splits of the audio embedding with two workgroups per CU (M2M_EMBED_SPLITS) -- 2 stays", {'S2': '2 splits (default)', 'S3': '3 splits', 'S4': '4 splits', 'S1': 'no split'})),
+    ('r5f', ("re-pack: four embedding slots per thread so that the grid fits one round of four workgroups per CU -- no change, not kept", {'SPT4': '4 slots per thread', 'SPT1': '1 slot per thread'})),
+    ('r5h', ("re-pack: the embeddings' packed slots from two 16-byte row loads instead of eight 4-byte gathers -- kept (re-pack -1.3 us)", {'NEW': '16-byte row loads', 'OLD': 'previous build'})),
+    ('r5k', ("embedding forward: patch slots four stages ahead, weight fragments two (two rings) -- embedding launch +0.7 us on a cache-resident batch, step -0.25 %: not kept", {'NEW': 'two rings', 'OLD': 'one ring of two stages'})),
+    ('r5l', ("one-launch Adam + re-pack with W2 in 8-row x 512-column tiles (M2M_AP_ROWTILES=1), moments still plain: the update itself 70 -> 57 us, but the plain moment streams slow the other launches", {'SEP': 'flat Adam, then re-pack', 'FUR': 'one launch, row tiles', 'FUC': 'one launch, 32-column-group tiles'})),
+    ('r5m', ("the same with the moment streams non-temporal (compile-time switch: large models) -- kept, now the default", {'SEP': 'flat Adam, then re-pack', 'FUR': 'one launch, row tiles, nt moments', 'FURP': 'one launch, row tiles, plain moments'})),
+    ('r5n', ("one-launch form: tile width and non-temporal masters -- 512 columns, plain masters stay", {'W512': '512 columns (default)', 'NTP': '+ masters non-temporal', 'W1024': '1024 columns', 'W256': '256 columns'})),
 ])
 
 
@@ -79,6 +85,8 @@ SEC = collections.OrderedDict([
              {'POOL': 'heads pool (default)', 'SEP': 'token-mean launches', 'MLPOLD': 'heads pool, old MLP chains'})),
     ('r5d', ("MIMIC-H: the static MLP as extra workgroups of the time tower's token-mixing launches (M2M_MLP_RIDE)", {'RIDE': 'MLP rides (default)', 'NORIDE': "MLP's own two launches"})),
     ('r5e', ("MIMIC-H: the input projection's weight gradient in the towers' weight-gradient launch (M2M_MIMIC_EMBED_WGRAD_MERGED)", {'MERGED': 'merged (default)', 'SEP': 'launch of its own'})),
+    ('r5g', ("one-launch update: the embeddings' slots with 16-byte row accesses instead of per-lane 4-byte gathers", {'VEC': '16-byte accesses', 'OLD': 'previous build'})),
+    ('r5o', ("one-launch update: W2 in 8-row x 512-column tiles (M2M_AP_ROWTILES; MIMIC-H's towers are narrower than a tile: unchanged)", {'RT': 'row tiles (default)', 'CT': '32-column-group tiles'})),
 ])
 
 
