@@ -803,8 +803,10 @@ static __device__ __forceinline__ void adam_pack_w2_rows(const AdamPackPlan& pl,
     }
 }
 
-template <int P, bool LOWP, bool NTMV>
-__global__ __launch_bounds__(256) void adam_pack_all_kernel(const PackAllArgs a, const AdamPackPlan* __restrict__ plan, int embed_wgs) {
+// DK: 0 = towers of any hidden_dim (run-time switch: the kernel's register allocation is then that of the widest instantiation, 254
+// VGPRs = two workgroups per CU), else the hidden_dim every tower of the launch has (128: ~100 registers, five workgroups per CU)
+template <int P, bool LOWP, bool NTMV, int DK>
+__global__ __launch_bounds__(256, (DK == 64 || DK == 128) ? 4 : 1) void adam_pack_all_kernel(const PackAllArgs a, const AdamPackPlan* __restrict__ plan, int embed_wgs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const AdamPackPlan& pl = *plan;
     const AdamConsts c = adam_consts(pl);
@@ -820,6 +822,8 @@ __global__ __launch_bounds__(256) void adam_pack_all_kernel(const PackAllArgs a,
                 const int nq = tw.Cp >> 5, nch = a.rowtiles[t], per_block = nq + (tw.D / 8) * nch;
                 const int block = id / per_block, r = id % per_block;
                 if (r < nq) {
+                    if constexpr (DK != 0) adam_pack_w1_tile<P, LOWP, DK, NTMV>(pl, c, tw, block, r, smem, a.skip_w1tc[t] != 0);
+                    else
                     switch (tw.D) {
                         case 32:  adam_pack_w1_tile<P, LOWP, 32, NTMV>(pl, c, tw, block, r, smem, a.skip_w1tc[t] != 0); break;
                         case 64:  adam_pack_w1_tile<P, LOWP, 64, NTMV>(pl, c, tw, block, r, smem, a.skip_w1tc[t] != 0); break;
@@ -831,6 +835,8 @@ __global__ __launch_bounds__(256) void adam_pack_all_kernel(const PackAllArgs a,
             }
         }
         const int nq = tw.Cp >> 5, block = id / nq, q = id % nq;
+        if constexpr (DK != 0) adam_pack_tile<P, LOWP, DK, NTMV>(pl, c, tw, block, q, smem, a.skip_w1tc[t] != 0);
+        else
         switch (tw.D) {                                  // (workgroup-uniform)
             case 32:  adam_pack_tile<P, LOWP, 32, NTMV>(pl, c, tw, block, q, smem, a.skip_w1tc[t] != 0); break;
             case 64:  adam_pack_tile<P, LOWP, 64, NTMV>(pl, c, tw, block, q, smem, a.skip_w1tc[t] != 0); break;
@@ -1088,12 +1094,19 @@ extern "C" int m2m_adam_pack_all(const m2m_tower* const* towers, int ntowers, co
     const dim3 grid((unsigned)(tiles + embed_wgs + flat_wgs));
     const AdamPackPlan* pd = reinterpret_cast<const AdamPackPlan*>(plan_dev);
     static size_t attr_lds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int dk = towers[0]->D;                                  // one hidden_dim for the whole launch: the instantiation built for it
+    for (int i = 1; i < ntowers; ++i) if (towers[i]->D != dk) dk = 0;
+    if (dk != 64 && dk != 128 && dk != 256) dk = 0;
 #define M2M_APA_GO(PP, LP, NT, slot_)                                                                                                         \
     do {                                                                                                                                      \
-        auto kern = adam_pack_all_kernel<PP, LP, NT>;                                                                                         \
-        if (lds > attr_lds[slot_]) {                                                                                                          \
+        auto kern = dk == 128 ? adam_pack_all_kernel<PP, LP, NT, 128> : dk == 256 ? adam_pack_all_kernel<PP, LP, NT, 256>                     \
+                  : dk == 64 ? adam_pack_all_kernel<PP, LP, NT, 64> : adam_pack_all_kernel<PP, LP, NT, 0>;                                   \
+        static size_t attr_lds_k[4] = {0, 0, 0, 0};                                                                                           \
+        size_t& attr_ref = attr_lds_k[dk == 128 ? 1 : dk == 256 ? 2 : dk == 64 ? 3 : 0];                                                       \
+        (void)attr_lds;                                                                                                                       \
+        if (lds > attr_ref) {                                                                                                                 \
             M2M_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
-            attr_lds[slot_] = lds;                                                                                                            \
+            attr_ref = lds;                                                                                                                   \
         }                                                                                                                                     \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a, pd, embed_wgs);                                                                 \
     } while (0)
