@@ -1057,7 +1057,8 @@ extern "C" int m2m_adam_pack_all(const m2m_tower* const* towers, int ntowers, co
             if (towers[i]->prec != prec) { m2m_set_error("adam_pack_all: one precision per launch", __FILE__, __LINE__); return -1; }
             a.tw[i] = m2m_shrink(towers[i]);
             a.skip_w1tc[i] = pack_skips_w1tc(towers[i]);
-            static const int rowtiles = [] { const char* e = getenv("M2M_AP_ROWTILES"); return e ? atoi(e) : 1; }();
+            const char* rt_env = getenv("M2M_AP_ROWTILES");       // (read per call: the tests switch it inside one process)
+            const int rowtiles = rt_env ? atoi(rt_env) : 1;
             if (rowtiles && prec == PREC_BF16 && towers[i]->Cp >= AP_W) {      // (narrow towers keep the column-group tiles)
                 a.rowtiles[i] = (int)ceil_div((long)towers[i]->Cp, AP_W);
                 tiles += towers[i]->nblocks * (towers[i]->Cp / 32 + (towers[i]->D / 8) * a.rowtiles[i]);

@@ -233,6 +233,45 @@ def test_one_launch_update_is_bit_identical_to_adam_then_repack_bf16(rowtiles, d
         assert torch.equal(es._keep["wn"], ef._keep["wn"])
 
 
+def test_update_from_a_bf16_gradient_copy_agrees_in_all_three_forms(dev, monkeypatch):
+    """optimizer_step(scale, grad_bf16) -- the update after a bf16-compressed exchange (`--grad-compress bf16`): Adam takes the
+    gradient VALUES from a bf16 copy of the flat gradient.  The flat Adam + re-pack, the one-launch form in row tiles and the
+    one-launch form in column-group tiles must leave bit-identical parameters, moments and packed copies, and the result must be
+    the fp32 update to within bf16 rounding of the gradient."""
+    from m2_mixer_amd.engine import AVMnistEngine
+    cfg, B = dict(G.AVMNIST["B"]), 16
+    batch = tuple(t.to(dev) for t in G.avmnist_batch(B, 5, cfg))
+    engs = []
+    for fused, rowtiles in (("0", "1"), ("1", "1"), ("1", "0")):
+        monkeypatch.setenv("M2M_FUSED_UPDATE", fused)
+        e = AVMnistEngine(cfg, B, device=dev, precision="bf16", lr=1e-2, seed=3)
+        if engs:
+            e.load_state_dict(engs[0].state_dict())
+            e.pack()
+        engs.append(e)
+    ref = AVMnistEngine(cfg, B, device=dev, precision="bf16", lr=1e-2, seed=3)
+    ref.load_state_dict(engs[0].state_dict())
+    ref.pack()
+    for e, rowtiles in zip(engs, ("1", "1", "0")):
+        monkeypatch.setenv("M2M_AP_ROWTILES", rowtiles)          # (the library reads it at every one-launch update)
+        e.forward_backward(*batch)
+        e.optimizer_step(0.5, e.flat_g.to(torch.bfloat16))
+    ref.forward_backward(*batch)
+    ref.optimizer_step(0.5)
+    torch.cuda.synchronize()
+    a = engs[0]
+    for e in engs[1:]:
+        assert torch.equal(a.flat_p, e.flat_p) and torch.equal(a.flat_m, e.flat_m) and torch.equal(a.flat_v, e.flat_v)
+        for ta, te in zip((a.t_a, a.t_b, a.t_fus), (e.t_a, e.t_b, e.t_fus)):
+            for i in range(ta.nblocks):
+                for k, v in ta._keep[f"packed{i}"].items():
+                    if k == "w1tc" and ta.pack_all_skips_w1tc():
+                        continue
+                    assert torch.equal(v, te._keep[f"packed{i}"][k]), (i, k)
+    # against the fp32-gradient update: first moment m = 0.1 g, so bf16 rounding of g (2^-9 relative) shows there directly
+    assert relerr(a.flat_m, ref.flat_m) < 2.0 ** -8
+
+
 @pytest.mark.parametrize("task,B", [("mimic", 128), ("mmimdb", 32), ("mmimdb", 256)])
 def test_wide_models_bf16_at_config_batches_vs_oracle(task, B, dev):
     """MIMIC-H at its cfg batch (128), MM-IMDb at its cfg batch (32 per GPU) and at 256 (the D = 256 token backward
