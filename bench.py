@@ -235,9 +235,32 @@ def module_path_point(cfg, B, device, precision, budget_s=4.0):
         step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"value": round(B * n / dt, 1), "unit": "samples/s", "ms_per_step": round(dt / n * 1e3, 4), "steps": n,
-            "what": "m2_mixer_amd.models.AVMnistMixerMultiLoss (registry-built m2_mixer_amd.modules towers under torch autograd): "
-                    f"shared_step -> loss.backward() -> torch.optim.Adam.step(), eager, {precision}, batch {B}"}
+    out = {"value": round(B * n / dt, 1), "unit": "samples/s", "ms_per_step": round(dt / n * 1e3, 4), "steps": n,
+           "what": "m2_mixer_amd.models.AVMnistMixerMultiLoss (registry-built m2_mixer_amd.modules towers under torch autograd): "
+                   f"shared_step -> loss.backward() -> torch.optim.Adam.step(), eager, {precision}, batch {B}"}
+    # the same step replayed as ONE hipGraph (m2_mixer_amd.graphs.GraphedStep: capturable Adam, dropout counters on the device)
+    try:
+        from m2_mixer_amd import config as MC
+        from m2_mixer_amd.graphs import GraphedStep
+        torch.manual_seed(42)
+        net2 = MD.AVMnistMixerMultiLoss({"dropout": cfg["dropout"], "modalities": mods}, {"lr": 1e-2, "betas": (0.9, 0.999), "scheduler_patience": 2}).to(device)
+        net2.train()
+        gs = GraphedStep(net2, net2.configure_optimizers()["optimizer"], batch)
+        for _ in range(5):
+            gs(batch)
+        torch.cuda.synchronize()
+        n2 = 200
+        t0 = time.perf_counter()
+        for _ in range(n2):
+            gs(batch)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t0
+        out["graphed"] = {"value": round(B * n2 / dt2, 1), "unit": "samples/s", "ms_per_step": round(dt2 / n2 * 1e3, 4), "steps": n2,
+                          "what": "the same shared_step -> backward -> Adam(capturable) step replayed as one hipGraph (m2_mixer_amd.graphs.GraphedStep)"}
+        MC.set_device_dropout_step(False)
+    except Exception as e:                                   # (a diagnostic leg: never takes the bench line down)
+        out["graphed"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+    return out
 
 
 def log(msg):

@@ -58,7 +58,8 @@ class _TowerFunction(torch.autograd.Function):
         B = x.shape[0]
         N, D = rts[0].N, rts[0].D
         dropping = owner.training and owner.dropout_p > 0
-        seed, step = config.dropout_seed(), owner._bump_step() if dropping else 0
+        seed = config.dropout_seed()
+        step, step_dev = owner._step_args(x.device) if dropping else (0, None)
         p_drop = float(owner.dropout_p) if dropping else 0.0
         saved = []
         cur = x
@@ -72,10 +73,10 @@ class _TowerFunction(torch.autograd.Function):
                 # activations -- into a scratch set, NOT into the set a pending differentiated forward left bound in the
                 # descriptor (its backward re-binds its own set: use_saved)
                 rt.fresh_saved(B)
-            rt.forward(cur, N * D, B, out, N * D, None, need_grad or dropping, seed, step)
+            rt.forward(cur, N * D, B, out, N * D, None, need_grad or dropping, seed, step, step_dev)
             cur = out
         ctx.saved = saved if need_grad else None
-        ctx.owner, ctx.B, ctx.seed, ctx.step, ctx.p_drop = owner, B, seed, step, p_drop
+        ctx.owner, ctx.B, ctx.seed, ctx.step, ctx.step_dev, ctx.p_drop = owner, B, seed, step, step_dev, p_drop
         ctx.nparams = len(params)
         return cur
 
@@ -96,8 +97,8 @@ class _TowerFunction(torch.autograd.Function):
             flat = torch.zeros(rt.grad_numel(), device=dout.device, dtype=torch.float32)
             views = rt.bind_grads(flat)
             dx = torch.empty(B, N, D, device=dout.device, dtype=torch.float32)
-            rt.backward(B, g, N * D, None, dx, N * D, ctx.seed, ctx.step)
-            rt.wgrad(B, ctx.seed, ctx.step)
+            rt.backward(B, g, N * D, None, dx, N * D, ctx.seed, ctx.step, ctx.step_dev)
+            rt.wgrad(B, ctx.seed, ctx.step, ctx.step_dev)
             grads_per_chunk.append(views)
             g = dx
         # parameter order of _run_tower: the blocks' fields chunk by chunk, then the final LayerNorm (in the last chunk's views)
@@ -142,6 +143,18 @@ class _HipTower(nn.Module):
     def _bump_step(self) -> int:
         self._drop_step += 1
         return self._drop_step
+
+    def _step_args(self, device):
+        """(step, step_dev) of the next dropout draw: a host integer, or -- config.set_device_dropout_step(True), for steps
+        replayed from a hipGraph -- 0 and a device counter that a one-thread launch has just advanced."""
+        if not config.device_dropout_step():
+            return self._bump_step(), None
+        ctr = getattr(self, "_drop_counter", None)
+        if ctr is None or ctr.device != device:
+            ctr = self._drop_counter = torch.full((1,), self._drop_step, dtype=torch.int32, device=device)
+        L.check(L.lib().m2m_counter_add(ctr.data_ptr(), 1, L.stream_ptr()), "counter_add")
+        self._drop_step += 1                 # (host mirror: exact in eager mode; replays advance only the device counter)
+        return 0, ctr
 
     def _tower_blocks(self) -> List["MixerBlock"]:
         raise NotImplementedError

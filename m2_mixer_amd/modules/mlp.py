@@ -10,6 +10,7 @@ from typing import Optional
 import torch
 from torch import nn
 
+from .. import _lib as L
 from .. import config
 from ..runtime import MlpRuntime
 
@@ -24,9 +25,9 @@ class _MlpFunction(torch.autograd.Function):
         out = torch.empty(B, rt.dims[-1], device=x.device, dtype=torch.float32)
         dropping = training and owner.dropout_p > 0
         rt.desc.p_drop = float(owner.dropout_p) if dropping else 0.0
-        step = owner._bump_step() if dropping else 0
+        step, step_dev = owner._step_args(x.device) if dropping else (0, None)
         ctx.acts = rt.fresh_acts(B, x.device)        # this forward's own saved activations: the module path is re-entrant
-        rt.forward(x, B, out, rt.dims[-1], None, True, config.dropout_seed(), step)     # training=True: keep the activations
+        rt.forward(x, B, out, rt.dims[-1], None, True, config.dropout_seed(), step, step_dev)     # training=True: keep the activations
         ctx.owner, ctx.B = owner, B
         ctx.save_for_backward(x)
         return out
@@ -62,6 +63,17 @@ class MLP(nn.Module):
     def _bump_step(self) -> int:
         self._drop_step += 1
         return self._drop_step
+
+    def _step_args(self, device):
+        """(step, step_dev): see modules.mixer._HipTower._step_args."""
+        if not config.device_dropout_step():
+            return self._bump_step(), None
+        ctr = getattr(self, "_drop_counter", None)
+        if ctr is None or ctr.device != device:
+            ctr = self._drop_counter = torch.full((1,), self._drop_step, dtype=torch.int32, device=device)
+        L.check(L.lib().m2m_counter_add(ctr.data_ptr(), 1, L.stream_ptr()), "counter_add")
+        self._drop_step += 1
+        return 0, ctr
 
     def _linears(self):
         return [m for m in self.module_list if isinstance(m, nn.Linear)]

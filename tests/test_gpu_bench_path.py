@@ -272,6 +272,72 @@ def test_update_from_a_bf16_gradient_copy_agrees_in_all_three_forms(dev, monkeyp
     assert relerr(a.flat_m, ref.flat_m) < 2.0 ** -8
 
 
+def _module_path_net(cfg, B, dev):
+    import m2_mixer_amd as M
+    from m2_mixer_amd import models as MD
+    M.set_precision("bf16")
+    npatch = lambda c: (c["image_size"][0] // c["patch_size"]) * (c["image_size"][1] // c["patch_size"])
+    mods = {"image": dict(cfg["image"], block_type="MLPMixer"), "audio": dict(cfg["audio"], block_type="MLPMixer"),
+            "multimodal": dict(cfg["multimodal"], block_type="FusionMixer", fusion_function="ConcatFusion"),
+            "classification": dict(classifier="StandardClassifier", num_classes=cfg["num_classes"],
+                                   input_shape=[B, npatch(cfg["image"]) + npatch(cfg["audio"]), cfg["multimodal"]["hidden_dim"]])}
+    torch.manual_seed(42)
+    net = MD.AVMnistMixerMultiLoss({"dropout": cfg["dropout"], "modalities": mods}, {"lr": 1e-2, "betas": (0.9, 0.999), "scheduler_patience": 2}).to(dev)
+    net.train()
+    return net
+
+
+def test_module_path_step_replayed_as_one_graph(dev):
+    """m2_mixer_amd.graphs.GraphedStep: the import-swap path's training step (shared_step -> backward -> Adam) captured into ONE
+    hipGraph.  (a) dropout off: three replayed steps on three batches leave the parameters of three eager steps (to 1e-3: a tenth
+    of one step's lr), and constructing the GraphedStep did not train; (b) dropout 0.5, lr = 0: two replays on the SAME batch give different losses
+    -- the dropout step counter lives on the device and advances inside the graph (a host integer would be baked in)."""
+    from m2_mixer_amd import config
+    from m2_mixer_amd.graphs import GraphedStep
+    B = 8
+    try:
+        cfg = dict(G.AVMNIST["S"], dropout=0.0)
+        batches = []
+        for i in range(3):
+            image, audio, labels = G.avmnist_batch(B, 30 + i, cfg)
+            batches.append({"image": image.to(dev), "audio": audio.to(dev), "label": labels.to(dev)})
+        eager = _module_path_net(cfg, B, dev)
+        graphed = _module_path_net(cfg, B, dev)
+        graphed.load_state_dict(eager.state_dict())
+        before = [p.detach().clone() for p in graphed.parameters()]
+        opt_e = eager.configure_optimizers()["optimizer"]
+        opt_g = graphed.configure_optimizers()["optimizer"]
+        for g in opt_e.param_groups:
+            g["capturable"] = True
+        gs = GraphedStep(graphed, opt_g, batches[0])
+        assert all(torch.equal(a, p) for a, p in zip(before, graphed.parameters()))          # construction did not train
+        for b in batches:
+            opt_e.zero_grad(set_to_none=True)
+            eager.shared_step(b, mode="train")["loss"].backward()
+            opt_e.step()
+            gs(b)
+        torch.cuda.synchronize()
+        # (not bit for bit: the graphed optimizer reads its learning rate from a device tensor -- another rounding of
+        # lr / bias_correction than the float path -- and the module path's embedding gradients use float atomics; a
+        # parameter moves by up to lr = 1e-2 per step, the two runs must agree to a small fraction of that)
+        worst = 0.0
+        for (k, a), bpar in zip(eager.named_parameters(), graphed.parameters()):
+            worst = max(worst, float((a.detach() - bpar.detach()).abs().max()))
+        observe("graphed vs eager module-path step, max parameter difference after 3 steps (abs)", worst, 1e-3)
+        assert worst < 1e-3
+        # (b) the dropout stream advances inside the graph
+        cfg = dict(G.AVMNIST["S"], dropout=0.5)
+        net = _module_path_net(cfg, B, dev)
+        opt = net.configure_optimizers()["optimizer"]
+        gs = GraphedStep(net, opt, batches[0])
+        gs.set_lr(0.0)
+        l1 = float(gs(batches[0])["loss"].detach())
+        l2 = float(gs(batches[0])["loss"].detach())
+        assert l1 != l2 and abs(l1 - l2) < 0.5 * abs(l1)
+    finally:
+        config.set_device_dropout_step(False)
+
+
 @pytest.mark.parametrize("task,B", [("mimic", 128), ("mmimdb", 32), ("mmimdb", 256)])
 def test_wide_models_bf16_at_config_batches_vs_oracle(task, B, dev):
     """MIMIC-H at its cfg batch (128), MM-IMDb at its cfg batch (32 per GPU) and at 256 (the D = 256 token backward
