@@ -22,7 +22,7 @@ from . import config
 
 class GraphedStep:
     def __init__(self, net: torch.nn.Module, optimizer: torch.optim.Optimizer, example_batch: Dict[str, torch.Tensor],
-                 step_fn: Optional[Callable] = None, warmup: int = 2):
+                 step_fn: Optional[Callable] = None, warmup: int = 2, fused: bool = True):
         """step_fn(net, batch) -> dict with a "loss" entry (default: net.shared_step(batch, mode="train")).  The optimizer must not
         have taken a step yet unless it was built with capturable=True."""
         if not isinstance(optimizer, (torch.optim.Adam, torch.optim.AdamW)):
@@ -35,6 +35,11 @@ class GraphedStep:
                 if any(len(optimizer.state.get(p, {})) for p in g["params"]):
                     raise RuntimeError("GraphedStep: this optimizer has already stepped without capturable=True; build it with capturable=True")
                 g["capturable"] = True
+            # the fused implementation (one multi-tensor kernel instead of ~12 foreach passes over 33 MB): 2.06 -> 1.3 ms per
+            # replayed step of M2-Mixer-B.  (It does not advance the parameters' version counters; the modules re-pack their
+            # operand copies unconditionally in training mode: modules/mixer.py, _train_repack.)
+            if fused and all(p.is_cuda and torch.is_floating_point(p) for p in g["params"]):
+                g["fused"], g["foreach"] = True, False
             if not torch.is_tensor(g["lr"]):
                 g["lr"] = torch.tensor(float(g["lr"]), dtype=torch.float32, device=dev)      # replays read the CURRENT value
         config.set_device_dropout_step(True)

@@ -24,6 +24,11 @@ from ..runtime import BLOCK_FIELDS, BLOCK_KEYS, EmbedRuntime, TowerRuntime
 _site_counter = itertools.count(0)
 
 
+def _train_repack(module: nn.Module) -> bool:
+    """Re-pack the operand copies regardless of the parameters' version counters?  (see _HipTower._runtime)"""
+    return module.training and torch.is_grad_enabled()
+
+
 def _param_holder_ff(dim: int, hidden: int, dropout: float, out_dim: Optional[int] = None) -> nn.Module:
     return FeedForward(dim, hidden, dropout, out_dim)
 
@@ -186,8 +191,13 @@ class _HipTower(nn.Module):
                 l = lnf if ci == len(chunks) - 1 else None
                 if rt.params_changed(blocks, l):
                     rt.bind_params(blocks, l)
+        # Version counters catch in-place edits by ordinary ops (optimizers' foreach kernels, load_state_dict, p.mul_()) -- but NOT
+        # torch's fused optimizers (torch.optim.Adam(fused=True) updates the values and leaves `_version` alone: measured on
+        # torch 2.10 / ROCm).  A module in training mode with gradients enabled is about to be stepped: re-pack unconditionally
+        # there (one ~12 us launch per tower, which a training step pays anyway); evaluation keeps the version check.
+        force = _train_repack(self)
         for rt in self._rts:
-            rt.pack()
+            rt.pack(force=force)
         self._rt = self._rts[0]
         return self._rt
 
@@ -275,7 +285,7 @@ class MLPMixer(_HipTower):
             self._ert.bind_params(conv.weight, conv.bias)
         elif self._ert.params_changed(conv.weight, conv.bias):
             self._ert.bind_params(conv.weight, conv.bias)
-        self._ert.pack()
+        self._ert.pack(force=_train_repack(self))
         return _EmbedFunction.apply(x.contiguous().float(), self, conv.weight, conv.bias)
 
     def forward(self, x):
@@ -315,6 +325,6 @@ class MLPMixerNoPatching(_HipTower):
             self._ert.bind_params(self.proj.weight, self.proj.bias)
         elif self._ert.params_changed(self.proj.weight, self.proj.bias):
             self._ert.bind_params(self.proj.weight, self.proj.bias)
-        self._ert.pack()
+        self._ert.pack(force=_train_repack(self))
         x0 = _EmbedFunction.apply(x.contiguous().float(), self, self.proj.weight, self.proj.bias)
         return self._run_tower(x0)

@@ -44,6 +44,8 @@ def main():
     net, opt = build(cfg, B, dev, precision)
     for g in opt.param_groups:
         g["capturable"] = True
+        if len(sys.argv) > 1 and sys.argv[1] == "fused":
+            g["fused"], g["foreach"] = True, False
 
     def step():
         opt.zero_grad(set_to_none=True)

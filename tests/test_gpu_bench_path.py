@@ -309,7 +309,7 @@ def test_module_path_step_replayed_as_one_graph(dev):
         opt_g = graphed.configure_optimizers()["optimizer"]
         for g in opt_e.param_groups:
             g["capturable"] = True
-        gs = GraphedStep(graphed, opt_g, batches[0])
+        gs = GraphedStep(graphed, opt_g, batches[0], fused=False)      # (the same optimizer implementation on both sides)
         assert all(torch.equal(a, p) for a, p in zip(before, graphed.parameters()))          # construction did not train
         for b in batches:
             opt_e.zero_grad(set_to_none=True)
@@ -325,6 +325,29 @@ def test_module_path_step_replayed_as_one_graph(dev):
             worst = max(worst, float((a.detach() - bpar.detach()).abs().max()))
         observe("graphed vs eager module-path step, max parameter difference after 3 steps (abs)", worst, 1e-3)
         assert worst < 1e-3
+        # (c) torch's FUSED Adam updates the parameters without advancing their version counters: the modules must re-pack their
+        #     operand copies anyway (training mode), or the towers would keep computing with the weights of the first pack
+        config.set_device_dropout_step(False)
+        net = _module_path_net(cfg, B, dev)
+        opt = net.configure_optimizers()["optimizer"]
+        for g in opt.param_groups:
+            g["fused"], g["foreach"] = True, False
+        for b in batches[:2]:
+            opt.zero_grad(set_to_none=True)
+            net.shared_step(b, mode="train")["loss"].backward()
+            opt.step()
+        net.shared_step(batches[2], mode="train")                 # the forward after the last update: its packed copies ...
+        torch.cuda.synchronize()
+        towers = [m for m in net.modules() if getattr(m, "_rts", None)]
+        assert towers
+        for m in towers:
+            for rt in m._rts:
+                for i in range(rt.nblocks):
+                    have = {k: v.clone() for k, v in rt._keep[f"packed{i}"].items()}
+                    rt.pack(force=True)                           # ... must be those of the CURRENT weights
+                    torch.cuda.synchronize()
+                    for k, v in rt._keep[f"packed{i}"].items():
+                        assert torch.equal(v, have[k]), (type(m).__name__, i, k)
         # (b) the dropout stream advances inside the graph
         cfg = dict(G.AVMNIST["S"], dropout=0.5)
         net = _module_path_net(cfg, B, dev)
