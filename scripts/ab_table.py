@@ -47,6 +47,8 @@ LABELS = collections.OrderedDict([
     ('r5l', ("one-launch Adam + re-pack with W2 in 8-row x 512-column tiles (M2M_AP_ROWTILES=1), moments still plain: the update itself 70 -> 57 us, but the plain moment streams slow the other launches", {'SEP': 'flat Adam, then re-pack', 'FUR': 'one launch, row tiles', 'FUC': 'one launch, 32-column-group tiles'})),
     ('r5m', ("the same with the moment streams non-temporal (compile-time switch: large models) -- kept, now the default", {'SEP': 'flat Adam, then re-pack', 'FUR': 'one launch, row tiles, nt moments', 'FURP': 'one launch, row tiles, plain moments'})),
     ('r5n', ("one-launch form: tile width and non-temporal masters -- 512 columns, plain masters stay", {'W512': '512 columns (default)', 'NTP': '+ masters non-temporal', 'W1024': '1024 columns', 'W256': '256 columns'})),
+    ('r5w', ("heads kernel with 8 samples per workgroup (-DHEAD_S=8) -- heads 9.0 -> 10.9 us: 16 stays", {'S16': '16 samples per workgroup (default)', 'S8': '8 samples per workgroup'})),
+    ('r5y', ("backward column loop: s_setprio 3 around the weight-prefetch issue -- no change", {'BASE': 'default', 'PRIO': 's_setprio around the prefetch'})),
     ('r5p', ("one-launch form instantiated per hidden_dim (128 instead of 254 registers: four workgroups per CU) -- kept", {'DK': 'per-hidden_dim instantiation', 'OLD': 'run-time switch over hidden_dim'})),
 ])
 
